@@ -1,0 +1,220 @@
+"""ctypes loader for the CPU oracle (oracle/brush_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg. Nothing under brush_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_DIR, "libbrush_oracle.so")
+
+FLAG_MIP = 1
+FLAG_BWD_INFO = 2
+FLAG_SMOOTH_CUTOFF = 4
+
+
+class BoCamera(C.Structure):
+    _fields_ = [
+        ("vm", C.c_float * 12),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("lim_pos_x", C.c_float), ("lim_pos_y", C.c_float),
+        ("lim_neg_x", C.c_float), ("lim_neg_y", C.c_float),
+        ("cam_pos", C.c_float * 3),
+        ("img_w", C.c_uint32), ("img_h", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(_DIR, "brush_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        L.bo_expf.restype = C.c_float; L.bo_expf.argtypes = [C.c_float]
+        L.bo_logf.restype = C.c_float; L.bo_logf.argtypes = [C.c_float]
+        L.bo_calc_sigma.restype = C.c_float; L.bo_calc_sigma.argtypes = [C.c_float] * 7
+        L.bo_powi.restype = C.c_float; L.bo_powi.argtypes = [C.c_float, C.c_int]
+        L.bo_camera_setup.restype = None
+        L.bo_camera_setup.argtypes = [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BoCamera)]
+        L.bo_focal_to_fov.restype = C.c_double; L.bo_focal_to_fov.argtypes = [C.c_double, C.c_uint32]
+        L.bo_fov_to_focal.restype = C.c_double; L.bo_fov_to_focal.argtypes = [C.c_double, C.c_uint32]
+        L.bo_render_create.restype = C.c_void_p
+        L.bo_render_free.argtypes = [C.c_void_p]
+        L.bo_render_forward.restype = C.c_int
+        L.bo_render_forward.argtypes = [C.c_void_p, C.POINTER(BoCamera), C.c_uint32, C.c_uint32, fp, fp, fp, fp, C.c_uint32]
+        L.bo_render_backward.restype = C.c_int
+        L.bo_render_backward.argtypes = [C.c_void_p, fp, fp, fp, fp]
+        for nm in ("bo_num_visible", "bo_num_intersections", "bo_num_tiles"):
+            getattr(L, nm).restype = C.c_uint32
+            getattr(L, nm).argtypes = [C.c_void_p]
+        L.bo_stage_seconds.restype = C.c_double; L.bo_stage_seconds.argtypes = [C.c_void_p, C.c_int]
+        L.bo_radix_argsort.restype = None
+        L.bo_radix_argsort.argtypes = [u32p, u32p, C.c_uint64, C.c_uint32, u32p, u32p]
+        L.bo_prefix_sum.restype = None
+        L.bo_prefix_sum.argtypes = [u32p, C.c_uint64, u32p]
+        L.bo_image_loss_forward.restype = None
+        L.bo_image_loss_forward.argtypes = [fp, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, fp, C.c_int, C.c_int, fp]
+        L.bo_image_loss_backward.restype = None
+        L.bo_image_loss_backward.argtypes = [fp, u32p, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, fp, C.c_int, C.c_int, fp]
+        L.bo_adam_step.restype = None
+        L.bo_adam_step.argtypes = [fp, fp, fp, fp, C.c_uint64, C.c_uint32, fp, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_float]
+        L.bo_gather_stats.restype = None
+        L.bo_gather_stats.argtypes = [fp, fp, fp, fp, fp, fp, C.c_uint64]
+        L.bo_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def camera(pos=(0.0, 0.0, 0.0), rot_xyzw=(0.0, 0.0, 0.0, 1.0), fov_x=1.0, fov_y=1.0, center_uv=(0.5, 0.5), img_w=64, img_h=64):
+    """brush-render/src/camera.rs Camera -> kernel uniforms (oracle restatement)."""
+    cam = BoCamera()
+    p = f32(pos)
+    r = f32(rot_xyzw)
+    lib().bo_camera_setup(_fp(p), _fp(r), float(fov_x), float(fov_y), float(center_uv[0]), float(center_uv[1]), int(img_w), int(img_h), C.byref(cam))
+    return cam
+
+
+_GETTERS = {
+    "intersect_counts": np.uint32, "max_radius": np.float32, "depths_sorted": np.float32,
+    "global_from_compact_gid": np.uint32, "cum_tiles_hit": np.uint32, "projected": np.float32,
+    "tile_id_unsorted": np.uint32, "gid_unsorted": np.uint32,
+    "tile_id_from_isect": np.uint32, "compact_gid_from_isect": np.uint32,
+    "tile_offsets_pre": np.uint32, "tile_offsets": np.uint32, "out_img": np.float32,
+    "out_packed": np.uint32, "visible": np.float32, "v_combined": np.float32,
+    "v_transforms": np.float32, "v_coeffs": np.float32, "v_raw_opac": np.float32, "v_refine": np.float32,
+}
+
+
+class Render:
+    """One forward (+ optional backward) of the oracle. Mirrors RenderOutput /
+    RenderAuxInner (brush-render/src/render_aux.rs:17-68)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(lib().bo_render_create())
+
+    def __del__(self):
+        try:
+            lib().bo_render_free(self._h)
+        except Exception:
+            pass
+
+    def forward(self, cam, transforms, sh, raw_opac, bg=(0.0, 0.0, 0.0), flags=FLAG_BWD_INFO):
+        self.transforms = f32(transforms).reshape(-1, 10)
+        n = self.transforms.shape[0]
+        self.sh = f32(sh).reshape(n, -1, 3) if n else f32(sh).reshape(0, 1, 3)
+        ncoef = self.sh.shape[1]
+        self.sh_degree = int(round(ncoef ** 0.5)) - 1
+        assert (self.sh_degree + 1) ** 2 == ncoef
+        self.raw_opac = f32(raw_opac).reshape(n)
+        self.cam = cam
+        self.flags = flags
+        bgv = f32(bg)
+        rc = lib().bo_render_forward(self._h, C.byref(cam), n, self.sh_degree, _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac), _fp(bgv), flags)
+        if rc != 0:
+            raise RuntimeError("bo_render_forward failed (rc=%d)" % rc)
+        self.num_visible = lib().bo_num_visible(self._h)
+        self.num_intersections = lib().bo_num_intersections(self._h)
+        self.num_tiles = lib().bo_num_tiles(self._h)
+        return self
+
+    def backward(self, v_output):
+        v = f32(v_output).reshape(self.cam.img_h, self.cam.img_w, 4)
+        rc = lib().bo_render_backward(self._h, _fp(v), _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac))
+        if rc != 0:
+            raise RuntimeError("bo_render_backward failed (rc=%d)" % rc)
+        return self
+
+    def get(self, name):
+        cnt = C.c_uint64(0)
+        fn = getattr(lib(), "bo_get_" + name)
+        ct = C.c_float if _GETTERS[name] == np.float32 else C.c_uint32
+        fn.restype = C.POINTER(ct)
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        p = fn(self._h, C.byref(cnt))
+        if cnt.value == 0:
+            return np.zeros(0, dtype=_GETTERS[name])
+        return np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()
+
+    def image(self):
+        return self.get("out_img").reshape(self.cam.img_h, self.cam.img_w, 4)
+
+    def stage_seconds(self):
+        names = ["project_forward", "depth_sort", "scan", "project_visible", "map_isect", "tile_sort", "tile_offsets", "rasterize", "rasterize_bwd", "project_bwd"]
+        return {k: lib().bo_stage_seconds(self._h, i) for i, k in enumerate(names)}
+
+
+def radix_argsort(keys, vals, bits=32):
+    k = np.ascontiguousarray(keys, dtype=np.uint32)
+    v = np.ascontiguousarray(vals, dtype=np.uint32)
+    ok, ov = np.empty_like(k), np.empty_like(v)
+    lib().bo_radix_argsort(_u32p(k), _u32p(v), k.size, bits, _u32p(ok), _u32p(ov))
+    return ok, ov
+
+
+def prefix_sum(x):
+    a = np.ascontiguousarray(x, dtype=np.uint32)
+    o = np.empty_like(a)
+    lib().bo_prefix_sum(_u32p(a), a.size, _u32p(o))
+    return o
+
+
+def image_loss_forward(pred_chw, gt_packed, l1_w, ssim_w, bg=None, mask=False):
+    p = f32(pred_chw)
+    c, h, w = p.shape
+    g = np.ascontiguousarray(gt_packed, dtype=np.uint32).reshape(h, w)
+    out = np.zeros_like(p)
+    bgv = f32(bg if bg is not None else (0, 0, 0))
+    lib().bo_image_loss_forward(_fp(p), _u32p(g), c, h, w, l1_w, ssim_w, _fp(bgv), int(bg is not None), int(mask), _fp(out))
+    return out
+
+
+def image_loss_backward(pred_chw, gt_packed, dl_dmap, l1_w, ssim_w, bg=None, mask=False):
+    p = f32(pred_chw)
+    c, h, w = p.shape
+    g = np.ascontiguousarray(gt_packed, dtype=np.uint32).reshape(h, w)
+    d = f32(dl_dmap).reshape(c, h, w)
+    out = np.zeros_like(p)
+    bgv = f32(bg if bg is not None else (0, 0, 0))
+    lib().bo_image_loss_backward(_fp(p), _u32p(g), _fp(d), c, h, w, l1_w, ssim_w, _fp(bgv), int(bg is not None), int(mask), _fp(out))
+    return out
+
+
+def adam_step(param, grad, m1, m2, lr, t, col_scale=None, reduce_m2=False, beta1=0.9, beta2=0.999, eps=1e-15):
+    """In place on param/m1/m2 (float32 C-contiguous arrays). param is [rows, row_len]."""
+    assert param.dtype == np.float32 and param.flags.c_contiguous
+    rows = param.shape[0]
+    row_len = int(param.size // rows) if rows else 1
+    g = f32(grad)
+    cs = f32(col_scale) if col_scale is not None else None
+    lib().bo_adam_step(_fp(param), _fp(g), _fp(m1), _fp(m2), rows, row_len, _fp(cs) if cs is not None else None, lr, t, int(reduce_m2), beta1, beta2, eps)
+
+
+def num_threads():
+    return lib().bo_num_threads()

@@ -1,0 +1,1560 @@
+// brush_oracle.cpp — CPU ORACLE. TEST INFRASTRUCTURE ONLY.
+//
+// A plain C++ restatement of the reference's (ArthurBrussee/brush) CubeCL
+// kernels for the differentiable splat rasterizer + train step.  It exists to
+// CHECK the HIP product path; nothing under brush_amd/ may include, link or
+// call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg use it.
+//
+// Parity status: forward is pinned by the reference's golden tensors
+// (crates/brush-bench-test/test_cases/{tiny,basic}_case.safetensors, tolerance
+// of crates/brush-bench-test/src/reference.rs:50-51).  Backward / loss / Adam
+// have no golden numbers anywhere in the reference: for those
+// rows parity is oracle-defined and the oracle's backward is validated by
+// central finite differences (tests/test_oracle_finite_diff.py) the way
+// crates/brush-bench-test/tests/finite_diff.rs validates the reference.
+//
+// Numerical specification choices (the reference leaves them to the WGSL
+// shader compiler, so any faithful choice is a valid execution of it):
+//   * + - * / sqrt are IEEE-754 binary32, no FMA contraction, in the operation
+//     order of the #[cube] sources (compile with -ffp-contract=off).
+//   * exp / ln are the fixed polynomials bo_expf / bo_logf below (≈1 ulp);
+//     the HIP kernels restate the same polynomials so integer outputs (tile
+//     assignment, sort order, counts) can be compared bit-exactly.
+//   * calc_sigma uses two explicit fmaf (see calc_sigma) — the one place the
+//     restatement fixes a contraction, again mirrored by the HIP kernels.
+//   * visible-splat compaction is deterministic (ascending splat id) where the
+//     reference uses an atomic slot counter; equal-depth order is therefore
+//     "by splat id", a strict refinement of the reference.
+//
+// Every function cites the reference file:line it follows (paths relative to
+// /root/reference/crates/).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// bit helpers
+// ---------------------------------------------------------------------------
+inline uint32_t f2u(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
+inline float u2f(uint32_t u) { float x; std::memcpy(&x, &u, 4); return x; }
+
+// brush-cube/src/lib.rs:566-570
+inline bool is_finite_f32(float x) { return ((f2u(x) >> 23) & 0xFFu) != 0xFFu; }
+
+// Fixed-polynomial expf (Cephes-style, Cody-Waite reduction, explicit fma).
+// Stands in for WGSL `exp` (brush-cube/src/lib.rs:562, kernels/helpers.rs:331).
+inline float bo_expf_impl(float x) {
+    if (x != x) return x;
+    if (x > 88.72283f) return INFINITY;
+    if (x < -103.9f) return 0.0f;
+    const float k = rintf(x * 1.44269504088896341f);
+    float r = fmaf(k, -0.693359375f, x);
+    r = fmaf(k, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float y = fmaf(p, r2, r);
+    y = y + 1.0f;
+    return ldexpf(y, (int)k);
+}
+
+// Fixed-polynomial logf (Cephes-style). Stands in for WGSL `log`
+// (kernels/project_forward.rs:96, kernels/map_gaussians.rs:30).
+inline float bo_logf_impl(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (!is_finite_f32(x)) return x;
+    uint32_t bits = f2u(x);
+    int e_adj = 0;
+    if (((bits >> 23) & 0xFFu) == 0u) {  // denormal: scale up by 2^23 (exact)
+        x = x * 8388608.0f;
+        bits = f2u(x);
+        e_adj = -23;
+    }
+    int e = (int)((bits >> 23) & 0xFFu) - 126 + e_adj;
+    float m = u2f((bits & 0x807FFFFFu) | 0x3F000000u);  // [0.5, 1)
+    if (m < 0.70710678118654752440f) {
+        e = e - 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    const float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+// brush-cube/src/lib.rs:560-563
+inline float sigmoid(float x) { return 1.0f / (1.0f + bo_expf_impl(-x)); }
+
+inline float clampf(float x, float lo, float hi) {
+    // WGSL/cubecl clamp = min(max(x, lo), hi); NaN handling is not relied on.
+    return std::fmin(std::fmax(x, lo), hi);
+}
+
+// ---------------------------------------------------------------------------
+// math aggregates — brush-cube/src/lib.rs:39-538
+// ---------------------------------------------------------------------------
+struct Vec3A { float x, y, z; };
+struct Vec2 { float x, y; };
+struct Quat { float w, x, y, z; };
+struct Mat3 { float c0x, c0y, c0z, c1x, c1y, c1z, c2x, c2y, c2z; };
+struct Mat2x3 { Vec2 c0, c1, c2; };
+struct Sym2 { float c00, c01, c11; };
+struct Sym3 { float c00, c01, c02, c11, c12, c22; };
+
+inline Vec3A v3(float x, float y, float z) { return {x, y, z}; }
+inline Vec3A add(Vec3A a, Vec3A b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3A sub(Vec3A a, Vec3A b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3A scale(Vec3A a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+// lib.rs:84-88 — 4-lane product, lane 3 is zero.
+inline float dot(Vec3A a, Vec3A b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + 0.0f; }
+inline float length(Vec3A a) { return sqrtf(dot(a, a)); }
+inline Vec3A normalize(Vec3A a) { return scale(a, 1.0f / length(a)); }
+inline bool finite3(Vec3A a) { return is_finite_f32(a.x) && is_finite_f32(a.y) && is_finite_f32(a.z); }
+
+inline Vec2 add(Vec2 a, Vec2 b) { return {a.x + b.x, a.y + b.y}; }
+inline Vec2 scale(Vec2 a, float s) { return {a.x * s, a.y * s}; }
+inline float dot(Vec2 a, Vec2 b) { return a.x * b.x + a.y * b.y; }
+
+inline float qdot(Quat a, Quat b) { return ((a.w * b.w + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+inline Quat qscale(Quat q, float s) { return {q.w * s, q.x * s, q.y * s, q.z * s}; }
+inline Quat qnormalize(Quat q) { return qscale(q, 1.0f / sqrtf(qdot(q, q))); }
+
+// lib.rs:191-216
+inline Mat3 quat_to_mat3(Quat q) {
+    const float w = q.w, qx = q.x, qy = q.y, qz = q.z;
+    const float x2 = qx * qx, y2 = qy * qy, z2 = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz;
+    const float wx = w * qx, wy = w * qy, wz = w * qz;
+    Mat3 m;
+    m.c0x = 1.0f - 2.0f * (y2 + z2);
+    m.c0y = 2.0f * (xy + wz);
+    m.c0z = 2.0f * (xz - wy);
+    m.c1x = 2.0f * (xy - wz);
+    m.c1y = 1.0f - 2.0f * (x2 + z2);
+    m.c1z = 2.0f * (yz + wx);
+    m.c2x = 2.0f * (xz + wy);
+    m.c2y = 2.0f * (yz - wx);
+    m.c2z = 1.0f - 2.0f * (x2 + y2);
+    return m;
+}
+inline Vec3A col0(const Mat3& m) { return {m.c0x, m.c0y, m.c0z}; }
+inline Vec3A col1(const Mat3& m) { return {m.c1x, m.c1y, m.c1z}; }
+inline Vec3A col2(const Mat3& m) { return {m.c2x, m.c2y, m.c2z}; }
+inline Vec3A row0(const Mat3& m) { return {m.c0x, m.c1x, m.c2x}; }
+inline Vec3A row1(const Mat3& m) { return {m.c0y, m.c1y, m.c2y}; }
+inline Vec3A row2(const Mat3& m) { return {m.c0z, m.c1z, m.c2z}; }
+inline Mat3 from_cols(Vec3A a, Vec3A b, Vec3A c) { return {a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z}; }
+// lib.rs:263-268
+inline Vec3A mul_vec3(const Mat3& m, Vec3A v) {
+    return add(add(scale(col0(m), v.x), scale(col1(m), v.y)), scale(col2(m), v.z));
+}
+inline Vec3A transpose_mul_vec3(const Mat3& m, Vec3A v) { return {dot(col0(m), v), dot(col1(m), v), dot(col2(m), v)}; }
+inline Mat3 mul_mat3(const Mat3& m, const Mat3& n) {
+    return from_cols(mul_vec3(m, col0(n)), mul_vec3(m, col1(n)), mul_vec3(m, col2(n)));
+}
+inline Mat3 mul_diag(const Mat3& m, Vec3A s) { return from_cols(scale(col0(m), s.x), scale(col1(m), s.y), scale(col2(m), s.z)); }
+// lib.rs:306-318
+inline Sym3 outer_product_self(const Mat3& m) {
+    const Vec3A r0 = row0(m), r1 = row1(m), r2 = row2(m);
+    return {dot(r0, r0), dot(r0, r1), dot(r0, r2), dot(r1, r1), dot(r1, r2), dot(r2, r2)};
+}
+// lib.rs:342-347
+inline Vec2 mul_vec3(const Mat2x3& m, Vec3A v) { return add(add(scale(m.c0, v.x), scale(m.c1, v.y)), scale(m.c2, v.z)); }
+inline Mat2x3 mul_mat3(const Mat2x3& m, const Mat3& n) { return {mul_vec3(m, col0(n)), mul_vec3(m, col1(n)), mul_vec3(m, col2(n))}; }
+inline Vec3A row0(const Mat2x3& m) { return {m.c0.x, m.c1.x, m.c2.x}; }
+inline Vec3A row1(const Mat2x3& m) { return {m.c0.y, m.c1.y, m.c2.y}; }
+// lib.rs:372-378
+inline Sym2 gram_matrix(const Mat2x3& m) {
+    Sym2 s;
+    s.c00 = m.c0.x * m.c0.x + m.c1.x * m.c1.x + m.c2.x * m.c2.x;
+    s.c01 = m.c0.x * m.c0.y + m.c1.x * m.c1.y + m.c2.x * m.c2.y;
+    s.c11 = m.c0.y * m.c0.y + m.c1.y * m.c1.y + m.c2.y * m.c2.y;
+    return s;
+}
+inline Vec2 sym2_mul_vec2(Sym2 s, Vec2 v) { return add(scale(Vec2{s.c00, s.c01}, v.x), scale(Vec2{s.c01, s.c11}, v.y)); }
+inline Mat2x3 sym2_mul_mat2x3(Sym2 s, const Mat2x3& n) { return {sym2_mul_vec2(s, n.c0), sym2_mul_vec2(s, n.c1), sym2_mul_vec2(s, n.c2)}; }
+// lib.rs:358-370
+inline Sym3 transpose_congruence_sym2(const Mat2x3& m, Sym2 sym) {
+    const Vec2 sc0 = sym2_mul_vec2(sym, m.c0), sc1 = sym2_mul_vec2(sym, m.c1), sc2 = sym2_mul_vec2(sym, m.c2);
+    return {dot(m.c0, sc0), dot(m.c0, sc1), dot(m.c0, sc2), dot(m.c1, sc1), dot(m.c1, sc2), dot(m.c2, sc2)};
+}
+inline Sym2 sym2_scale(Sym2 s, float k) { return {s.c00 * k, s.c01 * k, s.c11 * k}; }
+inline float sym2_max_abs(Sym2 s) { return std::fmax(std::fmax(fabsf(s.c00), fabsf(s.c11)), fabsf(s.c01)); }
+// lib.rs:431-440
+inline Sym2 sym2_inverse(Sym2 s) {
+    const float det = s.c00 * s.c11 - s.c01 * s.c01;
+    const float inv_det = det > 0.0f ? 1.0f / det : 0.0f;
+    return {s.c11 * inv_det, -s.c01 * inv_det, s.c00 * inv_det};
+}
+// lib.rs:444-448
+inline float det2_strict(Sym2 s) {
+    const float ad = s.c00 * s.c11;
+    const float bc = s.c01 * s.c01;
+    return ad - bc;
+}
+inline bool sym2_finite(Sym2 s) { return is_finite_f32(s.c00) && is_finite_f32(s.c11) && is_finite_f32(s.c01); }
+inline Vec3A s3row0(Sym3 s) { return {s.c00, s.c01, s.c02}; }
+inline Vec3A s3row1(Sym3 s) { return {s.c01, s.c11, s.c12}; }
+inline Vec3A s3row2(Sym3 s) { return {s.c02, s.c12, s.c22}; }
+inline Vec3A sym3_mul_vec3(Sym3 s, Vec3A v) { return add(add(scale(s3row0(s), v.x), scale(s3row1(s), v.y)), scale(s3row2(s), v.z)); }
+inline Sym3 sym3_scale(Sym3 s, float k) { return {s.c00 * k, s.c01 * k, s.c02 * k, s.c11 * k, s.c12 * k, s.c22 * k}; }
+inline Mat3 sym3_mul_mat3(Sym3 s, const Mat3& m) { return from_cols(sym3_mul_vec3(s, col0(m)), sym3_mul_vec3(s, col1(m)), sym3_mul_vec3(s, col2(m))); }
+// lib.rs:510-522
+inline Sym3 congruence(Sym3 s, const Mat3& m) {
+    const Vec3A sr0 = sym3_mul_vec3(s, row0(m)), sr1 = sym3_mul_vec3(s, row1(m)), sr2 = sym3_mul_vec3(s, row2(m));
+    return {dot(row0(m), sr0), dot(row0(m), sr1), dot(row0(m), sr2), dot(row1(m), sr1), dot(row1(m), sr2), dot(row2(m), sr2)};
+}
+// lib.rs:525-537
+inline Sym3 transpose_congruence(Sym3 s, const Mat3& m) {
+    const Vec3A sc0 = sym3_mul_vec3(s, col0(m)), sc1 = sym3_mul_vec3(s, col1(m)), sc2 = sym3_mul_vec3(s, col2(m));
+    return {dot(col0(m), sc0), dot(col0(m), sc1), dot(col0(m), sc2), dot(col1(m), sc1), dot(col1(m), sc2), dot(col2(m), sc2)};
+}
+
+// brush-cube/src/lib.rs:573-578 — `0.5*(c00*dx*dx + c11*dy*dy) + c01*dx*dy`.
+// Specification fix: the two sums are single-rounded (fmaf); see file header.
+inline float calc_sigma(float px, float py, Sym2 conic, float xy_x, float xy_y) {
+    const float dx = px - xy_x;
+    const float dy = py - xy_y;
+    const float q = fmaf(conic.c11 * dy, dy, (conic.c00 * dx) * dx);
+    return fmaf(conic.c01 * dx, dy, 0.5f * q);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C-visible types
+// ---------------------------------------------------------------------------
+extern "C" {
+
+// Host-computed view uniforms: brush-render/src/kernels/types.rs:53-81
+// (ProjectUniforms) minus the per-launch counters.
+struct BoCamera {
+    float vm[12];  // 3x4 world-to-camera, column-major: vm0(x,y,z) vm1 vm2 vm3
+    float fx, fy, cx, cy;
+    float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y;
+    float cam_pos[3];
+    uint32_t img_w, img_h;
+};
+
+enum { BO_FLAG_MIP = 1, BO_FLAG_BWD_INFO = 2, BO_FLAG_SMOOTH_CUTOFF = 4 };
+
+float bo_expf(float x) { return bo_expf_impl(x); }
+float bo_logf(float x) { return bo_logf_impl(x); }
+float bo_calc_sigma(float px, float py, float c00, float c01, float c11, float x, float y) {
+    return calc_sigma(px, py, Sym2{c00, c01, c11}, x, y);
+}
+
+// brush-render/src/camera.rs:63-101,200-254 + render.rs:72-91 (pinhole).
+// glam (un-vendored dependency, 0.30.x): Affine3A::from_rotation_translation,
+// Mat3A::from_quat, Affine3A::inverse restated in f32.
+// `rot` is glam order (x, y, z, w).
+void bo_camera_setup(const float pos[3], const float rot_xyzw[4], double fov_x, double fov_y,
+                     float center_u, float center_v, uint32_t img_w, uint32_t img_h, BoCamera* out) {
+    const float x = rot_xyzw[0], y = rot_xyzw[1], z = rot_xyzw[2], w = rot_xyzw[3];
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xx = x * x2, xy = x * y2, xz = x * z2;
+    const float yy = y * y2, yz = y * z2, zz = z * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    // local_to_world rotation columns
+    const Vec3A ax = {1.0f - (yy + zz), xy + wz, xz - wy};
+    const Vec3A ay = {xy - wz, 1.0f - (xx + zz), yz + wx};
+    const Vec3A az = {xz + wy, yz - wx, 1.0f - (xx + yy)};
+    auto cross = [](Vec3A a, Vec3A b) { return Vec3A{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; };
+    auto dot3 = [](Vec3A a, Vec3A b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); };
+    const Vec3A t0 = cross(ay, az), t1 = cross(az, ax), t2 = cross(ax, ay);
+    const float det = dot3(az, t2);
+    const float inv_det = 1.0f / det;
+    // inverse = from_cols(t0*inv, t1*inv, t2*inv).transpose()
+    const Vec3A r0 = scale(t0, inv_det), r1 = scale(t1, inv_det), r2 = scale(t2, inv_det);
+    // columns of the inverse (after transpose): col_i = (r0[i], r1[i], r2[i])
+    const Vec3A c0 = {r0.x, r1.x, r2.x}, c1 = {r0.y, r1.y, r2.y}, c2 = {r0.z, r1.z, r2.z};
+    const Vec3A p = {pos[0], pos[1], pos[2]};
+    // translation = -(inv * p) ; glam Mat3A * Vec3A = c0*p.x + c1*p.y + c2*p.z
+    const Vec3A ip = add(add(scale(c0, p.x), scale(c1, p.y)), scale(c2, p.z));
+    out->vm[0] = c0.x; out->vm[1] = c0.y; out->vm[2] = c0.z;
+    out->vm[3] = c1.x; out->vm[4] = c1.y; out->vm[5] = c1.z;
+    out->vm[6] = c2.x; out->vm[7] = c2.y; out->vm[8] = c2.z;
+    out->vm[9] = -ip.x; out->vm[10] = -ip.y; out->vm[11] = -ip.z;
+    // camera.rs:85-101 (f64), camera.rs:49-54 (cast to f32)
+    const double fxd = ((double)img_w / 2.0) / std::tan(fov_x / 2.0);
+    const double fyd = ((double)img_h / 2.0) / std::tan(fov_y / 2.0);
+    out->fx = (float)fxd;
+    out->fy = (float)fyd;
+    out->cx = center_u * (float)img_w;
+    out->cy = center_v * (float)img_h;
+    // camera.rs:221-226
+    const float wf = (float)img_w, hf = (float)img_h;
+    out->lim_pos_x = (1.15f * wf - out->cx) / out->fx;
+    out->lim_pos_y = (1.15f * hf - out->cy) / out->fy;
+    out->lim_neg_x = (-0.15f * wf - out->cx) / out->fx;
+    out->lim_neg_y = (-0.15f * hf - out->cy) / out->fy;
+    out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2];
+    out->img_w = img_w; out->img_h = img_h;
+}
+
+// camera.rs:104-120 (pinhole)
+double bo_focal_to_fov(double focal, uint32_t pixels) { return 2.0 * std::atan(((double)pixels / 2.0) / focal); }
+double bo_fov_to_focal(double fov, uint32_t pixels) { return ((double)pixels / 2.0) / std::tan(fov / 2.0); }
+
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t TILE_WIDTH = 16;  // kernels/helpers.rs:15
+constexpr uint32_t TILE_SIZE = 256;  // kernels/helpers.rs:16
+constexpr float ALPHA_CUTOFF_MID = 1.0f / 255.0f;   // helpers.rs:23
+constexpr float ALPHA_CUTOFF_BAND = 1.0e-3f;        // helpers.rs:24
+
+// helpers.rs:26-34
+inline float alpha_cutoff_weight(float alpha) {
+    const float t = clampf((alpha - (ALPHA_CUTOFF_MID - 0.5f * ALPHA_CUTOFF_BAND)) / ALPHA_CUTOFF_BAND, 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+// helpers.rs:36-47
+inline float alpha_cutoff_weight_deriv(float alpha) {
+    const float low = ALPHA_CUTOFF_MID - 0.5f * ALPHA_CUTOFF_BAND;
+    const float high = ALPHA_CUTOFF_MID + 0.5f * ALPHA_CUTOFF_BAND;
+    const bool inside = alpha > low && alpha < high;
+    const float t = (alpha - low) / ALPHA_CUTOFF_BAND;
+    return inside ? (6.0f * t - 6.0f * t * t) / ALPHA_CUTOFF_BAND : 0.0f;
+}
+
+struct Uniforms {
+    Mat3 view_rot;
+    Vec3A view_trans;
+    float fx, fy, cx, cy;
+    float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y;
+    Vec3A cam_pos;
+    uint32_t img_w, img_h, tile_bw, tile_bh;
+};
+
+Uniforms make_uniforms(const BoCamera& c) {
+    Uniforms u;
+    u.view_rot = {c.vm[0], c.vm[1], c.vm[2], c.vm[3], c.vm[4], c.vm[5], c.vm[6], c.vm[7], c.vm[8]};
+    u.view_trans = {c.vm[9], c.vm[10], c.vm[11]};
+    u.fx = c.fx; u.fy = c.fy; u.cx = c.cx; u.cy = c.cy;
+    u.lim_pos_x = c.lim_pos_x; u.lim_pos_y = c.lim_pos_y; u.lim_neg_x = c.lim_neg_x; u.lim_neg_y = c.lim_neg_y;
+    u.cam_pos = {c.cam_pos[0], c.cam_pos[1], c.cam_pos[2]};
+    u.img_w = c.img_w; u.img_h = c.img_h;
+    u.tile_bw = (c.img_w + TILE_WIDTH - 1) / TILE_WIDTH;  // render.rs:30-35
+    u.tile_bh = (c.img_h + TILE_WIDTH - 1) / TILE_WIDTH;
+    return u;
+}
+
+// helpers.rs:317-320
+inline Vec3A world_to_cam(Vec3A mean, const Uniforms& u) { return add(mul_vec3(u.view_rot, mean), u.view_trans); }
+
+// camera_model/pinhole.rs:25-31
+inline void project_pinhole(Vec3A p, const Uniforms& u, float& ox, float& oy) {
+    const float inv_z = 1.0f / p.z;
+    ox = u.fx * p.x * inv_z + u.cx;
+    oy = u.fy * p.y * inv_z + u.cy;
+}
+
+// camera_model/pinhole.rs:33-57
+inline Mat2x3 jacobian_pinhole(Vec3A p, const Uniforms& u) {
+    const float inv_z = 1.0f / p.z;
+    const float dx = u.fx * inv_z;
+    const float dy = u.fy * inv_z;
+    const float clamped_x = clampf(p.x * inv_z, u.lim_neg_x, u.lim_pos_x);
+    const float clamped_y = clampf(p.y * inv_z, u.lim_neg_y, u.lim_pos_y);
+    Mat2x3 j;
+    j.c0 = {dx, 0.0f};
+    j.c1 = {0.0f, dy};
+    j.c2 = {-dx * clamped_x, -dy * clamped_y};
+    return j;
+}
+
+// helpers.rs:145-175
+inline Sym2 calc_cov2d(Vec3A scl, Quat quat, Vec3A mean_c, const Uniforms& u) {
+    const Mat3 ns = mul_diag(mul_mat3(u.view_rot, quat_to_mat3(quat)), scl);
+    const Mat2x3 jac = jacobian_pinhole(mean_c, u);
+    const Mat2x3 v = mul_mat3(jac, ns);
+    const Sym2 raw = gram_matrix(v);
+    const float lim = 1.0e18f;
+    const float max_abs = sym2_max_abs(raw);
+    const float scale_down = max_abs > lim ? lim / max_abs : 1.0f;
+    return sym2_scale(raw, scale_down);
+}
+
+// helpers.rs:180-195
+inline Sym2 compensate_cov2d(Sym2 c, bool mip, float& filter_comp) {
+    const float cov_blur = mip ? 0.1f : 0.3f;
+    const Sym2 blurred = {c.c00 + cov_blur, c.c01, c.c11 + cov_blur};
+    filter_comp = 1.0f;
+    if (mip) {
+        const float det_raw = std::fmax(det2_strict(c), 0.0f);
+        const float det_blurred = det2_strict(blurred);
+        filter_comp = sqrtf(det_raw / det_blurred);
+    }
+    return blurred;
+}
+
+// helpers.rs:83-94
+inline void compute_bbox_extent(Sym2 conic, float power_threshold, float& ex, float& ey) {
+    const float det = conic.c00 * conic.c11 - conic.c01 * conic.c01;
+    const bool degenerate = det <= 0.0f;
+    const float inv_det = degenerate ? 0.0f : 1.0f / det;
+    const float e_x = sqrtf(2.0f * power_threshold * conic.c11 * inv_det);
+    const float e_y = sqrtf(2.0f * power_threshold * conic.c00 * inv_det);
+    ex = degenerate ? -1.0f : e_x;
+    ey = degenerate ? -1.0f : e_y;
+}
+
+struct TileBbox { uint32_t min_x, min_y, max_x, max_y; };
+
+// helpers.rs:110-140
+inline TileBbox get_tile_bbox(float cx, float cy, float ex, float ey, uint32_t bw, uint32_t bh) {
+    const float tw = (float)TILE_WIDTH;
+    const float x = cx / tw, y = cy / tw, dx = ex / tw, dy = ey / tw;
+    const float bwf = (float)bw, bhf = (float)bh;
+    TileBbox b;
+    b.min_x = (uint32_t)clampf(x - dx, 0.0f, bwf);
+    b.min_y = (uint32_t)clampf(y - dy, 0.0f, bhf);
+    b.max_x = (uint32_t)clampf(x + dx + 1.0f, 0.0f, bwf);
+    b.max_y = (uint32_t)clampf(y + dy + 1.0f, 0.0f, bhf);
+    return b;
+}
+
+// helpers.rs:226-264 (StopThePop tile test); rect from helpers.rs:96-106.
+inline bool will_primitive_contribute(uint32_t tx, uint32_t ty, float mx, float my, Sym2 conic, float power_threshold) {
+    const float rmin_x = (float)(tx * TILE_WIDTH);
+    const float rmin_y = (float)(ty * TILE_WIDTH);
+    const float rmax_x = rmin_x + (float)TILE_WIDTH;
+    const float rmax_y = rmin_y + (float)TILE_WIDTH;
+    const bool x_left = mx < rmin_x;
+    const bool x_right = mx > rmax_x;
+    const bool in_x_range = !(x_left || x_right);
+    const bool y_above = my < rmin_y;
+    const bool y_below = my > rmax_y;
+    const bool in_y_range = !(y_above || y_below);
+    bool hit = in_x_range && in_y_range;
+    if (!hit) {
+        const float corner_x = x_left ? rmin_x : rmax_x;
+        const float corner_y = y_above ? rmin_y : rmax_y;
+        const float width = rmax_x - rmin_x;
+        const float height = rmax_y - rmin_y;
+        const float dxf = x_left ? width : -width;
+        const float dyf = y_above ? height : -height;
+        const float diff_x = mx - corner_x;
+        const float diff_y = my - corner_y;
+        const float tx_raw = (dxf * conic.c00 * diff_x + dxf * conic.c01 * diff_y) / (dxf * conic.c00 * dxf);
+        const float ty_raw = (dyf * conic.c01 * diff_x + dyf * conic.c11 * diff_y) / (dyf * conic.c11 * dyf);
+        const float t_x = in_y_range ? 0.0f : clampf(tx_raw, 0.0f, 1.0f);
+        const float t_y = in_x_range ? 0.0f : clampf(ty_raw, 0.0f, 1.0f);
+        const float max_x = corner_x + t_x * dxf;
+        const float max_y = corner_y + t_y * dyf;
+        hit = calc_sigma(max_x, max_y, conic, mx, my) <= power_threshold;
+    }
+    return hit;
+}
+
+// helpers.rs:204-223
+inline uint32_t count_contributing_tiles(TileBbox bb, float x, float y, Sym2 conic, float pt) {
+    const uint32_t bb_w = bb.max_x - bb.min_x;
+    const uint32_t n = (bb.max_y - bb.min_y) * bb_w;
+    uint32_t hit = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t tx = (i % bb_w) + bb.min_x;
+        const uint32_t ty = (i / bb_w) + bb.min_y;
+        if (will_primitive_contribute(tx, ty, x, y, conic, pt)) hit++;
+    }
+    return hit;
+}
+
+inline uint32_t num_sh_coeffs(uint32_t degree) { return (degree + 1) * (degree + 1); }
+
+// kernels/sh.rs:47-136
+Vec3A sh_coeffs_to_color(const float* c, uint32_t degree, Vec3A v) {
+    auto rc = [&](uint32_t off) { return Vec3A{c[off], c[off + 1], c[off + 2]}; };
+    const float SH_C0 = 0.2820948f;
+    Vec3A color = scale(rc(0), SH_C0);
+    if (degree >= 1) {
+        const float f0a = 0.4886025f;
+        color = add(color, scale(rc(3), -f0a * v.y));
+        color = add(color, scale(rc(6), f0a * v.z));
+        color = add(color, scale(rc(9), -f0a * v.x));
+        if (degree >= 2) {
+            const float z2 = v.z * v.z;
+            const float f0b = -1.0925485f * v.z;
+            const float f1a = 0.54627424f;
+            const float fc1 = v.x * v.x - v.y * v.y;
+            const float fs1 = 2.0f * v.x * v.y;
+            const float p4 = f1a * fs1, p5 = f0b * v.y, p6 = 0.9461747f * z2 - 0.31539157f, p7 = f0b * v.x, p8 = f1a * fc1;
+            color = add(color, scale(rc(12), p4));
+            color = add(color, scale(rc(15), p5));
+            color = add(color, scale(rc(18), p6));
+            color = add(color, scale(rc(21), p7));
+            color = add(color, scale(rc(24), p8));
+            if (degree >= 3) {
+                const float f0c = -2.285229f * z2 + 0.4570458f;
+                const float f1b = 1.4453057f * v.z;
+                const float f2a = -0.5900436f;
+                const float fc2 = v.x * fc1 - v.y * fs1;
+                const float fs2 = v.x * fs1 + v.y * fc1;
+                const float p12 = v.z * (1.8658817f * z2 - 1.119529f);
+                const float p9 = f2a * fs2, p10 = f1b * fs1, p11 = f0c * v.y, p13 = f0c * v.x, p14 = f1b * fc1, p15 = f2a * fc2;
+                color = add(color, scale(rc(27), p9));
+                color = add(color, scale(rc(30), p10));
+                color = add(color, scale(rc(33), p11));
+                color = add(color, scale(rc(36), p12));
+                color = add(color, scale(rc(39), p13));
+                color = add(color, scale(rc(42), p14));
+                color = add(color, scale(rc(45), p15));
+                if (degree >= 4) {
+                    const float f0d = v.z * (-4.683326f * z2 + 2.0071396f);
+                    const float f1c = 3.3116114f * z2 - 0.47308735f;
+                    const float f2b = -1.7701308f * v.z;
+                    const float f3a = 0.62583575f;
+                    const float fc3 = v.x * fc2 - v.y * fs2;
+                    const float fs3 = v.x * fs2 + v.y * fc2;
+                    const float p20 = 1.9843135f * v.z * p12 - 1.0062306f * p6;
+                    const float p16 = f3a * fs3, p17 = f2b * fs2, p18 = f1c * fs1, p19 = f0d * v.y;
+                    const float p21 = f0d * v.x, p22 = f1c * fc1, p23 = f2b * fc2, p24 = f3a * fc3;
+                    color = add(color, scale(rc(48), p16));
+                    color = add(color, scale(rc(51), p17));
+                    color = add(color, scale(rc(54), p18));
+                    color = add(color, scale(rc(57), p19));
+                    color = add(color, scale(rc(60), p20));
+                    color = add(color, scale(rc(63), p21));
+                    color = add(color, scale(rc(66), p22));
+                    color = add(color, scale(rc(69), p23));
+                    color = add(color, scale(rc(72), p24));
+                }
+            }
+        }
+    }
+    return color;
+}
+
+// kernels/sh.rs:143-271
+Vec3A sh_color_viewdir_vjp(const float* c, uint32_t degree, Vec3A v, Vec3A vc) {
+    auto rc = [&](uint32_t off) { return Vec3A{c[off], c[off + 1], c[off + 2]}; };
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    if (degree >= 1) {
+        const float f0a = 0.4886025f;
+        {
+            const float s_n1 = dot(rc(3), vc), s_z0 = dot(rc(6), vc), s_p1 = dot(rc(9), vc);
+            gx += -f0a * s_p1;
+            gy += -f0a * s_n1;
+            gz += f0a * s_z0;
+        }
+        if (degree >= 2) {
+            const float z = v.z, x = v.x, y = v.y;
+            const float c2 = -1.0925485f;
+            const float f1a = 0.54627424f;
+            {
+                const float s_n2 = dot(rc(12), vc), s_n1 = dot(rc(15), vc), s_z0 = dot(rc(18), vc), s_p1 = dot(rc(21), vc), s_p2 = dot(rc(24), vc);
+                gx += 2.0f * f1a * y * s_n2 + c2 * z * s_p1 + 2.0f * f1a * x * s_p2;
+                gy += 2.0f * f1a * x * s_n2 + c2 * z * s_n1 - 2.0f * f1a * y * s_p2;
+                gz += c2 * y * s_n1 + 2.0f * 0.9461747f * z * s_z0 + c2 * x * s_p1;
+            }
+            if (degree >= 3) {
+                const float z2 = z * z, x2 = x * x, y2 = y * y;
+                const float f2a = -0.5900436f;
+                const float c1b = 1.4453057f;
+                const float f1b = c1b * z;
+                const float c0c = -2.285229f;
+                const float f0c = c0c * z2 + 0.4570458f;
+                const float f0c_dz = 2.0f * c0c * z;
+                {
+                    const float s_n3 = dot(rc(27), vc), s_n2 = dot(rc(30), vc), s_n1 = dot(rc(33), vc), s_z0 = dot(rc(36), vc);
+                    const float s_p1 = dot(rc(39), vc), s_p2 = dot(rc(42), vc), s_p3 = dot(rc(45), vc);
+                    const float d12_z = 3.0f * 1.8658817f * z2 - 1.119529f;
+                    gx += f2a * 6.0f * x * y * s_n3 + 2.0f * f1b * y * s_n2 + f0c * s_p1 + 2.0f * f1b * x * s_p2 + f2a * 3.0f * (x2 - y2) * s_p3;
+                    gy += f2a * 3.0f * (x2 - y2) * s_n3 + 2.0f * f1b * x * s_n2 + f0c * s_n1 + (-2.0f) * f1b * y * s_p2 + f2a * (-6.0f) * x * y * s_p3;
+                    gz += 2.0f * c1b * x * y * s_n2 + f0c_dz * y * s_n1 + d12_z * s_z0 + f0c_dz * x * s_p1 + c1b * (x2 - y2) * s_p2;
+                }
+                if (degree >= 4) {
+                    const float fc1 = x2 - y2;
+                    const float fs1 = 2.0f * x * y;
+                    const float fc2 = x * fc1 - y * fs1;
+                    const float fs2 = x * fs1 + y * fc1;
+                    const float f0d = z * (-4.683326f * z2 + 2.0071396f);
+                    const float f0d_dz = -14.049978f * z2 + 2.0071396f;
+                    const float f1c = 3.3116114f * z2 - 0.47308735f;
+                    const float f1c_dz = 2.0f * 3.3116114f * z;
+                    const float f2b_dz_const = -1.7701308f;
+                    const float f2b = f2b_dz_const * z;
+                    const float f3a = 0.62583575f;
+                    const float p_sh12 = z * (1.8658817f * z2 - 1.119529f);
+                    const float dp_sh12_dz = 3.0f * 1.8658817f * z2 - 1.119529f;
+                    const float dp_sh6_dz = 2.0f * 0.9461747f * z;
+                    const float dp_sh20_dz = 1.9843135f * (p_sh12 + z * dp_sh12_dz) - 1.0062306f * dp_sh6_dz;
+                    const float s_n4 = dot(rc(48), vc), s_n3 = dot(rc(51), vc), s_n2 = dot(rc(54), vc), s_n1 = dot(rc(57), vc), s_z0 = dot(rc(60), vc);
+                    const float s_p1 = dot(rc(63), vc), s_p2 = dot(rc(66), vc), s_p3 = dot(rc(69), vc), s_p4 = dot(rc(72), vc);
+                    gx += f3a * 4.0f * fs2 * s_n4 + f2b * 3.0f * fs1 * s_n3 + f1c * 2.0f * y * s_n2 + f0d * s_p1 + f1c * 2.0f * x * s_p2 + f2b * 3.0f * fc1 * s_p3 + f3a * 4.0f * fc2 * s_p4;
+                    gy += f3a * 4.0f * fc2 * s_n4 + f2b * 3.0f * fc1 * s_n3 + f1c * 2.0f * x * s_n2 + f0d * s_n1 + f1c * (-2.0f) * y * s_p2 + f2b * (-3.0f) * fs1 * s_p3 + f3a * (-4.0f) * fs2 * s_p4;
+                    gz += f2b_dz_const * fs2 * s_n3 + f1c_dz * fs1 * s_n2 + f0d_dz * y * s_n1 + dp_sh20_dz * s_z0 + f0d_dz * x * s_p1 + f1c_dz * fc1 * s_p2 + f2b_dz_const * fc2 * s_p3;
+                }
+            }
+        }
+    }
+    return {gx, gy, gz};
+}
+
+// kernels/sh.rs:277-355
+void sh_coeffs_to_color_vjp(float* vcoef, uint32_t degree, Vec3A v, Vec3A vc) {
+    auto wc = [&](uint32_t off, Vec3A val) { vcoef[off] = val.x; vcoef[off + 1] = val.y; vcoef[off + 2] = val.z; };
+    const float SH_C0 = 0.2820948f;
+    wc(0, scale(vc, SH_C0));
+    if (degree >= 1) {
+        const float f0a = 0.4886025f;
+        wc(3, scale(vc, -f0a * v.y));
+        wc(6, scale(vc, f0a * v.z));
+        wc(9, scale(vc, -f0a * v.x));
+        if (degree >= 2) {
+            const float z2 = v.z * v.z;
+            const float f0b = -1.0925485f * v.z;
+            const float f1a = 0.54627424f;
+            const float fc1 = v.x * v.x - v.y * v.y;
+            const float fs1 = 2.0f * v.x * v.y;
+            const float p4 = f1a * fs1, p5 = f0b * v.y, p6 = 0.9461747f * z2 - 0.31539157f, p7 = f0b * v.x, p8 = f1a * fc1;
+            wc(12, scale(vc, p4)); wc(15, scale(vc, p5)); wc(18, scale(vc, p6)); wc(21, scale(vc, p7)); wc(24, scale(vc, p8));
+            if (degree >= 3) {
+                const float f0c = -2.285229f * z2 + 0.4570458f;
+                const float f1b = 1.4453057f * v.z;
+                const float f2a = -0.5900436f;
+                const float fc2 = v.x * fc1 - v.y * fs1;
+                const float fs2 = v.x * fs1 + v.y * fc1;
+                const float p12 = v.z * (1.8658817f * z2 - 1.119529f);
+                const float p9 = f2a * fs2, p10 = f1b * fs1, p11 = f0c * v.y, p13 = f0c * v.x, p14 = f1b * fc1, p15 = f2a * fc2;
+                wc(27, scale(vc, p9)); wc(30, scale(vc, p10)); wc(33, scale(vc, p11)); wc(36, scale(vc, p12));
+                wc(39, scale(vc, p13)); wc(42, scale(vc, p14)); wc(45, scale(vc, p15));
+                if (degree >= 4) {
+                    const float f0d = v.z * (-4.683326f * z2 + 2.0071396f);
+                    const float f1c = 3.3116114f * z2 - 0.47308735f;
+                    const float f2b = -1.7701308f * v.z;
+                    const float f3a = 0.62583575f;
+                    const float fc3 = v.x * fc2 - v.y * fs2;
+                    const float fs3 = v.x * fs2 + v.y * fc2;
+                    const float p20 = 1.9843135f * v.z * p12 + -1.0062306f * p6;
+                    const float p16 = f3a * fs3, p17 = f2b * fs2, p18 = f1c * fs1, p19 = f0d * v.y;
+                    const float p21 = f0d * v.x, p22 = f1c * fc1, p23 = f2b * fc2, p24 = f3a * fc3;
+                    wc(48, scale(vc, p16)); wc(51, scale(vc, p17)); wc(54, scale(vc, p18)); wc(57, scale(vc, p19)); wc(60, scale(vc, p20));
+                    wc(63, scale(vc, p21)); wc(66, scale(vc, p22)); wc(69, scale(vc, p23)); wc(72, scale(vc, p24));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Render state (everything SplatOps::render returns or saves for backward:
+// brush-render/src/render_aux.rs:17-68, bwd/burn_glue.rs:336-371)
+// ---------------------------------------------------------------------------
+struct Render {
+    Uniforms u;
+    BoCamera cam;
+    uint32_t n = 0, sh_degree = 0, flags = 0;
+    float bg[3] = {0, 0, 0};
+    uint32_t num_visible = 0, num_intersections = 0;
+    std::vector<uint32_t> intersect_counts;        // [N]
+    std::vector<float> max_radius;                 // [N]
+    std::vector<float> depths_presort;             // [Nv] (ascending gid order)
+    std::vector<uint32_t> gid_presort;             // [Nv]
+    std::vector<float> depths_sorted;              // [Nv]
+    std::vector<uint32_t> global_from_compact_gid; // [Nv]
+    std::vector<uint32_t> cum_tiles_hit;           // [Nv]
+    std::vector<float> projected;                  // [Nv,9]
+    std::vector<uint32_t> tile_id_unsorted, gid_unsorted;  // [I]
+    std::vector<uint32_t> tile_id_from_isect, compact_gid_from_isect;  // [I] sorted
+    std::vector<uint32_t> tile_offsets_pre;        // [T,2] as written by get_tile_offsets
+    std::vector<uint32_t> tile_offsets;            // [T,2] after rasterize (shrunk in bwd mode)
+    std::vector<float> out_img;                    // [H,W,4] (bwd_info)
+    std::vector<uint32_t> out_packed;              // [H,W] (forward only)
+    std::vector<float> visible;                    // [N]
+    // backward outputs
+    std::vector<float> v_combined;                 // [Nv,10]
+    std::vector<float> v_transforms, v_coeffs, v_raw_opac, v_refine;
+    // per-stage wall seconds of the last forward/backward (cpu_baseline)
+    double t_stage[16] = {0};
+};
+
+double now_s() {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+// kernels/project_forward.rs:22-125 (pinhole). Returns visibility.
+inline bool project_forward_one(const float* tr, float raw_opac, const Uniforms& u, bool mip,
+                                float& depth, uint32_t& tiles_hit, float& radius) {
+    const Vec3A mean_c = world_to_cam(v3(tr[0], tr[1], tr[2]), u);
+    if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) return false;
+    if (mean_c.z < 0.01f) return false;
+    const Vec3A scl = v3(bo_expf_impl(tr[7]), bo_expf_impl(tr[8]), bo_expf_impl(tr[9]));  // helpers.rs:329-335
+    if (!finite3(scl)) return false;
+    const Quat qu = {tr[3], tr[4], tr[5], tr[6]};
+    const float qn = qdot(qu, qu);
+    if (!(qn >= 1.0e-6f && is_finite_f32(qn))) return false;
+    if (!is_finite_f32(raw_opac)) return false;
+    const Quat q = qnormalize(qu);
+    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    float filter_comp;
+    const Sym2 cov = compensate_cov2d(raw_cov, mip, filter_comp);
+    const float opac = sigmoid(raw_opac) * filter_comp;
+    if (!sym2_finite(cov)) return false;
+    float mx, my;
+    project_pinhole(mean_c, u, mx, my);
+    if (!(opac >= 1.0f / 255.0f)) return false;
+    const float pt = bo_logf_impl(opac * 255.0f);
+    const Sym2 conic = sym2_inverse(cov);
+    float ex, ey;
+    compute_bbox_extent(conic, pt, ex, ey);
+    if (!(ex >= 0.0f && ey >= 0.0f)) return false;
+    const float wf = (float)u.img_w, hf = (float)u.img_h;
+    const bool on_screen = mx + ex > 0.0f && mx - ex < wf && my + ey > 0.0f && my - ey < hf;
+    if (!on_screen) return false;
+    const TileBbox bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_bh);
+    tiles_hit = count_contributing_tiles(bb, mx, my, conic, pt);
+    radius = std::fmax(ex / wf, ey / hf);
+    depth = mean_c.z;
+    return true;
+}
+
+// kernels/project_visible.rs:23-88
+inline void project_visible_one(const float* tr, const float* coeffs, float raw_opac, const Uniforms& u,
+                                bool mip, uint32_t sh_degree, float* out9) {
+    const Vec3A mean = v3(tr[0], tr[1], tr[2]);
+    const Vec3A scl = v3(bo_expf_impl(tr[7]), bo_expf_impl(tr[8]), bo_expf_impl(tr[9]));
+    const Quat q = qnormalize(Quat{tr[3], tr[4], tr[5], tr[6]});
+    const Vec3A mean_c = world_to_cam(mean, u);
+    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    float filter_comp;
+    const Sym2 cov = compensate_cov2d(raw_cov, mip, filter_comp);
+    const float opac = sigmoid(raw_opac) * filter_comp;
+    const Sym2 conic = sym2_inverse(cov);
+    float mx, my;
+    project_pinhole(mean_c, u, mx, my);
+    const Vec3A v = normalize(sub(mean, u.cam_pos));
+    const Vec3A raw = sh_coeffs_to_color(coeffs, sh_degree, v);
+    const float cr = raw.x + 0.5f, cg = raw.y + 0.5f, cb = raw.z + 0.5f;
+    out9[0] = mx; out9[1] = my;
+    out9[2] = conic.c00; out9[3] = conic.c01; out9[4] = conic.c11;
+    out9[5] = opac;
+    out9[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
+    out9[7] = clampf(is_finite_f32(cg) ? cg : 0.0f, -100.0f, 100.0f);
+    out9[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
+}
+
+// Stable LSD radix semantics of brush-sort/src/lib.rs:16-125 on the low `bits`
+// bits of the key (only the result is contractual).
+void stable_argsort_bits(const std::vector<uint32_t>& keys, const std::vector<uint32_t>& vals, uint32_t bits,
+                         std::vector<uint32_t>& out_keys, std::vector<uint32_t>& out_vals) {
+    const size_t n = keys.size();
+    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    std::vector<uint32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return (keys[a] & mask) < (keys[b] & mask); });
+    out_keys.resize(n);
+    out_vals.resize(n);
+    for (size_t i = 0; i < n; ++i) { out_keys[i] = keys[idx[i]]; out_vals[i] = vals[idx[i]]; }
+}
+
+// brush-render/src/render.rs:37-314
+int render_forward(Render& R, const BoCamera& cam, uint32_t n, uint32_t sh_degree, const float* transforms,
+                   const float* sh, const float* raw_opac, const float bg[3], uint32_t flags) {
+    if (cam.img_w == 0 || cam.img_h == 0) return -1;  // render.rs:50-53
+    R.cam = cam;
+    R.u = make_uniforms(cam);
+    R.n = n; R.sh_degree = sh_degree; R.flags = flags;
+    R.bg[0] = bg[0]; R.bg[1] = bg[1]; R.bg[2] = bg[2];
+    const Uniforms& u = R.u;
+    const bool mip = flags & BO_FLAG_MIP;
+    const bool bwd_info = flags & BO_FLAG_BWD_INFO;
+    const bool smooth = flags & BO_FLAG_SMOOTH_CUTOFF;
+    const uint32_t C = num_sh_coeffs(sh_degree);
+    const uint32_t num_tiles = u.tile_bw * u.tile_bh;
+    double t0 = now_s();
+
+    // --- K1 project_forward (render.rs:104-135)
+    R.intersect_counts.assign(n, 0u);
+    R.max_radius.assign(n, 0.0f);
+    std::vector<float> depth_all(n);
+    std::vector<uint8_t> vis_flag(n, 0);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        float d = 0.0f, r = 0.0f;
+        uint32_t th = 0;
+        if (project_forward_one(transforms + (size_t)i * 10, raw_opac[i], u, mip, d, th, r)) {
+            vis_flag[i] = 1;
+            depth_all[i] = d;
+            R.intersect_counts[i] = th;
+            R.max_radius[i] = r;
+        }
+    }
+    R.gid_presort.clear();
+    R.depths_presort.clear();
+    uint64_t isect_total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (vis_flag[i]) {
+            R.gid_presort.push_back(i);
+            R.depths_presort.push_back(depth_all[i]);
+            isect_total += R.intersect_counts[i];
+        }
+    }
+    R.num_visible = (uint32_t)R.gid_presort.size();
+    R.num_intersections = (uint32_t)isect_total;
+    const uint32_t nv = R.num_visible;
+    R.t_stage[0] = now_s() - t0; t0 = now_s();
+
+    // --- K2 depth sort (render.rs:177-184): f32 bits as u32 keys, 32 bits.
+    {
+        std::vector<uint32_t> keys(nv), out_keys;
+        for (uint32_t i = 0; i < nv; ++i) keys[i] = f2u(R.depths_presort[i]);
+        stable_argsort_bits(keys, R.gid_presort, 32, out_keys, R.global_from_compact_gid);
+        R.depths_sorted.resize(nv);
+        for (uint32_t i = 0; i < nv; ++i) R.depths_sorted[i] = u2f(out_keys[i]);
+    }
+    R.t_stage[1] = now_s() - t0; t0 = now_s();
+
+    // --- K3 gather + inclusive prefix sum (render.rs:185-187; brush-prefix-sum/src/lib.rs:11)
+    R.cum_tiles_hit.resize(nv);
+    {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < nv; ++i) { acc += R.intersect_counts[R.global_from_compact_gid[i]]; R.cum_tiles_hit[i] = acc; }
+    }
+    R.t_stage[2] = now_s() - t0; t0 = now_s();
+
+    // --- K4 project_visible (render.rs:193-211)
+    R.projected.assign((size_t)nv * 9, 0.0f);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nv; ++i) {
+        const uint32_t g = R.global_from_compact_gid[i];
+        project_visible_one(transforms + (size_t)g * 10, sh + (size_t)g * C * 3, raw_opac[g], u, mip, sh_degree, &R.projected[(size_t)i * 9]);
+    }
+    R.t_stage[3] = now_s() - t0; t0 = now_s();
+
+    // --- K5 map_gaussians_to_intersect (kernels/map_gaussians.rs:15-80)
+    const uint32_t I = R.num_intersections;
+    R.tile_id_unsorted.assign(I, 0u);
+    R.gid_unsorted.assign(I, 0u);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < (int64_t)nv; ++i) {
+        const float* p = &R.projected[(size_t)i * 9];
+        const Sym2 conic = {p[2], p[3], p[4]};
+        const float pt = bo_logf_impl(p[5] * 255.0f);
+        float ex, ey;
+        compute_bbox_extent(conic, pt, ex, ey);
+        const TileBbox bb = get_tile_bbox(p[0], p[1], ex, ey, u.tile_bw, u.tile_bh);
+        const uint32_t base = i == 0 ? 0u : R.cum_tiles_hit[i - 1];
+        const uint32_t pf_count = R.cum_tiles_hit[i] - base;
+        const uint32_t sentinel = u.tile_bw * u.tile_bh;
+        const uint32_t bb_w = bb.max_x - bb.min_x;
+        const uint32_t nb = (bb.max_y - bb.min_y) * bb_w;
+        uint32_t hit = 0;
+        for (uint32_t t = 0; t < nb; ++t) {
+            const uint32_t tx = (t % bb_w) + bb.min_x, ty = (t / bb_w) + bb.min_y;
+            if (will_primitive_contribute(tx, ty, p[0], p[1], conic, pt) && hit < pf_count) {
+                R.tile_id_unsorted[base + hit] = tx + ty * u.tile_bw;
+                R.gid_unsorted[base + hit] = (uint32_t)i;
+                hit++;
+            }
+        }
+        for (uint32_t k = hit; k < pf_count; ++k) { R.tile_id_unsorted[base + k] = sentinel; R.gid_unsorted[base + k] = (uint32_t)i; }
+    }
+    R.t_stage[4] = now_s() - t0; t0 = now_s();
+
+    // --- K6 tile sort (render.rs:228-230): bits = 32 - clz(num_tiles)
+    {
+        uint32_t bits = 0;
+        while (bits < 32 && (num_tiles >> bits) != 0) bits++;
+        // counting sort by tile id == stable LSD radix on `bits` bits (all ids <= num_tiles < 2^bits)
+        std::vector<uint32_t> cnt((size_t)num_tiles + 2, 0u);
+        for (uint32_t i = 0; i < I; ++i) cnt[R.tile_id_unsorted[i] + 1]++;
+        for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+        R.tile_id_from_isect.resize(I);
+        R.compact_gid_from_isect.resize(I);
+        for (uint32_t i = 0; i < I; ++i) {
+            const uint32_t pos = cnt[R.tile_id_unsorted[i]]++;
+            R.tile_id_from_isect[pos] = R.tile_id_unsorted[i];
+            R.compact_gid_from_isect[pos] = R.gid_unsorted[i];
+        }
+        (void)bits;
+    }
+    R.t_stage[5] = now_s() - t0; t0 = now_s();
+
+    // --- K15 get_tile_offsets (get_tile_offset.rs:11-58)
+    R.tile_offsets_pre.assign((size_t)num_tiles * 2, 0u);
+    for (uint32_t i = 0; i < I; ++i) {
+        const uint32_t tid = R.tile_id_from_isect[i];
+        if (tid < num_tiles) {
+            if (i == I - 1) R.tile_offsets_pre[(size_t)tid * 2 + 1] = i + 1;
+            if (i == 0) {
+                R.tile_offsets_pre[(size_t)tid * 2] = 0;
+            } else {
+                const uint32_t prev = R.tile_id_from_isect[i - 1];
+                if (tid != prev) {
+                    if (prev < num_tiles) R.tile_offsets_pre[(size_t)prev * 2 + 1] = i;
+                    R.tile_offsets_pre[(size_t)tid * 2] = i;
+                }
+            }
+        }
+    }
+    R.tile_offsets = R.tile_offsets_pre;
+    R.t_stage[6] = now_s() - t0; t0 = now_s();
+
+    // --- K16 rasterize (kernels/rasterize.rs:27-190)
+    const uint32_t W = u.img_w, H = u.img_h;
+    if (bwd_info) { R.out_img.assign((size_t)W * H * 4, 0.0f); R.out_packed.clear(); }
+    else { R.out_packed.assign((size_t)W * H, 0u); R.out_img.clear(); }
+    R.visible.assign(bwd_info ? n : 1, 0.0f);
+    std::vector<uint8_t> vis_mark(bwd_info ? nv : 0, 0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t tile = 0; tile < (int64_t)num_tiles; ++tile) {
+        const uint32_t range_lo = R.tile_offsets_pre[(size_t)tile * 2];
+        const uint32_t range_hi = R.tile_offsets_pre[(size_t)tile * 2 + 1];
+        const uint32_t tx0 = ((uint32_t)tile % u.tile_bw) * TILE_WIDTH;
+        const uint32_t ty0 = ((uint32_t)tile / u.tile_bw) * TILE_WIDTH;
+        uint32_t max_useful = range_lo;
+        for (uint32_t py = ty0; py < ty0 + TILE_WIDTH; ++py) {
+            for (uint32_t px = tx0; px < tx0 + TILE_WIDTH; ++px) {
+                if (!(px < W && py < H)) continue;
+                const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
+                float t_acc = 1.0f, pr = 0.0f, pg = 0.0f, pb = 0.0f;
+                uint32_t last_useful = range_lo;
+                for (uint32_t is = range_lo; is < range_hi; ++is) {
+                    const uint32_t cg = R.compact_gid_from_isect[is];
+                    const float* s = &R.projected[(size_t)cg * 9];
+                    const float sigma = calc_sigma(pcx, pcy, Sym2{s[2], s[3], s[4]}, s[0], s[1]);
+                    const float alpha = std::fmin(0.999f, s[5] * bo_expf_impl(-sigma));
+                    const float w_cut = smooth ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
+                    if (sigma >= 0.0f && w_cut > 0.0f) {
+                        const float alpha_eff = alpha * w_cut;
+                        const float next_t = t_acc * (1.0f - alpha_eff);
+                        if (next_t <= 1.0e-4f) break;  // done (rasterize.rs:139-140)
+                        if (bwd_info) vis_mark[cg] = 1;  // benign race: all writers store 1
+                        const float vis = alpha_eff * t_acc;
+                        pr += std::fmax(s[6], 0.0f) * vis;
+                        pg += std::fmax(s[7], 0.0f) * vis;
+                        pb += std::fmax(s[8], 0.0f) * vis;
+                        t_acc = next_t;
+                        last_useful = is + 1;
+                    }
+                }
+                const float fr = pr + t_acc * R.bg[0], fg = pg + t_acc * R.bg[1], fb = pb + t_acc * R.bg[2];
+                const float fa = 1.0f - t_acc;
+                const size_t pix = (size_t)px + (size_t)py * W;
+                if (bwd_info) {
+                    R.out_img[pix * 4] = fr; R.out_img[pix * 4 + 1] = fg; R.out_img[pix * 4 + 2] = fb; R.out_img[pix * 4 + 3] = fa;
+                } else {
+                    const uint32_t r8 = (uint32_t)clampf(fr * 255.0f, 0.0f, 255.0f);
+                    const uint32_t g8 = (uint32_t)clampf(fg * 255.0f, 0.0f, 255.0f);
+                    const uint32_t b8 = (uint32_t)clampf(fb * 255.0f, 0.0f, 255.0f);
+                    const uint32_t a8 = (uint32_t)clampf(fa * 255.0f, 0.0f, 255.0f);
+                    R.out_packed[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+                }
+                max_useful = std::max(max_useful, last_useful);
+            }
+        }
+        if (bwd_info) R.tile_offsets[(size_t)tile * 2 + 1] = max_useful;  // rasterize.rs:183-189
+    }
+    if (bwd_info) {
+        for (uint32_t i = 0; i < nv; ++i) if (vis_mark[i]) R.visible[R.global_from_compact_gid[i]] = 1.0f;
+    }
+    R.t_stage[7] = now_s() - t0;
+    return 0;
+}
+
+// bwd/kernels/rasterize_backwards.rs:101-390 — per (tile, splat) partials are
+// accumulated over pixels in ascending pixel_rank (the diagonal schedule visits
+// them in that order for a fixed splat), then added to v_combined in tile order
+// (one valid ordering of the reference's float atomics).
+void rasterize_backward(Render& R, const float* v_output) {
+    const Uniforms& u = R.u;
+    const bool smooth = R.flags & BO_FLAG_SMOOTH_CUTOFF;
+    const uint32_t W = u.img_w, H = u.img_h;
+    const uint32_t num_tiles = u.tile_bw * u.tile_bh;
+    const uint32_t nv = std::max(R.num_visible, 1u);
+    R.v_combined.assign((size_t)nv * 10, 0.0f);
+    const uint32_t I = R.num_intersections;
+    std::vector<float> part((size_t)I * 10, 0.0f);
+    const float* out = R.out_img.data();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t tile = 0; tile < (int64_t)num_tiles; ++tile) {
+        const uint32_t range_lo = R.tile_offsets[(size_t)tile * 2];
+        const uint32_t range_hi = R.tile_offsets[(size_t)tile * 2 + 1];
+        if (range_hi <= range_lo) continue;
+        const uint32_t tx0 = ((uint32_t)tile % u.tile_bw) * TILE_WIDTH;
+        const uint32_t ty0 = ((uint32_t)tile / u.tile_bw) * TILE_WIDTH;
+        float st[TILE_SIZE][4];
+        // load_pixel_state (rasterize_backwards.rs:186-228)
+        for (uint32_t r = 0; r < TILE_SIZE; ++r) {
+            const uint32_t px = tx0 + r % TILE_WIDTH, py = ty0 + r / TILE_WIDTH;
+            if (px < W && py < H) {
+                const size_t b = ((size_t)px + (size_t)py * W) * 4;
+                const float t_final = 1.0f - out[b + 3];
+                st[r][0] = out[b] - t_final * R.bg[0];
+                st[r][1] = out[b + 1] - t_final * R.bg[1];
+                st[r][2] = out[b + 2] - t_final * R.bg[2];
+                st[r][3] = 1.0f;
+            } else {
+                st[r][0] = st[r][1] = st[r][2] = st[r][3] = 0.0f;
+            }
+        }
+        for (uint32_t is = range_lo; is < range_hi; ++is) {
+            const uint32_t cg = R.compact_gid_from_isect[is];
+            const float* s = &R.projected[(size_t)cg * 9];
+            const Sym2 conic = {s[2], s[3], s[4]};
+            const float color_a = s[5];
+            const float cr = std::fmax(s[6], 0.0f), cgc = std::fmax(s[7], 0.0f), cb = std::fmax(s[8], 0.0f);
+            float g[10] = {0};
+            for (uint32_t r = 0; r < TILE_SIZE; ++r) {
+                const float sx = st[r][0], sy = st[r][1], sz = st[r][2], sw = st[r][3];
+                if (!(sw > 1.0e-4f)) continue;
+                const uint32_t px = tx0 + r % TILE_WIDTH, py = ty0 + r / TILE_WIDTH;
+                const float pcx = (float)px + 0.5f, pcy = (float)py + 0.5f;
+                const float dx = s[0] - pcx, dy = s[1] - pcy;
+                // same value as calc_sigma(pix, conic, xy): (-dx)^2 terms are sign-symmetric
+                const float sigma = calc_sigma(pcx, pcy, conic, s[0], s[1]);
+                const float gaussian = bo_expf_impl(-sigma);
+                const float alpha = std::fmin(0.999f, color_a * gaussian);
+                const float w_cut = smooth ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
+                if (sigma >= 0.0f && w_cut > 0.0f) {
+                    const float alpha_eff = alpha * w_cut;
+                    const float next_t = sw * (1.0f - alpha_eff);
+                    if (next_t <= 1.0e-4f) {
+                        st[r][3] = 0.0f;
+                    } else {
+                        const float vis = alpha_eff * sw;
+                        const size_t pb = ((size_t)px + (size_t)py * W) * 4;
+                        const float vox = v_output[pb], voy = v_output[pb + 1], voz = v_output[pb + 2], va = v_output[pb + 3];
+                        const float final_a = out[pb + 3];
+                        const float t_final = 1.0f - final_a;
+                        const float v_o_w = (va - (R.bg[0] * vox + R.bg[1] * voy + R.bg[2] * voz)) * t_final;
+                        g[5] += s[6] >= 0.0f ? vis * vox : 0.0f;
+                        g[6] += s[7] >= 0.0f ? vis * voy : 0.0f;
+                        g[7] += s[8] >= 0.0f ? vis * voz : 0.0f;
+                        const float ra = 1.0f / (1.0f - alpha_eff);
+                        const float dot_rgb = ((sw * cr - sx) * vox + (sw * cgc - sy) * voy + (sw * cb - sz) * voz) * ra;
+                        const float nrx = sx - vis * cr, nry = sy - vis * cgc, nrz = sz - vis * cb;
+                        const float v_alpha_eff = dot_rgb + v_o_w * ra;
+                        const float dw = smooth ? alpha_cutoff_weight_deriv(alpha) : 0.0f * alpha;
+                        const float v_alpha = v_alpha_eff * (w_cut + alpha * dw);
+                        const float v_sigma = -alpha * v_alpha;
+                        const float vxy_x = v_sigma * (conic.c00 * dx + conic.c01 * dy);
+                        const float vxy_y = v_sigma * (conic.c01 * dx + conic.c11 * dy);
+                        if (color_a * gaussian <= 0.999f) {
+                            g[2] += 0.5f * v_sigma * dx * dx;
+                            g[3] += v_sigma * dx * dy;
+                            g[4] += 0.5f * v_sigma * dy * dy;
+                            g[0] += vxy_x;
+                            g[1] += vxy_y;
+                            g[8] += v_alpha * gaussian;
+                            const float isx = (float)W, isy = (float)H;
+                            const float len = sqrtf(vxy_x * isx * vxy_x * isx + vxy_y * isy * vxy_y * isy);
+                            g[9] += len / std::fmax(final_a, 1.0e-5f);
+                        }
+                        st[r][0] = nrx; st[r][1] = nry; st[r][2] = nrz; st[r][3] = next_t;
+                    }
+                }
+            }
+            for (int k = 0; k < 10; ++k) part[(size_t)is * 10 + k] = g[k];
+        }
+    }
+    // atomics, in tile-major order
+    for (uint32_t t = 0; t < num_tiles; ++t) {
+        const uint32_t lo = R.tile_offsets[(size_t)t * 2], hi = R.tile_offsets[(size_t)t * 2 + 1];
+        for (uint32_t is = lo; is < hi; ++is) {
+            const uint32_t cg = R.compact_gid_from_isect[is];
+            for (int k = 0; k < 10; ++k) R.v_combined[(size_t)cg * 10 + k] += part[(size_t)is * 10 + k];
+        }
+    }
+}
+
+// bwd/kernels/project_backwards.rs:19-98
+inline Quat apply_normalize_vjp(Quat q, Quat g) {
+    const float lsq = qdot(q, q);
+    const float l = sqrtf(lsq);
+    const float inv = 1.0f / (l * lsq);
+    const float qw = q.w, qx = q.x, qy = q.y, qz = q.z;
+    const float gw = g.w, gx = g.x, gy = g.y, gz = g.z;
+    const float cc0 = -qw * qx, cc1 = -qx * qy, cc2 = -qy * qw;
+    const float cs0 = -qw * qz, cs1 = -qx * qz, cs2 = -qy * qz;
+    const float sw = qw * qw, sx = qx * qx, sy = qy * qy, sz = qz * qz;
+    return {((lsq - sw) * gw + cc0 * gx + cc2 * gy + cs0 * gz) * inv,
+            (cc0 * gw + (lsq - sx) * gx + cc1 * gy + cs1 * gz) * inv,
+            (cc2 * gw + cc1 * gx + (lsq - sy) * gy + cs2 * gz) * inv,
+            (cs0 * gw + cs1 * gx + cs2 * gy + (lsq - sz) * gz) * inv};
+}
+inline Quat quat_to_mat_vjp(Quat q, const Mat3& v) {
+    const float qw = q.w, qx = q.x, qy = q.y, qz = q.z;
+    const float w_grad = qx * (v.c1z - v.c2y) + qy * (v.c2x - v.c0z) + qz * (v.c0y - v.c1x);
+    const float x_grad = -2.0f * qx * (v.c1y + v.c2z) + qy * (v.c0y + v.c1x) + qz * (v.c0z + v.c2x) + qw * (v.c1z - v.c2y);
+    const float y_grad = qx * (v.c0y + v.c1x) - 2.0f * qy * (v.c0x + v.c2z) + qz * (v.c1z + v.c2y) + qw * (v.c2x - v.c0z);
+    const float z_grad = qx * (v.c0z + v.c2x) + qy * (v.c1z + v.c2y) - 2.0f * qz * (v.c0x + v.c1y) + qw * (v.c0y - v.c1x);
+    return {2.0f * w_grad, 2.0f * x_grad, 2.0f * y_grad, 2.0f * z_grad};
+}
+inline Sym2 inverse2x2_vjp(Sym2 minv, Sym2 v) {
+    const float tmp00 = -minv.c00 * v.c00 + -minv.c01 * v.c01;
+    const float tmp01 = -minv.c01 * v.c00 + -minv.c11 * v.c01;
+    const float tmp10 = -minv.c00 * v.c01 + -minv.c01 * v.c11;
+    const float tmp11 = -minv.c01 * v.c01 + -minv.c11 * v.c11;
+    return {tmp00 * minv.c00 + tmp10 * minv.c01, tmp01 * minv.c00 + tmp11 * minv.c01, tmp01 * minv.c01 + tmp11 * minv.c11};
+}
+
+// camera_model/pinhole.rs:59-123
+inline Vec3A projection_vjp_pinhole(const Mat2x3& jac, Vec3A mean_c, Sym3 cov_c, const Uniforms& u, Sym2 v_cov2d, Vec2 v_mean2d) {
+    const float fx = u.fx, fy = u.fy;
+    const float mx = mean_c.x, my = mean_c.y, mz = mean_c.z;
+    const float inv_z = 1.0f / mz;
+    const float mx_rz_raw = mx * inv_z, my_rz_raw = my * inv_z;
+    const float mx_rz = clampf(mx_rz_raw, u.lim_neg_x, u.lim_pos_x);
+    const float my_rz = clampf(my_rz_raw, u.lim_neg_y, u.lim_pos_y);
+    const bool in_x = mx_rz_raw <= u.lim_pos_x && mx_rz_raw >= u.lim_neg_x;
+    const bool in_y = my_rz_raw <= u.lim_pos_y && my_rz_raw >= u.lim_neg_y;
+    const float inv_z2 = inv_z * inv_z;
+    const float inv_z3 = inv_z2 * inv_z;
+    float v_mx = fx * inv_z * v_mean2d.x;
+    float v_my = fy * inv_z * v_mean2d.y;
+    float v_mz = -(fx * mx * v_mean2d.x + fy * my * v_mean2d.y) * inv_z2;
+    const Mat2x3 tmp = sym2_mul_mat2x3(v_cov2d, jac);
+    const float vj00 = 2.0f * dot(row0(tmp), s3row0(cov_c));
+    const float vj11 = 2.0f * dot(row1(tmp), s3row1(cov_c));
+    const float vj20 = 2.0f * dot(row0(tmp), s3row2(cov_c));
+    const float vj21 = 2.0f * dot(row1(tmp), s3row2(cov_c));
+    const float tx = mz * mx_rz;
+    const float ty = mz * my_rz;
+    if (in_x) v_mx += -fx * inv_z2 * vj20; else v_mz += -fx * inv_z3 * vj20 * tx;
+    if (in_y) v_my += -fy * inv_z2 * vj21; else v_mz += -fy * inv_z3 * vj21 * ty;
+    v_mz += -fx * inv_z2 * vj00 - fy * inv_z2 * vj11 + 2.0f * fx * tx * inv_z3 * vj20 + 2.0f * fy * ty * inv_z3 * vj21;
+    return {v_mx, v_my, v_mz};
+}
+
+// bwd/kernels/project_backwards.rs:101-254; host bwd/render_bwd.rs:102-171
+void project_backward(Render& R, const float* transforms, const float* sh, const float* raw_opac) {
+    const Uniforms& u = R.u;
+    const bool mip = R.flags & BO_FLAG_MIP;
+    const uint32_t n = R.n, C = num_sh_coeffs(R.sh_degree), nv = R.num_visible;
+    R.v_transforms.assign((size_t)n * 10, 0.0f);
+    R.v_coeffs.assign((size_t)n * C * 3, 0.0f);
+    R.v_raw_opac.assign(n, 0.0f);
+    R.v_refine.assign(n, 0.0f);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)nv; ++i) {
+        const uint32_t gid = R.global_from_compact_gid[i];
+        const float* rg = &R.v_combined[(size_t)i * 10];
+        bool any = false;
+        for (int k = 0; k < 10; ++k) any = any || (rg[k] != 0.0f);
+        if (!any) continue;
+        const float* tr = transforms + (size_t)gid * 10;
+        const Vec3A mean = v3(tr[0], tr[1], tr[2]);
+        const Vec3A scl = v3(bo_expf_impl(tr[7]), bo_expf_impl(tr[8]), bo_expf_impl(tr[9]));
+        const Quat qu = {tr[3], tr[4], tr[5], tr[6]};
+        const Quat q = qnormalize(qu);
+        const Vec3A u_world = sub(mean, u.cam_pos);
+        const float u_len = length(u_world);
+        const Vec3A v = scale(u_world, 1.0f / u_len);
+        const Vec3A v_color = v3(rg[5], rg[6], rg[7]);
+        sh_coeffs_to_color_vjp(&R.v_coeffs[(size_t)gid * C * 3], R.sh_degree, v, v_color);
+        const Vec3A v_v_sh = sh_color_viewdir_vjp(sh + (size_t)gid * C * 3, R.sh_degree, v, v_color);
+        const float v_dot_vv = dot(v, v_v_sh);
+        const Vec3A v_mean_from_sh = scale(sub(v_v_sh, scale(v, v_dot_vv)), 1.0f / u_len);
+        const Vec3A mean_c = world_to_cam(mean, u);
+        const Mat3 r = quat_to_mat3(q);
+        const Mat3 m = mul_diag(r, scl);
+        const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+        float filter_comp;
+        const Sym2 cov = compensate_cov2d(raw_cov, mip, filter_comp);
+        const float os = sigmoid(raw_opac[gid]);
+        R.v_raw_opac[gid] = filter_comp * rg[8] * os * (1.0f - os);
+        const float refine_clean = is_finite_f32(rg[9]) ? rg[9] : 0.0f;
+        R.v_refine[gid] = clampf(refine_clean, 0.0f, 1.0e32f);
+        const Sym2 conic_inv = sym2_inverse(cov);
+        const Sym2 v_inv = {rg[2], rg[3] * 0.5f, rg[4]};
+        const Sym2 v_cov2d = inverse2x2_vjp(conic_inv, v_inv);
+        const Sym3 covar = outer_product_self(m);
+        const Sym3 cov_c = congruence(covar, u.view_rot);
+        const Mat2x3 jac = jacobian_pinhole(mean_c, u);
+        const Vec3A v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, Vec2{rg[0], rg[1]});
+        const Sym3 vcc = transpose_congruence_sym2(jac, v_cov2d);
+        const Vec3A v_mean = add(transpose_mul_vec3(u.view_rot, v_mean_c), v_mean_from_sh);
+        const Mat3 v_m = sym3_mul_mat3(sym3_scale(transpose_congruence(vcc, u.view_rot), 2.0f), m);
+        const Vec3A v_scale = v3(dot(col0(r), col0(v_m)) * scl.x, dot(col1(r), col1(v_m)) * scl.y, dot(col2(r), col2(v_m)) * scl.z);
+        const Quat q_grad = quat_to_mat_vjp(q, mul_diag(v_m, scl));
+        const Quat v_q = apply_normalize_vjp(qu, q_grad);
+        float* vt = &R.v_transforms[(size_t)gid * 10];
+        vt[0] = v_mean.x; vt[1] = v_mean.y; vt[2] = v_mean.z;
+        vt[3] = v_q.w; vt[4] = v_q.x; vt[5] = v_q.y; vt[6] = v_q.z;
+        vt[7] = v_scale.x; vt[8] = v_scale.y; vt[9] = v_scale.z;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Image loss — brush-loss/src/lib.rs:45-661
+// ---------------------------------------------------------------------------
+struct GaussTaps { float w[11]; };
+// lib.rs:55-68 (f32 arithmetic, std f32::exp -> libm expf is the host-side
+// comptime evaluation in the reference, so libm is the faithful choice here)
+GaussTaps gauss_taps() {
+    GaussTaps g;
+    const float sigma = 1.5f;
+    float sum = 0.0f;
+    for (int i = 0; i < 11; ++i) {
+        const float x = (float)i - 5.0f;
+        g.w[i] = expf(-x * x / (2.0f * sigma * sigma));
+        sum += g.w[i];
+    }
+    for (int i = 0; i < 11; ++i) g.w[i] /= sum;
+    return g;
+}
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+constexpr float INV_255 = 1.0f / 255.0f;
+
+inline float gt_channel(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) & 0xffu) * INV_255; }
+
+struct LossCfg { float l1_w, ssim_w; float bg[3]; int composite; int mask; };
+
+// effective gt sample at (y,x) channel c with zero padding (lib.rs:110-176, 240-257)
+inline void sample_pg(const float* pred, const uint32_t* gt, const LossCfg& cfg, uint32_t c, int64_t y, int64_t x,
+                      uint32_t h, uint32_t w, float& pv, float& ge) {
+    if (y < 0 || x < 0 || y >= (int64_t)h || x >= (int64_t)w) { pv = 0.0f; ge = 0.0f; return; }
+    pv = pred[(size_t)c * h * w + (size_t)y * w + (size_t)x];
+    const uint32_t val = gt[(size_t)y * w + (size_t)x];
+    const float gc = gt_channel(val, c), ga = gt_channel(val, 3);
+    ge = cfg.composite ? gc + (1.0f - ga) * cfg.bg[c] : gc;
+}
+
+// 5 blurred moments at pixel (y,x): horizontal 11-tap (pairs folded, lib.rs:262-300)
+// then vertical (lib.rs:304-330), in the reference's accumulation order.
+inline void hblur5(const float* pred, const uint32_t* gt, const LossCfg& cfg, const GaussTaps& g, uint32_t c,
+                   int64_t y, int64_t x, uint32_t h, uint32_t w, float o[5]) {
+    float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+    for (int d = 1; d < 6; ++d) {
+        const float wd = g.w[5 - d];
+        float xl, yl, xr, yr;
+        sample_pg(pred, gt, cfg, c, y, x - d, h, w, xl, yl);
+        sample_pg(pred, gt, cfg, c, y, x + d, h, w, xr, yr);
+        sx += (xl + xr) * wd;
+        sx2 += (xl * xl + xr * xr) * wd;
+        sy += (yl + yr) * wd;
+        sy2 += (yl * yl + yr * yr) * wd;
+        sxy += (xl * yl + xr * yr) * wd;
+    }
+    float xc, yc;
+    sample_pg(pred, gt, cfg, c, y, x, h, w, xc, yc);
+    const float wc = g.w[5];
+    sx += xc * wc; sx2 += xc * xc * wc; sy += yc * wc; sy2 += yc * yc * wc; sxy += xc * yc * wc;
+    o[0] = sx; o[1] = sx2; o[2] = sy; o[3] = sy2; o[4] = sxy;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- render object API ----------------------------------------------------
+void* bo_render_create() { return new Render(); }
+void bo_render_free(void* r) { delete (Render*)r; }
+
+int bo_render_forward(void* r, const BoCamera* cam, uint32_t n, uint32_t sh_degree, const float* transforms,
+                      const float* sh, const float* raw_opac, const float* bg, uint32_t flags) {
+    return render_forward(*(Render*)r, *cam, n, sh_degree, transforms, sh, raw_opac, bg, flags);
+}
+
+// v_output [H,W,4]. Needs a BWD_INFO forward on the same object.
+int bo_render_backward(void* r, const float* v_output, const float* transforms, const float* sh, const float* raw_opac) {
+    Render& R = *(Render*)r;
+    if (!(R.flags & BO_FLAG_BWD_INFO)) return -1;
+    double t0 = now_s();
+    rasterize_backward(R, v_output);
+    R.t_stage[8] = now_s() - t0; t0 = now_s();
+    project_backward(R, transforms, sh, raw_opac);
+    R.t_stage[9] = now_s() - t0;
+    return 0;
+}
+
+uint32_t bo_num_visible(void* r) { return ((Render*)r)->num_visible; }
+uint32_t bo_num_intersections(void* r) { return ((Render*)r)->num_intersections; }
+uint32_t bo_num_tiles(void* r) { Render& R = *(Render*)r; return R.u.tile_bw * R.u.tile_bh; }
+double bo_stage_seconds(void* r, int i) { return ((Render*)r)->t_stage[i]; }
+
+#define BO_GETTER(name, field, type) \
+    const type* bo_get_##name(void* r, uint64_t* count) { Render& R = *(Render*)r; *count = R.field.size(); return R.field.data(); }
+BO_GETTER(intersect_counts, intersect_counts, uint32_t)
+BO_GETTER(max_radius, max_radius, float)
+BO_GETTER(depths_sorted, depths_sorted, float)
+BO_GETTER(global_from_compact_gid, global_from_compact_gid, uint32_t)
+BO_GETTER(cum_tiles_hit, cum_tiles_hit, uint32_t)
+BO_GETTER(projected, projected, float)
+BO_GETTER(tile_id_unsorted, tile_id_unsorted, uint32_t)
+BO_GETTER(gid_unsorted, gid_unsorted, uint32_t)
+BO_GETTER(tile_id_from_isect, tile_id_from_isect, uint32_t)
+BO_GETTER(compact_gid_from_isect, compact_gid_from_isect, uint32_t)
+BO_GETTER(tile_offsets_pre, tile_offsets_pre, uint32_t)
+BO_GETTER(tile_offsets, tile_offsets, uint32_t)
+BO_GETTER(out_img, out_img, float)
+BO_GETTER(out_packed, out_packed, uint32_t)
+BO_GETTER(visible, visible, float)
+BO_GETTER(v_combined, v_combined, float)
+BO_GETTER(v_transforms, v_transforms, float)
+BO_GETTER(v_coeffs, v_coeffs, float)
+BO_GETTER(v_raw_opac, v_raw_opac, float)
+BO_GETTER(v_refine, v_refine, float)
+
+// ---- sort / scan semantics (brush-sort/src/lib.rs:16, brush-prefix-sum/src/lib.rs:11)
+void bo_radix_argsort(const uint32_t* keys, const uint32_t* vals, uint64_t n, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals) {
+    std::vector<uint32_t> k(keys, keys + n), v(vals, vals + n), ok, ov;
+    stable_argsort_bits(k, v, bits, ok, ov);
+    std::memcpy(out_keys, ok.data(), n * 4);
+    std::memcpy(out_vals, ov.data(), n * 4);
+}
+void bo_prefix_sum(const uint32_t* in, uint64_t n, uint32_t* out) {
+    uint32_t acc = 0;
+    for (uint64_t i = 0; i < n; ++i) { acc += in[i]; out[i] = acc; }
+}
+
+// ---- image loss -------------------------------------------------------------
+// pred [C,H,W] (C = 3 or 4), gt_packed [H,W], loss_map [C,H,W].  lib.rs:181-359
+void bo_image_loss_forward(const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h, uint32_t w, float l1_w,
+                           float ssim_w, const float* bg, int composite, int mask, float* loss_map) {
+    const GaussTaps g = gauss_taps();
+    LossCfg cfg{l1_w, ssim_w, {bg ? bg[0] : 0.f, bg ? bg[1] : 0.f, bg ? bg[2] : 0.f}, composite, mask};
+    for (uint32_t c = 0; c < channels; ++c) {
+        if (c == 3) {
+#pragma omp parallel for
+            for (int64_t i = 0; i < (int64_t)h * w; ++i) {
+                const float ga = gt_channel(gt[i], 3);
+                float v = fabsf(pred[(size_t)3 * h * w + i] - ga);
+                if (mask) v = v * ga;
+                loss_map[(size_t)3 * h * w + i] = v;
+            }
+            continue;
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t y = 0; y < (int64_t)h; ++y) {
+            for (int64_t x = 0; x < (int64_t)w; ++x) {
+                float o[5] = {0, 0, 0, 0, 0};
+                for (int d = 1; d < 6; ++d) {
+                    const float wd = g.w[5 - d];
+                    float t[5], b[5];
+                    hblur5(pred, gt, cfg, g, c, y - d, x, h, w, t);
+                    hblur5(pred, gt, cfg, g, c, y + d, x, h, w, b);
+                    for (int k = 0; k < 5; ++k) o[k] += (t[k] + b[k]) * wd;
+                }
+                float cc[5];
+                hblur5(pred, gt, cfg, g, c, y, x, h, w, cc);
+                for (int k = 0; k < 5; ++k) o[k] += cc[k] * g.w[5];
+                const float mu1 = o[0], mu2 = o[2];
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+                const float s1 = std::fmax(0.0f, o[1] - mu1_sq), s2 = std::fmax(0.0f, o[3] - mu2_sq);
+                const float s12 = o[4] - mu1 * mu2;
+                const float a = mu1_sq + mu2_sq + SSIM_C1;
+                const float b = s1 + s2 + SSIM_C2;
+                const float c_top = 2.0f * mu1 * mu2 + SSIM_C1;
+                const float d_top = 2.0f * s12 + SSIM_C2;
+                const float raw = (c_top * d_top) / (a * b);
+                const float val = clampf(raw, -1.0f, 1.0f);
+                float p1, p2;
+                sample_pg(pred, gt, cfg, c, y, x, h, w, p1, p2);
+                float lv = l1_w * fabsf(p1 - p2) + ssim_w * val;
+                if (mask) lv = lv * gt_channel(gt[(size_t)y * w + x], 3);
+                loss_map[(size_t)c * h * w + (size_t)y * w + x] = lv;
+            }
+        }
+    }
+}
+
+// lib.rs:371-661. dl_dmap [C,H,W] -> dl_dpred [C,H,W]
+void bo_image_loss_backward(const float* pred, const uint32_t* gt, const float* dl_dmap, uint32_t channels, uint32_t h,
+                            uint32_t w, float l1_w, float ssim_w, const float* bg, int composite, int mask, float* dl_dpred) {
+    const GaussTaps g = gauss_taps();
+    LossCfg cfg{l1_w, ssim_w, {bg ? bg[0] : 0.f, bg ? bg[1] : 0.f, bg ? bg[2] : 0.f}, composite, mask};
+    const size_t hw = (size_t)h * w;
+    for (uint32_t c = 0; c < channels; ++c) {
+        if (c == 3) {
+#pragma omp parallel for
+            for (int64_t i = 0; i < (int64_t)hw; ++i) {
+                const float ga = gt_channel(gt[i], 3);
+                const float diff = pred[3 * hw + i] - ga;
+                const float sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+                float chain = dl_dmap[3 * hw + i];
+                if (mask) chain = chain * ga;
+                dl_dpred[3 * hw + i] = sign * chain;
+            }
+            continue;
+        }
+        // chain * partials per pixel (zero outside the image: the chain read is OOB-zero)
+        std::vector<float> part(hw * 3);
+#pragma omp parallel for schedule(static)
+        for (int64_t y = 0; y < (int64_t)h; ++y) {
+            for (int64_t x = 0; x < (int64_t)w; ++x) {
+                float o[5] = {0, 0, 0, 0, 0};
+                for (int d = 1; d < 6; ++d) {
+                    const float wd = g.w[5 - d];
+                    float t[5], b[5];
+                    hblur5(pred, gt, cfg, g, c, y - d, x, h, w, t);
+                    hblur5(pred, gt, cfg, g, c, y + d, x, h, w, b);
+                    for (int k = 0; k < 5; ++k) o[k] += (t[k] + b[k]) * wd;
+                }
+                float cc[5];
+                hblur5(pred, gt, cfg, g, c, y, x, h, w, cc);
+                for (int k = 0; k < 5; ++k) o[k] += cc[k] * g.w[5];
+                const float mu1 = o[0], mu2 = o[2];
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+                const float s1 = std::fmax(0.0f, o[1] - mu1_sq), s2 = std::fmax(0.0f, o[3] - mu2_sq);
+                const float s12 = o[4] - mu1 * mu2;
+                const float a = mu1_sq + mu2_sq + SSIM_C1;
+                const float b = s1 + s2 + SSIM_C2;
+                const float c_top = 2.0f * mu1 * mu2 + SSIM_C1;
+                const float d_top = 2.0f * s12 + SSIM_C2;
+                const float inv_ab = 1.0f / (a * b);
+                const float cd = c_top * d_top * inv_ab;
+                const bool clamped = cd < -1.0f || cd > 1.0f;
+                const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (1.0f / a - 1.0f / b);
+                const float ds1 = clamped ? 0.0f : -cd / b;
+                const float ds12 = clamped ? 0.0f : 2.0f * c_top * inv_ab;
+                float chain = dl_dmap[(size_t)c * hw + (size_t)y * w + x];
+                if (mask) chain = chain * gt_channel(gt[(size_t)y * w + x], 3);
+                float* p = &part[((size_t)y * w + x) * 3];
+                p[0] = dmu1 * chain; p[1] = ds1 * chain; p[2] = ds12 * chain;
+            }
+        }
+        auto P = [&](int64_t y, int64_t x, int k) -> float {
+            if (y < 0 || x < 0 || y >= (int64_t)h || x >= (int64_t)w) return 0.0f;
+            return part[((size_t)y * w + x) * 3 + k];
+        };
+        auto hb3 = [&](int64_t y, int64_t x, float a3[3]) {
+            float a0 = 0, a1 = 0, a2 = 0;
+            for (int d = 1; d < 6; ++d) {
+                const float wd = g.w[5 - d];
+                a0 += (P(y, x - d, 0) + P(y, x + d, 0)) * wd;
+                a1 += (P(y, x - d, 1) + P(y, x + d, 1)) * wd;
+                a2 += (P(y, x - d, 2) + P(y, x + d, 2)) * wd;
+            }
+            a0 += P(y, x, 0) * g.w[5]; a1 += P(y, x, 1) * g.w[5]; a2 += P(y, x, 2) * g.w[5];
+            a3[0] = a0; a3[1] = a1; a3[2] = a2;
+        };
+#pragma omp parallel for schedule(static)
+        for (int64_t y = 0; y < (int64_t)h; ++y) {
+            for (int64_t x = 0; x < (int64_t)w; ++x) {
+                float s[3] = {0, 0, 0};
+                for (int d = 1; d < 6; ++d) {
+                    const float wd = g.w[5 - d];
+                    float t[3], b[3];
+                    hb3(y - d, x, t);
+                    hb3(y + d, x, b);
+                    for (int k = 0; k < 3; ++k) s[k] += (t[k] + b[k]) * wd;
+                }
+                float cc[3];
+                hb3(y, x, cc);
+                for (int k = 0; k < 3; ++k) s[k] += cc[k] * g.w[5];
+                float p1, ge;
+                sample_pg(pred, gt, cfg, c, y, x, h, w, p1, ge);
+                const float ssim_grad = s[0] + (2.0f * p1) * s[1] + ge * s[2];
+                const float diff = p1 - ge;
+                const float l1_sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+                float chain_c = dl_dmap[(size_t)c * hw + (size_t)y * w + x];
+                if (mask) chain_c = chain_c * gt_channel(gt[(size_t)y * w + x], 3);
+                dl_dpred[(size_t)c * hw + (size_t)y * w + x] = ssim_w * ssim_grad + l1_w * l1_sign * chain_c;
+            }
+        }
+    }
+}
+
+// ---- Adam -------------------------------------------------------------------
+// compiler-rt __powisf2, the lowering of Rust's f32::powi (adam_scaled.rs:131-138)
+float bo_powi(float a, int b) {
+    const int recip = b < 0;
+    float r = 1.0f;
+    while (1) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+// brush-train/src/adam_scaled.rs:75-147. `rows` x `row_len` parameter; `t` is the
+// 1-based step count AFTER this step (state.time); t == 1 means "no prior state".
+// col_scale [row_len] or NULL; reduce_m2: second moment is one scalar per row
+// (mean of g^2 over the row, adam_scaled.rs:99-104,152-165), m2 then has `rows` entries.
+void bo_adam_step(float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
+                  const float* col_scale, float lr, uint32_t t, int reduce_m2, float beta1, float beta2, float eps) {
+    const float f1 = 1.0f - beta1, f2 = 1.0f - beta2;
+    const float bc1 = 1.0f - bo_powi(beta1, (int)t), bc2 = 1.0f - bo_powi(beta2, (int)t);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)rows; ++r) {
+        float row_gsq = 0.0f;
+        if (reduce_m2) {
+            float s = 0.0f;
+            for (uint32_t c = 0; c < row_len; ++c) { const float g = grad[(size_t)r * row_len + c]; s += g * g; }
+            row_gsq = s / (float)row_len;
+            m2[r] = t == 1 ? row_gsq * f2 : m2[r] * beta2 + row_gsq * f2;
+        }
+        for (uint32_t c = 0; c < row_len; ++c) {
+            const size_t i = (size_t)r * row_len + c;
+            const float g = grad[i];
+            m1[i] = t == 1 ? g * f1 : m1[i] * beta1 + g * f1;
+            float v;
+            if (reduce_m2) {
+                v = m2[r];
+            } else {
+                const float gsq = g * g;
+                m2[i] = t == 1 ? gsq * f2 : m2[i] * beta2 + gsq * f2;
+                v = m2[i];
+            }
+            const float m1c = m1[i] / bc1;
+            const float m2c = v / bc2;
+            const float upd = m1c / (sqrtf(m2c) + eps);
+            const float step = col_scale ? col_scale[c] * lr : lr;
+            param[i] = param[i] - upd * step;
+        }
+    }
+}
+
+// brush-train/src/stats.rs:40-50
+void bo_gather_stats(float* refine_weight_norm, float* vis_weight, float* max_screen_size, const float* refine_weight,
+                     const float* visible, const float* screen_radius, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        refine_weight_norm[i] = std::fmax(refine_weight[i], refine_weight_norm[i]);
+        vis_weight[i] = vis_weight[i] + visible[i];
+        max_screen_size[i] = std::fmax(screen_radius[i], max_screen_size[i]);
+    }
+}
+
+int bo_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"
