@@ -1,0 +1,24 @@
+"""brush_amd — host-side mirror (Python) of the Brush operator surface for the
+splat-rasterizer hot path, above the C ABI of libbrush_hip.so.
+
+Names and argument meaning follow the reference (paths under
+/root/reference/crates/):
+    Camera            brush-render/src/camera.rs:12-19
+    Splats            brush-render/src/gaussian_splats.rs:62-74
+    RasterPass        brush-render/src/gaussian_splats.rs:28-48
+    render_splats     brush-render/src/gaussian_splats.rs:365-446 (forward / eval)
+    render_splats_bwd brush-render/src/bwd/burn_glue.rs:223-311 (+ RenderBackwards::backward :121-182)
+    radix_argsort     brush-sort/src/lib.rs:16
+    prefix_sum        brush-prefix-sum/src/lib.rs:11
+    image_loss        brush-loss/src/lib.rs:1075-1104
+    SplatTrainer      brush-train/src/train.rs:140-429
+
+torch is used only for device memory, streams and torch.distributed; every
+computation runs in the hand-written HIP kernels. No CPU fallback exists.
+"""
+from .host import (  # noqa: F401
+    Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
+    get_context, image_loss, image_loss_backward, prefix_sum, radix_argsort, render_splats,
+    render_splats_bwd, adam_step,
+)
+from ._ffi import BrushHipError  # noqa: F401

@@ -1,0 +1,128 @@
+"""ctypes binding of libbrush_hip.so (include/brush_hip.h).
+
+There is NO fallback path: if the HIP library is missing this module raises, and
+every entry point raises on a non-zero status with bh_last_error()'s message.
+"""
+import ctypes as C
+import os
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libbrush_hip.so")
+
+FLAG_MIP = 1
+FLAG_BWD_INFO = 2
+FLAG_SMOOTH_CUTOFF = 4
+
+fp = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+
+class BhCamera(C.Structure):
+    _fields_ = [
+        ("vm", C.c_float * 12),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("lim_pos_x", C.c_float), ("lim_pos_y", C.c_float),
+        ("lim_neg_x", C.c_float), ("lim_neg_y", C.c_float),
+        ("cam_pos", C.c_float * 3),
+        ("img_w", C.c_uint32), ("img_h", C.c_uint32),
+    ]
+
+
+class BhRenderOut(C.Structure):
+    _fields_ = [
+        ("num_visible", C.c_uint32), ("num_intersections", C.c_uint32),
+        ("num_tiles", C.c_uint32), ("tile_bw", C.c_uint32), ("tile_bh", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("out_img", C.c_void_p), ("out_img_packed", C.c_void_p), ("visible", C.c_void_p),
+        ("max_radius", C.c_void_p), ("tile_offsets", C.c_void_p), ("projected", C.c_void_p),
+        ("compact_gid_from_isect", C.c_void_p), ("tile_id_from_isect", C.c_void_p),
+        ("global_from_compact_gid", C.c_void_p), ("cum_tiles_hit", C.c_void_p),
+        ("intersect_counts", C.c_void_p), ("depths_sorted", C.c_void_p),
+    ]
+
+
+class BhLossConfig(C.Structure):
+    _fields_ = [("l1_weight", C.c_float), ("ssim_weight", C.c_float), ("bg", C.c_float * 3),
+                ("composite_bg", C.c_int32), ("mask", C.c_int32)]
+
+
+class BhTrainConfig(C.Structure):
+    _fields_ = [
+        ("lr_mean", C.c_double), ("lr_mean_end", C.c_double), ("total_train_iters", C.c_uint32),
+        ("lr_coeffs_dc", C.c_double), ("lr_coeffs_sh_scale", C.c_float), ("lr_opac", C.c_double),
+        ("lr_scale", C.c_double), ("lr_rotation", C.c_double), ("ssim_weight", C.c_float),
+        ("match_alpha_weight", C.c_float), ("mean_noise_weight", C.c_float), ("background", C.c_float * 3),
+        ("median_scene_scale", C.c_float), ("render_mip", C.c_int32),
+    ]
+
+
+class BhTrainState(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32), ("sh_degree", C.c_uint32),
+        ("transforms", C.c_void_p), ("sh_coeffs", C.c_void_p), ("raw_opacities", C.c_void_p),
+        ("m1_transforms", C.c_void_p), ("m2_transforms", C.c_void_p),
+        ("m1_sh", C.c_void_p), ("m2_sh", C.c_void_p),
+        ("m1_opac", C.c_void_p), ("m2_opac", C.c_void_p),
+        ("refine_weight_norm", C.c_void_p), ("vis_weight", C.c_void_p), ("max_screen_size", C.c_void_p),
+        ("step_count", C.c_uint32),
+    ]
+
+
+class BhTrainBatch(C.Structure):
+    _fields_ = [
+        ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
+        ("background", C.c_float * 3), ("noise_samples", C.c_void_p),
+    ]
+
+
+class BhTrainStats(C.Structure):
+    _fields_ = [("num_visible", C.c_uint32), ("num_intersections", C.c_uint32), ("lr_mean", C.c_double), ("loss", C.c_float)]
+
+
+GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+
+# every symbol include/brush_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "bh_create": (C.c_void_p, [C.c_int, C.c_void_p, C.c_int]),
+    "bh_destroy": (None, [C.c_void_p]),
+    "bh_last_error": (C.c_char_p, [C.c_void_p]),
+    "bh_sync": (C.c_int, [C.c_void_p]),
+    "bh_version": (C.c_char_p, []),
+    "bh_camera_setup": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BhCamera)]),
+    "bh_render_forward": (C.c_int, [C.c_void_p, C.POINTER(BhCamera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, fp, C.c_uint32, C.POINTER(BhRenderOut)]),
+    "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
+    "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
+    "bh_radix_argsort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bh_prefix_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bh_image_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
+    "bh_image_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
+    "bh_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "bh_gather_stats": (C.c_int, [C.c_void_p] * 7 + [C.c_uint64]),
+    "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
+    "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
+}
+
+_lib = None
+
+
+class BrushHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libbrush_hip.so and bind every declared symbol. Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BrushHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

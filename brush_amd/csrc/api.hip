@@ -1,0 +1,597 @@
+// api.hip — the extern "C" surface of libbrush_hip.so (include/brush_hip.h):
+// context / arena / error plumbing and the host-side orchestration of the
+// forward pipeline (render.rs:37-314), the backward (bwd/render_bwd.rs:21-171)
+// and SplatTrainer::step (brush-train/src/train.rs:176-429).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "context.h"
+
+namespace bh {
+
+int launch_image_loss_forward_strided(bh_ctx* ctx, const float* pred, uint32_t pix_stride, uint32_t ch_stride, const uint32_t* gt,
+                                      uint32_t channels, uint32_t h, uint32_t w, const BhLossConfig& cfg, float* loss_map);
+int launch_image_loss_backward_strided(bh_ctx* ctx, const float* pred, uint32_t pix_stride, uint32_t ch_stride, const uint32_t* gt,
+                                       const float* dl_dmap, float dl_rgb, float dl_alpha, uint32_t channels, uint32_t h, uint32_t w,
+                                       const BhLossConfig& cfg, float* dl_dpred);
+
+int set_error(bh_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->last_error = msg;
+    return code;
+}
+
+int check_hip(bh_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return set_error(ctx, e == hipErrorOutOfMemory ? BH_ERR_OOM : BH_ERR_HIP, m);
+}
+
+void* ensure(bh_ctx* ctx, Slot s, size_t bytes) {
+    Buffer& b = ctx->slots[s];
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return b.ptr;
+    // growing: wait for queued work that may still read the old block
+    if (b.ptr) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.cap = 0;
+    }
+    size_t cap = bytes + bytes / 4;  // head-room so slowly growing scenes do not realloc every step
+    cap = (cap + 255) & ~(size_t)255;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cap = (bytes + 255) & ~(size_t)255;
+        e = hipMalloc(&p, cap);
+    }
+    if (e != hipSuccess) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "hipMalloc(%zu bytes) for scratch slot %d failed: %s", cap, (int)s, hipGetErrorString(e));
+        (void)hipGetLastError();
+        set_error(ctx, BH_ERR_OOM, msg);
+        return nullptr;
+    }
+    b.ptr = p;
+    b.cap = cap;
+    return p;
+}
+
+ViewUniforms make_uniforms(const BhCamera& c) {
+    ViewUniforms u;
+    for (int i = 0; i < 12; ++i) u.vm[i] = c.vm[i];
+    u.fx = c.fx; u.fy = c.fy; u.cx = c.cx; u.cy = c.cy;
+    u.lim_pos_x = c.lim_pos_x; u.lim_pos_y = c.lim_pos_y; u.lim_neg_x = c.lim_neg_x; u.lim_neg_y = c.lim_neg_y;
+    u.cam_x = c.cam_pos[0]; u.cam_y = c.cam_pos[1]; u.cam_z = c.cam_pos[2];
+    u.img_w = c.img_w; u.img_h = c.img_h;
+    u.tile_bw = (c.img_w + TILE_WIDTH - 1) / TILE_WIDTH;  // render.rs:30-35
+    u.tile_bh = (c.img_h + TILE_WIDTH - 1) / TILE_WIDTH;
+    return u;
+}
+
+// ---- profiling -----------------------------------------------------------------
+static int prof_index(Profiler& p, const char* name) {
+    for (int i = 0; i < p.count; ++i)
+        if (p.names[i] == name || std::strcmp(p.names[i], name) == 0) return i;
+    if (p.count >= MAX_PROF) return -1;
+    p.names[p.count] = name;
+    p.ms[p.count] = 0.0f;
+    p.calls[p.count] = 0;
+    return p.count++;
+}
+static hipEvent_t prof_event(Profiler& p) {
+    if (!p.pool.empty()) {
+        hipEvent_t e = p.pool.back();
+        p.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_resolve(bh_ctx* ctx) {
+    Profiler& p = ctx->prof;
+    for (auto& pe : p.pending) {
+        (void)hipEventSynchronize(pe.b);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess && pe.idx >= 0) {
+            p.ms[pe.idx] += ms;
+            p.calls[pe.idx] += 1;
+        }
+        p.pool.push_back(pe.a);
+        p.pool.push_back(pe.b);
+    }
+    p.pending.clear();
+}
+
+ProfScope::ProfScope(bh_ctx* c, const char* name) : ctx(c) {
+    if (!c->prof.on) return;
+    idx = prof_index(c->prof, name);
+    a = prof_event(c->prof);
+    b = prof_event(c->prof);
+    (void)hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof.pending.push_back({idx, a, b});
+}
+
+}  // namespace bh
+
+using namespace bh;
+
+extern "C" {
+
+const char* bh_version(void) { return "brush_hip 0.1 (gfx950)"; }
+
+bh_ctx* bh_create(int device, void* stream, int own_stream) {
+    bh_ctx* ctx = new (std::nothrow) bh_ctx();
+    if (!ctx) return nullptr;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        delete ctx;
+        return nullptr;
+    }
+    if (!own_stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->owns_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            delete ctx;
+            return nullptr;
+        }
+        ctx->owns_stream = true;
+    }
+    if (hipHostMalloc((void**)&ctx->host_counters, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return nullptr;
+    }
+    std::memset(ctx->host_counters, 0, 64);
+    return ctx;
+}
+
+void bh_destroy(bh_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
+    for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
+    for (auto& b : ctx->slots)
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* bh_last_error(bh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int bh_sync(bh_ctx* ctx) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int bh_profile_enable(bh_ctx* ctx, int on) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    ctx->prof.on = on != 0;
+    return 0;
+}
+
+int bh_profile_fetch(bh_ctx* ctx, const char** names, float* ms, uint32_t* calls, int cap) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    prof_resolve(ctx);
+    Profiler& p = ctx->prof;
+    const int n = p.count < cap ? p.count : cap;
+    for (int i = 0; i < n; ++i) {
+        names[i] = p.names[i];
+        ms[i] = p.ms[i];
+        calls[i] = p.calls[i];
+    }
+    p.count = 0;
+    return n;
+}
+
+// brush-render/src/camera.rs:63-101,200-254; glam 0.30 Affine3A/Mat3A restated in f32.
+int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u, float center_v,
+                    uint32_t img_w, uint32_t img_h, BhCamera* out) {
+    if (!pos || !rot_xyzw || !out || img_w == 0 || img_h == 0) return BH_ERR_INVALID_ARG;
+    const float x = rot_xyzw[0], y = rot_xyzw[1], z = rot_xyzw[2], w = rot_xyzw[3];
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xx = x * x2, xy = x * y2, xz = x * z2;
+    const float yy = y * y2, yz = y * z2, zz = z * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    // camera-to-world rotation columns (Mat3A::from_quat)
+    const float ax[3] = {1.0f - (yy + zz), xy + wz, xz - wy};
+    const float ay[3] = {xy - wz, 1.0f - (xx + zz), yz + wx};
+    const float az[3] = {xz + wy, yz - wx, 1.0f - (xx + yy)};
+    auto cross = [](const float* a, const float* b, float* o) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    float t0[3], t1[3], t2[3];
+    cross(ay, az, t0);
+    cross(az, ax, t1);
+    cross(ax, ay, t2);
+    const float det = (az[0] * t2[0]) + (az[1] * t2[1]) + (az[2] * t2[2]);
+    const float inv_det = 1.0f / det;
+    // Mat3A::inverse = from_cols(t0, t1, t2) * inv_det, transposed
+    float r0[3], r1[3], r2[3];
+    for (int i = 0; i < 3; ++i) { r0[i] = t0[i] * inv_det; r1[i] = t1[i] * inv_det; r2[i] = t2[i] * inv_det; }
+    const float c0[3] = {r0[0], r1[0], r2[0]}, c1[3] = {r0[1], r1[1], r2[1]}, c2[3] = {r0[2], r1[2], r2[2]};
+    for (int i = 0; i < 3; ++i) {
+        out->vm[i] = c0[i];
+        out->vm[3 + i] = c1[i];
+        out->vm[6 + i] = c2[i];
+        const float ip = (c0[i] * pos[0] + c1[i] * pos[1]) + c2[i] * pos[2];
+        out->vm[9 + i] = -ip;
+    }
+    out->fx = (float)(((double)img_w / 2.0) / std::tan(fov_x / 2.0));
+    out->fy = (float)(((double)img_h / 2.0) / std::tan(fov_y / 2.0));
+    out->cx = center_u * (float)img_w;
+    out->cy = center_v * (float)img_h;
+    const float wf = (float)img_w, hf = (float)img_h;
+    out->lim_pos_x = (1.15f * wf - out->cx) / out->fx;
+    out->lim_pos_y = (1.15f * hf - out->cy) / out->fy;
+    out->lim_neg_x = (-0.15f * wf - out->cx) / out->fx;
+    out->lim_neg_y = (-0.15f * hf - out->cy) / out->fy;
+    out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2];
+    out->img_w = img_w;
+    out->img_h = img_h;
+    return 0;
+}
+
+// ---- forward -------------------------------------------------------------------
+int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_degree, const float* transforms,
+                      const float* sh_coeffs, const float* raw_opacities, const float* background, uint32_t flags,
+                      BhRenderOut* out) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!cam || !out || !background) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null argument");
+    if (cam->img_w == 0 || cam->img_h == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "Can't render images with 0 size.");  // render.rs:50-53
+    if (sh_degree > 4) return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    if (n > 0 && (!transforms || !sh_coeffs || !raw_opacities)) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null splat tensor");
+    if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->have_forward = false;
+    const bool mip = flags & BH_FLAG_MIP, bwd_info = flags & BH_FLAG_BWD_INFO, smooth = flags & BH_FLAG_SMOOTH_CUTOFF;
+    const ViewUniforms u = make_uniforms(*cam);
+    const uint32_t num_tiles = u.tile_bw * u.tile_bh;
+    const size_t npad = n ? n : 1;
+
+    auto* counters = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 16);
+    auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
+    auto* isect_counts = (uint32_t*)ensure(ctx, SLOT_ISECT_COUNTS, npad * 4);
+    auto* max_radius = (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
+    if (!counters || !depth_keys || !isect_counts || !max_radius) return BH_ERR_OOM;
+
+    uint32_t nv = 0, ni = 0;
+    if (n > 0) {
+        {
+            ProfScope ps(ctx, "ProjectSplats");
+            BH_HIP(ctx, hipMemsetAsync(counters, 0, 16, ctx->stream));
+            BH_TRY(launch_project_forward(ctx, u, n, mip, transforms, raw_opacities, depth_keys, isect_counts, max_radius, counters));
+        }
+        // the one mid-pipeline readback, as render.rs:146-168
+        auto* hc = reinterpret_cast<unsigned long long*>(ctx->host_counters);
+        BH_HIP(ctx, hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
+        nv = (uint32_t)hc[0];
+        ni = (uint32_t)hc[1];
+    }
+
+    const size_t nvpad = nv ? nv : 1, nipad = ni ? ni : 1;
+    auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
+    auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
+    auto* cum = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, nvpad * 4);
+    auto* projected = (float*)ensure(ctx, SLOT_PROJECTED, nvpad * 9 * 4);
+    auto* tile_ids = (uint32_t*)ensure(ctx, SLOT_TILE_IDS, nipad * 4);
+    auto* isect_gids = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS, nipad * 4);
+    auto* tile_ids_sorted = (uint32_t*)ensure(ctx, SLOT_TILE_IDS_SORTED, nipad * 4);
+    auto* isect_gids_sorted = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS_SORTED, nipad * 4);
+    auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, (size_t)num_tiles * 2 * 4);
+    const size_t pixels = (size_t)u.img_w * u.img_h;
+    void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
+    auto* visible = (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
+    if (!gfc || !depths_sorted || !cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted ||
+        !tile_offsets || !out_img || !visible)
+        return BH_ERR_OOM;
+
+    if (n > 0) {
+        ProfScope ps(ctx, "DepthSort");
+        // culled splats carry key 0xFFFFFFFF and sort behind every visible one:
+        // the stable sort is also the (deterministic) compaction.
+        BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
+    }
+    if (nv > 0) {
+        {
+            ProfScope ps(ctx, "PrefixSumGaussHits");
+            BH_TRY(prefix_sum(ctx, isect_counts, gfc, nv, cum, false));
+        }
+        {
+            ProfScope ps(ctx, "ProjectVisible");
+            BH_TRY(launch_project_visible(ctx, u, nv, mip, sh_degree, transforms, sh_coeffs, raw_opacities, gfc, projected));
+        }
+        if (ni > 0) {
+            {
+                ProfScope ps(ctx, "MapGaussiansToIntersect");
+                BH_TRY(launch_map_gaussians(ctx, nv, u.tile_bw, u.tile_bh, projected, cum, tile_ids, isect_gids));
+            }
+            {
+                ProfScope ps(ctx, "TileSort");
+                uint32_t bits = 0;
+                while (bits < 32 && (num_tiles >> bits) != 0) bits++;  // render.rs:228
+                BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, bits, tile_ids_sorted, isect_gids_sorted));
+            }
+        }
+    }
+    {
+        ProfScope ps(ctx, "GetTileOffsets");
+        BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets));
+    }
+    {
+        ProfScope ps(ctx, "Rasterize");
+        if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, npad * 4, ctx->stream));
+        BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
+                                bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible));
+    }
+
+    BhRenderOut r{};
+    r.num_visible = nv;
+    r.num_intersections = ni;
+    r.num_tiles = num_tiles;
+    r.tile_bw = u.tile_bw;
+    r.tile_bh = u.tile_bh;
+    r.flags = flags;
+    r.out_img = bwd_info ? (float*)out_img : nullptr;
+    r.out_img_packed = bwd_info ? nullptr : (uint32_t*)out_img;
+    r.visible = bwd_info ? visible : nullptr;
+    r.max_radius = max_radius;
+    r.tile_offsets = tile_offsets;
+    r.projected = projected;
+    r.compact_gid_from_isect = isect_gids_sorted;
+    r.tile_id_from_isect = tile_ids_sorted;
+    r.global_from_compact_gid = gfc;
+    r.cum_tiles_hit = cum;
+    r.intersect_counts = isect_counts;
+    r.depths_sorted = (float*)depths_sorted;
+    *out = r;
+    ctx->last = r;
+    ctx->cam = *cam;
+    ctx->uniforms = u;
+    ctx->n = n;
+    ctx->sh_degree = sh_degree;
+    ctx->flags = flags;
+    ctx->bg[0] = background[0]; ctx->bg[1] = background[1]; ctx->bg[2] = background[2];
+    ctx->have_forward = true;
+    return 0;
+}
+
+// ---- backward ------------------------------------------------------------------
+int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
+                       const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities,
+                       float* v_refine_weight) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!ctx->have_forward || !(ctx->flags & BH_FLAG_BWD_INFO))
+        return set_error(ctx, BH_ERR_STATE, "render_backward needs a preceding BH_FLAG_BWD_INFO forward on this context");
+    if (!v_output || !v_transforms || !v_sh_coeffs || !v_raw_opacities || !v_refine_weight)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    const BhRenderOut& r = ctx->last;
+    const uint32_t n = ctx->n, nv = r.num_visible, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
+    const size_t nvpad = nv ? nv : 1;
+    auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4);
+    if (!v_combined) return BH_ERR_OOM;
+    {
+        ProfScope ps(ctx, "RasterizeBackwards");
+        BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
+        if (r.num_intersections > 0)
+            BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
+                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined));
+    }
+    {
+        ProfScope ps(ctx, "ProjectBackwards");
+        if (n > 0) {
+            // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
+            BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
+            BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
+            BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
+            BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
+        }
+        BH_TRY(launch_project_backward(ctx, ctx->uniforms, nv, ctx->flags & BH_FLAG_MIP, ctx->sh_degree, transforms, sh_coeffs,
+                                       raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
+                                       v_raw_opacities, v_refine_weight));
+    }
+    return 0;
+}
+
+const float* bh_last_v_combined(bh_ctx* ctx) { return ctx ? (const float*)ctx->slots[SLOT_V_COMBINED].ptr : nullptr; }
+
+// ---- primitives ----------------------------------------------------------------
+int bh_radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                     uint32_t* out_keys, uint32_t* out_vals) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (n > 0 && (!keys || !out_keys || !out_vals)) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return radix_argsort(ctx, keys, vals, n, bits, out_keys, out_vals);
+}
+
+int bh_prefix_sum(bh_ctx* ctx, const uint32_t* in, uint32_t n, uint32_t* out) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (n > 0 && (!in || !out)) return set_error(ctx, BH_ERR_INVALID_ARG, "prefix_sum: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return prefix_sum(ctx, in, nullptr, n, out, false);
+}
+
+int bh_image_loss_forward(bh_ctx* ctx, const float* pred_chw, const uint32_t* gt_packed, uint32_t channels, uint32_t h,
+                          uint32_t w, const BhLossConfig* cfg, float* loss_map) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!pred_chw || !gt_packed || !cfg || !loss_map || h == 0 || w == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "image_loss_forward: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_image_loss_forward(ctx, pred_chw, gt_packed, channels, h, w, *cfg, loss_map);
+}
+
+int bh_image_loss_backward(bh_ctx* ctx, const float* pred_chw, const uint32_t* gt_packed, const float* dl_dmap,
+                           uint32_t channels, uint32_t h, uint32_t w, const BhLossConfig* cfg, float* dl_dpred) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!pred_chw || !gt_packed || !dl_dmap || !cfg || !dl_dpred || h == 0 || w == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "image_loss_backward: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_image_loss_backward(ctx, pred_chw, gt_packed, dl_dmap, 0.0f, channels, h, w, *cfg, dl_dpred);
+}
+
+int bh_adam_step(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
+                 const float* col_scale, float lr, uint32_t t, int reduce_m2, float beta1, float beta2, float eps) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (rows > 0 && (!param || !grad || !m1 || !m2)) return set_error(ctx, BH_ERR_INVALID_ARG, "adam_step: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_adam(ctx, param, grad, m1, m2, rows, row_len, col_scale, lr, t, reduce_m2 != 0, beta1, beta2, eps);
+}
+
+int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
+                    const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_gather_stats(ctx, refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, n);
+}
+
+}  // extern "C"
+
+// ---- training step -------------------------------------------------------------
+namespace bh {
+
+struct ScaleTable { float v[96]; };
+
+__global__ void fill_table_kernel(float* dst, ScaleTable t, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = t.v[i];
+}
+
+__global__ void scale_kernel(float* x, uint64_t n, float s) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x[i] * s;
+}
+
+}  // namespace bh
+
+extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
+                             bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!cfg || !st || !batch || !stats) return set_error(ctx, BH_ERR_INVALID_ARG, "train_step: null argument");
+    if (!st->transforms || !st->sh_coeffs || !st->raw_opacities || !st->m1_transforms || !st->m2_transforms || !st->m1_sh ||
+        !st->m2_sh || !st->m1_opac || !st->m2_opac || !st->refine_weight_norm || !st->vis_weight || !st->max_screen_size ||
+        !batch->gt_packed)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "train_step: null state tensor");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = st->n, C = (st->sh_degree + 1) * (st->sh_degree + 1);
+    const uint32_t W = batch->camera.img_w, H = batch->camera.img_h;
+    st->step_count += 1;  // train.rs:183
+    const uint32_t step = st->step_count;
+
+    // ---- forward (train.rs:211-215)
+    BhRenderOut ro;
+    const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
+    BH_TRY(bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
+                             batch->background, flags, &ro));
+
+    // ---- loss (train.rs:227-260)
+    const bool ssim_on = cfg->ssim_weight > 0.0f;
+    BhLossConfig lc{};
+    lc.l1_weight = ssim_on ? 1.0f - cfg->ssim_weight : 1.0f;
+    lc.ssim_weight = ssim_on ? -cfg->ssim_weight : 0.0f;
+    const bool bg_nonzero = batch->background[0] != 0.0f || batch->background[1] != 0.0f || batch->background[2] != 0.0f;
+    lc.composite_bg = (batch->has_alpha && bg_nonzero) ? 1 : 0;
+    lc.bg[0] = batch->background[0]; lc.bg[1] = batch->background[1]; lc.bg[2] = batch->background[2];
+    lc.mask = batch->alpha_is_mask ? 1 : 0;
+    const bool alpha_match = batch->has_alpha && !batch->alpha_is_mask && cfg->match_alpha_weight > 0.0f;
+    const uint32_t channels = alpha_match ? 4 : 3;
+    const size_t hw = (size_t)W * H;
+    auto* loss_map = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * channels * 4);
+    auto* v_output = (float*)ensure(ctx, SLOT_V_OUTPUT, hw * 16);
+    auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
+    const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
+    auto* grads = (float*)ensure(ctx, SLOT_GRADS, (grad_count ? grad_count : 1) * 4);
+    auto* stat_buf = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 3 * 4);
+    auto* col_scale = (float*)ensure(ctx, SLOT_COL_SCALE, 256 * 4);
+    if (!loss_map || !v_output || !loss_dev || !grads || !stat_buf || !col_scale) return BH_ERR_OOM;
+    const float dl_rgb = 1.0f / (float)(hw * 3);
+    const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
+    {
+        ProfScope ps(ctx, "ImageLoss");
+        // the loss kernels read the rasterizer's [H,W,4] image in place (pixel stride 4, channel stride 1)
+        BH_TRY(launch_image_loss_forward_strided(ctx, ro.out_img, 4, 1, batch->gt_packed, channels, H, W, lc, loss_map));
+        BH_TRY(launch_sum(ctx, loss_map, hw * 3, dl_rgb, loss_dev, false));
+        if (alpha_match) BH_TRY(launch_sum(ctx, loss_map + hw * 3, hw, dl_alpha, loss_dev, true));
+    }
+    {
+        ProfScope ps(ctx, "ImageLossBackward");
+        if (channels == 3) BH_HIP(ctx, hipMemsetAsync(v_output, 0, hw * 16, ctx->stream));
+        BH_TRY(launch_image_loss_backward_strided(ctx, ro.out_img, 4, 1, batch->gt_packed, nullptr, dl_rgb, dl_alpha, channels, H, W, lc, v_output));
+    }
+
+    // ---- backward (train.rs:278)
+    float* g_tr = grads;
+    float* g_sh = grads + (size_t)n * 10;
+    float* g_op = g_sh + (size_t)n * 3 * C;
+    float* s_refine = stat_buf;
+    float* s_visible = stat_buf + n;
+    float* s_radius = stat_buf + 2 * (size_t)n;
+    BH_TRY(bh_render_backward(ctx, v_output, st->transforms, st->sh_coeffs, st->raw_opacities, g_tr, g_sh, g_op, s_refine));
+    if (n > 0) {
+        BH_HIP(ctx, hipMemcpyAsync(s_visible, ro.visible, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        BH_HIP(ctx, hipMemcpyAsync(s_radius, ro.max_radius, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // ---- data-parallel exchange (not in the reference: SURVEY.md §8e)
+    if (hook) {
+        ProfScope ps(ctx, "GradExchange");
+        const int rc = hook(hook_user, grads, grad_count, stat_buf, (uint64_t)n * 3);
+        if (rc != 0) return set_error(ctx, BH_ERR_STATE, "gradient hook failed");
+    }
+    if (grad_scale != 1.0f && grad_count > 0) {
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((grad_count + 255) / 256)), dim3(256), 0, ctx->stream, grads, (uint64_t)grad_count, grad_scale);
+        BH_LAUNCH_CHECK(ctx, "scale_kernel");
+    }
+    // ---- refine statistics (train.rs:280-298)
+    {
+        ProfScope ps(ctx, "GatherStats");
+        BH_TRY(launch_gather_stats(ctx, st->refine_weight_norm, st->vis_weight, st->max_screen_size, s_refine, s_visible, s_radius, n));
+    }
+    // ---- optimizer (train.rs:300-381)
+    const double decay = std::pow(cfg->lr_mean_end / cfg->lr_mean, 1.0 / (double)cfg->total_train_iters);
+    const double lr_mean = cfg->lr_mean * std::pow(decay, (double)((int)step - 1)) * (double)cfg->median_scene_scale;
+    {
+        ProfScope ps(ctx, "OptimizerStep");
+        ScaleTable tb{};
+        for (int i = 0; i < 3; ++i) tb.v[i] = (float)lr_mean;
+        for (int i = 3; i < 7; ++i) tb.v[i] = (float)cfg->lr_rotation;
+        for (int i = 7; i < 10; ++i) tb.v[i] = (float)cfg->lr_scale;
+        // sh: DC at full lr, bands >= 1 scaled by 1/lr_coeffs_sh_scale; one entry per (coeff, channel)
+        const float rest = 1.0f / cfg->lr_coeffs_sh_scale;
+        for (uint32_t k = 0; k < 3 * C; ++k) tb.v[10 + k] = (k / 3 == 0) ? 1.0f : rest;
+        hipLaunchKernelGGL(fill_table_kernel, dim3(1), dim3(128), 0, ctx->stream, col_scale, tb, 10 + 3 * C);
+        BH_LAUNCH_CHECK(ctx, "fill_table_kernel");
+        const float b1 = 0.9f, b2 = 0.999f, eps = 1e-15f;
+        BH_TRY(launch_adam(ctx, st->transforms, g_tr, st->m1_transforms, st->m2_transforms, n, 10, col_scale, 1.0f, step, false, b1, b2, eps));
+        BH_TRY(launch_adam(ctx, st->sh_coeffs, g_sh, st->m1_sh, st->m2_sh, n, 3 * C, col_scale + 10, (float)cfg->lr_coeffs_dc, step, true, b1, b2, eps));
+        BH_TRY(launch_adam(ctx, st->raw_opacities, g_op, st->m1_opac, st->m2_opac, n, 1, nullptr, (float)cfg->lr_opac, step, false, b1, b2, eps));
+    }
+    // ---- visibility-gated noise on the means (train.rs:389-416)
+    if (batch->noise_samples && cfg->mean_noise_weight > 0.0f) {
+        ProfScope ps(ctx, "MeanNoise");
+        BH_TRY(launch_mean_noise(ctx, st->transforms, st->raw_opacities, s_visible, batch->noise_samples, n,
+                                 (float)lr_mean * cfg->mean_noise_weight, cfg->median_scene_scale));
+    }
+    stats->num_visible = ro.num_visible;
+    stats->num_intersections = ro.num_intersections;
+    stats->lr_mean = lr_mean;
+    BH_HIP(ctx, hipMemcpyAsync(&stats->loss, loss_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}

@@ -1,0 +1,170 @@
+// context.h — internal host-side state of a bh_ctx and the kernel launcher
+// prototypes shared between the translation units of libbrush_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/brush_hip.h"
+#include "device_math.h"
+
+namespace bh {
+
+// Scratch arena: named slots that only ever grow, so the steady state of a
+// training loop performs no hipMalloc/hipFree (the reference allocates ~20
+// buffers per render, render.rs:104-268).
+enum Slot : int {
+    SLOT_COUNTERS = 0,       // [4] u32: num_visible, num_intersections
+    SLOT_DEPTH_KEYS,         // [N] u32 depth bits / sentinel
+    SLOT_ISECT_COUNTS,       // [N] u32
+    SLOT_MAX_RADIUS,         // [N] f32
+    SLOT_SORT_KEYS_A,        // ping-pong buffers for the radix sort
+    SLOT_SORT_KEYS_B,
+    SLOT_SORT_VALS_A,
+    SLOT_SORT_VALS_B,
+    SLOT_SORT_HIST,          // [256 * nblocks] u32
+    SLOT_SCAN_SUMS,          // block sums for the scan
+    SLOT_GLOBAL_FROM_COMPACT,
+    SLOT_DEPTHS_SORTED,
+    SLOT_CUM_TILES_HIT,
+    SLOT_PROJECTED,
+    SLOT_TILE_IDS,           // unsorted (tile, gid) pairs
+    SLOT_ISECT_GIDS,
+    SLOT_TILE_IDS_SORTED,
+    SLOT_ISECT_GIDS_SORTED,
+    SLOT_TILE_OFFSETS,
+    SLOT_OUT_IMG,
+    SLOT_VISIBLE,
+    SLOT_V_COMBINED,
+    SLOT_LOSS_PRED,          // train step: pred in CHW
+    SLOT_LOSS_MAP,
+    SLOT_LOSS_GRAD,          // dL/dpred CHW
+    SLOT_V_OUTPUT,           // [H,W,4]
+    SLOT_GRADS,              // fused gradient buffer
+    SLOT_STATS,              // refine | visible | radius
+    SLOT_LOSS_SCALAR,
+    SLOT_COL_SCALE,          // per-column lr tables
+    SLOT_MISC,
+    SLOT_COUNT
+};
+
+struct Buffer {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+constexpr int MAX_PROF = 32;
+
+struct Profiler {
+    bool on = false;
+    const char* names[MAX_PROF];
+    float ms[MAX_PROF];
+    uint32_t calls[MAX_PROF];
+    int count = 0;
+    // pending (start, stop) event pairs, resolved lazily at fetch / sync time
+    struct Pending { int idx; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace bh
+
+struct bh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+    bh::Buffer slots[bh::SLOT_COUNT];
+    uint32_t* host_counters = nullptr;  // pinned [4]
+    // state of the last forward (what RenderBackwards saves, bwd/burn_glue.rs:336-371)
+    bool have_forward = false;
+    BhCamera cam{};
+    bh::ViewUniforms uniforms{};
+    uint32_t n = 0, sh_degree = 0, flags = 0;
+    float bg[3] = {0, 0, 0};
+    BhRenderOut last{};
+    bh::Profiler prof;
+};
+
+namespace bh {
+
+int set_error(bh_ctx* ctx, int code, const std::string& msg);
+int check_hip(bh_ctx* ctx, hipError_t e, const char* what);
+// Grow-only allocation of a scratch slot; returns nullptr (and sets the error) on failure.
+void* ensure(bh_ctx* ctx, Slot s, size_t bytes);
+
+struct ProfScope {
+    bh_ctx* ctx;
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(bh_ctx* c, const char* name);
+    ~ProfScope();
+};
+
+#define BH_HIP(ctx, expr)                                            \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) return bh::check_hip(ctx, _e, #expr);  \
+    } while (0)
+#define BH_TRY(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc != 0) return _rc; \
+    } while (0)
+#define BH_LAUNCH_CHECK(ctx, what)                                      \
+    do {                                                                \
+        hipError_t _e = hipGetLastError();                              \
+        if (_e != hipSuccess) return bh::check_hip(ctx, _e, what);      \
+    } while (0)
+
+ViewUniforms make_uniforms(const BhCamera& c);
+
+// ---- launchers (each in its own TU) --------------------------------------------
+// project.hip
+int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, const float* transforms,
+                           const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
+                           uint32_t* counters);
+int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
+                           const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
+                           float* projected);
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* projected,
+                         const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
+int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
+                            const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
+                            const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
+                            float* v_refine);
+// sort.hip
+int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                  uint32_t* out_keys, uint32_t* out_vals);
+// scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
+int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive);
+// rasterize.hip
+int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
+                        uint32_t* tile_offsets);
+int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool bwd_info, bool smooth,
+                     const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,
+                     const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible);
+int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool smooth,
+                              const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
+                              const float* out_img, const float* v_output, float* v_combined);
+// loss.hip
+int launch_image_loss_forward(bh_ctx* ctx, const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h,
+                              uint32_t w, const BhLossConfig& cfg, float* loss_map);
+int launch_image_loss_backward(bh_ctx* ctx, const float* pred, const uint32_t* gt, const float* dl_dmap,
+                               float dl_const, uint32_t channels, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                               float* dl_dpred);
+// layout helpers used by the train step
+int launch_hwc4_to_chw(bh_ctx* ctx, const float* img_hwc4, uint32_t channels, uint32_t h, uint32_t w, float* chw);
+int launch_chw_to_hwc4(bh_ctx* ctx, const float* chw, uint32_t channels, uint32_t h, uint32_t w, float* hwc4);
+int launch_sum(bh_ctx* ctx, const float* x, uint64_t n, float scale, float* out_scalar, bool accumulate);
+// optim.hip
+int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
+                const float* col_scale, float lr, uint32_t t, bool reduce_m2, float beta1, float beta2, float eps);
+int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
+                        const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
+int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible,
+                      const float* samples, uint64_t n, float noise_scale, float clamp_abs);
+
+}  // namespace bh

@@ -1,0 +1,151 @@
+// optim.hip — AdamScaled step, refine statistics, visibility-gated mean noise.
+//
+// Reference: brush-train/src/adam_scaled.rs:75-147, stats.rs:40-50,
+// train.rs:389-416.  The reference expresses these as a few dozen burn tensor ops
+// (fused opportunistically by burn-fusion); here each is ONE pass over HBM:
+// 28 B/element for Adam (p,g,m,v read; p,m,v written), the floor for the update.
+#include "context.h"
+
+namespace bh {
+
+constexpr int OPT_WG = 256;
+
+struct AdamArgs {
+    float beta1, beta2, f1, f2, bc1, bc2, eps, lr;
+    uint32_t first;  // t == 1: initialise the moments instead of decaying them
+};
+
+BH_DEV void adam_elem(float& p, float g, float& m1, float v, const AdamArgs& a, float step) {
+    const float m1c = m1 / a.bc1;
+    const float m2c = v / a.bc2;
+    const float upd = m1c / (__builtin_sqrtf(m2c) + a.eps);
+    p = p - upd * step;
+}
+
+// full second moment: one thread per element
+__global__ __launch_bounds__(OPT_WG) void adam_full_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                          float* __restrict__ m1, float* __restrict__ m2, uint64_t count,
+                                                          uint32_t row_len, const float* __restrict__ col_scale, AdamArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
+    if (i >= count) return;
+    const float g = grad[i];
+    float mm1 = a.first ? g * a.f1 : m1[i] * a.beta1 + g * a.f1;
+    const float gsq = g * g;
+    const float mm2 = a.first ? gsq * a.f2 : m2[i] * a.beta2 + gsq * a.f2;
+    m1[i] = mm1;
+    m2[i] = mm2;
+    const float step = col_scale ? col_scale[i % row_len] * a.lr : a.lr;
+    float p = param[i];
+    adam_elem(p, g, mm1, mm2, a, step);
+    param[i] = p;
+}
+
+// second moment reduced to one scalar per row (adam_scaled.rs:99-104,152-165):
+// one thread per row, sequential sum in index order.
+__global__ __launch_bounds__(OPT_WG) void adam_rowreduced_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                                float* __restrict__ m1, float* __restrict__ m2, uint64_t rows,
+                                                                uint32_t row_len, const float* __restrict__ col_scale, AdamArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
+    if (r >= rows) return;
+    const float* g = grad + r * row_len;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < row_len; ++c) s += g[c] * g[c];
+    const float row_gsq = s / (float)row_len;
+    const float v = a.first ? row_gsq * a.f2 : m2[r] * a.beta2 + row_gsq * a.f2;
+    m2[r] = v;
+    for (uint32_t c = 0; c < row_len; ++c) {
+        const uint64_t i = r * row_len + c;
+        const float gi = g[c];
+        float mm1 = a.first ? gi * a.f1 : m1[i] * a.beta1 + gi * a.f1;
+        m1[i] = mm1;
+        const float step = col_scale ? col_scale[c] * a.lr : a.lr;
+        float p = param[i];
+        adam_elem(p, gi, mm1, v, a, step);
+        param[i] = p;
+    }
+}
+
+// compiler-rt __powisf2: the lowering of Rust's f32::powi (adam_scaled.rs:131-138)
+static float powi_f32(float a, int b) {
+    const bool recip = b < 0;
+    float r = 1.0f;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0f / r : r;
+}
+
+int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
+                const float* col_scale, float lr, uint32_t t, bool reduce_m2, float beta1, float beta2, float eps) {
+    if (rows == 0 || row_len == 0) return 0;
+    if (t == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "adam: t is 1-based");
+    AdamArgs a;
+    a.beta1 = beta1; a.beta2 = beta2;
+    a.f1 = 1.0f - beta1; a.f2 = 1.0f - beta2;
+    a.bc1 = 1.0f - powi_f32(beta1, (int)t);
+    a.bc2 = 1.0f - powi_f32(beta2, (int)t);
+    a.eps = eps; a.lr = lr;
+    a.first = t == 1 ? 1u : 0u;
+    if (reduce_m2) {
+        const uint64_t nb = (rows + OPT_WG - 1) / OPT_WG;
+        hipLaunchKernelGGL(adam_rowreduced_kernel, dim3((unsigned)nb), dim3(OPT_WG), 0, ctx->stream, param, grad, m1, m2, rows, row_len, col_scale, a);
+        BH_LAUNCH_CHECK(ctx, "adam_rowreduced_kernel");
+    } else {
+        const uint64_t count = rows * row_len;
+        const uint64_t nb = (count + OPT_WG - 1) / OPT_WG;
+        hipLaunchKernelGGL(adam_full_kernel, dim3((unsigned)nb), dim3(OPT_WG), 0, ctx->stream, param, grad, m1, m2, count, row_len, col_scale, a);
+        BH_LAUNCH_CHECK(ctx, "adam_full_kernel");
+    }
+    return 0;
+}
+
+// stats.rs:40-50
+__global__ __launch_bounds__(OPT_WG) void gather_stats_kernel(float* __restrict__ refine_weight_norm, float* __restrict__ vis_weight,
+                                                             float* __restrict__ max_screen_size, const float* __restrict__ refine_weight,
+                                                             const float* __restrict__ visible, const float* __restrict__ screen_radius,
+                                                             uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
+    if (i >= n) return;
+    refine_weight_norm[i] = __builtin_fmaxf(refine_weight[i], refine_weight_norm[i]);
+    vis_weight[i] = vis_weight[i] + visible[i];
+    max_screen_size[i] = __builtin_fmaxf(screen_radius[i], max_screen_size[i]);
+}
+
+int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
+                        const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)((n + OPT_WG - 1) / OPT_WG)), dim3(OPT_WG), 0, ctx->stream, refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, n);
+    BH_LAUNCH_CHECK(ctx, "gather_stats_kernel");
+    return 0;
+}
+
+// train.rs:389-416: means += clamp(sample * (1 - sigmoid(raw_opac))^150 * visible * scale, +-clamp_abs)
+__global__ __launch_bounds__(OPT_WG) void mean_noise_kernel(float* __restrict__ transforms, const float* __restrict__ raw_opac,
+                                                           const float* __restrict__ visible, const float* __restrict__ samples,
+                                                           uint64_t n, float noise_scale, float clamp_abs) {
+    const uint64_t i = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
+    if (i >= n) return;
+    const float inv_opac = 1.0f - sigmoid(raw_opac[i]);
+    // x^150 = x^128 * x^16 * x^4 * x^2
+    const float x2 = inv_opac * inv_opac, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32, x128 = x64 * x64;
+    const float w = clampf(x128 * x16 * x4 * x2, 0.0f, 1.0f) * visible[i];
+    const float wm = w * noise_scale;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float nz = clampf(samples[i * 3 + k] * wm, -clamp_abs, clamp_abs);
+        transforms[i * 10 + k] = transforms[i * 10 + k] + nz;
+    }
+}
+
+int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible, const float* samples,
+                      uint64_t n, float noise_scale, float clamp_abs) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mean_noise_kernel, dim3((unsigned)((n + OPT_WG - 1) / OPT_WG)), dim3(OPT_WG), 0, ctx->stream, transforms, raw_opac, visible, samples, n, noise_scale, clamp_abs);
+    BH_LAUNCH_CHECK(ctx, "mean_noise_kernel");
+    return 0;
+}
+
+}  // namespace bh

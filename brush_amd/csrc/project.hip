@@ -1,0 +1,372 @@
+// project.hip — per-splat kernels: project_forward (cull + count tiles),
+// project_visible (projected records + SH colour), map_gaussians_to_intersect
+// (emit (tile, splat) pairs) and project_backward (chain rasterizer grads back
+// to means / quats / log-scales / SH / opacity).
+//
+// Reference: brush-render/src/kernels/{project_forward,project_visible,map_gaussians}.rs,
+// brush-render/src/bwd/kernels/project_backwards.rs (paths under /root/reference/crates).
+//
+// MI355X notes: these are HBM-bound one-thread-per-splat kernels.  Where the
+// reference appends visible splats through a global atomic slot counter
+// (project_forward.rs:122-124, nondeterministic order), this build writes a
+// per-splat depth key (0xFFFFFFFF when culled) in place and lets the stable depth
+// sort do the compaction: no per-splat atomics, deterministic tie order (by id).
+#include "context.h"
+#include "device_sh.h"
+
+namespace bh {
+
+constexpr int PROJ_WG = 256;
+
+// ---------------------------------------------------------------------------
+// K1: project_forward  (kernels/project_forward.rs:22-125)
+// ---------------------------------------------------------------------------
+template <bool MIP>
+__global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
+    ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ raw_opacities,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts, float* __restrict__ max_radius,
+    unsigned long long* __restrict__ counters) {
+    const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
+    uint32_t key = 0xFFFFFFFFu;
+    uint32_t tiles_hit = 0;
+    float radius = 0.0f;
+    bool visible = false;
+    if (gid < n) {
+        const float* tr = transforms + (size_t)gid * 10;
+        do {
+            const Vec3A mean_c = world_to_cam(v3(tr[0], tr[1], tr[2]), u);
+            if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) break;
+            if (mean_c.z < 0.01f) break;
+            const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
+            if (!finite3(scl)) break;
+            const Quat qu = Quat{tr[3], tr[4], tr[5], tr[6]};
+            const float qn = qdot(qu, qu);
+            if (!(qn >= 1.0e-6f && is_finite_f32(qn))) break;
+            const float raw_opac = raw_opacities[gid];
+            if (!is_finite_f32(raw_opac)) break;
+            const Quat q = qnormalize(qu);
+            const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+            float filter_comp;
+            const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
+            const float opac = sigmoid(raw_opac) * filter_comp;
+            if (!sym2_finite(cov)) break;
+            float mx, my;
+            project_pinhole(mean_c, u, mx, my);
+            if (!(opac >= 1.0f / 255.0f)) break;
+            const float pt = bh_logf(opac * 255.0f);
+            const Sym2 conic = sym2_inverse(cov);
+            float ex, ey;
+            compute_bbox_extent(conic, pt, ex, ey);
+            if (!(ex >= 0.0f && ey >= 0.0f)) break;
+            const float wf = (float)u.img_w, hf = (float)u.img_h;
+            const bool on_screen = mx + ex > 0.0f && mx - ex < wf && my + ey > 0.0f && my - ey < hf;
+            if (!on_screen) break;
+            const TileBbox bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_bh);
+            // helpers.rs:204-223 count_contributing_tiles
+            const uint32_t bb_w = bb.max_x - bb.min_x;
+            const uint32_t nb = (bb.max_y - bb.min_y) * bb_w;
+            uint32_t tx = bb.min_x, ty = bb.min_y;
+            for (uint32_t i = 0; i < nb; ++i) {
+                if (will_primitive_contribute(tx, ty, mx, my, conic, pt)) tiles_hit++;
+                if (++tx == bb.max_x) { tx = bb.min_x; ++ty; }
+            }
+            radius = __builtin_fmaxf(ex / wf, ey / hf);
+            key = f2u(mean_c.z);
+            visible = true;
+        } while (false);
+        depth_keys[gid] = key;
+        isect_counts[gid] = tiles_hit;
+        max_radius[gid] = radius;
+    }
+    // block totals -> two global atomics per block (the reference does two per splat)
+    const unsigned long long ball = __ballot(visible);
+    uint32_t wave_hits = tiles_hit;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
+    __shared__ uint32_t s_vis[PROJ_WG / 64];
+    __shared__ uint32_t s_hit[PROJ_WG / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_vis[wave] = (uint32_t)__popcll(ball);
+        s_hit[wave] = wave_hits;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, h = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_WG / 64; ++w) { v += s_vis[w]; h += s_hit[w]; }
+        if (v) atomicAdd(&counters[0], (unsigned long long)v);
+        if (h) atomicAdd(&counters[1], (unsigned long long)h);
+    }
+}
+
+int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, const float* transforms,
+                           const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
+                           uint32_t* counters) {
+    if (n == 0) return 0;
+    const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    auto* c64 = reinterpret_cast<unsigned long long*>(counters);
+    if (mip)
+        hipLaunchKernelGGL(project_forward_kernel<true>, grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    else
+        hipLaunchKernelGGL(project_forward_kernel<false>, grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K4: project_visible  (kernels/project_visible.rs:23-88)
+// ---------------------------------------------------------------------------
+template <bool MIP, int DEG>
+__global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(
+    ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ coeffs,
+    const float* __restrict__ raw_opacities, const uint32_t* __restrict__ global_from_compact_gid,
+    float* __restrict__ projected) {
+    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    if (cg >= nv) return;
+    const uint32_t gid = global_from_compact_gid[cg];
+    const float* tr = transforms + (size_t)gid * 10;
+    const Vec3A mean = v3(tr[0], tr[1], tr[2]);
+    const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
+    const Quat q = qnormalize(Quat{tr[3], tr[4], tr[5], tr[6]});
+    const Vec3A mean_c = world_to_cam(mean, u);
+    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    float filter_comp;
+    const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
+    const float opac = sigmoid(raw_opacities[gid]) * filter_comp;
+    const Sym2 conic = sym2_inverse(cov);
+    float mx, my;
+    project_pinhole(mean_c, u, mx, my);
+    const Vec3A v = normalize(sub(mean, camera_pos(u)));
+    constexpr int C = (DEG + 1) * (DEG + 1);
+    const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
+    const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
+    float* o = projected + (size_t)cg * 9;
+    o[0] = mx;
+    o[1] = my;
+    o[2] = conic.c00;
+    o[3] = conic.c01;
+    o[4] = conic.c11;
+    o[5] = opac;
+    o[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
+    o[7] = clampf(is_finite_f32(cgc) ? cgc : 0.0f, -100.0f, 100.0f);
+    o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
+}
+
+template <bool MIP>
+static int launch_pv_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
+                         const float* ro, const uint32_t* gid, float* projected) {
+    const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    switch (deg) {
+        case 0: hipLaunchKernelGGL((project_visible_kernel<MIP, 0>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 1: hipLaunchKernelGGL((project_visible_kernel<MIP, 1>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 2: hipLaunchKernelGGL((project_visible_kernel<MIP, 2>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 3: hipLaunchKernelGGL((project_visible_kernel<MIP, 3>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 4: hipLaunchKernelGGL((project_visible_kernel<MIP, 4>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    }
+    BH_LAUNCH_CHECK(ctx, "project_visible_kernel");
+    return 0;
+}
+
+int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
+                           const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
+                           float* projected) {
+    if (nv == 0) return 0;
+    return mip ? launch_pv_deg<true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
+               : launch_pv_deg<false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
+}
+
+// ---------------------------------------------------------------------------
+// K5: map_gaussians_to_intersect  (kernels/map_gaussians.rs:15-80)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
+    uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* __restrict__ projected,
+    const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
+    uint32_t* __restrict__ compact_gid_from_isect) {
+    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    if (cg >= nv) return;
+    const float* p = projected + (size_t)cg * 9;
+    const float xy_x = p[0], xy_y = p[1];
+    const Sym2 conic = Sym2{p[2], p[3], p[4]};
+    const float pt = bh_logf(p[5] * 255.0f);
+    float ex, ey;
+    compute_bbox_extent(conic, pt, ex, ey);
+    const TileBbox bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_bh);
+    const uint32_t base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+    const uint32_t pf_count = cum_tiles_hit[cg] - base;
+    const uint32_t sentinel = tile_bw * tile_bh;
+    const uint32_t bb_w = bb.max_x - bb.min_x;
+    const uint32_t nb = (bb.max_y - bb.min_y) * bb_w;
+    uint32_t hit = 0;
+    uint32_t tx = bb.min_x, ty = bb.min_y;
+    for (uint32_t i = 0; i < nb; ++i) {
+        if (will_primitive_contribute(tx, ty, xy_x, xy_y, conic, pt) && hit < pf_count) {
+            tile_id_from_isect[base + hit] = tx + ty * tile_bw;
+            compact_gid_from_isect[base + hit] = cg;
+            hit++;
+        }
+        if (++tx == bb.max_x) { tx = bb.min_x; ++ty; }
+    }
+    // map_gaussians.rs:73-79: pad any leftover budget (cannot happen here: the count
+    // and the emit walk are the same inlined function with the same flags).
+    for (uint32_t k = hit; k < pf_count; ++k) {
+        tile_id_from_isect[base + k] = sentinel;
+        compact_gid_from_isect[base + k] = cg;
+    }
+}
+
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* projected,
+                         const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids) {
+    if (nv == 0) return 0;
+    const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, tile_bw, tile_bh, projected, cum_tiles_hit, tile_ids, isect_gids);
+    BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// K18: project_backward  (bwd/kernels/project_backwards.rs:101-254)
+// ---------------------------------------------------------------------------
+BH_DEV Quat apply_normalize_vjp(Quat q, Quat g) {
+    const float lsq = qdot(q, q);
+    const float l = __builtin_sqrtf(lsq);
+    const float inv = 1.0f / (l * lsq);
+    const float qw = q.w, qx = q.x, qy = q.y, qz = q.z;
+    const float gw = g.w, gx = g.x, gy = g.y, gz = g.z;
+    const float cc0 = -qw * qx, cc1 = -qx * qy, cc2 = -qy * qw;
+    const float cs0 = -qw * qz, cs1 = -qx * qz, cs2 = -qy * qz;
+    const float sw = qw * qw, sx = qx * qx, sy = qy * qy, sz = qz * qz;
+    return Quat{((lsq - sw) * gw + cc0 * gx + cc2 * gy + cs0 * gz) * inv,
+                (cc0 * gw + (lsq - sx) * gx + cc1 * gy + cs1 * gz) * inv,
+                (cc2 * gw + cc1 * gx + (lsq - sy) * gy + cs2 * gz) * inv,
+                (cs0 * gw + cs1 * gx + cs2 * gy + (lsq - sz) * gz) * inv};
+}
+BH_DEV Quat quat_to_mat_vjp(Quat q, const Mat3& v) {
+    const float qw = q.w, qx = q.x, qy = q.y, qz = q.z;
+    const float w_grad = qx * (v.c1z - v.c2y) + qy * (v.c2x - v.c0z) + qz * (v.c0y - v.c1x);
+    const float x_grad = -2.0f * qx * (v.c1y + v.c2z) + qy * (v.c0y + v.c1x) + qz * (v.c0z + v.c2x) + qw * (v.c1z - v.c2y);
+    const float y_grad = qx * (v.c0y + v.c1x) - 2.0f * qy * (v.c0x + v.c2z) + qz * (v.c1z + v.c2y) + qw * (v.c2x - v.c0z);
+    const float z_grad = qx * (v.c0z + v.c2x) + qy * (v.c1z + v.c2y) - 2.0f * qz * (v.c0x + v.c1y) + qw * (v.c0y - v.c1x);
+    return Quat{2.0f * w_grad, 2.0f * x_grad, 2.0f * y_grad, 2.0f * z_grad};
+}
+BH_DEV Sym2 inverse2x2_vjp(Sym2 minv, Sym2 v) {
+    const float tmp00 = -minv.c00 * v.c00 + -minv.c01 * v.c01;
+    const float tmp01 = -minv.c01 * v.c00 + -minv.c11 * v.c01;
+    const float tmp10 = -minv.c00 * v.c01 + -minv.c01 * v.c11;
+    const float tmp11 = -minv.c01 * v.c01 + -minv.c11 * v.c11;
+    return Sym2{tmp00 * minv.c00 + tmp10 * minv.c01, tmp01 * minv.c00 + tmp11 * minv.c01, tmp01 * minv.c01 + tmp11 * minv.c11};
+}
+// camera_model/pinhole.rs:59-123
+BH_DEV Vec3A projection_vjp_pinhole(const Mat2x3& jac, Vec3A mean_c, Sym3 cov_c, const ViewUniforms& u, Sym2 v_cov2d, Vec2 v_mean2d) {
+    const float fx = u.fx, fy = u.fy;
+    const float mx = mean_c.x, my = mean_c.y, mz = mean_c.z;
+    const float inv_z = 1.0f / mz;
+    const float mx_rz_raw = mx * inv_z, my_rz_raw = my * inv_z;
+    const float mx_rz = clampf(mx_rz_raw, u.lim_neg_x, u.lim_pos_x);
+    const float my_rz = clampf(my_rz_raw, u.lim_neg_y, u.lim_pos_y);
+    const bool in_x = mx_rz_raw <= u.lim_pos_x && mx_rz_raw >= u.lim_neg_x;
+    const bool in_y = my_rz_raw <= u.lim_pos_y && my_rz_raw >= u.lim_neg_y;
+    const float inv_z2 = inv_z * inv_z;
+    const float inv_z3 = inv_z2 * inv_z;
+    float v_mx = fx * inv_z * v_mean2d.x;
+    float v_my = fy * inv_z * v_mean2d.y;
+    float v_mz = -(fx * mx * v_mean2d.x + fy * my * v_mean2d.y) * inv_z2;
+    const Mat2x3 tmp = sym2_mul_mat2x3(v_cov2d, jac);
+    const float vj00 = 2.0f * dot(row0(tmp), s3row0(cov_c));
+    const float vj11 = 2.0f * dot(row1(tmp), s3row1(cov_c));
+    const float vj20 = 2.0f * dot(row0(tmp), s3row2(cov_c));
+    const float vj21 = 2.0f * dot(row1(tmp), s3row2(cov_c));
+    const float tx = mz * mx_rz;
+    const float ty = mz * my_rz;
+    if (in_x) v_mx += -fx * inv_z2 * vj20; else v_mz += -fx * inv_z3 * vj20 * tx;
+    if (in_y) v_my += -fy * inv_z2 * vj21; else v_mz += -fy * inv_z3 * vj21 * ty;
+    v_mz += -fx * inv_z2 * vj00 - fy * inv_z2 * vj11 + 2.0f * fx * tx * inv_z3 * vj20 + 2.0f * fy * ty * inv_z3 * vj21;
+    return Vec3A{v_mx, v_my, v_mz};
+}
+
+template <bool MIP, int DEG>
+__global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
+    ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ sh_coeffs,
+    const float* __restrict__ raw_opac, const uint32_t* __restrict__ global_from_compact_gid,
+    const float* __restrict__ v_combined, float* __restrict__ v_transforms, float* __restrict__ v_coeffs,
+    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight) {
+    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    if (cg >= nv) return;
+    const uint32_t gid = global_from_compact_gid[cg];
+    const float* rg = v_combined + (size_t)cg * 10;
+    float g[10];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { g[k] = rg[k]; any = any || (g[k] != 0.0f); }
+    if (!any) return;
+    const float* tr = transforms + (size_t)gid * 10;
+    const Vec3A mean = v3(tr[0], tr[1], tr[2]);
+    const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
+    const Quat qu = Quat{tr[3], tr[4], tr[5], tr[6]};
+    const Quat q = qnormalize(qu);
+    const Vec3A u_world = sub(mean, camera_pos(u));
+    const float u_len = length(u_world);
+    const Vec3A v = scale(u_world, 1.0f / u_len);
+    constexpr int C = (DEG + 1) * (DEG + 1);
+    const Vec3A v_color = v3(g[5], g[6], g[7]);
+    sh_coeffs_to_color_vjp<DEG>(v_coeffs + (size_t)gid * C * 3, v, v_color);
+    const Vec3A v_v_sh = sh_color_viewdir_vjp<DEG>(sh_coeffs + (size_t)gid * C * 3, v, v_color);
+    const float v_dot_vv = dot(v, v_v_sh);
+    const Vec3A v_mean_from_sh = scale(sub(v_v_sh, scale(v, v_dot_vv)), 1.0f / u_len);
+    const Vec3A mean_c = world_to_cam(mean, u);
+    const Mat3 r = quat_to_mat3(q);
+    const Mat3 m = mul_diag(r, scl);
+    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    float filter_comp;
+    const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
+    const float os = sigmoid(raw_opac[gid]);
+    v_raw_opac[gid] = filter_comp * g[8] * os * (1.0f - os);
+    const float refine_clean = is_finite_f32(g[9]) ? g[9] : 0.0f;
+    v_refine_weight[gid] = clampf(refine_clean, 0.0f, 1.0e32f);
+    const Sym2 conic_inv = sym2_inverse(cov);
+    const Sym2 v_inv = Sym2{g[2], g[3] * 0.5f, g[4]};
+    const Sym2 v_cov2d = inverse2x2_vjp(conic_inv, v_inv);
+    const Sym3 covar = outer_product_self(m);
+    const Mat3 view_rot = view_rotation(u);
+    const Sym3 cov_c = congruence(covar, view_rot);
+    const Mat2x3 jac = jacobian_pinhole(mean_c, u);
+    const Vec3A v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, Vec2{g[0], g[1]});
+    const Sym3 vcc = transpose_congruence_sym2(jac, v_cov2d);
+    const Vec3A v_mean = add(transpose_mul_vec3(view_rot, v_mean_c), v_mean_from_sh);
+    const Mat3 v_m = sym3_mul_mat3(sym3_scale(transpose_congruence(vcc, view_rot), 2.0f), m);
+    const Vec3A v_scale = v3(dot(col0(r), col0(v_m)) * scl.x, dot(col1(r), col1(v_m)) * scl.y, dot(col2(r), col2(v_m)) * scl.z);
+    const Quat q_grad = quat_to_mat_vjp(q, mul_diag(v_m, scl));
+    const Quat v_q = apply_normalize_vjp(qu, q_grad);
+    float* vt = v_transforms + (size_t)gid * 10;
+    vt[0] = v_mean.x; vt[1] = v_mean.y; vt[2] = v_mean.z;
+    vt[3] = v_q.w; vt[4] = v_q.x; vt[5] = v_q.y; vt[6] = v_q.z;
+    vt[7] = v_scale.x; vt[8] = v_scale.y; vt[9] = v_scale.z;
+}
+
+template <bool MIP>
+static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
+                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr) {
+    const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    switch (deg) {
+        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    }
+    BH_LAUNCH_CHECK(ctx, "project_backward_kernel");
+    return 0;
+}
+
+int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
+                            const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
+                            const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
+                            float* v_refine) {
+    if (nv == 0) return 0;
+    return mip ? launch_pb_deg<true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
+               : launch_pb_deg<false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
+}
+
+}  // namespace bh

@@ -1,0 +1,208 @@
+// sort.hip — stable LSD radix argsort of (u32 key, u32 value) pairs.
+//
+// Contract = brush_sort::radix_argsort (brush-sort/src/lib.rs:16-125): sort by the
+// low `bits` bits of the key, stable.  Only the result is contractual; the
+// reference's 4-bit FidelityFX-style passes (5 kernels per pass, kernels.rs:29-401)
+// are replaced by a wave64 design:
+//   * 8-bit digits: half the passes (4 for depth keys, 2 for <=16-bit tile ids);
+//   * per pass: histogram -> exclusive scan of the [digit][block] table -> scatter;
+//   * ranking inside a block uses wave-wide digit matching (8 ballots) so each wave
+//     ranks 64 keys per step without LDS atomics; waves own contiguous chunks so
+//     the block order is the input order (stability);
+//   * keys are re-ordered through LDS before the global write so every digit run
+//     leaves the block as one contiguous, coalesced burst.
+// HBM traffic per pass: 4 (hist read) + 8 (scatter read) + 8 (write) = 20 B/pair —
+// the algorithmic figure of SURVEY.md §8d.
+#include "context.h"
+
+namespace bh {
+
+constexpr int SORT_WG = 256;
+constexpr int SORT_WAVES = SORT_WG / 64;
+constexpr int SORT_KPT = 16;                       // keys per thread
+constexpr int SORT_TILE = SORT_WG * SORT_KPT;      // 4096 keys per block
+constexpr int RADIX = 256;
+
+// `mask` is 0xFF except in the last pass, where it keeps only the bits still
+// inside `bits` (the contract is "sort on the low `bits` bits").
+BH_DEV uint32_t digit_of(uint32_t key, uint32_t shift, uint32_t mask) { return (key >> shift) & mask; }
+
+// lanes of this wave whose digit equals mine
+BH_DEV unsigned long long match_digit(uint32_t d) {
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+// hist[digit * nblocks + block]
+__global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
+                                                            uint32_t mask, uint32_t nblocks, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[SORT_WAVES][RADIX];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_WG) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t idx = base + k * SORT_WG + tid;
+        if (idx < n) atomicAdd(&s_hist[wave][digit_of(keys[idx], shift, mask)], 1u);
+    }
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) total += s_hist[w][tid];
+    hist[(size_t)tid * nblocks + blockIdx.x] = total;
+}
+
+template <bool HAS_VALS>
+__global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                               uint32_t n, uint32_t shift, uint32_t mask, uint32_t nblocks,
+                                                               const uint32_t* __restrict__ offsets,  // exclusive scan of hist
+                                                               uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+    __shared__ uint32_t s_cnt[SORT_WAVES][RADIX];   // per-wave running digit counts -> wave bases
+    __shared__ uint32_t s_dbase[RADIX];             // exclusive scan of block digit totals
+    __shared__ uint32_t s_gofs[RADIX];              // global offset of (digit, block) minus s_dbase
+    __shared__ uint32_t s_keys[SORT_TILE];
+    __shared__ uint32_t s_vals[SORT_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_WG) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t block_base = blockIdx.x * SORT_TILE;
+    const uint32_t wave_base = block_base + wave * (64 * SORT_KPT);
+    uint32_t key[SORT_KPT], val[SORT_KPT], rank[SORT_KPT];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t idx = wave_base + k * 64 + lane;
+        const bool valid = idx < n;
+        key[k] = valid ? keys[idx] : 0xFFFFFFFFu;
+        val[k] = valid ? (HAS_VALS ? vals[idx] : idx) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        // invalid tail elements take digit 255 and sit at the highest in-block
+        // positions, so they never disturb the rank of a valid element.
+        const uint32_t idx = wave_base + k * 64 + lane;
+        const uint32_t d = idx < n ? digit_of(key[k], shift, mask) : 0xFFu;
+        const unsigned long long peers = match_digit(d);
+        const uint32_t prior = s_cnt[wave][d];
+        rank[k] = prior + (uint32_t)__popcll(peers & lt_mask);
+        // all lanes have read `prior` (one wave executes in lock-step and LDS ops
+        // retire in order) before the leader of each digit group bumps the count
+        if ((peers & lt_mask) == 0ull) s_cnt[wave][d] = prior + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    // per digit: exclusive scan over waves -> wave bases; block totals
+    uint32_t total;
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = run;
+            run += c;
+        }
+        total = run;
+    }
+    // exclusive scan of the 256 digit totals across the block
+    {
+        uint32_t incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        __shared__ uint32_t s_wsum[SORT_WAVES];
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t wofs = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) wofs += (w < wave) ? s_wsum[w] : 0u;
+        const uint32_t excl = incl - total + wofs;
+        s_dbase[tid] = excl;
+        s_gofs[tid] = offsets[(size_t)tid * nblocks + blockIdx.x] - excl;
+    }
+    __syncthreads();
+    // local reorder: position inside the block's digit-sorted tile
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t idx = wave_base + k * 64 + lane;
+        const uint32_t d = idx < n ? digit_of(key[k], shift, mask) : 0xFFu;
+        const uint32_t lpos = s_dbase[d] + s_cnt[wave][d] + rank[k];
+        s_keys[lpos] = key[k];
+        s_vals[lpos] = val[k];
+    }
+    __syncthreads();
+    const uint32_t valid_in_block = n - block_base < (uint32_t)SORT_TILE ? n - block_base : (uint32_t)SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_KPT; ++k) {
+        const uint32_t e = k * SORT_WG + tid;
+        if (e < valid_in_block) {
+            const uint32_t kk = s_keys[e];
+            const uint32_t pos = s_gofs[digit_of(kk, shift, mask)] + e;
+            out_keys[pos] = kk;
+            out_vals[pos] = s_vals[e];
+        }
+    }
+}
+
+int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                  uint32_t* out_keys, uint32_t* out_vals) {
+    if (bits > 32) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: bits must be <= 32");
+    if (n == 0) return 0;
+    const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
+    const uint32_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t bytes = (size_t)n * 4;
+    uint32_t* hist = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, (size_t)RADIX * nblocks * 4);
+    if (!hist) return BH_ERR_OOM;
+    // Ping-pong through two scratch pairs; pass 0 reads the caller's input (never
+    // written), the last pass lands in out_* unless that would alias its source
+    // (single-pass in-place call), in which case it is staged and copied.
+    uint32_t* sk[2] = {nullptr, nullptr};
+    uint32_t* sv[2] = {nullptr, nullptr};
+    const bool in_place = keys == out_keys || (vals && vals == out_vals);
+    if (passes > 1 || in_place) {
+        sk[0] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, bytes);
+        sv[0] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, bytes);
+        if (!sk[0] || !sv[0]) return BH_ERR_OOM;
+    }
+    if (passes > 2) {
+        sk[1] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_B, bytes);
+        sv[1] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_B, bytes);
+        if (!sk[1] || !sv[1]) return BH_ERR_OOM;
+    }
+    const uint32_t* src_k = keys;
+    const uint32_t* src_v = vals;
+    for (uint32_t p = 0; p < passes; ++p) {
+        const bool last = p + 1 == passes;
+        uint32_t* dst_k = sk[p & 1];
+        uint32_t* dst_v = sv[p & 1];
+        if (last && src_k != out_keys && src_v != out_vals) {
+            dst_k = out_keys;
+            dst_v = out_vals;
+        }
+        const uint32_t shift = p * 8;
+        const uint32_t rem = bits - (shift < bits ? shift : bits);
+        const uint32_t mask = rem >= 8 ? 0xFFu : ((1u << rem) - 1u);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
+        BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
+        BH_TRY(prefix_sum(ctx, hist, nullptr, RADIX * nblocks, hist, /*exclusive=*/true));
+        if (src_v)
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, dst_k, dst_v);
+        else
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, dst_k, dst_v);
+        BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    if (src_k != out_keys) BH_HIP(ctx, hipMemcpyAsync(out_keys, src_k, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (src_v != out_vals) BH_HIP(ctx, hipMemcpyAsync(out_vals, src_v, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+}  // namespace bh

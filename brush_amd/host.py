@@ -1,0 +1,540 @@
+"""Host-side mirror of the Brush operator surface over libbrush_hip.so.
+
+See brush_amd/__init__.py for the reference citations. Every function here is
+plumbing around one C-ABI call; tensors are torch CUDA(HIP) tensors used purely
+as device memory.
+"""
+import ctypes as C
+import enum
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import torch
+
+from . import _ffi
+from ._ffi import BrushHipError
+
+
+# ---------------------------------------------------------------------------
+# context
+# ---------------------------------------------------------------------------
+class Context:
+    """One bh_ctx: a HIP stream + scratch arena. Single-threaded by contract
+    (brush-async/src/lib.rs:1-17); make one per thread / per GPU."""
+
+    def __init__(self, device=None, use_torch_stream=True):
+        self.lib = _ffi.load()
+        if not torch.cuda.is_available():
+            raise BrushHipError("no HIP device visible: brush_amd has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        # submit on torch's current stream (handle 0 = the default stream) so tensor ops
+        # and brush_hip kernels are ordered without extra synchronisation
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        self._h = self.lib.bh_create(self.device.index, C.c_void_p(stream), 0 if use_torch_stream else 1)
+        if not self._h:
+            raise BrushHipError("bh_create failed on %s" % self.device)
+        self._h = C.c_void_p(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise BrushHipError("brush_hip error %d: %s" % (rc, self.lib.bh_last_error(self._h).decode()))
+
+    def sync(self):
+        self.check(self.lib.bh_sync(self._h))
+
+    def profile(self, on=True):
+        self.check(self.lib.bh_profile_enable(self._h, 1 if on else 0))
+
+    def profile_fetch(self):
+        """{stage: (total_ms, calls)} accumulated since the last fetch."""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        calls = (C.c_uint32 * cap)()
+        n = self.lib.bh_profile_fetch(self._h, names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}
+
+
+_CONTEXTS = {}
+
+
+def get_context(device=None) -> Context:
+    if not torch.cuda.is_available():
+        raise BrushHipError("no HIP device visible: brush_amd has no CPU path")
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    if idx not in _CONTEXTS:
+        _CONTEXTS[idx] = Context(torch.device("cuda", idx))
+    return _CONTEXTS[idx]
+
+
+class _DevArray:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _view(ptr, shape, dtype, device):
+    """Zero-copy torch view of ctx-owned device memory (valid until the next forward)."""
+    n = 1
+    for s in shape:
+        n *= s
+    if n == 0 or not ptr:
+        return torch.empty(shape, dtype=dtype, device=device)
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _f32c(t, device):
+    t = torch.as_tensor(t, dtype=torch.float32, device=device)
+    return t.contiguous()  # render.rs:57-59 into_contiguous
+
+
+# ---------------------------------------------------------------------------
+# Camera (brush-render/src/camera.rs)
+# ---------------------------------------------------------------------------
+@dataclass
+class Camera:
+    position: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    rotation: Tuple[float, float, float, float] = (0.0, 0.0, 0.0, 1.0)  # glam order x, y, z, w
+    fov_x: float = 1.0
+    fov_y: float = 1.0
+    center_uv: Tuple[float, float] = (0.5, 0.5)
+
+    def is_valid(self):
+        vals = list(self.position) + list(self.rotation) + [self.fov_x, self.fov_y] + list(self.center_uv)
+        return all(math.isfinite(v) for v in vals)
+
+    def uniforms(self, img_size) -> "_ffi.BhCamera":
+        """Kernel uniforms for an (img_w, img_h) render: pinhole params, 3x4 view
+        matrix, Jacobian clamp limits (camera.rs:63-101,200-254)."""
+        w, h = int(img_size[0]), int(img_size[1])
+        cam = _ffi.BhCamera()
+        pos = (C.c_float * 3)(*self.position)
+        rot = (C.c_float * 4)(*self.rotation)
+        rc = _ffi.load().bh_camera_setup(pos, rot, float(self.fov_x), float(self.fov_y), float(self.center_uv[0]),
+                                         float(self.center_uv[1]), w, h, C.byref(cam))
+        if rc != 0:
+            raise BrushHipError("bh_camera_setup failed (%d): image size must be non-zero" % rc)
+        return cam
+
+
+def fov_to_focal(fov, pixels):  # camera.rs:85-101 (pinhole)
+    return (pixels / 2.0) / math.tan(fov / 2.0)
+
+
+def focal_to_fov(focal, pixels):  # camera.rs:104-120 (pinhole)
+    return 2.0 * math.atan((pixels / 2.0) / focal)
+
+
+# ---------------------------------------------------------------------------
+# Splats (brush-render/src/gaussian_splats.rs:62-74)
+# ---------------------------------------------------------------------------
+class RasterPass(enum.Enum):
+    Forward = 0
+    Backward = 1
+    BackwardSmoothCutoff = 2
+
+    def bwd_info(self):
+        return self is not RasterPass.Forward
+
+    def smooth_cutoff(self):
+        return self is RasterPass.BackwardSmoothCutoff
+
+
+class Splats:
+    """transforms [N,10] = means(3) quat wxyz(4) log-scales(3); sh_coeffs [N,C,3];
+    raw_opacities [N] (logits)."""
+
+    def __init__(self, transforms, sh_coeffs, raw_opacities, render_mip=False, device=None):
+        device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.transforms = _f32c(transforms, device).reshape(-1, 10)
+        n = self.transforms.shape[0]
+        self.sh_coeffs = _f32c(sh_coeffs, device).reshape(n, -1, 3) if n else _f32c(sh_coeffs, device).reshape(0, 1, 3)
+        self.raw_opacities = _f32c(raw_opacities, device).reshape(n)
+        self.render_mip = bool(render_mip)
+        c = self.sh_coeffs.shape[1]
+        deg = int(round(math.sqrt(c))) - 1
+        if (deg + 1) ** 2 != c or deg > 4:
+            raise ValueError("sh_coeffs must have (d+1)^2 coefficients, d <= 4 (got %d)" % c)  # sh.rs sh_degree_from_coeffs
+        self._sh_degree = deg
+
+    @staticmethod
+    def from_tensor_data(means, rotations_wxyz, log_scales, sh_coeffs, raw_opacities, render_mip=False, device=None):
+        device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        tr = torch.cat([_f32c(means, device).reshape(-1, 3), _f32c(rotations_wxyz, device).reshape(-1, 4),
+                        _f32c(log_scales, device).reshape(-1, 3)], dim=1)
+        return Splats(tr, sh_coeffs, raw_opacities, render_mip, device)
+
+    def num_splats(self):
+        return self.transforms.shape[0]
+
+    def sh_degree(self):
+        return self._sh_degree
+
+    @property
+    def device(self):
+        return self.transforms.device
+
+    def clone(self):
+        return Splats(self.transforms.clone(), self.sh_coeffs.clone(), self.raw_opacities.clone(), self.render_mip, self.device)
+
+
+@dataclass
+class RenderAux:
+    """RenderAux (brush-render/src/render_aux.rs:17-68) + the tensors saved for backward."""
+    num_visible: int
+    num_intersections: int
+    img_size: Tuple[int, int]
+    visible: Optional[torch.Tensor]
+    max_radius: torch.Tensor
+    tile_offsets: torch.Tensor
+    projected_splats: torch.Tensor
+    compact_gid_from_isect: torch.Tensor
+    tile_id_from_isect: torch.Tensor
+    global_from_compact_gid: torch.Tensor
+    cum_tiles_hit: torch.Tensor
+    intersect_counts: torch.Tensor
+    depths_sorted: torch.Tensor
+
+    def validate(self, num_splats):
+        # render_aux.rs:30-45
+        tiles = self.tile_offsets.shape[0]
+        assert self.num_visible <= num_splats
+        assert self.num_intersections <= max(self.num_visible, 1) * max(tiles, 1)
+
+
+def _forward(ctx, splats, camera, img_size, background, pass_):
+    if img_size[0] <= 0 or img_size[1] <= 0:
+        raise BrushHipError("Can't render images with 0 size.")  # render.rs:50-53
+    cam = camera if isinstance(camera, _ffi.BhCamera) else camera.uniforms(img_size)
+    flags = (_ffi.FLAG_MIP if splats.render_mip else 0)
+    if pass_.bwd_info():
+        flags |= _ffi.FLAG_BWD_INFO
+    if pass_.smooth_cutoff():
+        flags |= _ffi.FLAG_SMOOTH_CUTOFF
+    out = _ffi.BhRenderOut()
+    bg = (C.c_float * 3)(*[float(b) for b in background])
+    n = splats.num_splats()
+    ctx.check(ctx.lib.bh_render_forward(ctx._h, C.byref(cam), n, splats.sh_degree(), _ptr(splats.transforms), _ptr(splats.sh_coeffs),
+                                        _ptr(splats.raw_opacities), bg, flags, C.byref(out)))
+    return cam, out
+
+
+def _aux_from(out, n, w, h, device, copy):
+    nv, ni, T = out.num_visible, out.num_intersections, out.num_tiles
+    i32, f32 = torch.int32, torch.float32
+
+    def mk(ptr, shape, dt):
+        v = _view(ptr, shape, dt, device)
+        return v.clone() if copy else v
+    return RenderAux(
+        num_visible=nv, num_intersections=ni, img_size=(w, h),
+        visible=mk(out.visible, (n,), f32) if out.visible else None,
+        max_radius=mk(out.max_radius, (n,), f32),
+        tile_offsets=mk(out.tile_offsets, (T, 2), i32),
+        projected_splats=mk(out.projected, (nv, 9), f32),
+        compact_gid_from_isect=mk(out.compact_gid_from_isect, (ni,), i32),
+        tile_id_from_isect=mk(out.tile_id_from_isect, (ni,), i32),
+        global_from_compact_gid=mk(out.global_from_compact_gid, (nv,), i32),
+        cum_tiles_hit=mk(out.cum_tiles_hit, (nv,), i32),
+        intersect_counts=mk(out.intersect_counts, (n,), i32),
+        depths_sorted=mk(out.depths_sorted, (nv,), f32),
+    )
+
+
+def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), pass_: RasterPass = RasterPass.Forward,
+                  ctx: Optional[Context] = None, copy=True):
+    """Forward render. RasterPass.Forward returns a packed rgba8 image [H,W] (int32
+    bit pattern, r in bits 0-7); the Backward variants return f32 [H,W,4].
+    Returns (image, RenderAux). With copy=False the tensors alias ctx scratch
+    memory and are only valid until the next render on `ctx`."""
+    ctx = ctx or get_context(splats.device)
+    w, h = int(img_size[0]), int(img_size[1])
+    _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
+    if pass_.bwd_info():
+        img = _view(out.out_img, (h, w, 4), torch.float32, splats.device)
+    else:
+        img = _view(out.out_img_packed, (h, w), torch.int32, splats.device)
+    if copy:
+        img = img.clone()
+    return img, _aux_from(out, splats.num_splats(), w, h, splats.device, copy)
+
+
+def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pass_: RasterPass = RasterPass.Backward,
+                      ctx: Optional[Context] = None):
+    """Differentiable render: forward (Backward pass flags) + backward for a given
+    dL/d(out_img) `v_output` [H,W,4] (a tensor, or a callable img -> v_output).
+    Returns dict(img, aux, v_transforms, v_sh_coeffs, v_raw_opacities, v_refine_weight, v_combined)."""
+    assert pass_.bwd_info(), "render_splats_bwd requires a Backward variant"  # bwd/burn_glue.rs:281-284
+    ctx = ctx or get_context(splats.device)
+    w, h = int(img_size[0]), int(img_size[1])
+    dev = splats.device
+    _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
+    img = _view(out.out_img, (h, w, 4), torch.float32, dev).clone()
+    aux = _aux_from(out, splats.num_splats(), w, h, dev, True)
+    if callable(v_output):
+        v_output = v_output(img)
+    v_output = _f32c(v_output, dev).reshape(h, w, 4)
+    n, c = splats.num_splats(), splats.sh_coeffs.shape[1]
+    v_t = torch.empty((n, 10), dtype=torch.float32, device=dev)
+    v_sh = torch.empty((n, c, 3), dtype=torch.float32, device=dev)
+    v_op = torch.empty((n,), dtype=torch.float32, device=dev)
+    v_rf = torch.empty((n,), dtype=torch.float32, device=dev)
+    ctx.check(ctx.lib.bh_render_backward(ctx._h, _ptr(v_output), _ptr(splats.transforms), _ptr(splats.sh_coeffs), _ptr(splats.raw_opacities),
+                                         _ptr(v_t), _ptr(v_sh), _ptr(v_op), _ptr(v_rf)))
+    vc = _view(ctx.lib.bh_last_v_combined(ctx._h), (max(out.num_visible, 1), 10), torch.float32, dev).clone()
+    return dict(img=img, aux=aux, v_transforms=v_t, v_sh_coeffs=v_sh, v_raw_opacities=v_op, v_refine_weight=v_rf, v_combined=vc)
+
+
+# ---------------------------------------------------------------------------
+# primitives
+# ---------------------------------------------------------------------------
+def _as_u32(t, device):
+    t = torch.as_tensor(t, device=device)
+    if t.dtype not in (torch.int32, torch.uint32):
+        t = t.to(torch.int64).to(torch.int32) if t.dtype != torch.int64 else (t & 0xFFFFFFFF).to(torch.int32)
+    return t.contiguous()
+
+
+def radix_argsort(keys, values=None, sorting_bits=32, ctx: Optional[Context] = None):
+    """Stable argsort of u32 keys (int32 bit patterns) on their low `sorting_bits`
+    bits; returns (sorted_keys, sorted_values). brush-sort/src/lib.rs:16-33 asserts."""
+    dev = keys.device if isinstance(keys, torch.Tensor) and keys.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or get_context(dev)
+    k = _as_u32(keys, dev)
+    if k.dim() != 1:
+        raise BrushHipError("radix_argsort: keys must be 1-D")
+    v = None
+    if values is not None:
+        v = _as_u32(values, dev)
+        if v.shape != k.shape:
+            raise BrushHipError("radix_argsort: input keys and values must have the same number of elements")
+    if sorting_bits > 32:
+        raise BrushHipError("radix_argsort: can only sort up to 32 bits")
+    ok, ov = torch.empty_like(k), torch.empty_like(k)
+    ctx.check(ctx.lib.bh_radix_argsort(ctx._h, _ptr(k), _ptr(v) if v is not None else None, k.numel(), int(sorting_bits), _ptr(ok), _ptr(ov)))
+    return ok, ov
+
+
+def prefix_sum(x, ctx: Optional[Context] = None):
+    """Inclusive u32 prefix sum (brush-prefix-sum/src/lib.rs:11)."""
+    dev = x.device if isinstance(x, torch.Tensor) and x.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or get_context(dev)
+    a = _as_u32(x, dev)
+    o = torch.empty_like(a)
+    ctx.check(ctx.lib.bh_prefix_sum(ctx._h, _ptr(a), a.numel(), _ptr(o)))
+    return o
+
+
+def _loss_cfg(l1_weight, ssim_weight, composite_bg, mask):
+    cfg = _ffi.BhLossConfig()
+    cfg.l1_weight, cfg.ssim_weight = float(l1_weight), float(ssim_weight)
+    bg = composite_bg if composite_bg is not None else (0.0, 0.0, 0.0)
+    cfg.bg[0], cfg.bg[1], cfg.bg[2] = [float(b) for b in bg]
+    cfg.composite_bg = 1 if composite_bg is not None else 0
+    cfg.mask = 1 if mask else 0
+    return cfg
+
+
+def image_loss(pred_hwc, gt_packed, l1_weight=0.8, ssim_weight=-0.2, composite_bg=None, mask=False, ctx: Optional[Context] = None):
+    """Per-pixel l1_w*|pred-gt| + ssim_w*SSIM loss map [H,W,C] (C=3, or 4 with the
+    alpha-match plane); gt_packed [H,W] rgba8 as int32. brush-loss/src/lib.rs:1075-1104."""
+    dev = pred_hwc.device
+    ctx = ctx or get_context(dev)
+    h, w, c = pred_hwc.shape
+    pred_chw = pred_hwc.permute(2, 0, 1).contiguous().float()  # lib.rs:1076
+    gt = _as_u32(gt_packed, dev).reshape(h, w)
+    out = torch.empty_like(pred_chw)
+    cfg = _loss_cfg(l1_weight, ssim_weight, composite_bg, mask)
+    ctx.check(ctx.lib.bh_image_loss_forward(ctx._h, _ptr(pred_chw), _ptr(gt), c, h, w, C.byref(cfg), _ptr(out)))
+    return out.permute(1, 2, 0).contiguous()
+
+
+def image_loss_backward(pred_hwc, gt_packed, dl_dmap_hwc, l1_weight=0.8, ssim_weight=-0.2, composite_bg=None, mask=False,
+                        ctx: Optional[Context] = None):
+    dev = pred_hwc.device
+    ctx = ctx or get_context(dev)
+    h, w, c = pred_hwc.shape
+    pred_chw = pred_hwc.permute(2, 0, 1).contiguous().float()
+    dl = dl_dmap_hwc.permute(2, 0, 1).contiguous().float()
+    gt = _as_u32(gt_packed, dev).reshape(h, w)
+    out = torch.empty_like(pred_chw)
+    cfg = _loss_cfg(l1_weight, ssim_weight, composite_bg, mask)
+    ctx.check(ctx.lib.bh_image_loss_backward(ctx._h, _ptr(pred_chw), _ptr(gt), _ptr(dl), c, h, w, C.byref(cfg), _ptr(out)))
+    return out.permute(1, 2, 0).contiguous()
+
+
+def adam_step(param, grad, m1, m2, lr, t, col_scale=None, reduce_m2=False, beta1=0.9, beta2=0.999, eps=1e-15, ctx: Optional[Context] = None):
+    """In-place AdamScaled step on a [rows, ...] parameter (adam_scaled.rs:75-147)."""
+    ctx = ctx or get_context(param.device)
+    rows = param.shape[0]
+    row_len = param.numel() // rows if rows else 1
+    ctx.check(ctx.lib.bh_adam_step(ctx._h, _ptr(param), _ptr(grad), _ptr(m1), _ptr(m2), rows, row_len,
+                                   _ptr(col_scale) if col_scale is not None else None, float(lr), int(t), int(bool(reduce_m2)),
+                                   float(beta1), float(beta2), float(eps)))
+
+
+# ---------------------------------------------------------------------------
+# training (brush-train)
+# ---------------------------------------------------------------------------
+@dataclass
+class TrainConfig:
+    """Subset of brush-train/src/config.rs:7-132 that defines step(); same defaults."""
+    total_train_iters: int = 30000
+    lr_mean: float = 2e-5
+    lr_mean_end: float = 2e-7
+    lr_coeffs_dc: float = 2e-3
+    lr_coeffs_sh_scale: float = 10.0
+    lr_opac: float = 0.012
+    lr_scale: float = 5e-3
+    lr_rotation: float = 2e-3
+    ssim_weight: float = 0.2
+    match_alpha_weight: float = 0.1
+    mean_noise_weight: float = 50.0
+    background_color: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    background_noise_strength: float = 0.1
+    render_mip: bool = False
+
+
+@dataclass
+class SceneBatch:
+    """brush-dataset/src/scene.rs:139-147: packed rgba8 GT [H,W] + camera."""
+    img_packed: torch.Tensor
+    camera: Camera
+    has_alpha: bool = False
+    alpha_is_mask: bool = False
+
+    def img_size(self):
+        return tuple(self.img_packed.shape)  # (h, w)
+
+
+@dataclass
+class TrainStepStats:
+    num_visible: int
+    num_intersections: int
+    lr_mean: float
+    loss: float
+
+
+class SplatTrainer:
+    """SplatTrainer::{new, step} (brush-train/src/train.rs:140-429). Owns the three
+    Adam states and the RefineRecord; `step` runs forward, L1+SSIM loss, backward,
+    statistics, Adam and the optional mean noise inside one C-ABI call.
+
+    Data parallel (not in the reference): pass `process_group` and the
+    per-rank gradients are summed with torch.distributed all_reduce (RCCL over xGMI)
+    between backward and Adam and scaled by 1/world; refine/visibility statistics are
+    MAX-reduced. Every rank then applies the identical update."""
+
+    def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None):
+        self.config = config
+        self.median_scene_scale = float(median_scene_scale)
+        self.step_count = 0
+        self.state = None
+        self.ctx = ctx
+        self.pg = process_group
+        self._hook = None
+        self.generator = None
+
+    def _init_state(self, splats: Splats):
+        dev = splats.device
+        n = splats.num_splats()
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.state = dict(m1_t=z(n, 10), m2_t=z(n, 10), m1_sh=z(*splats.sh_coeffs.shape), m2_sh=z(n), m1_o=z(n), m2_o=z(n),
+                          refine_weight_norm=z(n), vis_weight=z(n), max_screen_size=z(n))
+
+    def sample_background(self, rng=None):
+        # train.rs:896-908: base + U(-s, s)^3, clamped to [0,1]
+        s = self.config.background_noise_strength
+        base = self.config.background_color
+        if s <= 0.0 or rng is None:
+            return tuple(base)
+        return tuple(min(1.0, max(0.0, b + (rng.random() * 2.0 - 1.0) * s)) for b in base)
+
+    def _make_hook(self, dev):
+        import torch.distributed as dist
+        pg = self.pg
+        world = dist.get_world_size(pg)
+
+        def hook(_user, grads_ptr, grad_count, stats_ptr, stats_count):
+            try:
+                g = _view(grads_ptr, (int(grad_count),), torch.float32, dev)
+                s = _view(stats_ptr, (int(stats_count),), torch.float32, dev)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=pg)
+                dist.all_reduce(s, op=dist.ReduceOp.MAX, group=pg)
+                return 0
+            except Exception:  # never unwind across the C boundary
+                return 1
+        self._world = world
+        return _ffi.GRAD_HOOK(hook)
+
+    def step(self, batch: SceneBatch, splats: Splats, background=None, noise_samples=None) -> Tuple[Splats, TrainStepStats]:
+        """One optimisation step, in place on `splats`. `background` / `noise_samples`
+        [N,3] inject the two stochastic terms; None = base colour / no noise."""
+        ctx = self.ctx or get_context(splats.device)
+        dev = splats.device
+        if self.state is None:
+            self._init_state(splats)
+        cfg = _ffi.BhTrainConfig()
+        c = self.config
+        cfg.lr_mean, cfg.lr_mean_end, cfg.total_train_iters = c.lr_mean, c.lr_mean_end, c.total_train_iters
+        cfg.lr_coeffs_dc, cfg.lr_coeffs_sh_scale, cfg.lr_opac = c.lr_coeffs_dc, c.lr_coeffs_sh_scale, c.lr_opac
+        cfg.lr_scale, cfg.lr_rotation, cfg.ssim_weight = c.lr_scale, c.lr_rotation, c.ssim_weight
+        cfg.match_alpha_weight, cfg.mean_noise_weight = c.match_alpha_weight, c.mean_noise_weight
+        cfg.background[0], cfg.background[1], cfg.background[2] = c.background_color
+        cfg.median_scene_scale = self.median_scene_scale
+        cfg.render_mip = 1 if (c.render_mip or splats.render_mip) else 0
+        s = self.state
+        st = _ffi.BhTrainState()
+        st.n, st.sh_degree = splats.num_splats(), splats.sh_degree()
+        st.transforms, st.sh_coeffs, st.raw_opacities = splats.transforms.data_ptr(), splats.sh_coeffs.data_ptr(), splats.raw_opacities.data_ptr()
+        st.m1_transforms, st.m2_transforms = s["m1_t"].data_ptr(), s["m2_t"].data_ptr()
+        st.m1_sh, st.m2_sh = s["m1_sh"].data_ptr(), s["m2_sh"].data_ptr()
+        st.m1_opac, st.m2_opac = s["m1_o"].data_ptr(), s["m2_o"].data_ptr()
+        st.refine_weight_norm, st.vis_weight, st.max_screen_size = s["refine_weight_norm"].data_ptr(), s["vis_weight"].data_ptr(), s["max_screen_size"].data_ptr()
+        st.step_count = self.step_count
+        h, w = batch.img_size()
+        b = _ffi.BhTrainBatch()
+        b.camera = batch.camera if isinstance(batch.camera, _ffi.BhCamera) else batch.camera.uniforms((w, h))
+        gt = _as_u32(batch.img_packed, dev)
+        b.gt_packed = gt.data_ptr()
+        b.has_alpha, b.alpha_is_mask = int(batch.has_alpha), int(batch.alpha_is_mask)
+        bg = background if background is not None else c.background_color
+        b.background[0], b.background[1], b.background[2] = [float(v) for v in bg]
+        ns = None
+        if noise_samples is not None:
+            ns = _f32c(noise_samples, dev).reshape(-1, 3)
+            b.noise_samples = ns.data_ptr()
+        stats = _ffi.BhTrainStats()
+        hook, scale = None, 1.0
+        if self.pg is not None:
+            if self._hook is None:
+                self._hook = self._make_hook(dev)
+            hook, scale = self._hook, 1.0 / self._world
+        ctx.check(ctx.lib.bh_train_step(ctx._h, C.byref(cfg), C.byref(st), C.byref(b), C.cast(hook, C.c_void_p) if hook else None, None,
+                                        float(scale), C.byref(stats)))
+        self.step_count = st.step_count
+        self._last_stats = stats
+        self._keep = (gt, ns)
+        return splats, stats
+
+    def stats(self, ctx=None) -> TrainStepStats:
+        """Resolve the stats of the last step (synchronises)."""
+        (ctx or self.ctx or get_context()).sync()
+        s = self._last_stats
+        return TrainStepStats(s.num_visible, s.num_intersections, s.lr_mean, s.loss)

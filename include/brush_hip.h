@@ -1,0 +1,230 @@
+/* brush_hip.h — C ABI of libbrush_hip.so: the MI355X (gfx950) implementation of
+ * Brush's differentiable splat rasterizer + training step.
+ *
+ * This is the drop-in boundary.  Brush (Rust) has no C ABI at this level; its
+ * de-facto operator API for the hot path is a set of Rust traits/functions on
+ * burn tensor primitives.  Each entry point below replaces the body of one of
+ * them (paths relative to /root/reference/crates/):
+ *
+ *   bh_render_forward   <- <MainBackendBase as SplatOps>::render
+ *                          brush-render/src/lib.rs:55-77, render.rs:37-314
+ *   bh_render_backward  <- SplatBwdOps::{rasterize_bwd, project_bwd}
+ *                          brush-render/src/bwd/burn_glue.rs:62-92, bwd/render_bwd.rs:21-171
+ *   bh_radix_argsort    <- brush_sort::radix_argsort          brush-sort/src/lib.rs:16-125
+ *   bh_prefix_sum       <- brush_prefix_sum::prefix_sum       brush-prefix-sum/src/lib.rs:11-93
+ *   bh_image_loss_*     <- LossOps::{image_loss_forward, image_loss_backward}
+ *                          brush-loss/src/lib.rs:718-733 (kernels :181, :371)
+ *   bh_adam_step        <- AdamScaled::step                   brush-train/src/adam_scaled.rs:75-147
+ *   bh_gather_stats     <- RefineRecord::gather_stats         brush-train/src/stats.rs:40-50
+ *   bh_train_step       <- SplatTrainer::step                 brush-train/src/train.rs:176-429
+ *   bh_camera_setup     <- Camera::{build_pinhole_params, world_to_local},
+ *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-101,200-254
+ *
+ * Conventions (following the reference's only C ABI, apps/brush-c/src/lib.rs:109-163):
+ *   - every function returns 0 on success, <0 on error; nothing throws or
+ *     aborts across the boundary; bh_last_error(ctx) gives a host string;
+ *   - all pointers are HIP device pointers unless the parameter says "host";
+ *   - tensors use the reference's layouts: transforms [N,10] = mean(3),
+ *     quat (w,x,y,z) un-normalised (4), log-scale (3); sh_coeffs [N,C,3];
+ *     raw_opacities [N] (logits); projected [Nv,9] = xy, conic(3), alpha, rgb;
+ *   - a bh_ctx owns one HIP stream and a scratch arena and is single-threaded;
+ *     distinct contexts may be used from distinct threads (trainer vs viewer,
+ *     one per GPU) — the reference's Actor/stream-per-thread contract
+ *     (brush-async/src/lib.rs:1-17);
+ *   - calls are asynchronous on the ctx stream except bh_render_forward (it
+ *     reads the visible/intersection counts back, like render.rs:146-168),
+ *     bh_train_step (calls it) and bh_sync.
+ */
+#ifndef BRUSH_HIP_H
+#define BRUSH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bh_ctx bh_ctx;
+
+/* Error codes */
+enum {
+    BH_OK = 0,
+    BH_ERR_INVALID_ARG = -1,
+    BH_ERR_HIP = -2,
+    BH_ERR_OOM = -3,
+    BH_ERR_STATE = -4,
+    BH_ERR_UNSUPPORTED = -5
+};
+
+/* Render flags (RasterPass + SplatRenderMode, gaussian_splats.rs:17-48) */
+enum {
+    BH_FLAG_MIP = 1,           /* SplatRenderMode::Mip */
+    BH_FLAG_BWD_INFO = 2,      /* RasterPass::Backward: f32 RGBA out + visible[] + tile-end shrink */
+    BH_FLAG_SMOOTH_CUTOFF = 4  /* RasterPass::BackwardSmoothCutoff (test-only C^1 alpha cutoff) */
+};
+
+/* Host-side view uniforms = ProjectUniforms (kernels/types.rs:53-81) without the
+ * per-launch counters.  Pinhole only (the other camera models are SURVEY §8f). */
+typedef struct BhCamera {
+    float vm[12]; /* world-to-camera 3x4, column-major: col0(x,y,z) col1 col2 translation */
+    float fx, fy, cx, cy;
+    float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y; /* Jacobian clamp limits */
+    float cam_pos[3];
+    uint32_t img_w, img_h;
+} BhCamera;
+
+/* Forward outputs = RenderOutput + RenderAuxInner (render_aux.rs:17-68) and the
+ * state saved for backward (bwd/burn_glue.rs:336-371).  Device pointers are owned
+ * by the ctx and stay valid until the next bh_render_forward on the same ctx or
+ * bh_destroy. */
+typedef struct BhRenderOut {
+    uint32_t num_visible;       /* host scalars */
+    uint32_t num_intersections;
+    uint32_t num_tiles, tile_bw, tile_bh;
+    uint32_t flags;
+    float* out_img;                    /* [H,W,4] f32 (BH_FLAG_BWD_INFO) else NULL */
+    uint32_t* out_img_packed;          /* [H,W] rgba8 (forward-only) else NULL */
+    float* visible;                    /* [N] 1.0 where the splat touched a pixel (BWD_INFO) */
+    float* max_radius;                 /* [N] screen radius as a fraction of the image */
+    uint32_t* tile_offsets;            /* [T,2] start,end into the isect list */
+    float* projected;                  /* [Nv,9] */
+    uint32_t* compact_gid_from_isect;  /* [I] sorted by (tile, depth) */
+    uint32_t* tile_id_from_isect;      /* [I] sorted */
+    uint32_t* global_from_compact_gid; /* [Nv] splat ids front-to-back */
+    uint32_t* cum_tiles_hit;           /* [Nv] inclusive scan of per-splat tile counts */
+    uint32_t* intersect_counts;        /* [N] tiles hit per splat (0 when culled) */
+    float* depths_sorted;              /* [Nv] */
+} BhRenderOut;
+
+/* ---- context ------------------------------------------------------------- */
+/* own_stream != 0: the ctx creates (and owns) a non-blocking stream; `stream` is
+ * ignored.  own_stream == 0: submit on the caller's `stream` (a hipStream_t; NULL
+ * is the device's default stream), e.g. the host framework's current stream. */
+bh_ctx* bh_create(int device, void* stream, int own_stream);
+void bh_destroy(bh_ctx* ctx);
+const char* bh_last_error(bh_ctx* ctx); /* host string, valid until the next call */
+int bh_sync(bh_ctx* ctx);
+const char* bh_version(void);
+
+/* ---- camera (host only) --------------------------------------------------- */
+/* pos[3], rot_xyzw[4] (glam order), fov in radians (f64 like camera.rs), centre in uv. */
+int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u,
+                    float center_v, uint32_t img_w, uint32_t img_h, BhCamera* out /*host*/);
+
+/* ---- render ---------------------------------------------------------------- */
+int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uint32_t sh_degree,
+                      const float* transforms, const float* sh_coeffs, const float* raw_opacities,
+                      const float* background /*host [3]*/, uint32_t flags, BhRenderOut* out /*host*/);
+
+/* Backward of the last BH_FLAG_BWD_INFO forward on this ctx.  v_output [H,W,4].
+ * All four outputs are dense and fully overwritten (zero where the splat got no
+ * gradient).  v_refine_weight replaces the reference's "gradient of a dummy [1]
+ * tensor" side channel (bwd/burn_glue.rs:165-180). */
+int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
+                       const float* raw_opacities, float* v_transforms /*[N,10]*/, float* v_sh_coeffs /*[N,C,3]*/,
+                       float* v_raw_opacities /*[N]*/, float* v_refine_weight /*[N]*/);
+/* [Nv,10] rasterize-backward accumulator of the last bh_render_backward (RasterizeGrads). */
+const float* bh_last_v_combined(bh_ctx* ctx);
+
+/* ---- primitives ------------------------------------------------------------ */
+/* Stable LSD argsort on the low `bits` bits; vals may be NULL (= 0..n-1). */
+int bh_radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                     uint32_t* out_keys, uint32_t* out_vals);
+/* Inclusive prefix sum (wrapping u32). in == out allowed. */
+int bh_prefix_sum(bh_ctx* ctx, const uint32_t* in, uint32_t n, uint32_t* out);
+
+/* ---- image loss ------------------------------------------------------------ */
+typedef struct BhLossConfig {
+    float l1_weight, ssim_weight;
+    float bg[3];
+    int32_t composite_bg; /* gt_eff = gt + (1 - gt.a) * bg */
+    int32_t mask;         /* loss *= gt.a */
+} BhLossConfig;
+/* pred [C,H,W] (C = 3, or 4 for the alpha-match plane), gt_packed [H,W] rgba8, loss_map [C,H,W]. */
+int bh_image_loss_forward(bh_ctx* ctx, const float* pred_chw, const uint32_t* gt_packed, uint32_t channels,
+                          uint32_t h, uint32_t w, const BhLossConfig* cfg /*host*/, float* loss_map);
+int bh_image_loss_backward(bh_ctx* ctx, const float* pred_chw, const uint32_t* gt_packed, const float* dl_dmap,
+                           uint32_t channels, uint32_t h, uint32_t w, const BhLossConfig* cfg /*host*/,
+                           float* dl_dpred);
+
+/* ---- optimizer / stats ----------------------------------------------------- */
+/* One AdamScaled step on a [rows,row_len] parameter.  t = state.time after this
+ * step (1 on the first call: moments are initialised, not decayed).  col_scale
+ * [row_len] device or NULL.  reduce_m2 != 0: second moment is one scalar per row
+ * (m2 has `rows` entries).  beta1=.9 beta2=.999 eps=1e-15 in the reference. */
+int bh_adam_step(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows,
+                 uint32_t row_len, const float* col_scale, float lr, uint32_t t, int reduce_m2, float beta1,
+                 float beta2, float eps);
+int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
+                    const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
+
+/* ---- training step ---------------------------------------------------------- */
+/* TrainConfig subset that defines step() (brush-train/src/config.rs:7-132). */
+typedef struct BhTrainConfig {
+    double lr_mean, lr_mean_end;  /* 2e-5 -> 2e-7 over total_train_iters */
+    uint32_t total_train_iters;   /* 30000 */
+    double lr_coeffs_dc;          /* 2e-3 */
+    float lr_coeffs_sh_scale;     /* 10: bands >= 1 use lr/10 */
+    double lr_opac;               /* 0.012 */
+    double lr_scale;              /* 5e-3 */
+    double lr_rotation;           /* 2e-3 */
+    float ssim_weight;            /* 0.2 */
+    float match_alpha_weight;     /* 0.1 */
+    float mean_noise_weight;      /* 50; 0 disables the noise term */
+    float background[3];          /* base background colour */
+    float median_scene_scale;     /* bounds.median_size() */
+    int32_t render_mip;
+} BhTrainConfig;
+
+/* Parameters + optimizer state of one model replica, all device memory owned
+ * by the caller (Splats + SplatOptim + RefineRecord). */
+typedef struct BhTrainState {
+    uint32_t n, sh_degree;
+    float* transforms;    /* [N,10] */
+    float* sh_coeffs;     /* [N,C,3] */
+    float* raw_opacities; /* [N] */
+    float* m1_transforms; float* m2_transforms; /* [N,10] each */
+    float* m1_sh; float* m2_sh;                 /* [N,C,3], [N] (reduced) */
+    float* m1_opac; float* m2_opac;             /* [N] each */
+    float* refine_weight_norm; float* vis_weight; float* max_screen_size; /* [N] each */
+    uint32_t step_count; /* number of steps already taken (host; incremented by the call) */
+} BhTrainState;
+
+typedef struct BhTrainBatch {
+    BhCamera camera;
+    const uint32_t* gt_packed; /* [H,W] rgba8 device */
+    int32_t has_alpha;
+    int32_t alpha_is_mask;
+    /* Stochastic terms are injected so a step is reproducible (the reference draws
+     * them from burn's GPU PRNG / rand::rng(), train.rs:395-399,896-908): */
+    float background[3];       /* background actually used this step */
+    const float* noise_samples; /* [N,3] N(0,1) device, or NULL = no noise */
+} BhTrainBatch;
+
+typedef struct BhTrainStats {
+    uint32_t num_visible, num_intersections;
+    double lr_mean;
+    float loss; /* valid after bh_sync */
+} BhTrainStats;
+
+/* Gradient hook: called (if non-NULL) after the backward and before Adam with the
+ * fused gradient buffer [N*(10 + 3C + 1)] (v_transforms | v_sh | v_raw_opac) and the
+ * stats buffer [3N] (refine_weight | visible | max_radius) so a data-parallel
+ * caller can all-reduce them (SUM / MAX) on the ctx stream.  Return 0. */
+typedef int (*bh_grad_hook)(void* user, float* grads, uint64_t grad_count, float* stats, uint64_t stats_count);
+
+int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
+                  const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
+                  BhTrainStats* stats /*host*/);
+
+/* ---- profiling --------------------------------------------------------------- */
+/* When enabled, each pipeline stage is bracketed by HIP events on the ctx stream. */
+int bh_profile_enable(bh_ctx* ctx, int on);
+/* Fetch (and clear) accumulated per-stage milliseconds and launch counts; returns
+ * the number of stages written (<= cap).  names[i] are static strings. */
+int bh_profile_fetch(bh_ctx* ctx, const char** names /*host*/, float* ms /*host*/, uint32_t* calls /*host*/, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRUSH_HIP_H */
