@@ -1,0 +1,121 @@
+"""radix_argsort / prefix_sum on the GPU vs the oracle, with the reference's own test
+vectors (brush-sort/src/lib.rs:154-339, brush-prefix-sum/src/lib.rs:105-196). Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(ba, dev, keys, vals, bits=32):
+    k = torch.from_numpy(keys.view(np.int32)).to(dev)
+    v = torch.from_numpy(vals.view(np.int32)).to(dev) if vals is not None else None
+    ok, ov = ba.radix_argsort(k, v, bits)
+    return util.u32(ok), util.u32(ov)
+
+
+def test_sorting_reference_small(dev):
+    import brush_amd as ba
+    for i in range(128):
+        keys = np.array([5 + i * 4, i, 6, 123, 74657, 123, 999, 2 ** 24 + 123, 6, 7, 8, 0, i * 2, 16 + i, 128 * i], np.uint32)
+        vals = keys * 2 + 5
+        ok, ov = _sort(ba, dev, keys, vals)
+        idx = np.argsort(keys, kind="stable")
+        assert np.array_equal(ok, keys[idx]) and np.array_equal(ov, vals[idx])
+
+
+def test_sorting_big_gaussian_like(dev, oracle_lib):
+    """lib.rs:203-241: overlapping runs like per-tile splat ids."""
+    import brush_amd as ba
+    rng = np.random.default_rng(0)
+    keys = []
+    for i in range(10000):
+        start = rng.integers(i, i + 150)
+        end = rng.integers(start, start + 250)
+        r = np.arange(start, end)
+        keys.append(r[rng.random(r.size) < 0.5])
+    keys = np.concatenate(keys).astype(np.uint32)
+    vals = keys * 2 + 5
+    ok, ov = _sort(ba, dev, keys, vals)
+    rk, rv = oracle_lib.radix_argsort(keys, vals, 32)
+    assert np.array_equal(ok, rk) and np.array_equal(ov, rv)
+
+
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 32), (64, 7), (4095, 32), (4096, 16), (4097, 13), (123457, 32), (3_000_001, 13), (5_000_000, 32)])
+def test_sorting_sizes_bits_and_stability(dev, oracle_lib, n, bits):
+    import brush_amd as ba
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    if n > 1000:
+        keys[: n // 2] &= 0xFF  # many duplicates -> stability matters
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov = _sort(ba, dev, keys, vals, bits)
+    rk, rv = oracle_lib.radix_argsort(keys, vals, bits)
+    assert np.array_equal(ov, rv) and np.array_equal(ok, rk)
+
+
+def test_sorting_implicit_values_and_inplace(dev):
+    import brush_amd as ba
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2 ** 20, 70001, dtype=np.uint64).astype(np.uint32)
+    ok, ov = _sort(ba, dev, keys, None, 20)
+    idx = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok, keys[idx]) and np.array_equal(ov, idx.astype(np.uint32))
+
+
+def test_sorting_large_30m(dev):
+    """lib.rs:243-287: 30 M random keys < 1e6, values = indices."""
+    import brush_amd as ba
+    n = 30_000_000
+    g = torch.Generator(device="cpu").manual_seed(1)
+    keys = torch.randint(0, 1_000_000, (n,), generator=g, dtype=torch.int32)
+    k = keys.to(dev)
+    ok, ov = ba.radix_argsort(k, None, 32)
+    assert bool((ok[1:] >= ok[:-1]).all())
+    assert bool((k[ov.long()] == ok).all()), "values point at their keys"
+    # stability: equal keys keep ascending original index
+    same = ok[1:] == ok[:-1]
+    assert bool((ov[1:][same] > ov[:-1][same]).all())
+
+
+def test_sorting_70m_permutation(dev):
+    """lib.rs:289-339 regression (>67 M keys): a permutation sorts to the identity."""
+    import brush_amd as ba
+    n = 70_000_000
+    g = torch.Generator(device=dev).manual_seed(7)
+    perm = torch.randperm(n, generator=g, device=dev, dtype=torch.int32)
+    ok, ov = ba.radix_argsort(perm, None, 32)
+    assert bool((ok == torch.arange(n, device=dev, dtype=torch.int32)).all())
+    assert bool((perm[ov.long()] == ok).all())
+
+
+@pytest.mark.parametrize("n", [1, 4, 1024, 4096, 4097, 512 * 16 * 5 + 615, 1_000_003])
+def test_prefix_sum_sizes(dev, oracle_lib, n):
+    import brush_amd as ba
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 40000, n).astype(np.uint32)
+    o = util.u32(ba.prefix_sum(torch.from_numpy(x.view(np.int32)).to(dev)))
+    assert np.array_equal(o, oracle_lib.prefix_sum(x))
+
+
+def test_prefix_sum_large_30m(dev):
+    """brush-prefix-sum/src/lib.rs:162-188"""
+    import brush_amd as ba
+    n = 30_000_000
+    x = (torch.arange(n, dtype=torch.int64) % 100).to(torch.int32)
+    o = ba.prefix_sum(x.to(dev))
+    ref = torch.cumsum(x.to(torch.int64), 0)
+    for idx in (0, 1000, 10_000, 100_000, 1_000_000, 10_000_000, 19_999_999, n - 1):
+        assert int(o[idx].item()) & 0xFFFFFFFF == int(ref[idx].item()) & 0xFFFFFFFF
+
+
+def test_sort_argument_errors(dev):
+    """brush-sort/src/lib.rs:21-33 asserts -> errors, not crashes."""
+    import brush_amd as ba
+    k = torch.zeros(10, dtype=torch.int32, device=dev)
+    with pytest.raises(ba.BrushHipError):
+        ba.radix_argsort(k, torch.zeros(9, dtype=torch.int32, device=dev), 32)
+    with pytest.raises(ba.BrushHipError):
+        ba.radix_argsort(k, None, 33)
