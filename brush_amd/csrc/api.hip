@@ -339,8 +339,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets));
     }
     {
-        ProfScope ps(ctx, "Rasterize");
         if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, npad * 4, ctx->stream));
+        ProfScope ps(ctx, "Rasterize");
         BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
                                 bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible));
     }
@@ -392,14 +392,8 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4);
     if (!v_combined) return BH_ERR_OOM;
     {
-        ProfScope ps(ctx, "RasterizeBackwards");
+        ProfScope ps(ctx, "ZeroGradBuffers");
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
-        if (r.num_intersections > 0)
-            BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
-                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined));
-    }
-    {
-        ProfScope ps(ctx, "ProjectBackwards");
         if (n > 0) {
             // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
             BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
@@ -407,6 +401,15 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
             BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
             BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
         }
+    }
+    {
+        ProfScope ps(ctx, "RasterizeBackwards");
+        if (r.num_intersections > 0)
+            BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
+                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined));
+    }
+    {
+        ProfScope ps(ctx, "ProjectBackwards");
         BH_TRY(launch_project_backward(ctx, ctx->uniforms, nv, ctx->flags & BH_FLAG_MIP, ctx->sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
                                        v_raw_opacities, v_refine_weight));

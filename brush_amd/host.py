@@ -14,6 +14,7 @@ import torch
 
 from . import _ffi
 from ._ffi import BrushHipError
+from .parallel import allreduce_step_buffers
 
 
 # ---------------------------------------------------------------------------
@@ -475,8 +476,7 @@ class SplatTrainer:
             try:
                 g = _view(grads_ptr, (int(grad_count),), torch.float32, dev)
                 s = _view(stats_ptr, (int(stats_count),), torch.float32, dev)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=pg)
-                dist.all_reduce(s, op=dist.ReduceOp.MAX, group=pg)
+                allreduce_step_buffers(g, s, pg)
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1

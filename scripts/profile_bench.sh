@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + separate PMC passes of bench.py.
+# Usage: scripts/profile_bench.sh <tag>   -> gpurun_out/prof_<tag>/
+TAG=${1:-r1}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
+echo "trace exit $?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.err
+echo "fetch exit $?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $CMD > $OUT/bench_write.json 2> $OUT/write.err
+echo "write exit $?"
+find $OUT -name "*.csv" | head -20
+# keep only the small summaries (the raw kernel trace can be large)
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
+du -sh $OUT

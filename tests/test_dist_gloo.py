@@ -1,0 +1,65 @@
+"""N > 1 path on CPU: world_size-2 gloo process group (no GPU needed).
+Checks the collective semantics the data-parallel train step relies on (SUM of the fused
+gradient buffer, MAX of the statistics, identical result on every rank) and the view
+sharding used by bench.py / SplatTrainer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brush_amd.parallel import allreduce_step_buffers, view_for_rank
+    n, C = 1000, 4
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(n * (10 + 3 * C + 1), generator=g)
+    stats = torch.rand(n * 3, generator=g)
+    mine_g, mine_s = grads.clone(), stats.clone()
+    w = allreduce_step_buffers(grads, stats)
+    views = [view_for_rank(s, rank, world, 8) for s in range(4)]
+    q.put((rank, w, mine_g.numpy(), mine_s.numpy(), grads.numpy(), stats.numpy(), views))
+    dist.destroy_process_group()
+
+
+def test_allreduce_semantics_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, g0, s0, rg0, rs0, v0), (_, w1, g1, s1, rg1, rs1, v1) = res
+    assert w0 == w1 == 2
+    assert np.array_equal(rg0, rg1) and np.array_equal(rs0, rs1), "every rank holds the same reduced buffers"
+    assert np.allclose(rg0, g0 + g1, rtol=0, atol=1e-6)
+    assert np.array_equal(rs0, np.maximum(s0, s1))
+    # one pass over 8 views with 2 ranks x 4 steps visits every view exactly once
+    assert sorted(v0 + v1) == list(range(8))
+
+
+def test_view_sharding_properties():
+    from brush_amd.parallel import view_for_rank
+    for world in (1, 2, 4, 8):
+        seen = [view_for_rank(s, r, world, 16) for s in range(16 // world) for r in range(world)]
+        assert sorted(seen) == list(range(16))
+    assert view_for_rank(5, 0, 1, 3) == 2
