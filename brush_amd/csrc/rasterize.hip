@@ -61,8 +61,13 @@ struct RasterUniforms {
     float bg_r, bg_g, bg_b;
 };
 
-constexpr int SPLAT_STRIDE = 12;  // floats per staged splat (9 used): 16-B aligned rows
+// One staged splat = 12 floats (48 B, 16-B aligned rows):
+//   [0..3] x y c00 c01   [4..7] c11 alpha max(r,0) max(g,0)   [8] max(b,0)
+//   [9] sigma_cut  (conservative bound: alpha can only reach the cutoff where sigma <= sigma_cut)
+//   [10] colour gate bits (raw r/g/b >= 0)   [11] compact gid
+constexpr int SPLAT_STRIDE = 12;
 constexpr int BATCH = 64;
+constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend (~1e-7)
 
 // exp(x) for the blend loop: the bh_expf sequence without its range guards
 // (x <= 0 wherever the result is used; underflow goes to 0 through ldexp).
@@ -89,18 +94,34 @@ BH_DEV uint32_t tile_of_block(uint32_t b, uint32_t num_tiles) {
 }
 
 // Stage one batch of up to 64 splats of this tile into LDS (lane i stages splat i).
+// Everything that is per-splat rather than per-pixel is done here once by the
+// staging lane: colour clamp (rasterize.rs:147-149), the gate bits of the backward
+// and the conservative sigma bound used for the wave-uniform quadrant skip.
+template <bool SMOOTH>
 BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float* __restrict__ projected,
                             uint32_t batch_start, uint32_t cnt, int lane, float* s_splat) {
     uint32_t cg = 0;
     if ((uint32_t)lane < cnt) {
         cg = isect_gids[batch_start + lane];
         const float* p = projected + (size_t)cg * 9;
-        float* d = s_splat + lane * SPLAT_STRIDE;
+        float v[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) d[k] = p[k];
+        for (int k = 0; k < 9; ++k) v[k] = p[k];
+        const float thr = SMOOTH ? (ALPHA_CUTOFF_MID - 0.5f * ALPHA_CUTOFF_BAND) : ALPHA_CUTOFF_MID;
+        const float cut = __builtin_fmaxf(bh_logf(v[5] / thr) + SIGMA_CUT_MARGIN, 0.0f);
+        const uint32_t gate = (v[6] >= 0.0f ? 1u : 0u) | (v[7] >= 0.0f ? 2u : 0u) | (v[8] >= 0.0f ? 4u : 0u);
+        float4* d = reinterpret_cast<float4*>(s_splat + lane * SPLAT_STRIDE);
+        d[0] = make_float4(v[0], v[1], v[2], v[3]);
+        d[1] = make_float4(v[4], v[5], __builtin_fmaxf(v[6], 0.0f), __builtin_fmaxf(v[7], 0.0f));
+        d[2] = make_float4(__builtin_fmaxf(v[8], 0.0f), cut, u2f(gate), u2f(cg));
     }
     return cg;
 }
+
+// Pixel layout of the one wave that owns a 16x16 tile: lane l covers (l&7, l>>3)
+// inside each of the four 8x8 quadrants q (qx = q&1, qy = q>>1).  A quadrant is the
+// skip unit: if no live pixel of it can reach the alpha cutoff for this splat
+// (sigma test, before the exp) the whole wave steps over it with one scalar branch.
 
 // ---------------------------------------------------------------------------
 // K16: rasterize (kernels/rasterize.rs:27-190)
@@ -116,60 +137,65 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
     if (tile >= u.num_tiles) return;
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
-    const uint32_t px = tx0 + (lane & 15);
-    const uint32_t py0 = ty0 + (lane >> 4);
-    const float pcx = (float)px + 0.5f;
-    float pcy[4];
-    bool done[4];
-    float t_acc[4], pr[4], pg[4], pb[4];
+    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
+    const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
+    const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
+    // transmittance; a finished pixel keeps its final T with the sign flipped
+    float tr[4], pr[4], pg[4], pb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t py = py0 + 4 * j;
-        pcy[j] = (float)py + 0.5f;
-        done[j] = !(px < u.img_w && py < u.img_h);
-        t_acc[j] = 1.0f;
-        pr[j] = pg[j] = pb[j] = 0.0f;
+    for (int q = 0; q < 4; ++q) {
+        const bool inside = (px0 + 8 * (q & 1)) < u.img_w && (py0 + 8 * (q >> 1)) < u.img_h;
+        tr[q] = inside ? 1.0f : -1.0f;
+        pr[q] = pg[q] = pb[q] = 0.0f;
     }
     const uint32_t range_lo = tile_offsets[tile * 2];
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
     uint32_t last_useful = range_lo;
 
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
-        const bool all_done = done[0] && done[1] && done[2] && done[3];
-        if (__ballot(!all_done) == 0ull) break;
+        const bool live = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+        if (__ballot(live) == 0ull) break;
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
         __syncthreads();  // previous batch fully consumed (single wave: cheap)
-        const uint32_t cg = stage_batch(isect_gids, projected, batch_start, cnt, lane, s_splat);
+        const uint32_t cg = stage_batch<SMOOTH>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
         for (uint32_t t = 0; t < cnt; ++t) {
             const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00 c01
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11 a r g
-            const float sb = s_splat[t * SPLAT_STRIDE + 8];
-            const float dx = pcx - s0.x;
-            const float a_xx = (s0.z * dx) * dx;
-            const float b_x = s0.w * dx;
+            const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut
+            const uint32_t cut_bits = f2u(s2.y);
+            float a_xx[2], b_x[2], c_y[2], dy[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float dx = pcx[k] - s0.x;
+                a_xx[k] = (s0.z * dx) * dx;
+                b_x[k] = s0.w * dx;
+                dy[k] = pcy[k] - s0.y;
+                c_y[k] = s1.x * dy[k];
+            }
             bool any = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dy = pcy[j] - s0.y;
-                const float q = __builtin_fmaf(s1.x * dy, dy, a_xx);
-                const float sigma = __builtin_fmaf(b_x, dy, 0.5f * q);
-                const float alpha = __builtin_fminf(0.999f, s1.y * exp_blend(-sigma));
-                const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
-                if (!done[j] && sigma >= 0.0f && w_cut > 0.0f) {
-                    const float alpha_eff = alpha * w_cut;
-                    const float next_t = t_acc[j] * (1.0f - alpha_eff);
-                    if (next_t <= 1.0e-4f) {
-                        done[j] = true;
-                    } else {
-                        const float vis = alpha_eff * t_acc[j];
-                        pr[j] += __builtin_fmaxf(s1.z, 0.0f) * vis;
-                        pg[j] += __builtin_fmaxf(s1.w, 0.0f) * vis;
-                        pb[j] += __builtin_fmaxf(sb, 0.0f) * vis;
-                        t_acc[j] = next_t;
-                        any = true;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int k = q & 1, m = q >> 1;
+                const float qv = __builtin_fmaf(c_y[m], dy[m], a_xx[k]);
+                const float sigma = __builtin_fmaf(b_x[k], dy[m], 0.5f * qv);
+                // live pixel and 0 <= sigma <= sigma_cut (unsigned compare of the bit patterns)
+                const bool pre = tr[q] > 0.0f && f2u(sigma) <= cut_bits;
+                if (__ballot(pre) != 0ull) {
+                    const float alpha = __builtin_fminf(0.999f, s1.y * exp_blend(-sigma));
+                    const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
+                    const bool ok = pre && w_cut > 0.0f;  // pre already implies sigma >= 0
+                    const float alpha_eff = SMOOTH ? alpha * w_cut : alpha;
+                    const float next_t = tr[q] * (1.0f - alpha_eff);
+                    const bool sat = next_t <= 1.0e-4f;
+                    const bool contrib = ok && !sat;
+                    const float vis = contrib ? alpha_eff * tr[q] : 0.0f;
+                    pr[q] += s1.z * vis;
+                    pg[q] += s1.w * vis;
+                    pb[q] += s2.x * vis;
+                    tr[q] = ok ? (sat ? -tr[q] : next_t) : tr[q];
+                    any = any || contrib;
                 }
             }
             if (BWD_INFO) {
@@ -186,13 +212,14 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
     }
 
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t py = py0 + 4 * j;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
         if (px < u.img_w && py < u.img_h) {
-            const float fr = pr[j] + t_acc[j] * u.bg_r;
-            const float fg = pg[j] + t_acc[j] * u.bg_g;
-            const float fb = pb[j] + t_acc[j] * u.bg_b;
-            const float fa = 1.0f - t_acc[j];
+            const float tf = __builtin_fabsf(tr[q]);
+            const float fr = pr[q] + tf * u.bg_r;
+            const float fg = pg[q] + tf * u.bg_g;
+            const float fb = pb[q] + tf * u.bg_b;
+            const float fa = 1.0f - tf;
             const size_t pix = (size_t)px + (size_t)py * u.img_w;
             if (BWD_INFO) {
                 *reinterpret_cast<float4*>(&out_img[pix * 4]) = make_float4(fr, fg, fb, fa);
@@ -233,10 +260,29 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
 // ---------------------------------------------------------------------------
 // K17: rasterize_backwards (bwd/kernels/rasterize_backwards.rs:101-390)
 // ---------------------------------------------------------------------------
-BH_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// Wave-wide sum of ten per-lane values in 28 VALU ops (a ds_bpermute butterfly
+// needs 60 LDS permutes + 60 adds): v_permlane32_swap / v_permlane16_swap fold two
+// registers into one per step ("transpose-reduce"), then a DPP rotate-add finishes
+// inside each 16-lane row.  Afterwards every lane of row r of k[i] holds component
+// comp(i, r): k0 -> g0 g2 g1 g3, k1 -> g4 g6 g5 g7, k2 -> g8 - g9 -.
+BH_DEV float swap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(f2u(a), f2u(b), false, false);
+    return u2f(r[0]) + u2f(r[1]);
+}
+BH_DEV float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(f2u(a), f2u(b), false, false);
+    return u2f(r[0]) + u2f(r[1]);
+}
+template <int CTRL>
+BH_DEV float dpp_rot_add(float x) {
+    return x + u2f(__builtin_amdgcn_update_dpp(0u, f2u(x), CTRL, 0xF, 0xF, false));
+}
+BH_DEV float row_allreduce(float x) {
+    x = dpp_rot_add<0x128>(x);  // row_ror:8
+    x = dpp_rot_add<0x124>(x);  // row_ror:4
+    x = dpp_rot_add<0x122>(x);  // row_ror:2
+    x = dpp_rot_add<0x121>(x);  // row_ror:1
+    return x;
 }
 
 template <bool SMOOTH>
@@ -254,109 +300,131 @@ __global__ __launch_bounds__(64) void rasterize_backward_kernel(RasterUniforms u
     if (range_hi <= range_lo) return;
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
-    const uint32_t px = tx0 + (lane & 15);
-    const uint32_t py0 = ty0 + (lane >> 4);
-    const float pcx = (float)px + 0.5f;
+    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
+    const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
+    const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
     const float img_w_f = (float)u.img_w, img_h_f = (float)u.img_h;
-    float pcy[4];
-    // pixel replay state (rasterize_backwards.rs:186-228): remaining rgb and T
+    // which reduced component this lane adds to v_combined (see the reduction above)
+    const int ri = lane & 15, row = lane >> 4;
+    const int comp = ri * 4 + (((row & 1) << 1) | (row >> 1));
+    const bool atom_lane = ri < 3 && comp < 10;
+    // pixel replay state (rasterize_backwards.rs:186-228): remaining rgb and T (0 = finished)
     float sx[4], sy[4], sz[4], sw[4];
-    float vox[4], voy[4], voz[4], v_o_w[4], fa_c[4];
+    float vox[4], voy[4], voz[4], v_o_w[4], inv_fa[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t py = py0 + 4 * j;
-        pcy[j] = (float)py + 0.5f;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
         if (px < u.img_w && py < u.img_h) {
             const size_t pix = ((size_t)px + (size_t)py * u.img_w) * 4;
             const float4 o = *reinterpret_cast<const float4*>(&out_img[pix]);
             const float4 vo = *reinterpret_cast<const float4*>(&v_output[pix]);
             const float t_final = 1.0f - o.w;
-            sx[j] = o.x - t_final * u.bg_r;
-            sy[j] = o.y - t_final * u.bg_g;
-            sz[j] = o.z - t_final * u.bg_b;
-            sw[j] = 1.0f;
-            vox[j] = vo.x; voy[j] = vo.y; voz[j] = vo.z;
-            v_o_w[j] = (vo.w - (u.bg_r * vo.x + u.bg_g * vo.y + u.bg_b * vo.z)) * t_final;
-            fa_c[j] = __builtin_fmaxf(o.w, 1.0e-5f);
+            sx[q] = o.x - t_final * u.bg_r;
+            sy[q] = o.y - t_final * u.bg_g;
+            sz[q] = o.z - t_final * u.bg_b;
+            sw[q] = 1.0f;
+            vox[q] = vo.x; voy[q] = vo.y; voz[q] = vo.z;
+            v_o_w[q] = (vo.w - (u.bg_r * vo.x + u.bg_g * vo.y + u.bg_b * vo.z)) * t_final;
+            inv_fa[q] = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
         } else {
-            sx[j] = sy[j] = sz[j] = sw[j] = 0.0f;
-            vox[j] = voy[j] = voz[j] = v_o_w[j] = 0.0f;
-            fa_c[j] = 1.0f;
+            sx[q] = sy[q] = sz[q] = sw[q] = 0.0f;
+            vox[q] = voy[q] = voz[q] = v_o_w[q] = 0.0f;
+            inv_fa[q] = 1.0f;
         }
     }
 
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
         __syncthreads();
-        const uint32_t cg_mine = stage_batch(isect_gids, projected, batch_start, cnt, lane, s_splat);
+        stage_batch<SMOOTH>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
         for (uint32_t t = 0; t < cnt; ++t) {
-            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);
-            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);
-            const float sb = s_splat[t * SPLAT_STRIDE + 8];
+            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00 c01
+            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11 a r g (clamped)
+            const float4 s2 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b cut gate gid
             const float c00 = s0.z, c01 = s0.w, c11 = s1.x, color_a = s1.y;
-            const float cr = __builtin_fmaxf(s1.z, 0.0f), cgc = __builtin_fmaxf(s1.w, 0.0f), cb = __builtin_fmaxf(sb, 0.0f);
-            const float dxp = pcx - s0.x;   // pixel - mean (forward convention)
-            const float a_xx = (c00 * dxp) * dxp;
-            const float b_x = c01 * dxp;
-            const float dx = s0.x - pcx;    // mean - pixel (backward convention, rasterize_backwards.rs:300-301)
+            const float cr = s1.z, cgc = s1.w, cb = s2.x;
+            const uint32_t cut_bits = f2u(s2.y);
+            float dxp[2], dyp[2], a_xx[2], b_x[2], c_y[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                dxp[k] = pcx[k] - s0.x;  // pixel - mean (forward convention)
+                a_xx[k] = (c00 * dxp[k]) * dxp[k];
+                b_x[k] = c01 * dxp[k];
+                dyp[k] = pcy[k] - s0.y;
+                c_y[k] = c11 * dyp[k];
+            }
             float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f, g9 = 0.f;
             bool any = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dyp = pcy[j] - s0.y;
-                const float q = __builtin_fmaf(c11 * dyp, dyp, a_xx);
-                const float sigma = __builtin_fmaf(b_x, dyp, 0.5f * q);
-                const float gaussian = exp_blend(-sigma);
-                const float alpha = __builtin_fminf(0.999f, color_a * gaussian);
-                const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
-                if (sw[j] > 1.0e-4f && sigma >= 0.0f && w_cut > 0.0f) {
-                    const float alpha_eff = alpha * w_cut;
-                    const float next_t = sw[j] * (1.0f - alpha_eff);
-                    if (next_t <= 1.0e-4f) {
-                        sw[j] = 0.0f;
-                    } else {
-                        const float dy = s0.y - pcy[j];
-                        const float vis = alpha_eff * sw[j];
-                        g5 += s1.z >= 0.0f ? vis * vox[j] : 0.0f;
-                        g6 += s1.w >= 0.0f ? vis * voy[j] : 0.0f;
-                        g7 += sb >= 0.0f ? vis * voz[j] : 0.0f;
-                        const float ra = 1.0f / (1.0f - alpha_eff);
-                        const float dot_rgb = ((sw[j] * cr - sx[j]) * vox[j] + (sw[j] * cgc - sy[j]) * voy[j] + (sw[j] * cb - sz[j]) * voz[j]) * ra;
-                        const float v_alpha_eff = dot_rgb + v_o_w[j] * ra;
-                        const float dw = SMOOTH ? alpha_cutoff_weight_deriv(alpha) : 0.0f * alpha;
-                        const float v_alpha = v_alpha_eff * (w_cut + alpha * dw);
-                        const float v_sigma = -alpha * v_alpha;
-                        const float vxy_x = v_sigma * (c00 * dx + c01 * dy);
-                        const float vxy_y = v_sigma * (c01 * dx + c11 * dy);
-                        if (color_a * gaussian <= 0.999f) {
-                            g2 += 0.5f * v_sigma * dx * dx;
-                            g3 += v_sigma * dx * dy;
-                            g4 += 0.5f * v_sigma * dy * dy;
-                            g0 += vxy_x;
-                            g1 += vxy_y;
-                            g8 += v_alpha * gaussian;
-                            const float len = __builtin_sqrtf(vxy_x * img_w_f * vxy_x * img_w_f + vxy_y * img_h_f * vxy_y * img_h_f);
-                            g9 += len / fa_c[j];
-                        }
-                        sx[j] = sx[j] - vis * cr;
-                        sy[j] = sy[j] - vis * cgc;
-                        sz[j] = sz[j] - vis * cb;
-                        sw[j] = next_t;
-                        any = true;
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int k = q & 1, m = q >> 1;
+                // --- replay: identical arithmetic to the forward kernel -------------
+                const float qv = __builtin_fmaf(c_y[m], dyp[m], a_xx[k]);
+                const float sigma = __builtin_fmaf(b_x[k], dyp[m], 0.5f * qv);
+                const bool pre = sw[q] > 0.0f && f2u(sigma) <= cut_bits;
+                if (__ballot(pre) != 0ull) {
+                    const float gaussian = exp_blend(-sigma);
+                    const float alpha_raw = color_a * gaussian;
+                    const float alpha = __builtin_fminf(0.999f, alpha_raw);
+                    const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
+                    const bool ok = pre && w_cut > 0.0f;  // pre already implies sigma >= 0
+                    const float alpha_eff = SMOOTH ? alpha * w_cut : alpha;
+                    const float one_m = 1.0f - alpha_eff;
+                    const float next_t = sw[q] * one_m;
+                    const bool sat = next_t <= 1.0e-4f;
+                    const bool contrib = ok && !sat;
+                    const float T = sw[q];
+                    const float vis = contrib ? alpha_eff * T : 0.0f;
+                    // --- gradients (rasterize_backwards.rs:286-381); tolerance-checked, so
+                    //     explicit fma / v_rcp / v_sqrt are used freely here ------------------
+                    g5 = __builtin_fmaf(vis, vox[q], g5);
+                    g6 = __builtin_fmaf(vis, voy[q], g6);
+                    g7 = __builtin_fmaf(vis, voz[q], g7);
+                    const float ra = __builtin_amdgcn_rcpf(one_m);
+                    float dot_rgb = __builtin_fmaf(T, cr, -sx[q]) * vox[q];
+                    dot_rgb = __builtin_fmaf(__builtin_fmaf(T, cgc, -sy[q]), voy[q], dot_rgb);
+                    dot_rgb = __builtin_fmaf(__builtin_fmaf(T, cb, -sz[q]), voz[q], dot_rgb);
+                    const float v_alpha_eff = (dot_rgb + v_o_w[q]) * ra;
+                    const float dw = SMOOTH ? alpha_cutoff_weight_deriv(alpha) : 0.0f;
+                    const float v_alpha = SMOOTH ? v_alpha_eff * (w_cut + alpha * dw) : v_alpha_eff;
+                    // geometry / opacity / refine grads only below the alpha clamp (…:332)
+                    const bool geo = contrib && alpha_raw <= 0.999f;
+                    const float v_sigma = geo ? -alpha * v_alpha : 0.0f;
+                    const float dx = -dxp[k], dy = -dyp[m];  // mean - pixel (…:300-301)
+                    const float vxy_x = v_sigma * __builtin_fmaf(c01, dy, c00 * dx);
+                    const float vxy_y = v_sigma * __builtin_fmaf(c11, dy, c01 * dx);
+                    const float hs = 0.5f * v_sigma;
+                    g2 = __builtin_fmaf(hs * dx, dx, g2);
+                    g3 = __builtin_fmaf(v_sigma * dx, dy, g3);
+                    g4 = __builtin_fmaf(hs * dy, dy, g4);
+                    g0 += vxy_x;
+                    g1 += vxy_y;
+                    g8 += geo ? v_alpha * gaussian : 0.0f;
+                    const float wx = vxy_x * img_w_f, wy = vxy_y * img_h_f;
+                    g9 = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaf(wx, wx, wy * wy)), inv_fa[q], g9);
+                    // --- state update ---------------------------------------------------------
+                    sx[q] = __builtin_fmaf(-vis, cr, sx[q]);
+                    sy[q] = __builtin_fmaf(-vis, cgc, sy[q]);
+                    sz[q] = __builtin_fmaf(-vis, cb, sz[q]);
+                    sw[q] = ok ? (sat ? 0.0f : next_t) : T;
+                    any = any || contrib;
                 }
             }
             if (__ballot(any) != 0ull) {
-                g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2); g3 = wave_sum(g3); g4 = wave_sum(g4);
-                g5 = wave_sum(g5); g6 = wave_sum(g6); g7 = wave_sum(g7); g8 = wave_sum(g8); g9 = wave_sum(g9);
-                // lanes 0..9 each own one component -> a single 10-lane atomic instruction
-                float mine = g0;
-                mine = lane == 1 ? g1 : mine; mine = lane == 2 ? g2 : mine; mine = lane == 3 ? g3 : mine;
-                mine = lane == 4 ? g4 : mine; mine = lane == 5 ? g5 : mine; mine = lane == 6 ? g6 : mine;
-                mine = lane == 7 ? g7 : mine; mine = lane == 8 ? g8 : mine; mine = lane == 9 ? g9 : mine;
-                const uint32_t cg = __shfl(cg_mine, (int)t);
-                if (lane < 10) unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + lane], mine);
+                // colour gradients only where the raw colour was >= 0 (…:321-323); wave-uniform
+                const uint32_t gate = f2u(s2.z);
+                g5 = (gate & 1u) ? g5 : 0.0f;
+                g6 = (gate & 2u) ? g6 : 0.0f;
+                g7 = (gate & 4u) ? g7 : 0.0f;
+                const float h0 = swap32_add(g0, g1), h1 = swap32_add(g2, g3), h2 = swap32_add(g4, g5);
+                const float h3 = swap32_add(g6, g7), h4 = swap32_add(g8, g9);
+                const float k0 = row_allreduce(swap16_add(h0, h1));
+                const float k1 = row_allreduce(swap16_add(h2, h3));
+                const float k2 = row_allreduce(swap16_add(h4, 0.0f));
+                const float mine = ri == 0 ? k0 : (ri == 1 ? k1 : k2);
+                const uint32_t cg = f2u(s2.w);
+                if (atom_lane) unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + comp], mine);
             }
         }
     }
