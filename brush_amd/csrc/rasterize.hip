@@ -72,6 +72,9 @@ constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend 
 // exp(x) for the blend loop: the bh_expf sequence without its range guards
 // (x <= 0 wherever the result is used; underflow goes to 0 through ldexp).
 BH_DEV float exp_blend(float x) {
+#ifdef BH_HW_EXP  // measurement-only variant (not the shipped numerical spec)
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#endif
     const float k = __builtin_rintf(x * 1.44269504088896341f);
     float r = __builtin_fmaf(k, -0.693359375f, x);
     r = __builtin_fmaf(k, 2.12194440e-4f, r);
@@ -285,8 +288,11 @@ BH_DEV float row_allreduce(float x) {
     return x;
 }
 
+#ifndef BH_BWD_WAVES
+#define BH_BWD_WAVES 4
+#endif
 template <bool SMOOTH>
-__global__ __launch_bounds__(64) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+__global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                                const uint32_t* __restrict__ tile_offsets,
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
