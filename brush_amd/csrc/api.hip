@@ -258,6 +258,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (!cam || !out || !background) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null argument");
     if (cam->img_w == 0 || cam->img_h == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "Can't render images with 0 size.");  // render.rs:50-53
     if (sh_degree > 4) return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    if (cam->img_w > 16368 || cam->img_h > 16368) return set_error(ctx, BH_ERR_UNSUPPORTED, "images larger than 16368 px per side are not supported (tile grid <= 1023 x 1023)");
     if (n > 0 && (!transforms || !sh_coeffs || !raw_opacities)) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null splat tensor");
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
     BH_HIP(ctx, hipSetDevice(ctx->device));

@@ -17,6 +17,74 @@
 namespace bh {
 
 constexpr int PROJ_WG = 256;
+constexpr int PROJ_WAVES = PROJ_WG / 64;
+
+// ---------------------------------------------------------------------------
+// Load-balanced tile walk shared by K1 (count) and K5 (emit).
+//
+// The reference walks each splat's tile bounding box with one thread
+// (helpers.rs:204-223, map_gaussians.rs:46-72): a wave then runs as long as its
+// largest splat.  Here a wave flattens the boxes of its 64 splats into one
+// candidate list (wave prefix sum of the box areas), and lane l tests candidates
+// l, l+64, ...: every lane is busy whatever the size distribution.  A candidate
+// finds its splat with a 6-step search over the 64 prefix sums in LDS.  The
+// per-(splat, tile) test is the same inlined will_primitive_contribute for both
+// kernels, so count and emit cannot disagree.
+// ---------------------------------------------------------------------------
+struct WalkLds {
+    uint32_t end[64];     // inclusive prefix sum of box areas
+    uint32_t count[64];   // hits per splat (K1) / emit cursor (K5)
+    float mx[64], my[64], c00[64], c01[64], c11[64], pt[64], rcp_w[64];
+    uint32_t box[64];     // min_x | min_y << 10 | width << 20   (tile grids up to 1023 x 1023)
+};
+
+BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// first index o in [0,63] with end[o] > c   (requires c < end[63])
+BH_DEV uint32_t walk_owner(const uint32_t* end, uint32_t c) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step > 0; step >>= 1)
+        if (end[lo + step - 1] <= c) lo += step;
+    return lo;
+}
+
+// Visits every (splat, tile) candidate of the wave; calls on_hit(owner_lane, tile_x, tile_y)
+// for the contributing ones.  `nb` = box area of this lane's splat (0 = none).
+template <class OnHit>
+BH_DEV void flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
+                           OnHit on_hit) {
+    const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
+    const uint32_t bb_w = bb.max_x - bb.min_x;
+    w.end[lane] = incl;
+    w.count[lane] = 0;
+    w.mx[lane] = mx; w.my[lane] = my;
+    w.c00[lane] = conic.c00; w.c01[lane] = conic.c01; w.c11[lane] = conic.c11;
+    w.pt[lane] = pt;
+    w.rcp_w[lane] = 1.0f / (float)(bb_w ? bb_w : 1u);
+    w.box[lane] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
+    __syncthreads();
+    const uint32_t tot = w.end[63];
+    for (uint32_t c = lane; c < tot; c += 64) {
+        const uint32_t o = walk_owner(w.end, c);
+        const uint32_t i = c - (o ? w.end[o - 1] : 0u);
+        const uint32_t box = w.box[o];
+        const uint32_t bw = box >> 20;
+        // i / bw via float: exact for boxes up to 1023 tiles high (error <= rows * 2^-23 << 0.5 / bw)
+        const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[o]);
+        const uint32_t tx = (box & 1023u) + (i - row * bw);
+        const uint32_t ty = ((box >> 10) & 1023u) + row;
+        if (will_primitive_contribute(tx, ty, w.mx[o], w.my[o], Sym2{w.c00[o], w.c01[o], w.c11[o]}, w.pt[o])) on_hit(o, tx, ty);
+    }
+    __syncthreads();
+}
 
 // ---------------------------------------------------------------------------
 // K1: project_forward  (kernels/project_forward.rs:22-125)
@@ -26,11 +94,17 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ raw_opacities,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts, float* __restrict__ max_radius,
     unsigned long long* __restrict__ counters) {
+    __shared__ WalkLds s_walk[PROJ_WAVES];
+    __shared__ uint32_t s_vis[PROJ_WAVES];
+    __shared__ uint32_t s_hit[PROJ_WAVES];
     const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t key = 0xFFFFFFFFu;
-    uint32_t tiles_hit = 0;
     float radius = 0.0f;
     bool visible = false;
+    float mx = 0.0f, my = 0.0f, pt = 0.0f;
+    Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
+    TileBbox bb = TileBbox{0, 0, 0, 0};
     if (gid < n) {
         const float* tr = transforms + (size_t)gid * 10;
         do {
@@ -50,30 +124,28 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
             const float opac = sigmoid(raw_opac) * filter_comp;
             if (!sym2_finite(cov)) break;
-            float mx, my;
             project_pinhole(mean_c, u, mx, my);
             if (!(opac >= 1.0f / 255.0f)) break;
-            const float pt = bh_logf(opac * 255.0f);
-            const Sym2 conic = sym2_inverse(cov);
+            pt = bh_logf(opac * 255.0f);
+            conic = sym2_inverse(cov);
             float ex, ey;
             compute_bbox_extent(conic, pt, ex, ey);
             if (!(ex >= 0.0f && ey >= 0.0f)) break;
             const float wf = (float)u.img_w, hf = (float)u.img_h;
             const bool on_screen = mx + ex > 0.0f && mx - ex < wf && my + ey > 0.0f && my - ey < hf;
             if (!on_screen) break;
-            const TileBbox bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_bh);
-            // helpers.rs:204-223 count_contributing_tiles
-            const uint32_t bb_w = bb.max_x - bb.min_x;
-            const uint32_t nb = (bb.max_y - bb.min_y) * bb_w;
-            uint32_t tx = bb.min_x, ty = bb.min_y;
-            for (uint32_t i = 0; i < nb; ++i) {
-                if (will_primitive_contribute(tx, ty, mx, my, conic, pt)) tiles_hit++;
-                if (++tx == bb.max_x) { tx = bb.min_x; ++ty; }
-            }
+            bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_bh);
             radius = __builtin_fmaxf(ex / wf, ey / hf);
             key = f2u(mean_c.z);
             visible = true;
         } while (false);
+    }
+    // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
+    const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
+    WalkLds& w = s_walk[wave];
+    flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t o, uint32_t, uint32_t) { atomicAdd(&w.count[o], 1u); });
+    const uint32_t tiles_hit = w.count[lane];
+    if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
         max_radius[gid] = radius;
@@ -83,9 +155,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     uint32_t wave_hits = tiles_hit;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
-    __shared__ uint32_t s_vis[PROJ_WG / 64];
-    __shared__ uint32_t s_hit[PROJ_WG / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         s_vis[wave] = (uint32_t)__popcll(ball);
         s_hit[wave] = wave_hits;
@@ -94,7 +163,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     if (threadIdx.x == 0) {
         uint32_t v = 0, h = 0;
 #pragma unroll
-        for (int w = 0; w < PROJ_WG / 64; ++w) { v += s_vis[w]; h += s_hit[w]; }
+        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; }
         if (v) atomicAdd(&counters[0], (unsigned long long)v);
         if (h) atomicAdd(&counters[1], (unsigned long long)h);
     }
@@ -184,33 +253,42 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect) {
+    __shared__ WalkLds s_walk[PROJ_WAVES];
+    __shared__ uint32_t s_base[PROJ_WAVES][64];
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
-    if (cg >= nv) return;
-    const float* p = projected + (size_t)cg * 9;
-    const float xy_x = p[0], xy_y = p[1];
-    const Sym2 conic = Sym2{p[2], p[3], p[4]};
-    const float pt = bh_logf(p[5] * 255.0f);
-    float ex, ey;
-    compute_bbox_extent(conic, pt, ex, ey);
-    const TileBbox bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_bh);
-    const uint32_t base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
-    const uint32_t pf_count = cum_tiles_hit[cg] - base;
-    const uint32_t sentinel = tile_bw * tile_bh;
-    const uint32_t bb_w = bb.max_x - bb.min_x;
-    const uint32_t nb = (bb.max_y - bb.min_y) * bb_w;
-    uint32_t hit = 0;
-    uint32_t tx = bb.min_x, ty = bb.min_y;
-    for (uint32_t i = 0; i < nb; ++i) {
-        if (will_primitive_contribute(tx, ty, xy_x, xy_y, conic, pt) && hit < pf_count) {
-            tile_id_from_isect[base + hit] = tx + ty * tile_bw;
-            compact_gid_from_isect[base + hit] = cg;
-            hit++;
-        }
-        if (++tx == bb.max_x) { tx = bb.min_x; ++ty; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
+    Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
+    TileBbox bb = TileBbox{0, 0, 0, 0};
+    uint32_t base = 0, pf_count = 0, nb = 0;
+    if (cg < nv) {
+        const float* p = projected + (size_t)cg * 9;
+        xy_x = p[0]; xy_y = p[1];
+        conic = Sym2{p[2], p[3], p[4]};
+        pt = bh_logf(p[5] * 255.0f);
+        float ex, ey;
+        compute_bbox_extent(conic, pt, ex, ey);
+        bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_bh);
+        base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+        pf_count = cum_tiles_hit[cg] - base;
+        nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
     }
+    WalkLds& w = s_walk[wave];
+    uint32_t* wbase = s_base[wave];
+    wbase[lane] = base;
+    const uint32_t cg0 = cg - (uint32_t)lane;
+    // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
+    // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
+    flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t o, uint32_t tx, uint32_t ty) {
+        const uint32_t k = atomicAdd(&w.count[o], 1u);
+        const uint32_t idx = wbase[o] + k;
+        tile_id_from_isect[idx] = tx + ty * tile_bw;
+        compact_gid_from_isect[idx] = cg0 + o;
+    });
     // map_gaussians.rs:73-79: pad any leftover budget (cannot happen here: the count
     // and the emit walk are the same inlined function with the same flags).
-    for (uint32_t k = hit; k < pf_count; ++k) {
+    const uint32_t sentinel = tile_bw * tile_bh;
+    for (uint32_t k = w.count[lane]; k < pf_count; ++k) {
         tile_id_from_isect[base + k] = sentinel;
         compact_gid_from_isect[base + k] = cg;
     }
