@@ -18,7 +18,7 @@ computation runs in the hand-written HIP kernels. No CPU fallback exists.
 """
 from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
-    get_context, image_loss, image_loss_backward, prefix_sum, radix_argsort, render_splats,
+    get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
     render_splats_bwd, adam_step,
 )
 from ._ffi import BrushHipError  # noqa: F401

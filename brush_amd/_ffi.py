@@ -96,6 +96,7 @@ SYMBOLS = {
     "bh_radix_argsort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bh_prefix_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bh_image_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
+    "bh_image_loss_value_and_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_float, C.c_void_p, C.c_void_p]),
     "bh_image_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
     "bh_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_float]),
     "bh_gather_stats": (C.c_int, [C.c_void_p] * 7 + [C.c_uint64]),

@@ -17,6 +17,9 @@ int launch_image_loss_backward_strided(bh_ctx* ctx, const float* pred, uint32_t 
                                        const float* dl_dmap, float dl_rgb, float dl_alpha, uint32_t channels, uint32_t h, uint32_t w,
                                        const BhLossConfig& cfg, float* dl_dpred);
 
+int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output);
+
 int set_error(bh_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
     return code;
@@ -452,6 +455,18 @@ int bh_image_loss_backward(bh_ctx* ctx, const float* pred_chw, const uint32_t* g
     return launch_image_loss_backward(ctx, pred_chw, gt_packed, dl_dmap, 0.0f, channels, h, w, *cfg, dl_dpred);
 }
 
+int bh_image_loss_value_and_grad(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt_packed, uint32_t h, uint32_t w,
+                                 const BhLossConfig* cfg, float alpha_weight, float* loss_out, float* v_output) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!img_hwc4 || !gt_packed || !cfg || !loss_out || !v_output || h == 0 || w == 0)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "image_loss_value_and_grad: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t hw = (size_t)h * w;
+    const bool alpha = alpha_weight > 0.0f;
+    return launch_image_loss_fused(ctx, img_hwc4, gt_packed, h, w, *cfg, alpha, 1.0f / (float)(hw * 3), alpha ? alpha_weight / (float)hw : 0.0f,
+                                   loss_out, v_output);
+}
+
 int bh_adam_step(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
                  const float* col_scale, float lr, uint32_t t, int reduce_m2, float beta1, float beta2, float eps) {
     if (!ctx) return BH_ERR_INVALID_ARG;
@@ -516,30 +531,18 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     lc.bg[0] = batch->background[0]; lc.bg[1] = batch->background[1]; lc.bg[2] = batch->background[2];
     lc.mask = batch->alpha_is_mask ? 1 : 0;
     const bool alpha_match = batch->has_alpha && !batch->alpha_is_mask && cfg->match_alpha_weight > 0.0f;
-    const uint32_t channels = alpha_match ? 4 : 3;
     const size_t hw = (size_t)W * H;
-    auto* loss_map = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * channels * 4);
     auto* v_output = (float*)ensure(ctx, SLOT_V_OUTPUT, hw * 16);
     auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
     const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
     auto* grads = (float*)ensure(ctx, SLOT_GRADS, (grad_count ? grad_count : 1) * 4);
     auto* stat_buf = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 3 * 4);
     auto* col_scale = (float*)ensure(ctx, SLOT_COL_SCALE, 256 * 4);
-    if (!loss_map || !v_output || !loss_dev || !grads || !stat_buf || !col_scale) return BH_ERR_OOM;
+    if (!v_output || !loss_dev || !grads || !stat_buf || !col_scale) return BH_ERR_OOM;
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
-    {
-        ProfScope ps(ctx, "ImageLoss");
-        // the loss kernels read the rasterizer's [H,W,4] image in place (pixel stride 4, channel stride 1)
-        BH_TRY(launch_image_loss_forward_strided(ctx, ro.out_img, 4, 1, batch->gt_packed, channels, H, W, lc, loss_map));
-        BH_TRY(launch_sum(ctx, loss_map, hw * 3, dl_rgb, loss_dev, false));
-        if (alpha_match) BH_TRY(launch_sum(ctx, loss_map + hw * 3, hw, dl_alpha, loss_dev, true));
-    }
-    {
-        ProfScope ps(ctx, "ImageLossBackward");
-        if (channels == 3) BH_HIP(ctx, hipMemsetAsync(v_output, 0, hw * 16, ctx->stream));
-        BH_TRY(launch_image_loss_backward_strided(ctx, ro.out_img, 4, 1, batch->gt_packed, nullptr, dl_rgb, dl_alpha, channels, H, W, lc, v_output));
-    }
+    // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
+    BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output));
 
     // ---- backward (train.rs:278)
     float* g_tr = grads;

@@ -1,0 +1,316 @@
+// loss_fused.hip — the image loss as the train step uses it (train.rs:227-260):
+// loss = mean(L1/SSIM map) [+ alpha-match], v_output = dloss/d(out_img).
+//
+// Reference: brush-loss/src/lib.rs:181-359 (forward), :371-661 (backward), and the
+// autodiff node :1041-1104.  The reference's backward kernel recomputes the blurred
+// moments on a 28x28 apron per 8x8 block because its forward only keeps the loss map.
+// In a train step both passes always run back to back on the same image, so here
+//   pass A  (one block per 16x16 tile, all colour planes): moments -> SSIM -> per-block
+//           loss partial sum AND the three per-pixel SSIM partials (dmu1, dsigma1,
+//           dsigma12) x chain, written once as 9 planes;
+//   pass B  blurs those planes (26x26 halo) and writes v_output [H,W,4] directly.
+// The apron recompute, the CHW loss map, its grid-wide sum, the v_output memset and the
+// HWC<->CHW permutes (lib.rs:1076,1103) all disappear.  Per-output arithmetic is the
+// same tap-pair accumulation order as loss.hip, so the results match the stand-alone
+// kernels (tests/test_gpu_loss_optim.py::test_fused_loss_matches_standalone).
+#include <cmath>
+
+#include "context.h"
+
+namespace bh {
+
+namespace {
+
+constexpr int LB = 16;
+constexpr int HALO = 5;
+constexpr int SH = LB + 2 * HALO;  // 26
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+constexpr float INV_255 = 1.0f / 255.0f;
+
+struct Taps { float w[11]; };
+
+Taps gauss_taps() {  // lib.rs:55-68
+    Taps g;
+    const float sigma = 1.5f;
+    float sum = 0.0f;
+    for (int i = 0; i < 11; ++i) {
+        const float x = (float)i - 5.0f;
+        g.w[i] = expf(-x * x / (2.0f * sigma * sigma));
+        sum += g.w[i];
+    }
+    for (int i = 0; i < 11; ++i) g.w[i] /= sum;
+    return g;
+}
+
+struct FusedArgs {
+    uint32_t h, w;
+    float l1_w, ssim_w;
+    float bg[3];
+    int composite, mask, alpha_match;
+    float dl_rgb, dl_alpha;
+    Taps taps;
+};
+
+BH_DEV float gt_ch(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) & 0xffu) * INV_255; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// pass A
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float* __restrict__ img /*[H,W,4]*/,
+                                                                    const uint32_t* __restrict__ gt,
+                                                                    float* __restrict__ partials /*[9,H,W]*/,
+                                                                    float* __restrict__ block_sums, FusedArgs a) {
+    __shared__ float2 s_tile[3][SH * SH];          // (pred, gt_eff) per colour plane
+    __shared__ float s_h[3][SH * LB * 5];          // horizontally blurred moments
+    __shared__ float s_red[LB * LB / 64];
+    const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int rank = ly * LB + lx;
+    const size_t hw = (size_t)a.h * a.w;
+    for (int i = rank; i < SH * SH; i += LB * LB) {
+        const int r = i / SH, q = i - r * SH;
+        const int y = ty0 + r - HALO, x = tx0 + q - HALO;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w) {  // zero padding (lib.rs:110-176)
+            const size_t p = (size_t)y * a.w + (size_t)x;
+            pv = *reinterpret_cast<const float4*>(&img[p * 4]);
+            const uint32_t val = gt[p];
+            const float ga = gt_ch(val, 3);
+            g0 = gt_ch(val, 0); g1 = gt_ch(val, 1); g2 = gt_ch(val, 2);
+            if (a.composite) {
+                g0 = g0 + (1.0f - ga) * a.bg[0];
+                g1 = g1 + (1.0f - ga) * a.bg[1];
+                g2 = g2 + (1.0f - ga) * a.bg[2];
+            }
+        }
+        s_tile[0][i] = make_float2(pv.x, g0);
+        s_tile[1][i] = make_float2(pv.y, g1);
+        s_tile[2][i] = make_float2(pv.z, g2);
+    }
+    __syncthreads();
+    // horizontal blur of (x, x^2, y, y^2, xy): 3 planes x 26 rows x 16 columns
+    for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
+        const int c = i / (SH * LB), rem = i - c * (SH * LB);
+        const int r = rem / LB, col = (rem - r * LB) + HALO;
+        const float2* row = &s_tile[c][r * SH];
+        float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+#pragma unroll
+        for (int d = 1; d < 6; ++d) {
+            const float wd = a.taps.w[5 - d];
+            const float2 l = row[col - d], rr = row[col + d];
+            sx += (l.x + rr.x) * wd;
+            sx2 += (l.x * l.x + rr.x * rr.x) * wd;
+            sy += (l.y + rr.y) * wd;
+            sy2 += (l.y * l.y + rr.y * rr.y) * wd;
+            sxy += (l.x * l.y + rr.x * rr.y) * wd;
+        }
+        const float2 cc = row[col];
+        const float wc = a.taps.w[5];
+        sx += cc.x * wc;
+        sx2 += cc.x * cc.x * wc;
+        sy += cc.y * wc;
+        sy2 += cc.y * cc.y * wc;
+        sxy += cc.x * cc.y * wc;
+        float* o = &s_h[c][rem * 5];
+        o[0] = sx; o[1] = sx2; o[2] = sy; o[3] = sy2; o[4] = sxy;
+    }
+    __syncthreads();
+    const int py = ty0 + ly, pxx = tx0 + lx;
+    const bool inside = pxx < (int)a.w && py < (int)a.h;
+    float acc_rgb = 0.0f, acc_alpha = 0.0f;
+    if (inside) {
+        const size_t p = (size_t)py * a.w + (size_t)pxx;
+        const uint32_t val = gt[p];
+        const float ga = gt_ch(val, 3);
+        float chain = a.dl_rgb;
+        if (a.mask) chain = chain * ga;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 1; d < 6; ++d) {
+                const float wd = a.taps.w[5 - d];
+                const float* t = &s_h[c][((ly + HALO - d) * LB + lx) * 5];
+                const float* b = &s_h[c][((ly + HALO + d) * LB + lx) * 5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) o[k] += (t[k] + b[k]) * wd;
+            }
+            const float* cc = &s_h[c][((ly + HALO) * LB + lx) * 5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] += cc[k] * a.taps.w[5];
+            const float mu1 = o[0], mu2 = o[2];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
+            const float s1 = __builtin_fmaxf(0.0f, o[1] - mu1_sq), s2 = __builtin_fmaxf(0.0f, o[3] - mu2_sq);
+            const float s12 = o[4] - mu1 * mu2;
+            const float A = mu1_sq + mu2_sq + SSIM_C1;
+            const float B = s1 + s2 + SSIM_C2;
+            const float c_top = 2.0f * mu1 * mu2 + SSIM_C1;
+            const float d_top = 2.0f * s12 + SSIM_C2;
+            // forward value (lib.rs:331-358)
+            const float raw = (c_top * d_top) / (A * B);
+            const float ssim = clampf(raw, -1.0f, 1.0f);
+            const float2 pg = s_tile[c][(ly + HALO) * SH + lx + HALO];
+            float lv = a.l1_w * __builtin_fabsf(pg.x - pg.y) + a.ssim_w * ssim;
+            if (a.mask) lv = lv * ga;
+            acc_rgb += lv;
+            // SSIM partials for the backward (lib.rs:455-520)
+            const float inv_ab = 1.0f / (A * B);
+            const float cd = c_top * d_top * inv_ab;
+            const bool clamped = cd < -1.0f || cd > 1.0f;
+            const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (1.0f / A - 1.0f / B);
+            const float ds1 = clamped ? 0.0f : -cd / B;
+            const float ds12 = clamped ? 0.0f : 2.0f * c_top * inv_ab;
+            partials[(size_t)(c * 3 + 0) * hw + p] = dmu1 * chain;
+            partials[(size_t)(c * 3 + 1) * hw + p] = ds1 * chain;
+            partials[(size_t)(c * 3 + 2) * hw + p] = ds12 * chain;
+        }
+        if (a.alpha_match) {  // lib.rs:203-214
+            const float pa = img[p * 4 + 3];
+            float v = __builtin_fabsf(pa - ga);
+            if (a.mask) v = v * ga;
+            acc_alpha = v;
+        }
+    }
+    // block partial of the scalar loss: dl_rgb * sum(rgb planes) + dl_alpha * sum(alpha plane)
+    float acc = acc_rgb * a.dl_rgb + acc_alpha * a.dl_alpha;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((rank & 63) == 0) s_red[rank >> 6] = acc;
+    __syncthreads();
+    if (rank == 0) block_sums[blockIdx.y * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// pass B
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
+                                                                     const float* __restrict__ partials,
+                                                                     float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
+    __shared__ float s_part[3][SH * SH * 3];   // chain * (dmu1, dsigma1, dsigma12)
+    __shared__ float s_h2[3][SH * LB * 3];
+    const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
+    const int lx = threadIdx.x, ly = threadIdx.y;
+    const int rank = ly * LB + lx;
+    const size_t hw = (size_t)a.h * a.w;
+    for (int i = rank; i < SH * SH; i += LB * LB) {
+        const int r = i / SH, q = i - r * SH;
+        const int y = ty0 + r - HALO, x = tx0 + q - HALO;
+        const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
+        const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_part[c][i * 3 + k] = in ? partials[(size_t)(c * 3 + k) * hw + p] : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
+        const int c = i / (SH * LB), rem = i - c * (SH * LB);
+        const int r = rem / LB, col = (rem - r * LB) + HALO;
+        float a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int d = 1; d < 6; ++d) {
+            const float wd = a.taps.w[5 - d];
+            const float* l = &s_part[c][(r * SH + col - d) * 3];
+            const float* rr = &s_part[c][(r * SH + col + d) * 3];
+            a0 += (l[0] + rr[0]) * wd;
+            a1 += (l[1] + rr[1]) * wd;
+            a2 += (l[2] + rr[2]) * wd;
+        }
+        const float* cc = &s_part[c][(r * SH + col) * 3];
+        a0 += cc[0] * a.taps.w[5];
+        a1 += cc[1] * a.taps.w[5];
+        a2 += cc[2] * a.taps.w[5];
+        float* o = &s_h2[c][rem * 3];
+        o[0] = a0; o[1] = a1; o[2] = a2;
+    }
+    __syncthreads();
+    const int py = ty0 + ly, pxx = tx0 + lx;
+    if (!(pxx < (int)a.w && py < (int)a.h)) return;
+    const size_t p = (size_t)py * a.w + (size_t)pxx;
+    const float4 pv = *reinterpret_cast<const float4*>(&img[p * 4]);
+    const uint32_t val = gt[p];
+    const float ga = gt_ch(val, 3);
+    float chain_c = a.dl_rgb;
+    if (a.mask) chain_c = chain_c * ga;
+    const float pred_c[3] = {pv.x, pv.y, pv.z};
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 1; d < 6; ++d) {
+            const float wd = a.taps.w[5 - d];
+            const float* t = &s_h2[c][((ly + HALO - d) * LB + lx) * 3];
+            const float* b = &s_h2[c][((ly + HALO + d) * LB + lx) * 3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s[k] += (t[k] + b[k]) * wd;
+        }
+        const float* cc = &s_h2[c][((ly + HALO) * LB + lx) * 3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += cc[k] * a.taps.w[5];
+        float ge = gt_ch(val, c);
+        if (a.composite) ge = ge + (1.0f - ga) * a.bg[c];
+        const float p1 = pred_c[c];
+        const float ssim_grad = s[0] + (2.0f * p1) * s[1] + ge * s[2];
+        const float diff = p1 - ge;
+        const float l1_sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+        out[c] = a.ssim_w * ssim_grad + a.l1_w * l1_sign * chain_c;
+    }
+    if (a.alpha_match) {  // lib.rs:392-412
+        const float diff = pv.w - ga;
+        const float sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+        float chain = a.dl_alpha;
+        if (a.mask) chain = chain * ga;
+        out[3] = sign * chain;
+    }
+    *reinterpret_cast<float4*>(&v_output[p * 4]) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+__global__ __launch_bounds__(256) void loss_block_sum_kernel(const float* __restrict__ block_sums, int nb, float* __restrict__ out) {
+    __shared__ float s_w[4];
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += block_sums[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// loss scalar -> loss_out[0];  dloss/d(out_img) -> v_output [H,W,4] (fully overwritten)
+int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output) {
+    const dim3 grid((w + LB - 1) / LB, (h + LB - 1) / LB), block(LB, LB);
+    const size_t hw = (size_t)h * w;
+    const int nb = (int)(grid.x * grid.y);
+    auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 9 * sizeof(float));
+    auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)nb * sizeof(float));
+    if (!partials || !block_sums) return BH_ERR_OOM;
+    FusedArgs a;
+    a.h = h; a.w = w;
+    a.l1_w = cfg.l1_weight; a.ssim_w = cfg.ssim_weight;
+    a.bg[0] = cfg.bg[0]; a.bg[1] = cfg.bg[1]; a.bg[2] = cfg.bg[2];
+    a.composite = cfg.composite_bg; a.mask = cfg.mask; a.alpha_match = alpha_match ? 1 : 0;
+    a.dl_rgb = dl_rgb; a.dl_alpha = dl_alpha;
+    a.taps = gauss_taps();
+    {
+        ProfScope ps(ctx, "ImageLoss");
+        hipLaunchKernelGGL(loss_fused_forward_kernel, grid, block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a);
+        BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
+        hipLaunchKernelGGL(loss_block_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, block_sums, nb, loss_out);
+        BH_LAUNCH_CHECK(ctx, "loss_block_sum_kernel");
+    }
+    {
+        ProfScope ps(ctx, "ImageLossBackward");
+        hipLaunchKernelGGL(loss_fused_backward_kernel, grid, block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
+        BH_LAUNCH_CHECK(ctx, "loss_fused_backward_kernel");
+    }
+    return 0;
+}
+
+}  // namespace bh

@@ -380,6 +380,24 @@ def image_loss_backward(pred_hwc, gt_packed, dl_dmap_hwc, l1_weight=0.8, ssim_we
     return out.permute(1, 2, 0).contiguous()
 
 
+def image_loss_value_and_grad(img_hwc4, gt_packed, l1_weight=0.8, ssim_weight=-0.2, composite_bg=None, mask=False,
+                              alpha_weight=0.0, ctx: Optional[Context] = None):
+    """Fused train-step loss: returns (loss [1] device tensor, dloss/dimg [H,W,4]).  Equivalent to
+    mean(image_loss(...)) (+ alpha term) and its gradient (train.rs:227-260), in two kernels."""
+    dev = img_hwc4.device
+    ctx = ctx or get_context(dev)
+    h, w, c = img_hwc4.shape
+    if c != 4:
+        raise ValueError("img must be [H,W,4]")
+    img = img_hwc4.contiguous().float()
+    gt = _as_u32(gt_packed, dev).reshape(h, w)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    v_out = torch.empty_like(img)
+    cfg = _loss_cfg(l1_weight, ssim_weight, composite_bg, mask)
+    ctx.check(ctx.lib.bh_image_loss_value_and_grad(ctx._h, _ptr(img), _ptr(gt), h, w, C.byref(cfg), float(alpha_weight), _ptr(loss), _ptr(v_out)))
+    return loss, v_out
+
+
 def adam_step(param, grad, m1, m2, lr, t, col_scale=None, reduce_m2=False, beta1=0.9, beta2=0.999, eps=1e-15, ctx: Optional[Context] = None):
     """In-place AdamScaled step on a [rows, ...] parameter (adam_scaled.rs:75-147)."""
     ctx = ctx or get_context(param.device)

@@ -147,6 +147,14 @@ int bh_image_loss_backward(bh_ctx* ctx, const float* pred_chw, const uint32_t* g
                            uint32_t channels, uint32_t h, uint32_t w, const BhLossConfig* cfg /*host*/,
                            float* dl_dpred);
 
+/* Fused value-and-gradient of the train-step loss (what SplatTrainer::step composes from
+ * image_loss + mean + autodiff, brush-train/src/train.rs:227-260, brush-loss/src/lib.rs:1041-1104):
+ *   loss = mean_{H,W,3}(l1_w*|p-g| + ssim_w*SSIM) + alpha_weight * mean_{H,W}|p.a - g.a|   (alpha term iff alpha_weight > 0)
+ * img_hwc4 [H,W,4] is the rasterizer output; loss_out is ONE device float; v_output [H,W,4] =
+ * dloss/dimg is fully overwritten (alpha channel 0 without the alpha term). */
+int bh_image_loss_value_and_grad(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt_packed, uint32_t h, uint32_t w,
+                                 const BhLossConfig* cfg /*host*/, float alpha_weight, float* loss_out, float* v_output);
+
 /* ---- optimizer / stats ----------------------------------------------------- */
 /* One AdamScaled step on a [rows,row_len] parameter.  t = state.time after this
  * step (1 on the first call: moments are initialised, not decayed).  col_scale

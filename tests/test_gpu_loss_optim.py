@@ -31,6 +31,37 @@ def test_image_loss_forward_backward_vs_oracle(dev, oracle_lib, h, w, ch, bg, ma
     assert np.abs(g - rg).max() <= 2e-6 * max(1.0, np.abs(rg).max())
 
 
+@pytest.mark.parametrize("h,w", [(40, 52), (16, 16), (1, 1), (67, 131), (270, 480)])
+@pytest.mark.parametrize("bg,mask,alpha_w", [(None, False, 0.0), ((0.3, 0.5, 0.2), False, 0.1), (None, True, 0.0)])
+def test_fused_loss_matches_oracle_and_standalone(dev, oracle_lib, h, w, bg, mask, alpha_w):
+    """bh_image_loss_value_and_grad (what bh_train_step runs) == mean(loss map) and its gradient
+    from the oracle's stand-alone forward/backward (train.rs:227-260)."""
+    import brush_amd as ba
+    rng = np.random.default_rng(h * 7 + w)
+    gt = _gt(rng, h, w)
+    img = rng.uniform(-0.1, 1.1, (h, w, 4)).astype(np.float32)
+    ch = 4 if alpha_w > 0 else 3
+    gt_t = torch.from_numpy(gt.view(np.int32)).to(dev)
+    loss, v_out = ba.image_loss_value_and_grad(torch.from_numpy(img).to(dev), gt_t, 0.8, -0.2, composite_bg=bg, mask=mask, alpha_weight=alpha_w)
+    pc = np.ascontiguousarray(img[..., :ch].transpose(2, 0, 1))
+    rlm = oracle_lib.image_loss_forward(pc, gt, 0.8, -0.2, bg=bg, mask=mask).astype(np.float64)
+    ref_loss = rlm[:3].mean() + (alpha_w * rlm[3].mean() if ch == 4 else 0.0)
+    dl = np.empty((ch, h, w), np.float32)
+    dl[:3] = 1.0 / (h * w * 3)
+    if ch == 4:
+        dl[3] = alpha_w / (h * w)
+    rg = oracle_lib.image_loss_backward(pc, gt, dl, 0.8, -0.2, bg=bg, mask=mask).transpose(1, 2, 0)
+    assert abs(float(loss.item()) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss))
+    g = v_out.cpu().numpy()
+    assert np.abs(g[..., :ch] - rg).max() <= 2e-6 * max(np.abs(rg).max(), 1e-12)
+    if ch == 3:
+        assert not g[..., 3].any()
+    # and against the stand-alone HIP kernels (same per-output arithmetic)
+    g2 = ba.image_loss_backward(torch.from_numpy(img[..., :ch].copy()).to(dev), gt_t, torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 2, 0))).to(dev),
+                                0.8, -0.2, composite_bg=bg, mask=mask).cpu().numpy()
+    assert np.abs(g[..., :ch] - g2).max() <= 1e-7 * max(np.abs(g2).max(), 1e-12)
+
+
 def test_ssim_of_identical_images_is_one(dev):
     """brush-loss/tests/reference.rs:57"""
     import brush_amd as ba
