@@ -430,7 +430,11 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 const float k2 = row_allreduce(swap16_add(h4, 0.0f));
                 const float mine = ri == 0 ? k0 : (ri == 1 ? k1 : k2);
                 const uint32_t cg = f2u(s2.w);
+#ifdef BH_NO_ATOMIC  // measurement-only variant
+                if (atom_lane && mine == 123.456f) v_combined[(size_t)cg * 10 + comp] = mine;
+#else
                 if (atom_lane) unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + comp], mine);
+#endif
             }
         }
     }

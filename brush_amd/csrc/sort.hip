@@ -5,7 +5,9 @@
 // reference's 4-bit FidelityFX-style passes (5 kernels per pass, kernels.rs:29-401)
 // are replaced by a wave64 design:
 //   * 8-bit digits: half the passes (4 for depth keys, 2 for <=16-bit tile ids);
-//   * per pass: histogram -> exclusive scan of the [digit][block] table -> scatter;
+//   * per pass: histogram (+ digit totals) -> one-launch row scan of the [digit][block]
+//     table -> scatter  (3 launches; a chained-scan "onesweep" was measured SLOWER on
+//     MI355X: every look-back hop is a cross-XCD fabric round trip);
 //   * ranking inside a block uses wave-wide digit matching (8 ballots) so each wave
 //     ranks 64 keys per step without LDS atomics; waves own contiguous chunks so
 //     the block order is the input order (stability);
@@ -58,10 +60,58 @@ __global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __r
     hist[(size_t)tid * nblocks + blockIdx.x] = total;
 }
 
+// Row-wise exclusive scan of the [digit][block] table in ONE launch (block d owns digit
+// row d and also emits the row total); the scatter kernel adds the 256-entry prefix over
+// the digit totals itself.  3 launches per pass instead of the 5 of a generic
+// reduce/spine/apply scan over the whole table.
+constexpr int ROWSCAN_MAX_EPT = 16;  // rows of up to 4096 blocks (16.7 M keys); longer tables use the generic scan
+__global__ __launch_bounds__(SORT_WG) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                               uint32_t* __restrict__ digit_totals) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t d = blockIdx.x;
+    uint32_t* row = hist + (size_t)d * nblocks;
+    // the row stays in registers: entry k*256 + tid (coalesced), up to ROWSCAN_MAX_EPT chunks
+    uint32_t v[ROWSCAN_MAX_EPT], incl[ROWSCAN_MAX_EPT];
+    __shared__ uint32_t s_chunk[ROWSCAN_MAX_EPT][SORT_WAVES];
+#pragma unroll
+    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+        const uint32_t i = (uint32_t)k * SORT_WG + tid;
+        v[k] = i < nblocks ? row[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+        uint32_t x = v[k];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(x, off);
+            if (lane >= off) x += t;
+        }
+        incl[k] = x;
+        if (lane == 63) s_chunk[k][wave] = x;
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = s_chunk[k][w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        const uint32_t i = (uint32_t)k * SORT_WG + tid;
+        if (i < nblocks) row[i] = run + before + incl[k] - v[k];
+        run += total;
+    }
+    if (tid == 0) digit_totals[d] = run;
+}
+
 template <bool HAS_VALS>
 __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                                uint32_t n, uint32_t shift, uint32_t mask, uint32_t nblocks,
                                                                const uint32_t* __restrict__ offsets,  // exclusive scan of hist
+                                                               const uint32_t* __restrict__ digit_totals,  // row-scan mode: offsets are per-row, add the digit prefix
                                                                uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX];   // per-wave running digit counts -> wave bases
     __shared__ uint32_t s_dbase[RADIX];             // exclusive scan of block digit totals
@@ -111,21 +161,23 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
     }
     // exclusive scan of the 256 digit totals across the block
     {
-        uint32_t incl = total;
+        const uint32_t gt = digit_totals ? digit_totals[tid] : 0u;
+        uint32_t incl = total, gincl = gt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+            const uint32_t t = __shfl_up(incl, off), g = __shfl_up(gincl, off);
+            if (lane >= off) { incl += t; gincl += g; }
         }
-        __shared__ uint32_t s_wsum[SORT_WAVES];
-        if (lane == 63) s_wsum[wave] = incl;
+        __shared__ uint32_t s_wsum[2][SORT_WAVES];
+        if (lane == 63) { s_wsum[0][wave] = incl; s_wsum[1][wave] = gincl; }
         __syncthreads();
-        uint32_t wofs = 0;
+        uint32_t wofs = 0, gofs = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) wofs += (w < wave) ? s_wsum[w] : 0u;
+        for (int w = 0; w < SORT_WAVES; ++w) { wofs += (w < wave) ? s_wsum[0][w] : 0u; gofs += (w < wave) ? s_wsum[1][w] : 0u; }
         const uint32_t excl = incl - total + wofs;
+        const uint32_t below = gincl - gt + gofs;  // keys with a smaller digit (0 when offsets already hold the full scan)
         s_dbase[tid] = excl;
-        s_gofs[tid] = offsets[(size_t)tid * nblocks + blockIdx.x] - excl;
+        s_gofs[tid] = below + offsets[(size_t)tid * nblocks + blockIdx.x] - excl;
     }
     __syncthreads();
     // local reorder: position inside the block's digit-sorted tile
@@ -158,8 +210,11 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
     const uint32_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t bytes = (size_t)n * 4;
-    uint32_t* hist = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, (size_t)RADIX * nblocks * 4);
-    if (!hist) return BH_ERR_OOM;
+    // [256] digit totals followed by the [256][nblocks] table
+    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * nblocks + RADIX) * 4);
+    if (!totals) return BH_ERR_OOM;
+    uint32_t* hist = totals + RADIX;
+    const bool rowscan = nblocks <= (uint32_t)ROWSCAN_MAX_EPT * SORT_WG;
     // Ping-pong through two scratch pairs; pass 0 reads the caller's input (never
     // written), the last pass lands in out_* unless that would alias its source
     // (single-pass in-place call), in which case it is staged and copied.
@@ -191,11 +246,16 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
         const uint32_t mask = rem >= 8 ? 0xFFu : ((1u << rem) - 1u);
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
         BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
-        BH_TRY(prefix_sum(ctx, hist, nullptr, RADIX * nblocks, hist, /*exclusive=*/true));
+        if (rowscan) {
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(SORT_WG), 0, ctx->stream, hist, nblocks, totals);
+            BH_LAUNCH_CHECK(ctx, "radix_rowscan_kernel");
+        } else {
+            BH_TRY(prefix_sum(ctx, hist, nullptr, RADIX * nblocks, hist, /*exclusive=*/true));
+        }
         if (src_v)
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, dst_k, dst_v);
+            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, rowscan ? totals : nullptr, dst_k, dst_v);
         else
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, dst_k, dst_v);
+            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, rowscan ? totals : nullptr, dst_k, dst_v);
         BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
         src_k = dst_k;
         src_v = dst_v;
