@@ -26,6 +26,7 @@ class BhCamera(C.Structure):
         ("lim_neg_x", C.c_float), ("lim_neg_y", C.c_float),
         ("cam_pos", C.c_float * 3),
         ("img_w", C.c_uint32), ("img_h", C.c_uint32),
+        ("tile_row_begin", C.c_uint32), ("tile_row_end", C.c_uint32),
     ]
 
 
@@ -73,6 +74,7 @@ class BhTrainBatch(C.Structure):
     _fields_ = [
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
         ("background", C.c_float * 3), ("noise_samples", C.c_void_p),
+        ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p),
     ]
 
 
@@ -81,6 +83,7 @@ class BhTrainStats(C.Structure):
 
 
 GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+IMAGE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 
 # every symbol include/brush_hip.h declares: (restype, argtypes)
 SYMBOLS = {

@@ -73,6 +73,9 @@ ViewUniforms make_uniforms(const BhCamera& c) {
     u.img_w = c.img_w; u.img_h = c.img_h;
     u.tile_bw = (c.img_w + TILE_WIDTH - 1) / TILE_WIDTH;  // render.rs:30-35
     u.tile_bh = (c.img_h + TILE_WIDTH - 1) / TILE_WIDTH;
+    const bool whole = c.tile_row_begin == 0 && c.tile_row_end == 0;
+    u.tile_y0 = whole ? 0u : c.tile_row_begin;
+    u.tile_y1 = whole ? u.tile_bh : c.tile_row_end;
     return u;
 }
 
@@ -250,6 +253,8 @@ int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, doubl
     out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2];
     out->img_w = img_w;
     out->img_h = img_h;
+    out->tile_row_begin = 0;
+    out->tile_row_end = 0;
     return 0;
 }
 
@@ -268,6 +273,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     ctx->have_forward = false;
     const bool mip = flags & BH_FLAG_MIP, bwd_info = flags & BH_FLAG_BWD_INFO, smooth = flags & BH_FLAG_SMOOTH_CUTOFF;
     const ViewUniforms u = make_uniforms(*cam);
+    if (u.tile_y0 >= u.tile_y1 || u.tile_y1 > u.tile_bh) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_row window must satisfy begin < end <= ceil(img_h / 16)");
     const uint32_t num_tiles = u.tile_bw * u.tile_bh;
     const size_t npad = n ? n : 1;
 
@@ -328,7 +334,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         if (ni > 0) {
             {
                 ProfScope ps(ctx, "MapGaussiansToIntersect");
-                BH_TRY(launch_map_gaussians(ctx, nv, u.tile_bw, u.tile_bh, projected, cum, tile_ids, isect_gids));
+                BH_TRY(launch_map_gaussians(ctx, nv, u, projected, cum, tile_ids, isect_gids));
             }
             {
                 ProfScope ps(ctx, "TileSort");
@@ -520,6 +526,14 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
     BH_TRY(bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
                              batch->background, flags, &ro));
+
+    // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
+    if (batch->image_hook) {
+        ProfScope ps(ctx, "ImageExchange");
+        const ViewUniforms wu = make_uniforms(batch->camera);
+        const uint32_t r0 = wu.tile_y0 * TILE_WIDTH, r1 = wu.tile_y1 * TILE_WIDTH < H ? wu.tile_y1 * TILE_WIDTH : H;
+        if (batch->image_hook(batch->image_hook_user, ro.out_img, H, W, r0, r1) != 0) return set_error(ctx, BH_ERR_STATE, "image hook failed");
+    }
 
     // ---- loss (train.rs:227-260)
     const bool ssim_on = cfg->ssim_weight > 0.0f;

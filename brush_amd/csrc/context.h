@@ -129,7 +129,7 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
 int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                            const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                            float* projected);
-int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* projected,
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
                          const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,

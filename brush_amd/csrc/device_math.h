@@ -217,6 +217,7 @@ struct ViewUniforms {
     float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y;
     float cam_x, cam_y, cam_z;
     uint32_t img_w, img_h, tile_bw, tile_bh;
+    uint32_t tile_y0, tile_y1;  // tile-row window [y0, y1) rendered by this call (0, tile_bh = whole image)
 };
 BH_DEV Mat3 view_rotation(const ViewUniforms& u) { return Mat3{u.vm[0], u.vm[1], u.vm[2], u.vm[3], u.vm[4], u.vm[5], u.vm[6], u.vm[7], u.vm[8]}; }
 BH_DEV Vec3A view_translation(const ViewUniforms& u) { return Vec3A{u.vm[9], u.vm[10], u.vm[11]}; }
@@ -283,15 +284,16 @@ BH_DEV void compute_bbox_extent(Sym2 conic, float power_threshold, float& ex, fl
 struct TileBbox { uint32_t min_x, min_y, max_x, max_y; };
 
 // helpers.rs:110-140
-BH_DEV TileBbox get_tile_bbox(float cx, float cy, float ex, float ey, uint32_t bw, uint32_t bh) {
+// `y0`, `y1`: the tile-row window (0, tile_bh for a whole-image render: the reference's clamp).
+BH_DEV TileBbox get_tile_bbox(float cx, float cy, float ex, float ey, uint32_t bw, uint32_t y0, uint32_t y1) {
     const float tw = (float)TILE_WIDTH;
     const float x = cx / tw, y = cy / tw, dx = ex / tw, dy = ey / tw;
-    const float bwf = (float)bw, bhf = (float)bh;
+    const float bwf = (float)bw, y0f = (float)y0, y1f = (float)y1;
     TileBbox b;
     b.min_x = (uint32_t)clampf(x - dx, 0.0f, bwf);
-    b.min_y = (uint32_t)clampf(y - dy, 0.0f, bhf);
+    b.min_y = (uint32_t)clampf(y - dy, y0f, y1f);
     b.max_x = (uint32_t)clampf(x + dx + 1.0f, 0.0f, bwf);
-    b.max_y = (uint32_t)clampf(y + dy + 1.0f, 0.0f, bhf);
+    b.max_y = (uint32_t)clampf(y + dy + 1.0f, y0f, y1f);
     return b;
 }
 

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             const float wf = (float)u.img_w, hf = (float)u.img_h;
             const bool on_screen = mx + ex > 0.0f && mx - ex < wf && my + ey > 0.0f && my - ey < hf;
             if (!on_screen) break;
-            bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_bh);
+            bb = get_tile_bbox(mx, my, ex, ey, u.tile_bw, u.tile_y0, u.tile_y1);
+            // strip render: a splat that misses every tile row of the window is not this rank's
+            const bool whole = u.tile_y0 == 0u && u.tile_y1 == u.tile_bh;
+            if (!whole && (bb.max_y <= bb.min_y || bb.max_x <= bb.min_x)) break;
             radius = __builtin_fmaxf(ex / wf, ey / hf);
             key = f2u(mean_c.z);
             visible = true;
@@ -250,7 +253,7 @@ int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool
 // K5: map_gaussians_to_intersect  (kernels/map_gaussians.rs:15-80)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
-    uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* __restrict__ projected,
+    uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
         pt = bh_logf(p[5] * 255.0f);
         float ex, ey;
         compute_bbox_extent(conic, pt, ex, ey);
-        bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_bh);
+        bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_y0, tile_y1);
         base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
         pf_count = cum_tiles_hit[cg] - base;
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
@@ -294,11 +297,11 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     }
 }
 
-int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, const float* projected,
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
                          const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, tile_bw, tile_bh, projected, cum_tiles_hit, tile_ids, isect_gids);
+    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected, cum_tiles_hit, tile_ids, isect_gids);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
 }

@@ -57,7 +57,8 @@ int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n
 // shared pieces of the two blend kernels
 // ---------------------------------------------------------------------------
 struct RasterUniforms {
-    uint32_t tile_bw, num_tiles, img_w, img_h;
+    uint32_t tile_bw, num_tiles, img_w, img_h;  // num_tiles = tiles of the rendered window
+    uint32_t tile_begin;                        // first tile id of the window
     float bg_r, bg_g, bg_b;
 };
 
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
                                                       float* __restrict__ visible) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    const uint32_t tile = tile_of_block(blockIdx.x, u.num_tiles);
-    if (tile >= u.num_tiles) return;
+    const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+    if (local_tile >= u.num_tiles) return;
+    const uint32_t tile = u.tile_begin + local_tile;
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
@@ -244,7 +246,8 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
                      const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible) {
     RasterUniforms u;
     u.tile_bw = vu.tile_bw;
-    u.num_tiles = vu.tile_bw * vu.tile_bh;
+    u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
+    u.tile_begin = vu.tile_bw * vu.tile_y0;
     u.img_w = vu.img_w;
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
@@ -299,8 +302,9 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                const float* __restrict__ v_output,
                                                                float* __restrict__ v_combined) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    const uint32_t tile = tile_of_block(blockIdx.x, u.num_tiles);
-    if (tile >= u.num_tiles) return;
+    const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+    if (local_tile >= u.num_tiles) return;
+    const uint32_t tile = u.tile_begin + local_tile;
     const uint32_t range_lo = tile_offsets[tile * 2];
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
     if (range_hi <= range_lo) return;
@@ -445,7 +449,8 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
                               const float* out_img, const float* v_output, float* v_combined) {
     RasterUniforms u;
     u.tile_bw = vu.tile_bw;
-    u.num_tiles = vu.tile_bw * vu.tile_bh;
+    u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
+    u.tile_begin = vu.tile_bw * vu.tile_y0;
     u.img_w = vu.img_w;
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];

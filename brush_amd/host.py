@@ -14,7 +14,7 @@ import torch
 
 from . import _ffi
 from ._ffi import BrushHipError
-from .parallel import allreduce_step_buffers
+from .parallel import allreduce_step_buffers, allgather_strips, strip_spans_px, tile_rows_for_rank
 
 
 # ---------------------------------------------------------------------------
@@ -120,9 +120,10 @@ class Camera:
         vals = list(self.position) + list(self.rotation) + [self.fov_x, self.fov_y] + list(self.center_uv)
         return all(math.isfinite(v) for v in vals)
 
-    def uniforms(self, img_size) -> "_ffi.BhCamera":
+    def uniforms(self, img_size, tile_rows=None) -> "_ffi.BhCamera":
         """Kernel uniforms for an (img_w, img_h) render: pinhole params, 3x4 view
-        matrix, Jacobian clamp limits (camera.rs:63-101,200-254)."""
+        matrix, Jacobian clamp limits (camera.rs:63-101,200-254).  `tile_rows` = (begin, end)
+        restricts the render to a strip of 16-px tile rows (one frame partitioned over GPUs)."""
         w, h = int(img_size[0]), int(img_size[1])
         cam = _ffi.BhCamera()
         pos = (C.c_float * 3)(*self.position)
@@ -131,6 +132,8 @@ class Camera:
                                          float(self.center_uv[1]), w, h, C.byref(cam))
         if rc != 0:
             raise BrushHipError("bh_camera_setup failed (%d): image size must be non-zero" % rc)
+        if tile_rows is not None:
+            cam.tile_row_begin, cam.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
         return cam
 
 
@@ -259,13 +262,15 @@ def _aux_from(out, n, w, h, device, copy):
 
 
 def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), pass_: RasterPass = RasterPass.Forward,
-                  ctx: Optional[Context] = None, copy=True):
+                  ctx: Optional[Context] = None, copy=True, tile_rows=None):
     """Forward render. RasterPass.Forward returns a packed rgba8 image [H,W] (int32
     bit pattern, r in bits 0-7); the Backward variants return f32 [H,W,4].
     Returns (image, RenderAux). With copy=False the tensors alias ctx scratch
     memory and are only valid until the next render on `ctx`."""
     ctx = ctx or get_context(splats.device)
     w, h = int(img_size[0]), int(img_size[1])
+    if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
+        camera = camera.uniforms((w, h), tile_rows)
     _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
     if pass_.bwd_info():
         img = _view(out.out_img, (h, w, 4), torch.float32, splats.device)
@@ -277,7 +282,7 @@ def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), 
 
 
 def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pass_: RasterPass = RasterPass.Backward,
-                      ctx: Optional[Context] = None):
+                      ctx: Optional[Context] = None, tile_rows=None):
     """Differentiable render: forward (Backward pass flags) + backward for a given
     dL/d(out_img) `v_output` [H,W,4] (a tensor, or a callable img -> v_output).
     Returns dict(img, aux, v_transforms, v_sh_coeffs, v_raw_opacities, v_refine_weight, v_combined)."""
@@ -285,6 +290,8 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     ctx = ctx or get_context(splats.device)
     w, h = int(img_size[0]), int(img_size[1])
     dev = splats.device
+    if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
+        camera = camera.uniforms((w, h), tile_rows)
     _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
     img = _view(out.out_img, (h, w, 4), torch.float32, dev).clone()
     aux = _aux_from(out, splats.num_splats(), w, h, dev, True)
@@ -460,7 +467,15 @@ class SplatTrainer:
     between backward and Adam and scaled by 1/world; refine/visibility statistics are
     MAX-reduced. Every rank then applies the identical update."""
 
-    def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None):
+    def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
+                 partition: str = "cameras"):
+        """partition (only with a process_group): "cameras" = data parallel, every rank its own view,
+        mean gradient; "tiles" = every rank renders a strip of tile rows of the SAME view, strips are
+        all-gathered before the loss and the partial gradients summed."""
+        if partition not in ("cameras", "tiles"):
+            raise ValueError("partition must be 'cameras' or 'tiles'")
+        self.partition = partition
+        self._img_hook = None
         self.config = config
         self.median_scene_scale = float(median_scene_scale)
         self.step_count = 0
@@ -501,6 +516,19 @@ class SplatTrainer:
         self._world = world
         return _ffi.GRAD_HOOK(hook)
 
+    def _make_image_hook(self, dev):
+        pg = self.pg
+
+        def hook(_user, img_ptr, h, w, r0, r1):
+            try:
+                img = _view(img_ptr, (int(h), int(w), 4), torch.float32, dev)
+                import torch.distributed as dist
+                allgather_strips(img, int(r0), int(r1), pg, spans=strip_spans_px(int(h), dist.get_world_size(pg)))
+                return 0
+            except Exception:  # never unwind across the C boundary
+                return 1
+        return _ffi.IMAGE_HOOK(hook)
+
     def step(self, batch: SceneBatch, splats: Splats, background=None, noise_samples=None) -> Tuple[Splats, TrainStepStats]:
         """One optimisation step, in place on `splats`. `background` / `noise_samples`
         [N,3] inject the two stochastic terms; None = base colour / no noise."""
@@ -529,6 +557,17 @@ class SplatTrainer:
         h, w = batch.img_size()
         b = _ffi.BhTrainBatch()
         b.camera = batch.camera if isinstance(batch.camera, _ffi.BhCamera) else batch.camera.uniforms((w, h))
+        tiles = self.pg is not None and self.partition == "tiles"
+        if tiles:
+            import torch.distributed as dist
+            rows = tile_rows_for_rank((h + 15) // 16, dist.get_rank(self.pg), dist.get_world_size(self.pg))
+            cam = _ffi.BhCamera()
+            C.memmove(C.byref(cam), C.byref(b.camera), C.sizeof(cam))
+            cam.tile_row_begin, cam.tile_row_end = rows
+            b.camera = cam
+            if self._img_hook is None:
+                self._img_hook = self._make_image_hook(dev)
+            b.image_hook = C.cast(self._img_hook, C.c_void_p)
         gt = _as_u32(batch.img_packed, dev)
         b.gt_packed = gt.data_ptr()
         b.has_alpha, b.alpha_is_mask = int(batch.has_alpha), int(batch.alpha_is_mask)
@@ -543,7 +582,7 @@ class SplatTrainer:
         if self.pg is not None:
             if self._hook is None:
                 self._hook = self._make_hook(dev)
-            hook, scale = self._hook, 1.0 / self._world
+            hook, scale = self._hook, (1.0 if tiles else 1.0 / self._world)
         ctx.check(ctx.lib.bh_train_step(ctx._h, C.byref(cfg), C.byref(st), C.byref(b), C.cast(hook, C.c_void_p) if hook else None, None,
                                         float(scale), C.byref(stats)))
         self.step_count = st.step_count

@@ -27,3 +27,72 @@ def allreduce_step_buffers(grads: torch.Tensor, stats: torch.Tensor, group=None)
     dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX, group=group)
     return dist.get_world_size(group)
+
+
+# ---------------------------------------------------------------------------
+# One frame partitioned over GPUs by strips of tile rows (BASELINE.json configs[4])
+# ---------------------------------------------------------------------------
+def tile_rows_for_rank(tile_bh, rank, world, weights=None):
+    """[begin, end) tile rows of `rank`: contiguous strips, sizes differing by at most one row.
+    With `weights` (per-row work, e.g. last frame's intersections per tile row) the cuts balance
+    the prefix sum of the weights instead of the row count."""
+    if world > tile_bh:
+        raise ValueError("more ranks (%d) than tile rows (%d)" % (world, tile_bh))
+    if weights is None:
+        base, extra = divmod(tile_bh, world)
+        begin = rank * base + min(rank, extra)
+        return begin, begin + base + (1 if rank < extra else 0)
+    w = [float(x) for x in weights]
+    if len(w) != tile_bh:
+        raise ValueError("weights must have one entry per tile row")
+    total = sum(w) or 1.0
+    cuts, acc, r = [0], 0.0, 1
+    for row, x in enumerate(w):
+        acc += x
+        # keep at least one row for every remaining rank
+        while r < world and acc >= total * r / world and row + 1 <= tile_bh - (world - r) and row + 1 > cuts[-1]:
+            cuts.append(row + 1)
+            r += 1
+    while len(cuts) < world:
+        cuts.append(max(cuts[-1] + 1, tile_bh - (world - len(cuts))))
+    cuts.append(tile_bh)
+    return cuts[rank], cuts[rank + 1]
+
+
+def strip_spans_px(img_h, world, weights=None):
+    """Pixel-row span [begin, end) of every rank's strip (host arithmetic, identical on all ranks)."""
+    tile_bh = (img_h + 15) // 16
+    out = []
+    for r in range(world):
+        b, e = tile_rows_for_rank(tile_bh, r, world, weights)
+        out.append((b * 16, min(e * 16, img_h)))
+    return out
+
+
+def allgather_strips(img: torch.Tensor, row_begin_px: int, row_end_px: int, group=None, spans=None):
+    """In place on img [H,W,C]: this rank owns pixel rows [row_begin_px, row_end_px); afterwards
+    every rank holds the whole image.  Strips are contiguous in the HWC layout, so each is one
+    message; heights may differ by a tile row, so strips are padded to the tallest one and moved
+    with a single all_gather_into_tensor."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    h = img.shape[0]
+    row_elems = img[0].numel()
+    if spans is None:  # exchange the spans (one small collective + a host read); callers that
+        # partition with tile_rows_for_rank pass strip_spans_px(...) and skip this
+        mine = torch.tensor([row_begin_px, row_end_px], dtype=torch.int64, device=img.device)
+        got = torch.empty(world * 2, dtype=torch.int64, device=img.device)
+        dist.all_gather_into_tensor(got, mine, group=group)
+        spans = [tuple(x) for x in got.view(world, 2).tolist()]
+    tallest = max(e - b for b, e in spans)
+    send = torch.zeros(tallest * row_elems, dtype=img.dtype, device=img.device)
+    send[: (row_end_px - row_begin_px) * row_elems] = img[row_begin_px:row_end_px].reshape(-1)
+    recv = torch.empty(world * tallest * row_elems, dtype=img.dtype, device=img.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, tallest * row_elems)
+    flat = img.view(h, row_elems)
+    for r, (b, e) in enumerate(spans):
+        if r != dist.get_rank(group):
+            flat[b:e] = recv[r, : (e - b) * row_elems].view(e - b, row_elems)

@@ -71,6 +71,11 @@ typedef struct BhCamera {
     float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y; /* Jacobian clamp limits */
     float cam_pos[3];
     uint32_t img_w, img_h;
+    /* Tile-row window [begin, end) of the 16x16 tile grid this call renders (0,0 = the
+     * whole image).  Used to partition ONE frame over GPUs by strips of tile rows
+     * (SURVEY.md 8e): splats are binned only into the window's tiles and only the window's
+     * pixels of out_img are written; per-tile splat lists are identical to a full render. */
+    uint32_t tile_row_begin, tile_row_end;
 } BhCamera;
 
 /* Forward outputs = RenderOutput + RenderAuxInner (render_aux.rs:17-68) and the
@@ -198,6 +203,11 @@ typedef struct BhTrainState {
     uint32_t step_count; /* number of steps already taken (host; incremented by the call) */
 } BhTrainState;
 
+/* Image hook: called (if non-NULL) after the forward render and before the loss with the
+ * ctx-owned out_img [H,W,4]; a tile-partitioned caller all-gathers the strips of the other
+ * ranks into it (pixel rows [row_begin_px, row_end_px) are this rank's).  Return 0. */
+typedef int (*bh_image_hook)(void* user, float* out_img, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px);
+
 typedef struct BhTrainBatch {
     BhCamera camera;
     const uint32_t* gt_packed; /* [H,W] rgba8 device */
@@ -207,6 +217,8 @@ typedef struct BhTrainBatch {
      * them from burn's GPU PRNG / rand::rng(), train.rs:395-399,896-908): */
     float background[3];       /* background actually used this step */
     const float* noise_samples; /* [N,3] N(0,1) device, or NULL = no noise */
+    bh_image_hook image_hook;   /* NULL unless the frame is tile-partitioned over ranks */
+    void* image_hook_user;
 } BhTrainBatch;
 
 typedef struct BhTrainStats {

@@ -63,3 +63,62 @@ def test_view_sharding_properties():
         seen = [view_for_rank(s, r, world, 16) for s in range(16 // world) for r in range(world)]
         assert sorted(seen) == list(range(16))
     assert view_for_rank(5, 0, 1, 3) == 2
+
+
+# ---- one frame partitioned by strips of tile rows (BASELINE.json configs[4]) ---------------
+def _strip_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brush_amd.parallel import allgather_strips, strip_spans_px
+    h, w = 150, 37   # 10 tile rows -> strips of 5 rows; the last strip is cut by the image edge
+    full = torch.arange(h * w * 4, dtype=torch.float32).reshape(h, w, 4)
+    spans = strip_spans_px(h, world)
+    b, e = spans[rank]
+    img = torch.full((h, w, 4), -1.0)
+    img[b:e] = full[b:e]
+    a = img.clone()
+    allgather_strips(a, b, e, spans=spans)
+    c = img.clone()
+    allgather_strips(c, b, e)   # spans exchanged by a collective
+    q.put((rank, bool(torch.equal(a, full)), bool(torch.equal(c, full)), spans))
+    dist.destroy_process_group()
+
+
+def test_allgather_strips_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ok_a, ok_c, spans in res:
+        assert ok_a and ok_c
+        assert spans == [(0, 80), (80, 150)]
+
+
+def test_tile_row_partition_properties():
+    from brush_amd.parallel import tile_rows_for_rank
+    for tile_bh in (1, 7, 68, 135):
+        for world in (1, 2, 3, 8):
+            if world > tile_bh:
+                with pytest.raises(ValueError):
+                    tile_rows_for_rank(tile_bh, 0, world)
+                continue
+            rows = [tile_rows_for_rank(tile_bh, r, world) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == tile_bh
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))       # contiguous, disjoint
+            sizes = [e - b for b, e in rows]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    # weighted cuts follow the work, keep every rank non-empty and stay a partition
+    w = [1.0] * 4 + [10.0] * 2 + [1.0] * 4
+    rows = [tile_rows_for_rank(10, r, 3, w) for r in range(3)]
+    assert rows[0][0] == 0 and rows[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert all(e > b for b, e in rows)
+    loads = [sum(w[b:e]) for b, e in rows]
+    assert max(loads) <= 0.6 * sum(w)
