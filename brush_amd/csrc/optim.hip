@@ -40,27 +40,54 @@ __global__ __launch_bounds__(OPT_WG) void adam_full_kernel(float* __restrict__ p
     param[i] = p;
 }
 
-// second moment reduced to one scalar per row (adam_scaled.rs:99-104,152-165):
-// one thread per row, sequential sum in index order.
+// second moment reduced to one scalar per row (adam_scaled.rs:99-104,152-165).
+// A block owns 256 consecutive rows: the gradient tile is staged through LDS with
+// coalesced loads (row pitch row_len+1: conflict-free for the per-row pass), thread r
+// forms row r's sum of squares sequentially in index order (the oracle's order, so the
+// result is bit-identical), and the update pass runs element-wise, coalesced, reading
+// the row's v back from LDS.  (One thread per row made every access a 4*row_len-byte
+// stride: 4.3 ms at 1 M splats / SH degree 3; this layout moves the same bytes at HBM speed.)
+constexpr int ADAM_ROWS = 256;
+
 __global__ __launch_bounds__(OPT_WG) void adam_rowreduced_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                                 float* __restrict__ m1, float* __restrict__ m2, uint64_t rows,
                                                                 uint32_t row_len, const float* __restrict__ col_scale, AdamArgs a) {
-    const uint64_t r = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
-    if (r >= rows) return;
-    const float* g = grad + r * row_len;
-    float s = 0.0f;
-    for (uint32_t c = 0; c < row_len; ++c) s += g[c] * g[c];
-    const float row_gsq = s / (float)row_len;
-    const float v = a.first ? row_gsq * a.f2 : m2[r] * a.beta2 + row_gsq * a.f2;
-    m2[r] = v;
-    for (uint32_t c = 0; c < row_len; ++c) {
-        const uint64_t i = r * row_len + c;
-        const float gi = g[c];
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_g = s_dyn;                                   // [ADAM_ROWS][row_len + 1]
+    float* s_v = s_dyn + ADAM_ROWS * (row_len + 1);       // [ADAM_ROWS]
+    const uint64_t row0 = (uint64_t)blockIdx.x * ADAM_ROWS;
+    const uint32_t nrows = (uint32_t)(rows - row0 < (uint64_t)ADAM_ROWS ? rows - row0 : (uint64_t)ADAM_ROWS);
+    const uint32_t count = nrows * row_len;
+    const uint64_t base = row0 * row_len;
+    const float rcp_len = 1.0f / (float)row_len;
+    const uint32_t pitch = row_len + 1;
+    for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+        const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);  // e / row_len, exact for e < 2^16
+        const uint32_t c = e - r * row_len;
+        s_g[r * pitch + c] = grad[base + e];
+    }
+    __syncthreads();
+    if (threadIdx.x < nrows) {
+        const float* g = s_g + threadIdx.x * pitch;
+        float s = 0.0f;
+        for (uint32_t c = 0; c < row_len; ++c) s += g[c] * g[c];
+        const float row_gsq = s / (float)row_len;
+        const uint64_t r = row0 + threadIdx.x;
+        const float v = a.first ? row_gsq * a.f2 : m2[r] * a.beta2 + row_gsq * a.f2;
+        m2[r] = v;
+        s_v[threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+        const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
+        const uint32_t c = e - r * row_len;
+        const uint64_t i = base + e;
+        const float gi = s_g[r * pitch + c];
         float mm1 = a.first ? gi * a.f1 : m1[i] * a.beta1 + gi * a.f1;
         m1[i] = mm1;
         const float step = col_scale ? col_scale[c] * a.lr : a.lr;
         float p = param[i];
-        adam_elem(p, gi, mm1, v, a, step);
+        adam_elem(p, gi, mm1, s_v[r], a, step);
         param[i] = p;
     }
 }
@@ -90,8 +117,17 @@ int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* 
     a.eps = eps; a.lr = lr;
     a.first = t == 1 ? 1u : 0u;
     if (reduce_m2) {
-        const uint64_t nb = (rows + OPT_WG - 1) / OPT_WG;
-        hipLaunchKernelGGL(adam_rowreduced_kernel, dim3((unsigned)nb), dim3(OPT_WG), 0, ctx->stream, param, grad, m1, m2, rows, row_len, col_scale, a);
+        if (row_len > 255) return set_error(ctx, BH_ERR_UNSUPPORTED, "adam (reduced second moment): row_len must be <= 255");
+        const uint64_t nb = (rows + ADAM_ROWS - 1) / ADAM_ROWS;
+        const size_t lds = ((size_t)ADAM_ROWS * (row_len + 1) + ADAM_ROWS) * sizeof(float);
+        if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (row_len > 62): opt in once per process
+            static bool raised = false;
+            if (!raised) {
+                BH_HIP(ctx, hipFuncSetAttribute((const void*)adam_rowreduced_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL(adam_rowreduced_kernel, dim3((unsigned)nb), dim3(OPT_WG), lds, ctx->stream, param, grad, m1, m2, rows, row_len, col_scale, a);
         BH_LAUNCH_CHECK(ctx, "adam_rowreduced_kernel");
     } else {
         const uint64_t count = rows * row_len;
