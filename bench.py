@@ -90,12 +90,12 @@ def main():
     cp = synth.default_camera_params(w, h)
     # one view per rank: rank r looks at the scene with a small extra yaw so the ranks'
     # gradients differ (data parallel over cameras); rank 0 is the named config's camera
-    tiles = args.parallel == "tiles" and world > 1
-    yaw = 0.0 if tiles else 0.02 * rank
+    tile_mode = args.parallel == "tiles" and world > 1
+    yaw = 0.0 if tile_mode else 0.02 * rank
     rot = (0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0))
     cam = ba.Camera(position=cp["pos"], rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"])
     splats = ba.Splats(scene["transforms"], scene["sh"], scene["raw_opac"], device=dev)
-    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tiles else rank)).view(np.int32)).to(dev)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
     batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
     ctx = ba.get_context(dev)
     trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=pg, ctx=ctx, partition=args.parallel)
@@ -150,19 +150,19 @@ def main():
         traffic, traffic_src = pmc_traffic_bytes("rasterize_backward_kernel")
         out = {
             "metric": "train views/sec @ 1M Gaussians, 1080p (fwd + L1/SSIM loss + bwd + Adam per view)",
-            "value": round((1 if tiles else world) * args.steps / dt, 3),
+            "value": round((1 if tile_mode else world) * args.steps / dt, 3),
             "unit": "views/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if tiles else "weak",
+            "scaling": "strong" if tile_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
-                       "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (RCCL all-gather of strips + all-reduce of gradients)" % world if tiles else
+                       "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (RCCL all-gather of strips + all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients)" % world) if world > 1 else "single GPU"},
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
