@@ -11,7 +11,7 @@ Names and argument meaning follow the reference (paths under
     radix_argsort     brush-sort/src/lib.rs:16
     prefix_sum        brush-prefix-sum/src/lib.rs:11
     image_loss        brush-loss/src/lib.rs:1075-1104
-    SplatTrainer      brush-train/src/train.rs:140-429
+    SplatTrainer      brush-train/src/train.rs:140-429 (step) and :431-893 (refine)
 
 torch is used only for device memory, streams and torch.distributed; every
 computation runs in the hand-written HIP kernels. No CPU fallback exists.
@@ -19,6 +19,6 @@ computation runs in the hand-written HIP kernels. No CPU fallback exists.
 from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
-    render_splats_bwd, adam_step,
+    render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size,
 )
 from ._ffi import BrushHipError  # noqa: F401

@@ -70,6 +70,20 @@ class BhTrainState(C.Structure):
     ]
 
 
+class BhRefineConfig(C.Structure):
+    _fields_ = [
+        ("iter", C.c_uint32), ("total_train_iters", C.c_uint32), ("growth_stop_iter", C.c_uint32), ("max_splats", C.c_uint32),
+        ("growth_grad_threshold", C.c_float), ("growth_select_fraction", C.c_float), ("split_at_screen_size", C.c_float),
+        ("opac_decay", C.c_float), ("bounds_center", C.c_float * 3), ("bounds_extent", C.c_float * 3), ("seed", C.c_uint64),
+    ]
+
+
+class BhRefineStats(C.Structure):
+    _fields_ = [("num_added", C.c_uint32), ("num_split_oversized", C.c_uint32), ("num_split_high_grad", C.c_uint32),
+                ("num_pruned", C.c_uint32), ("num_pruned_non_finite", C.c_uint32), ("total_splats", C.c_uint32),
+                ("num_resampled", C.c_uint32)]
+
+
 class BhTrainBatch(C.Structure):
     _fields_ = [
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
@@ -103,6 +117,10 @@ SYMBOLS = {
     "bh_image_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
     "bh_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_float]),
     "bh_gather_stats": (C.c_int, [C.c_void_p] * 7 + [C.c_uint64]),
+    "bh_refine_plan": (C.c_int, [C.c_void_p, C.POINTER(BhRefineConfig), C.POINTER(BhTrainState), C.POINTER(BhRefineStats)]),
+    "bh_refine_plan_flags": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "bh_refine_apply": (C.c_int, [C.c_void_p, C.POINTER(BhRefineConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainState)]),
+    "bh_splat_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
     "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),

@@ -47,6 +47,8 @@ enum Slot : int {
     SLOT_LOSS_SCALAR,
     SLOT_COL_SCALE,          // per-column lr tables
     SLOT_MISC,
+    SLOT_REFINE,             // refine plan: control block + 10 x [N] u32
+    SLOT_REFINE_BOUNDS,      // percentile bounds: keys / sorted keys / indices
     SLOT_COUNT
 };
 
@@ -85,6 +87,7 @@ struct bh_ctx {
     uint32_t n = 0, sh_degree = 0, flags = 0;
     float bg[3] = {0, 0, 0};
     BhRenderOut last{};
+    uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;
 };
 

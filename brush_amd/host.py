@@ -435,6 +435,43 @@ class TrainConfig:
     background_color: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     background_noise_strength: float = 0.1
     render_mip: bool = False
+    # refine options (config.rs:47-86)
+    max_splats: int = 10_000_000
+    refine_every: int = 200
+    growth_grad_threshold: float = 0.0025
+    growth_select_fraction: float = 0.25
+    growth_stop_iter: int = 15000
+    split_at_screen_size: float = 0.5
+    opac_decay: float = 0.004
+
+
+@dataclass
+class RefineStats:
+    """brush-train/src/msg.rs RefineStats (+ the number of splits drawn to refill the pruned budget)."""
+    num_added: int
+    num_split_oversized: int
+    num_split_high_grad: int
+    num_pruned: int
+    num_pruned_non_finite: int
+    total_splats: int
+    num_resampled: int = 0
+
+
+BOUND_PERCENTILE = 0.8  # train.rs:30
+
+
+def splat_bounds(splats, percentile=BOUND_PERCENTILE, ctx=None):
+    """get_splat_bounds (train.rs:124-133, splat_init.rs:130-160): (center[3], extent[3]) of the
+    per-axis percentile box of the means."""
+    ctx = ctx or get_context(splats.device)
+    c, e = (C.c_float * 3)(), (C.c_float * 3)()
+    ctx.check(ctx.lib.bh_splat_bounds(ctx._h, _ptr(splats.transforms), splats.num_splats(), float(percentile), c, e))
+    return tuple(c), tuple(e)
+
+
+def bounds_median_size(extent):
+    """BoundingBox::median_size (bounding_box.rs:23-29)."""
+    return sorted(float(x) for x in extent)[1] * 2.0
 
 
 @dataclass
@@ -476,6 +513,7 @@ class SplatTrainer:
             raise ValueError("partition must be 'cameras' or 'tiles'")
         self.partition = partition
         self._img_hook = None
+        self.bounds = None  # (center, extent); None = unit box scaled by median_scene_scale (set by refine / set_bounds)
         self.config = config
         self.median_scene_scale = float(median_scene_scale)
         self.step_count = 0
@@ -589,6 +627,63 @@ class SplatTrainer:
         self._last_stats = stats
         self._keep = (gt, ns)
         return splats, stats
+
+    def _train_state(self, splats, s):
+        st = _ffi.BhTrainState()
+        st.n, st.sh_degree = splats.num_splats(), splats.sh_degree()
+        st.transforms, st.sh_coeffs, st.raw_opacities = splats.transforms.data_ptr(), splats.sh_coeffs.data_ptr(), splats.raw_opacities.data_ptr()
+        st.m1_transforms, st.m2_transforms = s["m1_t"].data_ptr(), s["m2_t"].data_ptr()
+        st.m1_sh, st.m2_sh = s["m1_sh"].data_ptr(), s["m2_sh"].data_ptr()
+        st.m1_opac, st.m2_opac = s["m1_o"].data_ptr(), s["m2_o"].data_ptr()
+        st.refine_weight_norm, st.vis_weight, st.max_screen_size = s["refine_weight_norm"].data_ptr(), s["vis_weight"].data_ptr(), s["max_screen_size"].data_ptr()
+        st.step_count = self.step_count
+        return st
+
+    def set_bounds(self, center, extent):
+        self.bounds = (tuple(float(x) for x in center), tuple(float(x) for x in extent))
+        self.median_scene_scale = bounds_median_size(self.bounds[1])
+
+    def refine(self, iter: int, splats: Splats, seed: Optional[int] = None):
+        """SplatTrainer::refine (train.rs:431-663): prune dead / oversized / out-of-bounds / non-finite
+        splats, refill the pruned budget by opacity x visibility sampling, split splats that are too big
+        on screen or have a high positional gradient, reset their Adam moments, decay opacities and
+        recompute the scene bounds.  Returns (new Splats, RefineStats); the trainer's optimizer state
+        and RefineRecord are replaced.  `seed` (default: derived from iter) drives every random choice, so
+        data-parallel ranks stay identical."""
+        ctx = self.ctx or get_context(splats.device)
+        dev = splats.device
+        if self.state is None:
+            raise BrushHipError("Can only refine if refine stats are initialized")  # train.rs:445
+        if self.bounds is None:
+            self.set_bounds(*splat_bounds(splats, ctx=ctx))
+        c = self.config
+        cfg = _ffi.BhRefineConfig()
+        cfg.iter, cfg.total_train_iters = int(iter), max(int(c.total_train_iters), 1)
+        cfg.growth_stop_iter = min(int(c.growth_stop_iter), int(c.total_train_iters))  # train.rs:150
+        cfg.max_splats = int(c.max_splats)
+        cfg.growth_grad_threshold, cfg.growth_select_fraction = c.growth_grad_threshold, c.growth_select_fraction
+        cfg.split_at_screen_size, cfg.opac_decay = c.split_at_screen_size, c.opac_decay
+        for k in range(3):
+            cfg.bounds_center[k], cfg.bounds_extent[k] = self.bounds[0][k], self.bounds[1][k]
+        cfg.seed = int(seed) if seed is not None else (0x5EED0000 + int(iter))
+        st_in = self._train_state(splats, self.state)
+        rs = _ffi.BhRefineStats()
+        ctx.check(ctx.lib.bh_refine_plan(ctx._h, C.byref(cfg), C.byref(st_in), C.byref(rs)))
+        n2 = rs.total_splats
+        z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        coeffs = splats.sh_coeffs.shape[1]
+        new = Splats(z(n2, 10), z(n2, coeffs, 3), z(n2), splats.render_mip, dev)
+        ns = dict(m1_t=z(n2, 10), m2_t=z(n2, 10), m1_sh=z(n2, coeffs, 3), m2_sh=z(n2), m1_o=z(n2), m2_o=z(n2),
+                  refine_weight_norm=z(n2), vis_weight=z(n2), max_screen_size=z(n2))
+        st_out = self._train_state(new, ns)
+        self.last_refine_plan = {k: _view(ctx.lib.bh_refine_plan_flags(ctx._h, i), (st_in.n,), torch.int32, dev).clone()
+                                 for i, k in enumerate(("keep", "new_row", "split", "child_slot"))}
+        ctx.check(ctx.lib.bh_refine_apply(ctx._h, C.byref(cfg), C.byref(st_in), C.byref(st_out)))
+        self.state = ns
+        self.set_bounds(*splat_bounds(new, ctx=ctx))  # train.rs:634
+        stats = RefineStats(rs.num_added, rs.num_split_oversized, rs.num_split_high_grad, rs.num_pruned, rs.num_pruned_non_finite,
+                            rs.total_splats, rs.num_resampled)
+        return new, stats
 
     def stats(self, ctx=None) -> TrainStepStats:
         """Resolve the stats of the last step (synchronises)."""

@@ -237,6 +237,42 @@ int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* 
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);
 
+/* ---- refine (densify / prune) ------------------------------------------------ */
+/* SplatTrainer::refine (brush-train/src/train.rs:431-893) in two calls, because the caller
+ * owns all tensors and must size the outputs: bh_refine_plan decides on the device what is
+ * pruned and what is split (one 64-byte readback returns the counts), the caller allocates
+ * `total_splats` rows for every tensor, bh_refine_apply writes them.  All stochastic choices
+ * derive from `seed`: data-parallel ranks passing the same seed on their (identical) replicas
+ * take identical decisions. */
+typedef struct BhRefineConfig {
+    uint32_t iter, total_train_iters; /* opacity-decay schedule and growth gating */
+    uint32_t growth_stop_iter;        /* 15000 */
+    uint32_t max_splats;              /* 10000000 */
+    float growth_grad_threshold;      /* 0.0025 */
+    float growth_select_fraction;     /* 0.25 */
+    float split_at_screen_size;       /* 0.5; 0 disables */
+    float opac_decay;                 /* 0.004 */
+    float bounds_center[3], bounds_extent[3]; /* current scene bounds (train.rs:485,504-512) */
+    uint64_t seed;
+} BhRefineConfig;
+
+typedef struct BhRefineStats { /* RefineStats (brush-train/src/msg.rs) + the resample count */
+    uint32_t num_added, num_split_oversized, num_split_high_grad, num_pruned, num_pruned_non_finite, total_splats;
+    uint32_t num_resampled; /* splits drawn to refill the pruned budget */
+} BhRefineStats;
+
+int bh_refine_plan(bh_ctx* ctx, const BhRefineConfig* cfg /*host*/, const BhTrainState* state /*host*/, BhRefineStats* out /*host*/);
+/* Plan arrays of the last bh_refine_plan, each [N] u32, valid until bh_refine_apply:
+ * 0 keep flag, 1 new row of a kept splat, 2 split flag, 3 child slot (= kept count + this). */
+const uint32_t* bh_refine_plan_flags(bh_ctx* ctx, int which);
+/* `out`: caller-allocated state with n = total_splats of the plan (same sh_degree).  Kept rows are
+ * gathered in order, split parents rewritten, children appended (train.rs:665-806), Adam moments of
+ * both halves zeroed, opacity decay applied (train.rs:808-817), the RefineRecord zeroed. */
+int bh_refine_apply(bh_ctx* ctx, const BhRefineConfig* cfg /*host*/, const BhTrainState* in /*host*/, BhTrainState* out /*host*/);
+/* get_splat_bounds / bounds_from_pos (brush-train/src/splat_init.rs:130-160): per-axis percentile
+ * box of the means ([N,10] transforms, columns 0..2), non-finite values ignored; blocking. */
+int bh_splat_bounds(bh_ctx* ctx, const float* transforms, uint32_t n, float percentile, float* center /*host[3]*/, float* extent /*host[3]*/);
+
 /* ---- profiling --------------------------------------------------------------- */
 /* When enabled, each pipeline stage is bracketed by HIP events on the ctx stream. */
 int bh_profile_enable(bh_ctx* ctx, int on);
