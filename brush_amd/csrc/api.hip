@@ -114,8 +114,8 @@ static void prof_resolve(bh_ctx* ctx) {
     p.pending.clear();
 }
 
-ProfScope::ProfScope(bh_ctx* c, const char* name) : ctx(c) {
-    if (!c->prof.on) return;
+ProfScope::ProfScope(bh_ctx* c, const char* name, bool dominant) : ctx(c) {
+    if (c->prof.level == 0 || (c->prof.level == 2 && !dominant)) return;
     idx = prof_index(c->prof, name);
     a = prof_event(c->prof);
     b = prof_event(c->prof);
@@ -183,12 +183,16 @@ const char* bh_last_error(bh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 int bh_sync(bh_ctx* ctx) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_loss_dst) {  // the last train step's loss, staged through pinned memory
+        *ctx->pending_loss_dst = reinterpret_cast<float*>(ctx->host_counters)[15];
+        ctx->pending_loss_dst = nullptr;
+    }
     return 0;
 }
 
 int bh_profile_enable(bh_ctx* ctx, int on) {
     if (!ctx) return BH_ERR_INVALID_ARG;
-    ctx->prof.on = on != 0;
+    ctx->prof.level = on < 0 ? 0 : (on > 2 ? 1 : on);
     return 0;
 }
 
@@ -280,7 +284,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* counters = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 16);
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
     auto* isect_counts = (uint32_t*)ensure(ctx, SLOT_ISECT_COUNTS, npad * 4);
-    auto* max_radius = (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
+    auto* max_radius = ctx->ext_max_radius ? ctx->ext_max_radius : (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
     if (!counters || !depth_keys || !isect_counts || !max_radius) return BH_ERR_OOM;
 
     uint32_t nv = 0, ni = 0;
@@ -311,7 +315,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, (size_t)num_tiles * 2 * 4);
     const size_t pixels = (size_t)u.img_w * u.img_h;
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
-    auto* visible = (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
+    auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!gfc || !depths_sorted || !cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted ||
         !tile_offsets || !out_img || !visible)
         return BH_ERR_OOM;
@@ -406,14 +410,19 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
         if (n > 0) {
             // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
-            BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
-            BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
-            BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
+            if (v_sh_coeffs == v_transforms + (size_t)n * 10 && v_raw_opacities == v_sh_coeffs + (size_t)n * C * 3) {
+                // the train step's fused gradient buffer: one fill instead of three
+                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * (10 + 3 * C + 1) * 4, ctx->stream));
+            } else {
+                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
+                BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
+                BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
+            }
             BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
         }
     }
     {
-        ProfScope ps(ctx, "RasterizeBackwards");
+        ProfScope ps(ctx, "RasterizeBackwards", /*dominant=*/true);
         if (r.num_intersections > 0)
             BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
                                              r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined));
@@ -521,11 +530,18 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     st->step_count += 1;  // train.rs:183
     const uint32_t step = st->step_count;
 
-    // ---- forward (train.rs:211-215)
+    // ---- forward (train.rs:211-215); `visible` and `max_radius` land directly in the stats buffer
+    auto* stat_buf = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 3 * 4);
+    if (!stat_buf) return BH_ERR_OOM;
     BhRenderOut ro;
     const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
-    BH_TRY(bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
-                             batch->background, flags, &ro));
+    ctx->ext_visible = stat_buf + n;
+    ctx->ext_max_radius = stat_buf + 2 * (size_t)n;
+    const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
+                                      batch->background, flags, &ro);
+    ctx->ext_visible = nullptr;
+    ctx->ext_max_radius = nullptr;
+    BH_TRY(frc);
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
     if (batch->image_hook) {
@@ -550,9 +566,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
     const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
     auto* grads = (float*)ensure(ctx, SLOT_GRADS, (grad_count ? grad_count : 1) * 4);
-    auto* stat_buf = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 3 * 4);
     auto* col_scale = (float*)ensure(ctx, SLOT_COL_SCALE, 256 * 4);
-    if (!v_output || !loss_dev || !grads || !stat_buf || !col_scale) return BH_ERR_OOM;
+    if (!v_output || !loss_dev || !grads || !col_scale) return BH_ERR_OOM;
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
@@ -566,10 +581,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* s_visible = stat_buf + n;
     float* s_radius = stat_buf + 2 * (size_t)n;
     BH_TRY(bh_render_backward(ctx, v_output, st->transforms, st->sh_coeffs, st->raw_opacities, g_tr, g_sh, g_op, s_refine));
-    if (n > 0) {
-        BH_HIP(ctx, hipMemcpyAsync(s_visible, ro.visible, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        BH_HIP(ctx, hipMemcpyAsync(s_radius, ro.max_radius, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
     // ---- data-parallel exchange (not in the reference: SURVEY.md §8e)
     if (hook) {
         ProfScope ps(ctx, "GradExchange");
@@ -613,6 +624,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     stats->num_visible = ro.num_visible;
     stats->num_intersections = ro.num_intersections;
     stats->lr_mean = lr_mean;
-    BH_HIP(ctx, hipMemcpyAsync(&stats->loss, loss_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    // device -> pinned staging (truly asynchronous: a copy into the caller's pageable struct would
+    // stall the host until the whole step has run); bh_sync moves it into stats->loss
+    BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<float*>(ctx->host_counters) + 15, loss_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending_loss_dst = &stats->loss;
+    stats->loss = 0.0f;
     return 0;
 }

@@ -60,7 +60,7 @@ struct Buffer {
 constexpr int MAX_PROF = 32;
 
 struct Profiler {
-    bool on = false;
+    int level = 0;  // 0 off, 1 every stage, 2 only the dominant kernel (2 events per step)
     const char* names[MAX_PROF];
     float ms[MAX_PROF];
     uint32_t calls[MAX_PROF];
@@ -87,6 +87,9 @@ struct bh_ctx {
     uint32_t n = 0, sh_degree = 0, flags = 0;
     float bg[3] = {0, 0, 0};
     BhRenderOut last{};
+    float* ext_visible = nullptr;     // train step: the forward writes visible / max_radius here (stats buffer)
+    float* ext_max_radius = nullptr;
+    float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;
 };
@@ -102,7 +105,7 @@ struct ProfScope {
     bh_ctx* ctx;
     int idx = -1;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(bh_ctx* c, const char* name);
+    ProfScope(bh_ctx* c, const char* name, bool dominant = false);
     ~ProfScope();
 };
 

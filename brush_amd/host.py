@@ -56,7 +56,8 @@ class Context:
         self.check(self.lib.bh_sync(self._h))
 
     def profile(self, on=True):
-        self.check(self.lib.bh_profile_enable(self._h, 1 if on else 0))
+        """True/1: HIP events around every stage; 2: only around the dominant kernel; False/0: off."""
+        self.check(self.lib.bh_profile_enable(self._h, int(on)))
 
     def profile_fetch(self):
         """{stage: (total_ms, calls)} accumulated since the last fetch."""

@@ -20,7 +20,8 @@ tr = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, ctx=ctx)
 for _ in range(4):
     tr.step(batch, splats)
 torch.cuda.synchronize()
-ctx.profile(True); ctx.profile_fetch()
+prof = os.environ.get('PROFILE', '1') == '1'
+ctx.profile(prof); ctx.profile_fetch()
 import time
 t0 = time.perf_counter()
 for _ in range(steps):
