@@ -10,12 +10,18 @@
 //           dsigma12) x chain, written once as 9 planes;
 //   pass B  blurs those planes (26x26 halo) and writes v_output [H,W,4] directly.
 // The apron recompute, the CHW loss map, its grid-wide sum, the v_output memset and the
-// HWC<->CHW permutes (lib.rs:1076,1103) all disappear.  Per-output arithmetic is the
-// same tap-pair accumulation order as loss.hip, so the results match the stand-alone
-// kernels (tests/test_gpu_loss_optim.py::test_fused_loss_matches_standalone).
+// HWC<->CHW permutes (lib.rs:1076,1103) all disappear.  Per-output arithmetic keeps the
+// tap-pair accumulation order of loss.hip, but this file is compiled with FMA contraction
+// ON and uses v_rcp_f32 in the SSIM quotient chain: the loss has no integer-valued
+// outputs to keep reproducible, and the results stay within the 2e-6 the parity tests
+// allow against the oracle (tests/test_gpu_loss_optim.py::test_fused_loss_matches_oracle_and_standalone).
+// (An XCD-banded tile order was measured neutral here — the 256 MB Infinity Cache already
+// absorbs the 60 % halo overlap — and is not used.)
 #include <cmath>
 
 #include "context.h"
+
+#pragma clang fp contract(fast)
 
 namespace bh {
 
@@ -61,7 +67,7 @@ BH_DEV float gt_ch(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float* __restrict__ img /*[H,W,4]*/,
                                                                     const uint32_t* __restrict__ gt,
-                                                                    float* __restrict__ partials /*[9,H,W]*/,
+                                                                    float* __restrict__ partials /*[H,W,3,4]*/,
                                                                     float* __restrict__ block_sums, FusedArgs a) {
     __shared__ float2 s_tile[3][SH * SH];          // (pred, gt_eff) per colour plane
     __shared__ float s_h[3][SH * LB * 5];          // horizontally blurred moments
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
     const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * LB + lx;
-    const size_t hw = (size_t)a.h * a.w;
     for (int i = rank; i < SH * SH; i += LB * LB) {
         const int r = i / SH, q = i - r * SH;
         const int y = ty0 + r - HALO, x = tx0 + q - HALO;
@@ -92,31 +97,41 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
         s_tile[2][i] = make_float2(pv.z, g2);
     }
     __syncthreads();
-    // horizontal blur of (x, x^2, y, y^2, xy): 3 planes x 26 rows x 16 columns
-    for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
-        const int c = i / (SH * LB), rem = i - c * (SH * LB);
-        const int r = rem / LB, col = (rem - r * LB) + HALO;
-        const float2* row = &s_tile[c][r * SH];
-        float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+    // horizontal blur of (x, x^2, y, y^2, xy): 3 planes x 26 rows x 8 column PAIRS — an item loads
+    // the 12 pixels its two adjacent outputs share once and squares each of them once
+    for (int i = rank; i < 3 * SH * (LB / 2); i += LB * LB) {
+        const int c = i / (SH * (LB / 2)), rem = i - c * (SH * (LB / 2));
+        const int r = rem / (LB / 2), pair = rem - r * (LB / 2);
+        const float2* row = &s_tile[c][r * SH + 2 * pair];   // row[k] = pixel at tile column 2*pair - HALO + k
+        float x[12], y[12], xx[12], yy[12], xy[12];
 #pragma unroll
-        for (int d = 1; d < 6; ++d) {
-            const float wd = a.taps.w[5 - d];
-            const float2 l = row[col - d], rr = row[col + d];
-            sx += (l.x + rr.x) * wd;
-            sx2 += (l.x * l.x + rr.x * rr.x) * wd;
-            sy += (l.y + rr.y) * wd;
-            sy2 += (l.y * l.y + rr.y * rr.y) * wd;
-            sxy += (l.x * l.y + rr.x * rr.y) * wd;
+        for (int k = 0; k < 12; ++k) {
+            const float2 v = row[k];
+            x[k] = v.x; y[k] = v.y;
+            xx[k] = v.x * v.x; yy[k] = v.y * v.y; xy[k] = v.x * v.y;
         }
-        const float2 cc = row[col];
-        const float wc = a.taps.w[5];
-        sx += cc.x * wc;
-        sx2 += cc.x * cc.x * wc;
-        sy += cc.y * wc;
-        sy2 += cc.y * cc.y * wc;
-        sxy += cc.x * cc.y * wc;
-        float* o = &s_h[c][rem * 5];
-        o[0] = sx; o[1] = sx2; o[2] = sy; o[3] = sy2; o[4] = sxy;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int cc = HALO + o;
+            float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+#pragma unroll
+            for (int d = 1; d < 6; ++d) {
+                const float wd = a.taps.w[5 - d];
+                sx += (x[cc - d] + x[cc + d]) * wd;
+                sx2 += (xx[cc - d] + xx[cc + d]) * wd;
+                sy += (y[cc - d] + y[cc + d]) * wd;
+                sy2 += (yy[cc - d] + yy[cc + d]) * wd;
+                sxy += (xy[cc - d] + xy[cc + d]) * wd;
+            }
+            const float wc = a.taps.w[5];
+            sx += x[cc] * wc;
+            sx2 += xx[cc] * wc;
+            sy += y[cc] * wc;
+            sy2 += yy[cc] * wc;
+            sxy += xy[cc] * wc;
+            float* op = &s_h[c][(r * LB + 2 * pair + o) * 5];
+            op[0] = sx; op[1] = sx2; op[2] = sy; op[3] = sy2; op[4] = sxy;
+        }
     }
     __syncthreads();
     const int py = ty0 + ly, pxx = tx0 + lx;
@@ -150,23 +165,22 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
             const float B = s1 + s2 + SSIM_C2;
             const float c_top = 2.0f * mu1 * mu2 + SSIM_C1;
             const float d_top = 2.0f * s12 + SSIM_C2;
-            // forward value (lib.rs:331-358)
-            const float raw = (c_top * d_top) / (A * B);
-            const float ssim = clampf(raw, -1.0f, 1.0f);
+            // forward value (lib.rs:331-358); one reciprocal each of A and B serves both passes
+            const float inv_a = __builtin_amdgcn_rcpf(A), inv_b = __builtin_amdgcn_rcpf(B);
+            const float inv_ab = inv_a * inv_b;
+            const float cd = c_top * d_top * inv_ab;
+            const float ssim = clampf(cd, -1.0f, 1.0f);
             const float2 pg = s_tile[c][(ly + HALO) * SH + lx + HALO];
             float lv = a.l1_w * __builtin_fabsf(pg.x - pg.y) + a.ssim_w * ssim;
             if (a.mask) lv = lv * ga;
             acc_rgb += lv;
             // SSIM partials for the backward (lib.rs:455-520)
-            const float inv_ab = 1.0f / (A * B);
-            const float cd = c_top * d_top * inv_ab;
             const bool clamped = cd < -1.0f || cd > 1.0f;
-            const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (1.0f / A - 1.0f / B);
-            const float ds1 = clamped ? 0.0f : -cd / B;
+            const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (inv_a - inv_b);
+            const float ds1 = clamped ? 0.0f : -cd * inv_b;
             const float ds12 = clamped ? 0.0f : 2.0f * c_top * inv_ab;
-            partials[(size_t)(c * 3 + 0) * hw + p] = dmu1 * chain;
-            partials[(size_t)(c * 3 + 1) * hw + p] = ds1 * chain;
-            partials[(size_t)(c * 3 + 2) * hw + p] = ds12 * chain;
+            // [H,W,3,4]: one 16-byte store per colour plane (and one 16-byte load per tap in pass B)
+            *reinterpret_cast<float4*>(&partials[(p * 3 + c) * 4]) = make_float4(dmu1 * chain, ds1 * chain, ds12 * chain, 0.0f);
         }
         if (a.alpha_match) {  // lib.rs:203-214
             const float pa = img[p * 4 + 3];
@@ -188,45 +202,41 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
 // pass B
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
-                                                                     const float* __restrict__ partials,
+                                                                     const float* __restrict__ partials /*[H,W,3,4]*/,
                                                                      float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
-    __shared__ float s_part[3][SH * SH * 3];   // chain * (dmu1, dsigma1, dsigma12)
-    __shared__ float s_h2[3][SH * LB * 3];
+    __shared__ float4 s_part[3][SH * SH];      // chain * (dmu1, dsigma1, dsigma12, -)
+    __shared__ float4 s_h2[3][SH * LB];
     const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * LB + lx;
-    const size_t hw = (size_t)a.h * a.w;
     for (int i = rank; i < SH * SH; i += LB * LB) {
         const int r = i / SH, q = i - r * SH;
         const int y = ty0 + r - HALO, x = tx0 + q - HALO;
         const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
         const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s_part[c][i * 3 + k] = in ? partials[(size_t)(c * 3 + k) * hw + p] : 0.0f;
-        }
+        for (int c = 0; c < 3; ++c) s_part[c][i] = in ? *reinterpret_cast<const float4*>(&partials[(p * 3 + c) * 4]) : z;
     }
     __syncthreads();
     for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
         const int c = i / (SH * LB), rem = i - c * (SH * LB);
         const int r = rem / LB, col = (rem - r * LB) + HALO;
+        const float4* row = &s_part[c][r * SH];
         float a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
         for (int d = 1; d < 6; ++d) {
             const float wd = a.taps.w[5 - d];
-            const float* l = &s_part[c][(r * SH + col - d) * 3];
-            const float* rr = &s_part[c][(r * SH + col + d) * 3];
-            a0 += (l[0] + rr[0]) * wd;
-            a1 += (l[1] + rr[1]) * wd;
-            a2 += (l[2] + rr[2]) * wd;
+            const float4 l = row[col - d], rr = row[col + d];
+            a0 += (l.x + rr.x) * wd;
+            a1 += (l.y + rr.y) * wd;
+            a2 += (l.z + rr.z) * wd;
         }
-        const float* cc = &s_part[c][(r * SH + col) * 3];
-        a0 += cc[0] * a.taps.w[5];
-        a1 += cc[1] * a.taps.w[5];
-        a2 += cc[2] * a.taps.w[5];
-        float* o = &s_h2[c][rem * 3];
-        o[0] = a0; o[1] = a1; o[2] = a2;
+        const float4 cc = row[col];
+        a0 += cc.x * a.taps.w[5];
+        a1 += cc.y * a.taps.w[5];
+        a2 += cc.z * a.taps.w[5];
+        s_h2[c][rem] = make_float4(a0, a1, a2, 0.0f);
     }
     __syncthreads();
     const int py = ty0 + ly, pxx = tx0 + lx;
@@ -245,14 +255,16 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
 #pragma unroll
         for (int d = 1; d < 6; ++d) {
             const float wd = a.taps.w[5 - d];
-            const float* t = &s_h2[c][((ly + HALO - d) * LB + lx) * 3];
-            const float* b = &s_h2[c][((ly + HALO + d) * LB + lx) * 3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s[k] += (t[k] + b[k]) * wd;
+            const float4 t = s_h2[c][(ly + HALO - d) * LB + lx];
+            const float4 b = s_h2[c][(ly + HALO + d) * LB + lx];
+            s[0] += (t.x + b.x) * wd;
+            s[1] += (t.y + b.y) * wd;
+            s[2] += (t.z + b.z) * wd;
         }
-        const float* cc = &s_h2[c][((ly + HALO) * LB + lx) * 3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] += cc[k] * a.taps.w[5];
+        const float4 cc = s_h2[c][(ly + HALO) * LB + lx];
+        s[0] += cc.x * a.taps.w[5];
+        s[1] += cc.y * a.taps.w[5];
+        s[2] += cc.z * a.taps.w[5];
         float ge = gt_ch(val, c);
         if (a.composite) ge = ge + (1.0f - ga) * a.bg[c];
         const float p1 = pred_c[c];
@@ -288,7 +300,7 @@ int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* 
     const dim3 grid((w + LB - 1) / LB, (h + LB - 1) / LB), block(LB, LB);
     const size_t hw = (size_t)h * w;
     const int nb = (int)(grid.x * grid.y);
-    auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 9 * sizeof(float));
+    auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));
     auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)nb * sizeof(float));
     if (!partials || !block_sums) return BH_ERR_OOM;
     FusedArgs a;

@@ -56,10 +56,10 @@ def test_fused_loss_matches_oracle_and_standalone(dev, oracle_lib, h, w, bg, mas
     assert np.abs(g[..., :ch] - rg).max() <= 2e-6 * max(np.abs(rg).max(), 1e-12)
     if ch == 3:
         assert not g[..., 3].any()
-    # and against the stand-alone HIP kernels (same per-output arithmetic)
+    # and against the stand-alone HIP kernels (same tap order)
     g2 = ba.image_loss_backward(torch.from_numpy(img[..., :ch].copy()).to(dev), gt_t, torch.from_numpy(np.ascontiguousarray(dl.transpose(1, 2, 0))).to(dev),
                                 0.8, -0.2, composite_bg=bg, mask=mask).cpu().numpy()
-    assert np.abs(g[..., :ch] - g2).max() <= 1e-7 * max(np.abs(g2).max(), 1e-12)
+    assert np.abs(g[..., :ch] - g2).max() <= 2e-6 * max(np.abs(g2).max(), 1e-12)   # fused kernels contract to FMA / use v_rcp
 
 
 def test_ssim_of_identical_images_is_one(dev):
