@@ -96,7 +96,7 @@ class BhTrainStats(C.Structure):
     _fields_ = [("num_visible", C.c_uint32), ("num_intersections", C.c_uint32), ("lr_mean", C.c_double), ("loss", C.c_float)]
 
 
-GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 IMAGE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 
 # every symbol include/brush_hip.h declares: (restype, argtypes)

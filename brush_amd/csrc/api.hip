@@ -162,6 +162,13 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         return nullptr;
     }
     std::memset(ctx->host_counters, 0, 64);
+    if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(ctx->host_counters);
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return nullptr;
+    }
     return ctx;
 }
 
@@ -174,6 +181,7 @@ void bh_destroy(bh_ctx* ctx) {
     for (auto& b : ctx->slots)
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
+    if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -287,6 +295,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* max_radius = ctx->ext_max_radius ? ctx->ext_max_radius : (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
     if (!counters || !depth_keys || !isect_counts || !max_radius) return BH_ERR_OOM;
 
+    auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
+    auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
+    if (!gfc || !depths_sorted) return BH_ERR_OOM;
+
     uint32_t nv = 0, ni = 0;
     if (n > 0) {
         {
@@ -294,18 +306,25 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             BH_HIP(ctx, hipMemsetAsync(counters, 0, 16, ctx->stream));
             BH_TRY(launch_project_forward(ctx, u, n, mip, transforms, raw_opacities, depth_keys, isect_counts, max_radius, counters));
         }
-        // the one mid-pipeline readback, as render.rs:146-168
+        // the one mid-pipeline readback (render.rs:146-168).  The depth sort covers all n splats
+        // and needs neither count, so it is queued behind the copy BEFORE the host waits: the GPU
+        // sorts while the host reads the counts, sizes the buffers and queues the rest.
         auto* hc = reinterpret_cast<unsigned long long*>(ctx->host_counters);
         BH_HIP(ctx, hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, ctx->stream));
-        BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+        {
+            ProfScope ps(ctx, "DepthSort");
+            // culled splats carry key 0xFFFFFFFF and sort behind every visible one:
+            // the stable sort is also the (deterministic) compaction.
+            BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
+        }
+        BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
         nv = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
     }
 
     const size_t nvpad = nv ? nv : 1, nipad = ni ? ni : 1;
-    auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
-    auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
     auto* cum = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, nvpad * 4);
     auto* projected = (float*)ensure(ctx, SLOT_PROJECTED, nvpad * 9 * 4);
     auto* tile_ids = (uint32_t*)ensure(ctx, SLOT_TILE_IDS, nipad * 4);
@@ -316,16 +335,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const size_t pixels = (size_t)u.img_w * u.img_h;
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
-    if (!gfc || !depths_sorted || !cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted ||
+    if (!cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted ||
         !tile_offsets || !out_img || !visible)
         return BH_ERR_OOM;
 
-    if (n > 0) {
-        ProfScope ps(ctx, "DepthSort");
-        // culled splats carry key 0xFFFFFFFF and sort behind every visible one:
-        // the stable sort is also the (deterministic) compaction.
-        BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
-    }
     if (nv > 0) {
         {
             ProfScope ps(ctx, "PrefixSumGaussHits");
@@ -410,15 +423,16 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
         if (n > 0) {
             // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
-            if (v_sh_coeffs == v_transforms + (size_t)n * 10 && v_raw_opacities == v_sh_coeffs + (size_t)n * C * 3) {
-                // the train step's fused gradient buffer: one fill instead of three
-                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * (10 + 3 * C + 1) * 4, ctx->stream));
+            const bool fused = v_sh_coeffs == v_transforms + (size_t)n * 10 && v_raw_opacities == v_sh_coeffs + (size_t)n * C * 3;
+            if (fused && v_refine_weight == v_raw_opacities + n) {
+                // the train step's exchange buffer: one fill instead of four
+                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * (10 + 3 * C + 2) * 4, ctx->stream));
             } else {
                 BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
                 BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
                 BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
+                BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
             }
-            BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
         }
     }
     {
@@ -500,22 +514,6 @@ int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, f
 }  // extern "C"
 
 // ---- training step -------------------------------------------------------------
-namespace bh {
-
-struct ScaleTable { float v[96]; };
-
-__global__ void fill_table_kernel(float* dst, ScaleTable t, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = t.v[i];
-}
-
-__global__ void scale_kernel(float* x, uint64_t n, float s) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] = x[i] * s;
-}
-
-}  // namespace bh
-
 extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
                              bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats) {
     if (!ctx) return BH_ERR_INVALID_ARG;
@@ -530,13 +528,22 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     st->step_count += 1;  // train.rs:183
     const uint32_t step = st->step_count;
 
-    // ---- forward (train.rs:211-215); `visible` and `max_radius` land directly in the stats buffer
-    auto* stat_buf = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 3 * 4);
-    if (!stat_buf) return BH_ERR_OOM;
+    // ---- the exchange buffer: visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | v_refine[N].
+    // One buffer = one collective per step for a multi-GPU caller (see bh_grad_hook).
+    const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
+    const size_t exch_count = (size_t)n * (10 + 3 * C + 3);
+    auto* exch = (float*)ensure(ctx, SLOT_GRADS, (exch_count ? exch_count : 1) * 4);
+    auto* s_radius = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 4);
+    if (!exch || !s_radius) return BH_ERR_OOM;
+    float* s_visible = exch;
+    float* grads = exch + n;
+    float* s_refine = grads + grad_count;
+
+    // ---- forward (train.rs:211-215); `visible` lands directly in the exchange buffer
     BhRenderOut ro;
     const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
-    ctx->ext_visible = stat_buf + n;
-    ctx->ext_max_radius = stat_buf + 2 * (size_t)n;
+    ctx->ext_visible = s_visible;
+    ctx->ext_max_radius = s_radius;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
                                       batch->background, flags, &ro);
     ctx->ext_visible = nullptr;
@@ -564,10 +571,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const size_t hw = (size_t)W * H;
     auto* v_output = (float*)ensure(ctx, SLOT_V_OUTPUT, hw * 16);
     auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
-    const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
-    auto* grads = (float*)ensure(ctx, SLOT_GRADS, (grad_count ? grad_count : 1) * 4);
-    auto* col_scale = (float*)ensure(ctx, SLOT_COL_SCALE, 256 * 4);
-    if (!v_output || !loss_dev || !grads || !col_scale) return BH_ERR_OOM;
+    if (!v_output || !loss_dev) return BH_ERR_OOM;
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
@@ -577,43 +581,27 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* g_tr = grads;
     float* g_sh = grads + (size_t)n * 10;
     float* g_op = g_sh + (size_t)n * 3 * C;
-    float* s_refine = stat_buf;
-    float* s_visible = stat_buf + n;
-    float* s_radius = stat_buf + 2 * (size_t)n;
     BH_TRY(bh_render_backward(ctx, v_output, st->transforms, st->sh_coeffs, st->raw_opacities, g_tr, g_sh, g_op, s_refine));
-    // ---- data-parallel exchange (not in the reference: SURVEY.md §8e)
+    // ---- multi-GPU exchange (not in the reference: SURVEY.md §8e) — one SUM over the leading floats
+    const bool tile_mode = batch->image_hook != nullptr;
     if (hook) {
         ProfScope ps(ctx, "GradExchange");
-        const int rc = hook(hook_user, grads, grad_count, stat_buf, (uint64_t)n * 3);
+        const uint64_t sum_count = tile_mode ? (uint64_t)exch_count : (uint64_t)n + grad_count;
+        const int rc = hook(hook_user, exch, sum_count);
         if (rc != 0) return set_error(ctx, BH_ERR_STATE, "gradient hook failed");
     }
-    if (grad_scale != 1.0f && grad_count > 0) {
-        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((grad_count + 255) / 256)), dim3(256), 0, ctx->stream, grads, (uint64_t)grad_count, grad_scale);
-        BH_LAUNCH_CHECK(ctx, "scale_kernel");
-    }
-    // ---- refine statistics (train.rs:280-298)
-    {
-        ProfScope ps(ctx, "GatherStats");
-        BH_TRY(launch_gather_stats(ctx, st->refine_weight_norm, st->vis_weight, st->max_screen_size, s_refine, s_visible, s_radius, n));
-    }
-    // ---- optimizer (train.rs:300-381)
+    // ---- refine statistics (train.rs:280-298) + optimizer (train.rs:300-381): one launch
     const double decay = std::pow(cfg->lr_mean_end / cfg->lr_mean, 1.0 / (double)cfg->total_train_iters);
     const double lr_mean = cfg->lr_mean * std::pow(decay, (double)((int)step - 1)) * (double)cfg->median_scene_scale;
     {
         ProfScope ps(ctx, "OptimizerStep");
-        ScaleTable tb{};
-        for (int i = 0; i < 3; ++i) tb.v[i] = (float)lr_mean;
-        for (int i = 3; i < 7; ++i) tb.v[i] = (float)cfg->lr_rotation;
-        for (int i = 7; i < 10; ++i) tb.v[i] = (float)cfg->lr_scale;
-        // sh: DC at full lr, bands >= 1 scaled by 1/lr_coeffs_sh_scale; one entry per (coeff, channel)
-        const float rest = 1.0f / cfg->lr_coeffs_sh_scale;
-        for (uint32_t k = 0; k < 3 * C; ++k) tb.v[10 + k] = (k / 3 == 0) ? 1.0f : rest;
-        hipLaunchKernelGGL(fill_table_kernel, dim3(1), dim3(128), 0, ctx->stream, col_scale, tb, 10 + 3 * C);
-        BH_LAUNCH_CHECK(ctx, "fill_table_kernel");
-        const float b1 = 0.9f, b2 = 0.999f, eps = 1e-15f;
-        BH_TRY(launch_adam(ctx, st->transforms, g_tr, st->m1_transforms, st->m2_transforms, n, 10, col_scale, 1.0f, step, false, b1, b2, eps));
-        BH_TRY(launch_adam(ctx, st->sh_coeffs, g_sh, st->m1_sh, st->m2_sh, n, 3 * C, col_scale + 10, (float)cfg->lr_coeffs_dc, step, true, b1, b2, eps));
-        BH_TRY(launch_adam(ctx, st->raw_opacities, g_op, st->m1_opac, st->m2_opac, n, 1, nullptr, (float)cfg->lr_opac, step, false, b1, b2, eps));
+        float tab[10];
+        for (int i = 0; i < 3; ++i) tab[i] = (float)lr_mean;
+        for (int i = 3; i < 7; ++i) tab[i] = (float)cfg->lr_rotation;
+        for (int i = 7; i < 10; ++i) tab[i] = (float)cfg->lr_scale;
+        // sh: DC at full lr, bands >= 1 scaled by 1/lr_coeffs_sh_scale
+        BH_TRY(launch_train_update(ctx, st, g_tr, g_sh, g_op, s_refine, s_visible, s_radius, grad_scale, tile_mode, tab,
+                                   (float)cfg->lr_coeffs_dc, 1.0f / cfg->lr_coeffs_sh_scale, (float)cfg->lr_opac, step, 0.9f, 0.999f, 1e-15f));
     }
     // ---- visibility-gated noise on the means (train.rs:389-416)
     if (batch->noise_samples && cfg->mean_noise_weight > 0.0f) {

@@ -42,8 +42,8 @@ enum Slot : int {
     SLOT_LOSS_MAP,
     SLOT_LOSS_GRAD,          // dL/dpred CHW
     SLOT_V_OUTPUT,           // [H,W,4]
-    SLOT_GRADS,              // fused gradient buffer
-    SLOT_STATS,              // refine | visible | radius
+    SLOT_GRADS,              // exchange buffer: visible | v_transforms | v_sh | v_raw_opac | v_refine
+    SLOT_STATS,              // screen radius of the last train-step forward
     SLOT_LOSS_SCALAR,
     SLOT_COL_SCALE,          // per-column lr tables
     SLOT_MISC,
@@ -80,6 +80,7 @@ struct bh_ctx {
     std::string last_error;
     bh::Buffer slots[bh::SLOT_COUNT];
     uint32_t* host_counters = nullptr;  // pinned [4]
+    hipEvent_t readback_ev = nullptr;   // marks the count readback of the forward (the depth sort is queued behind it)
     // state of the last forward (what RenderBackwards saves, bwd/burn_glue.rs:336-371)
     bool have_forward = false;
     BhCamera cam{};
@@ -168,6 +169,11 @@ int launch_sum(bh_ctx* ctx, const float* x, uint64_t n, float scale, float* out_
 // optim.hip
 int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
                 const float* col_scale, float lr, uint32_t t, bool reduce_m2, float beta1, float beta2, float eps);
+// statistics + the three Adam updates of a train step in one launch (tab_t: per-column lr of `transforms`)
+int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
+                        const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
+                        bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
+                        float beta1, float beta2, float eps);
 int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
                         const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
 int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible,

@@ -138,6 +138,150 @@ int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* 
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The train step's whole "after the backward" tail in ONE launch: RefineRecord::gather_stats
+// (stats.rs:40-50) + the three AdamScaled updates (train.rs:300-381) with the data-parallel
+// 1/K gradient scale folded in.  A block owns 256 consecutive splats, so every tensor it touches
+// is one contiguous run: transforms 2560 floats, SH 256*3C floats (staged through LDS for the
+// per-row second moment, as adam_rowreduced_kernel), opacity / statistics 256 floats.  The
+// element arithmetic is that of the stand-alone kernels above (bit-identical results); what
+// goes away is five launches, the lr-table upload and the separate gradient-scale pass.
+// ---------------------------------------------------------------------------
+struct UpdateArgs {
+    AdamArgs a;            // betas / bias corrections of step t (shared: the three params step together)
+    float lr_sh, lr_opac;  // transforms use lr 1.0 with the per-column table (train.rs:328-350)
+    float gscale;          // 1/world for data parallel over cameras, else 1
+    uint32_t n, sh_len;    // splats, 3*C
+    uint32_t vis_clamp;    // tile-partitioned frame: visible arrives summed over strips -> min(v, 1)
+    float tab_t[10];       // lr_mean x3, lr_rotation x4, lr_scale x3
+    float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
+};
+
+__global__ __launch_bounds__(OPT_WG) void train_update_kernel(
+    float* __restrict__ transforms, float* __restrict__ m1_t, float* __restrict__ m2_t, const float* __restrict__ g_t,
+    float* __restrict__ sh, float* __restrict__ m1_sh, float* __restrict__ m2_sh, const float* __restrict__ g_sh,
+    float* __restrict__ opac, float* __restrict__ m1_o, float* __restrict__ m2_o, const float* __restrict__ g_o,
+    float* __restrict__ refine_weight_norm, float* __restrict__ vis_weight, float* __restrict__ max_screen_size,
+    const float* __restrict__ refine_weight, const float* __restrict__ visible, const float* __restrict__ screen_radius,
+    UpdateArgs u) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const AdamArgs& a = u.a;
+    const uint64_t row0 = (uint64_t)blockIdx.x * ADAM_ROWS;
+    const uint32_t nrows = (uint32_t)((uint64_t)u.n - row0 < (uint64_t)ADAM_ROWS ? (uint64_t)u.n - row0 : (uint64_t)ADAM_ROWS);
+    const uint32_t row_len = u.sh_len, pitch = row_len + 1;
+    float* s_g = s_dyn;                       // [ADAM_ROWS][row_len + 1]
+    float* s_v = s_dyn + ADAM_ROWS * pitch;   // [ADAM_ROWS]
+    // ---- SH gradients -> LDS (coalesced), issued first so the loads overlap the work below
+    {
+        const uint32_t count = nrows * row_len;
+        const uint64_t base = row0 * row_len;
+        const float rcp_len = 1.0f / (float)row_len;
+        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+            const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);  // e / row_len, exact for e < 2^16
+            const uint32_t c = e - r * row_len;
+            s_g[r * pitch + c] = g_sh[base + e] * u.gscale;
+        }
+    }
+    // ---- statistics + opacity: one splat per thread
+    if (threadIdx.x < nrows) {
+        const uint64_t i = row0 + threadIdx.x;
+        refine_weight_norm[i] = __builtin_fmaxf(refine_weight[i], refine_weight_norm[i]);
+        const float v = u.vis_clamp ? __builtin_fminf(visible[i], 1.0f) : visible[i];
+        vis_weight[i] = vis_weight[i] + v;
+        max_screen_size[i] = __builtin_fmaxf(screen_radius[i], max_screen_size[i]);
+        const float g = g_o[i] * u.gscale;
+        float mm1 = a.first ? g * a.f1 : m1_o[i] * a.beta1 + g * a.f1;
+        const float gsq = g * g;
+        const float mm2 = a.first ? gsq * a.f2 : m2_o[i] * a.beta2 + gsq * a.f2;
+        m1_o[i] = mm1;
+        m2_o[i] = mm2;
+        float p = opac[i];
+        adam_elem(p, g, mm1, mm2, a, u.lr_opac);
+        opac[i] = p;
+    }
+    // ---- transforms: full second moment, per-column lr
+    {
+        const uint32_t count = nrows * 10u;
+        const uint64_t base = row0 * 10u;
+        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+            const uint32_t c = e - ((e * 52429u) >> 19) * 10u;  // e % 10 (e < 2560)
+            const uint64_t i = base + e;
+            const float g = g_t[i] * u.gscale;
+            float mm1 = a.first ? g * a.f1 : m1_t[i] * a.beta1 + g * a.f1;
+            const float gsq = g * g;
+            const float mm2 = a.first ? gsq * a.f2 : m2_t[i] * a.beta2 + gsq * a.f2;
+            m1_t[i] = mm1;
+            m2_t[i] = mm2;
+            float p = transforms[i];
+            adam_elem(p, g, mm1, mm2, a, u.tab_t[c] * 1.0f);
+            transforms[i] = p;
+        }
+    }
+    // ---- SH: per-row second moment (adam_scaled.rs:99-104,152-165), row sums in index order
+    __syncthreads();
+    if (threadIdx.x < nrows) {
+        const float* g = s_g + threadIdx.x * pitch;
+        float acc = 0.0f;
+        for (uint32_t c = 0; c < row_len; ++c) acc += g[c] * g[c];
+        const float row_gsq = acc / (float)row_len;
+        const uint64_t r = row0 + threadIdx.x;
+        const float v = a.first ? row_gsq * a.f2 : m2_sh[r] * a.beta2 + row_gsq * a.f2;
+        m2_sh[r] = v;
+        s_v[threadIdx.x] = v;
+    }
+    __syncthreads();
+    {
+        const uint32_t count = nrows * row_len;
+        const uint64_t base = row0 * row_len;
+        const float rcp_len = 1.0f / (float)row_len;
+        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+            const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
+            const uint32_t c = e - r * row_len;
+            const uint64_t i = base + e;
+            const float gi = s_g[r * pitch + c];
+            float mm1 = a.first ? gi * a.f1 : m1_sh[i] * a.beta1 + gi * a.f1;
+            m1_sh[i] = mm1;
+            float p = sh[i];
+            adam_elem(p, gi, mm1, s_v[r], a, u.tab_sh[c] * u.lr_sh);
+            sh[i] = p;
+        }
+    }
+}
+
+int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
+                        const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
+                        bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
+                        float beta1, float beta2, float eps) {
+    const uint32_t n = st->n, C = (st->sh_degree + 1) * (st->sh_degree + 1);
+    if (n == 0) return 0;
+    if (t == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "adam: t is 1-based");
+    UpdateArgs u;
+    u.a.beta1 = beta1; u.a.beta2 = beta2;
+    u.a.f1 = 1.0f - beta1; u.a.f2 = 1.0f - beta2;
+    u.a.bc1 = 1.0f - powi_f32(beta1, (int)t);
+    u.a.bc2 = 1.0f - powi_f32(beta2, (int)t);
+    u.a.eps = eps; u.a.lr = 1.0f;
+    u.a.first = t == 1 ? 1u : 0u;
+    u.lr_sh = lr_sh; u.lr_opac = lr_opac; u.gscale = gscale;
+    u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
+    for (int i = 0; i < 10; ++i) u.tab_t[i] = tab_t[i];
+    for (uint32_t k = 0; k < 75; ++k) u.tab_sh[k] = (k / 3 == 0) ? 1.0f : sh_rest_scale;
+    const size_t lds = ((size_t)ADAM_ROWS * (u.sh_len + 1) + ADAM_ROWS) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
+    const unsigned nb = (unsigned)(((uint64_t)n + ADAM_ROWS - 1) / ADAM_ROWS);
+    hipLaunchKernelGGL(train_update_kernel, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
+                       st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
+                       st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
+    BH_LAUNCH_CHECK(ctx, "train_update_kernel");
+    return 0;
+}
+
 // stats.rs:40-50
 __global__ __launch_bounds__(OPT_WG) void gather_stats_kernel(float* __restrict__ refine_weight_norm, float* __restrict__ vis_weight,
                                                              float* __restrict__ max_screen_size, const float* __restrict__ refine_weight,
@@ -167,7 +311,8 @@ __global__ __launch_bounds__(OPT_WG) void mean_noise_kernel(float* __restrict__ 
     const float inv_opac = 1.0f - sigmoid(raw_opac[i]);
     // x^150 = x^128 * x^16 * x^4 * x^2
     const float x2 = inv_opac * inv_opac, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32, x128 = x64 * x64;
-    const float w = clampf(x128 * x16 * x4 * x2, 0.0f, 1.0f) * visible[i];
+    // visible is a 0/1 flag; a data-parallel caller hands in the SUM over its views -> gate with min(v, 1)
+    const float w = clampf(x128 * x16 * x4 * x2, 0.0f, 1.0f) * __builtin_fminf(visible[i], 1.0f);
     const float wm = w * noise_scale;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

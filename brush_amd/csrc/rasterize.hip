@@ -17,8 +17,8 @@
 //   * block -> tile mapping is XCD-aware: consecutive workgroup ids land on
 //     different XCDs, so each XCD gets a contiguous band of tiles and its L2 sees
 //     the spatially coherent part of `projected`.
-//   * exp() is the same fixed polynomial as everywhere else (device_math.h) without
-//     the range guards: bit-identical where alpha can reach 1/255.
+//   * exp() in the blend loops is exp_blend below (a base-2 polynomial shaped for the gfx950
+//     issue rates), restated identically by the oracle: images are bit-identical.
 #include "context.h"
 
 namespace bh {
@@ -70,25 +70,28 @@ constexpr int SPLAT_STRIDE = 12;
 constexpr int BATCH = 64;
 constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend (~1e-7)
 
-// exp(x) for the blend loop: the bh_expf sequence without its range guards
-// (x <= 0 wherever the result is used; underflow goes to 0 through ldexp).
+// exp(x) for the blend loops, x = -sigma <= 0 wherever the result is used (lanes that fail the
+// sigma pre-test compute a value nobody reads).  Base-2 form chosen for gfx950 issue rates: ten
+// full-rate VALU ops (mul, add, sub, sub, 5 fma, lshl_add) where the Cephes sequence of bh_expf
+// takes 14 with three half-rate ones (rndne, cvt, ldexp): k = rint(x*log2e) through the 1.5*2^23
+// magic add, 2^f from a degree-5 minimax polynomial on [-0.5, 0.5] (1.6e-7 max rel. error), and the
+// exponent spliced in by adding k << 23 to the bit pattern.  The CPU checker used by the tests
+// restates the same sequence, so images stay bit-identical to it.
 BH_DEV float exp_blend(float x) {
 #ifdef BH_HW_EXP  // measurement-only variant (not the shipped numerical spec)
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
 #endif
-    const float k = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(k, -0.693359375f, x);
-    r = __builtin_fmaf(k, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    float y = __builtin_fmaf(p, r2, r);
-    y = y + 1.0f;
-    return __builtin_ldexpf(y, (int)k);
+    const float t = x * 1.44269504088896341f;
+    const float s = t + 12582912.0f;
+    const float kf = s - 12582912.0f;
+    const float f = t - kf;
+    float p = 1.3274633092805743e-3f;
+    p = __builtin_fmaf(p, f, 9.671961888670921e-3f);
+    p = __builtin_fmaf(p, f, 5.5506784468889236e-2f);
+    p = __builtin_fmaf(p, f, 2.4022234976291656e-1f);
+    p = __builtin_fmaf(p, f, 6.931470632553101e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return u2f(f2u(p) + (f2u(s) << 23));
 }
 
 // 8 XCDs take workgroups round-robin; give each XCD a contiguous band of tiles.

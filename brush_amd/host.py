@@ -14,7 +14,7 @@ import torch
 
 from . import _ffi
 from ._ffi import BrushHipError
-from .parallel import allreduce_step_buffers, allgather_strips, strip_spans_px, tile_rows_for_rank
+from .parallel import allreduce_exchange, allreduce_refine_maxima, allgather_strips, strip_spans_px, tile_rows_for_rank
 
 
 # ---------------------------------------------------------------------------
@@ -501,9 +501,10 @@ class SplatTrainer:
     statistics, Adam and the optional mean noise inside one C-ABI call.
 
     Data parallel (not in the reference): pass `process_group` and the
-    per-rank gradients are summed with torch.distributed all_reduce (RCCL over xGMI)
-    between backward and Adam and scaled by 1/world; refine/visibility statistics are
-    MAX-reduced. Every rank then applies the identical update."""
+    per-rank gradients + visible flags are summed with ONE torch.distributed all_reduce
+    (RCCL over xGMI) between backward and Adam, the gradients scaled by 1/world inside the
+    update; every rank applies the identical update.  The RefineRecord's running maxima stay
+    rank-local until `sync_refine_stats()` (called by `refine`) MAX-reduces them."""
 
     def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
                  partition: str = "cameras"):
@@ -544,11 +545,9 @@ class SplatTrainer:
         pg = self.pg
         world = dist.get_world_size(pg)
 
-        def hook(_user, grads_ptr, grad_count, stats_ptr, stats_count):
+        def hook(_user, exch_ptr, sum_count):
             try:
-                g = _view(grads_ptr, (int(grad_count),), torch.float32, dev)
-                s = _view(stats_ptr, (int(stats_count),), torch.float32, dev)
-                allreduce_step_buffers(g, s, pg)
+                allreduce_exchange(_view(exch_ptr, (int(sum_count),), torch.float32, dev), int(sum_count), pg)
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1
@@ -640,6 +639,13 @@ class SplatTrainer:
         st.step_count = self.step_count
         return st
 
+    def sync_refine_stats(self):
+        """Multi-GPU: MAX-reduce the RefineRecord's running maxima (refine_weight_norm,
+        max_screen_size) over the ranks; afterwards every replica's RefineRecord is identical.
+        Needed once before refine, not per step (brush_amd/parallel.py)."""
+        if self.pg is not None and self.state is not None:
+            allreduce_refine_maxima(self.state["refine_weight_norm"], self.state["max_screen_size"], self.pg)
+
     def set_bounds(self, center, extent):
         self.bounds = (tuple(float(x) for x in center), tuple(float(x) for x in extent))
         self.median_scene_scale = bounds_median_size(self.bounds[1])
@@ -655,6 +661,7 @@ class SplatTrainer:
         dev = splats.device
         if self.state is None:
             raise BrushHipError("Can only refine if refine stats are initialized")  # train.rs:445
+        self.sync_refine_stats()
         if self.bounds is None:
             self.set_bounds(*splat_bounds(splats, ctx=ctx))
         c = self.config

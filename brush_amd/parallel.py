@@ -1,13 +1,17 @@
-"""Data-parallel helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL
+"""Multi-GPU helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL
 over xGMI on ROCm, "gloo" in the CPU tests).
 
 The reference is single-GPU, one view per step (brush-train/src/train.rs:176-186): data
 parallelism over cameras is a capability this build adds.  Semantics:
-every rank holds a full replica of the splats + Adam state, renders its own view, and
-between backward and Adam the fused gradient buffer is SUM-all-reduced and scaled by
-1/world (mean gradient over the K views); the refine statistics (refine weight, visible
-flag, max screen radius) are MAX-all-reduced so every rank applies the identical update
-and keeps identical RefineRecords.  K = 1 is bit-identical to the single-GPU step.
+every rank holds a full replica of the splats + Adam state and renders its own view; between
+backward and Adam the step's ONE exchange buffer (visible flags | fused gradients) is
+SUM-all-reduced — a single large message per step, the right shape for xGMI's per-link bound —
+and the gradients are scaled by 1/world inside the update (mean gradient over the K views), so
+every rank applies the identical update.  vis_weight counts the views that saw a splat.  The two
+running maxima of the RefineRecord (refine_weight_norm, max_screen_size) stay rank-local between
+refines and are MAX-reduced once, right before refine (`allreduce_refine_maxima`) — max is
+associative, so this equals reducing every step at 1/refine_every of the traffic.
+K = 1 is bit-identical to the single-GPU step.
 """
 import torch
 
@@ -19,14 +23,23 @@ def view_for_rank(step, rank, world, num_views):
     return (step * world + rank) % num_views
 
 
-def allreduce_step_buffers(grads: torch.Tensor, stats: torch.Tensor, group=None):
-    """In place: grads <- sum over ranks, stats <- max over ranks (one collective each:
-    the gradient buffer is a single fused [N*(10+3C+1)] tensor, 56 MB at 1 M splats / SH0,
-    so the all-reduce is one large message — the right shape for xGMI's per-link bound)."""
+def allreduce_exchange(exchange: torch.Tensor, sum_count: int, group=None):
+    """In place: the first `sum_count` floats of the step's exchange buffer <- sum over ranks
+    (bh_grad_hook contract, include/brush_hip.h).  At 1 M splats / SH0 that is 60 MB, 240 MB at SH3."""
     import torch.distributed as dist
-    dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(stats, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(exchange[:sum_count], op=dist.ReduceOp.SUM, group=group)
     return dist.get_world_size(group)
+
+
+def allreduce_refine_maxima(refine_weight_norm: torch.Tensor, max_screen_size: torch.Tensor, group=None):
+    """In place: both running maxima <- max over ranks (one collective on a fused staging tensor).
+    Called before refine, so every rank takes the identical prune / split decisions."""
+    import torch.distributed as dist
+    n = refine_weight_norm.numel()
+    both = torch.cat([refine_weight_norm.reshape(-1), max_screen_size.reshape(-1)])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    refine_weight_norm.copy_(both[:n].view_as(refine_weight_norm))
+    max_screen_size.copy_(both[n:].view_as(max_screen_size))
 
 
 # ---------------------------------------------------------------------------

@@ -228,11 +228,19 @@ typedef struct BhTrainStats {
                    0 until then, and only the most recent step's stats are completed */
 } BhTrainStats;
 
-/* Gradient hook: called (if non-NULL) after the backward and before Adam with the
- * fused gradient buffer [N*(10 + 3C + 1)] (v_transforms | v_sh | v_raw_opac) and the
- * stats buffer [3N] (refine_weight | visible | max_radius) so a data-parallel
- * caller can all-reduce them (SUM / MAX) on the ctx stream.  Return 0. */
-typedef int (*bh_grad_hook)(void* user, float* grads, uint64_t grad_count, float* stats, uint64_t stats_count);
+/* Exchange hook (multi-GPU callers; not in the reference, which is single-GPU): called (if
+ * non-NULL) after the backward and before the statistics / Adam update with the step's ONE
+ * exchange buffer on the ctx stream:
+ *     visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | refine_weight[N]
+ * The caller must SUM the first `sum_count` floats over its ranks, in place:
+ *   - data parallel over cameras: sum_count = N*(1 + 10 + 3C + 1) — the per-view visible flags and the
+ *     gradients (scaled by `grad_scale` = 1/K inside the update).  refine_weight stays local: the
+ *     RefineRecord keeps running MAXima (refine_weight_norm, max_screen_size), which a caller reduces
+ *     over ranks with MAX once, before refine — not every step.  vis_weight counts views.
+ *   - one frame partitioned by tile rows (image_hook set): sum_count = the whole buffer — the refine
+ *     weight is a per-pixel sum, so the strips' partial sums add; `visible` is clamped to 1 afterwards.
+ * One buffer = one collective per step.  Return 0. */
+typedef int (*bh_grad_hook)(void* user, float* exchange, uint64_t sum_count);
 
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,

@@ -73,6 +73,27 @@ inline float bo_expf_impl(float x) {
     return ldexpf(y, (int)k);
 }
 
+// exp for the blend loops (kernels/rasterize.rs:131, bwd/kernels/rasterize_backwards.rs:263): a
+// base-2 restatement that costs 10 full-rate VALU ops on gfx950 (the Cephes form above: 14, three
+// of them half rate) — k = rint(x*log2e) by the 1.5*2^23 magic add, 2^f by a degree-5 minimax
+// polynomial on [-0.5, 0.5] (max rel. error 1.6e-7 in f32), exponent spliced in with an integer
+// add.  Used only where 0 <= sigma: x <= 0.  Below -87 the result is defined as 0.
+inline float bo_exp_blend(float x) {
+    if (!(x >= -87.0f)) return 0.0f;
+    if (x > 0.0f) return 1.0f;  // sigma < 0: the caller discards the value
+    const float t = x * 1.44269504088896341f;
+    const float s = t + 12582912.0f;
+    const float kf = s - 12582912.0f;
+    const float f = t - kf;
+    float p = 1.3274633092805743e-3f;
+    p = fmaf(p, f, 9.671961888670921e-3f);
+    p = fmaf(p, f, 5.5506784468889236e-2f);
+    p = fmaf(p, f, 2.4022234976291656e-1f);
+    p = fmaf(p, f, 6.931470632553101e-1f);
+    p = fmaf(p, f, 1.0f);
+    return u2f(f2u(p) + (f2u(s) << 23));
+}
+
 // Fixed-polynomial logf (Cephes-style). Stands in for WGSL `log`
 // (kernels/project_forward.rs:96, kernels/map_gaussians.rs:30).
 inline float bo_logf_impl(float x) {
@@ -952,7 +973,7 @@ int render_forward(Render& R, const BoCamera& cam, uint32_t n, uint32_t sh_degre
                     const uint32_t cg = R.compact_gid_from_isect[is];
                     const float* s = &R.projected[(size_t)cg * 9];
                     const float sigma = calc_sigma(pcx, pcy, Sym2{s[2], s[3], s[4]}, s[0], s[1]);
-                    const float alpha = std::fmin(0.999f, s[5] * bo_expf_impl(-sigma));
+                    const float alpha = std::fmin(0.999f, s[5] * bo_exp_blend(-sigma));
                     const float w_cut = smooth ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
                     if (sigma >= 0.0f && w_cut > 0.0f) {
                         const float alpha_eff = alpha * w_cut;
@@ -1042,7 +1063,7 @@ void rasterize_backward(Render& R, const float* v_output) {
                 const float dx = s[0] - pcx, dy = s[1] - pcy;
                 // same value as calc_sigma(pix, conic, xy): (-dx)^2 terms are sign-symmetric
                 const float sigma = calc_sigma(pcx, pcy, conic, s[0], s[1]);
-                const float gaussian = bo_expf_impl(-sigma);
+                const float gaussian = bo_exp_blend(-sigma);
                 const float alpha = std::fmin(0.999f, color_a * gaussian);
                 const float w_cut = smooth ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
                 if (sigma >= 0.0f && w_cut > 0.0f) {

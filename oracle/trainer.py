@@ -54,10 +54,11 @@ class OracleTrainer:
         if dry_run:  # this rank's raw gradients only (data-parallel tests); no state change
             self.step_count -= 1
             return dict(g_tr=g_tr, g_sh=g_sh, g_op=g_op, refine=refine, vis=vis, radius=radius)
-        if extra_grads is not None:  # data-parallel: sum over ranks then scale by 1/world
+        if extra_grads is not None:  # data-parallel over cameras: gradients and visible flags are summed over
+            # ranks (vis_weight counts views), the gradients then scaled by 1/world; refine weight / radius feed running maxima
             for eg in extra_grads:
                 g_tr += eg["g_tr"]; g_sh += eg["g_sh"]; g_op += eg["g_op"]
-                refine = np.maximum(refine, eg["refine"]); vis = np.maximum(vis, eg["vis"]); radius = np.maximum(radius, eg["radius"])
+                refine = np.maximum(refine, eg["refine"]); vis = vis + eg["vis"]; radius = np.maximum(radius, eg["radius"])
         if world != 1:
             s = np.float32(1.0 / world)
             g_tr *= s; g_sh *= s; g_op *= s
@@ -76,7 +77,7 @@ class OracleTrainer:
         bo.adam_step(op2, g_op, st["m1_o"], st["m2_o"], np.float32(c.lr_opac), t)
         if noise is not None and c.mean_noise_weight > 0:
             sig = 1.0 / (1.0 + np.exp(-op.astype(np.float64)))
-            wgt = np.clip((1.0 - sig) ** 150, 0, 1) * vis
+            wgt = np.clip((1.0 - sig) ** 150, 0, 1) * np.minimum(vis, 1.0)
             wm = (wgt * (np.float32(lr_mean) * c.mean_noise_weight)).astype(np.float32)
             tr[:, :3] += np.clip(noise * wm[:, None], -self.median, self.median).astype(np.float32)
         grads = dict(g_tr=g_tr, g_sh=g_sh, g_op=g_op, refine=refine, vis=vis, radius=radius)

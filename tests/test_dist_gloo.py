@@ -1,7 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo process group (no GPU needed).
-Checks the collective semantics the data-parallel train step relies on (SUM of the fused
-gradient buffer, MAX of the statistics, identical result on every rank) and the view
-sharding used by bench.py / SplatTrainer."""
+Checks the collective semantics the data-parallel train step relies on (SUM of the leading
+part of the exchange buffer, the rest untouched; MAX of the RefineRecord maxima before refine;
+identical result on every rank) and the view sharding used by bench.py / SplatTrainer."""
 import os
 import socket
 
@@ -24,15 +24,17 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from brush_amd.parallel import allreduce_step_buffers, view_for_rank
+    from brush_amd.parallel import allreduce_exchange, allreduce_refine_maxima, view_for_rank
     n, C = 1000, 4
     g = torch.Generator().manual_seed(100 + rank)
-    grads = torch.randn(n * (10 + 3 * C + 1), generator=g)
-    stats = torch.rand(n * 3, generator=g)
-    mine_g, mine_s = grads.clone(), stats.clone()
-    w = allreduce_step_buffers(grads, stats)
+    exch = torch.randn(n * (10 + 3 * C + 3), generator=g)    # visible | grads | refine
+    sum_count = n * (10 + 3 * C + 2)                          # cameras mode: refine stays local
+    norm, screen = torch.rand(n, generator=g), torch.rand(n, generator=g)
+    mine_e, mine_n, mine_s = exch.clone(), norm.clone(), screen.clone()
+    w = allreduce_exchange(exch, sum_count)
+    allreduce_refine_maxima(norm, screen)
     views = [view_for_rank(s, rank, world, 8) for s in range(4)]
-    q.put((rank, w, mine_g.numpy(), mine_s.numpy(), grads.numpy(), stats.numpy(), views))
+    q.put((rank, w, sum_count, mine_e.numpy(), mine_n.numpy(), mine_s.numpy(), exch.numpy(), norm.numpy(), screen.numpy(), views))
     dist.destroy_process_group()
 
 
@@ -48,11 +50,13 @@ def test_allreduce_semantics_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0, g0, s0, rg0, rs0, v0), (_, w1, g1, s1, rg1, rs1, v1) = res
+    (_, w0, sc, e0, n0, s0, re0, rn0, rs0, v0), (_, w1, _, e1, n1, s1, re1, rn1, rs1, v1) = res
     assert w0 == w1 == 2
-    assert np.array_equal(rg0, rg1) and np.array_equal(rs0, rs1), "every rank holds the same reduced buffers"
-    assert np.allclose(rg0, g0 + g1, rtol=0, atol=1e-6)
-    assert np.array_equal(rs0, np.maximum(s0, s1))
+    assert np.array_equal(re0[:sc], re1[:sc]), "every rank holds the same reduced gradients"
+    assert np.allclose(re0[:sc], e0[:sc] + e1[:sc], rtol=0, atol=1e-6)
+    assert np.array_equal(re0[sc:], e0[sc:]) and np.array_equal(re1[sc:], e1[sc:]), "the tail (refine weight) stays rank-local"
+    assert np.array_equal(rn0, np.maximum(n0, n1)) and np.array_equal(rn0, rn1)
+    assert np.array_equal(rs0, np.maximum(s0, s1)) and np.array_equal(rs0, rs1)
     # one pass over 8 views with 2 ranks x 4 steps visits every view exactly once
     assert sorted(v0 + v1) == list(range(8))
 

@@ -47,7 +47,9 @@ def _worker(rank, world, port, q):
         trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
         trainer.stats()
         out.append((spl.transforms.cpu().numpy().copy(), spl.sh_coeffs.cpu().numpy().copy(), spl.raw_opacities.cpu().numpy().copy()))
-    q.put((rank, out, trainer.state["vis_weight"].cpu().numpy()))
+    trainer.sync_refine_stats()  # the running maxima are rank-local until refine asks for them
+    q.put((rank, out, trainer.state["vis_weight"].cpu().numpy(), trainer.state["refine_weight_norm"].cpu().numpy(),
+           trainer.state["max_screen_size"].cpu().numpy()))
     dist.destroy_process_group()
 
 
@@ -64,11 +66,12 @@ def test_two_rank_step_matches_oracle_mean_gradient(oracle_lib):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, o0, vis0), (_, o1, vis1) = res
+    (_, o0, vis0, norm0, scr0), (_, o1, vis1, norm1, scr1) = res
     for step in range(2):  # replicas stay bit-identical
         for a, b in zip(o0[step], o1[step]):
             assert np.array_equal(a, b)
-    assert np.array_equal(vis0, vis1)
+    assert np.array_equal(vis0, vis1) and np.array_equal(norm0, norm1) and np.array_equal(scr0, scr1)
+    assert vis0.max() == 4.0  # vis_weight counts views: 2 ranks x 2 steps
     # oracle: rank 0 steps with rank 1's raw gradients added, scaled by 1/2
     cfg = ba.TrainConfig()
     sc = _scene()

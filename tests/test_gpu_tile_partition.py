@@ -92,8 +92,10 @@ def _worker(rank, world, port, q, partition):
     for _ in range(2):
         trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
         losses.append(trainer.stats().loss)
+    trainer.sync_refine_stats()  # max_screen_size is strip-local until refine asks for it
     q.put((rank, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(), losses,
-           trainer.state["vis_weight"].cpu().numpy(), trainer.state["max_screen_size"].cpu().numpy()))
+           trainer.state["vis_weight"].cpu().numpy(), trainer.state["max_screen_size"].cpu().numpy(),
+           trainer.state["refine_weight_norm"].cpu().numpy()))
     dist.destroy_process_group()
 
 
@@ -131,3 +133,7 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
     assert np.abs(r0[3] - spl.raw_opacities.cpu().numpy()).max() <= 0.02 * cfg.lr_opac * 2
     assert np.abs(r0[2] - spl.sh_coeffs.cpu().numpy()).max() <= 0.02 * cfg.lr_coeffs_dc * 2
     assert np.mean(r0[5] != trainer.state["vis_weight"].cpu().numpy()) <= 2e-3
+    assert np.array_equal(r0[6], trainer.state["max_screen_size"].cpu().numpy())
+    # the refine weight is a per-pixel sum: the strips' partial sums add up to the single-GPU value
+    ref_norm = trainer.state["refine_weight_norm"].cpu().numpy()
+    assert np.abs(r0[7] - ref_norm).max() <= 1e-3 * ref_norm.max() + 1e-12
