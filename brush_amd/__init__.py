@@ -3,7 +3,8 @@ splat-rasterizer hot path, above the C ABI of libbrush_hip.so.
 
 Names and argument meaning follow the reference (paths under
 /root/reference/crates/):
-    Camera            brush-render/src/camera.rs:12-19
+    Camera            brush-render/src/camera.rs:12-19 (camera_model: kernels/camera_model/mod.rs:31-38)
+    fov_to_focal / focal_to_fov   brush-render/src/camera.rs:85-118
     Splats            brush-render/src/gaussian_splats.rs:62-74
     RasterPass        brush-render/src/gaussian_splats.rs:28-48
     render_splats     brush-render/src/gaussian_splats.rs:365-446 (forward / eval)
@@ -19,6 +20,6 @@ computation runs in the hand-written HIP kernels. No CPU fallback exists.
 from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
-    render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size,
+    render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
 )
 from ._ffi import BrushHipError  # noqa: F401

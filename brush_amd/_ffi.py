@@ -27,7 +27,11 @@ class BhCamera(C.Structure):
         ("cam_pos", C.c_float * 3),
         ("img_w", C.c_uint32), ("img_h", C.c_uint32),
         ("tile_row_begin", C.c_uint32), ("tile_row_end", C.c_uint32),
+        ("model", C.c_uint32), ("dist", C.c_float * 8), ("half_max_render_fov", C.c_float),
     ]
+
+
+CAMERA_PINHOLE, CAMERA_KANNALA_BRANDT_4, CAMERA_RADIAL_TANGENTIAL_8, CAMERA_THIN_PRISM_FISHEYE = 0, 1, 2, 3
 
 
 class BhRenderOut(C.Structure):
@@ -107,6 +111,9 @@ SYMBOLS = {
     "bh_sync": (C.c_int, [C.c_void_p]),
     "bh_version": (C.c_char_p, []),
     "bh_camera_setup": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BhCamera)]),
+    "bh_camera_setup_model": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(BhCamera)]),
+    "bh_fov_to_focal": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
+    "bh_focal_to_fov": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
     "bh_render_forward": (C.c_int, [C.c_void_p, C.POINTER(BhCamera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, fp, C.c_uint32, C.POINTER(BhRenderOut)]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),

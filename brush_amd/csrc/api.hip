@@ -76,6 +76,9 @@ ViewUniforms make_uniforms(const BhCamera& c) {
     const bool whole = c.tile_row_begin == 0 && c.tile_row_end == 0;
     u.tile_y0 = whole ? 0u : c.tile_row_begin;
     u.tile_y1 = whole ? u.tile_bh : c.tile_row_end;
+    u.model = c.model;
+    for (int i = 0; i < 8; ++i) u.dist[i] = c.dist[i];
+    u.half_fov = c.half_max_render_fov;
     return u;
 }
 
@@ -218,10 +221,85 @@ int bh_profile_fetch(bh_ctx* ctx, const char** names, float* ms, uint32_t* calls
     return n;
 }
 
-// brush-render/src/camera.rs:63-101,200-254; glam 0.30 Affine3A/Mat3A restated in f32.
-int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u, float center_v,
-                    uint32_t img_w, uint32_t img_h, BhCamera* out) {
-    if (!pos || !rot_xyzw || !out || img_w == 0 || img_h == 0) return BH_ERR_INVALID_ARG;
+// ---- lens laws in f64 (brush-render/src/camera.rs:85-198) ------------------------------------
+namespace {
+struct Kb4Law {  // d(theta) = theta + k1 theta^3 + k2 theta^5 + k3 theta^7 + k4 theta^9   (camera.rs:120-142)
+    double k[4];
+    explicit Kb4Law(const float* d) { for (int i = 0; i < 4; ++i) k[i] = d ? (double)d[i] : 0.0; }
+    double value(double th) const {
+        const double t2 = th * th, t3 = t2 * th, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+        return th + k[0] * t3 + k[1] * t5 + k[2] * t7 + k[3] * t9;
+    }
+    double slope(double th) const {
+        const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+        return 1.0 + 3.0 * k[0] * t2 + 5.0 * k[1] * t4 + 7.0 * k[2] * t6 + 9.0 * k[3] * t8;
+    }
+    // Newton on d(theta) = target, theta in [0, pi] (camera.rs:145-167)
+    double invert(double target) const {
+        if (target <= 0.0) return 0.0;
+        const double pi = 3.14159265358979323846;
+        double th = target < pi - 1e-6 ? target : pi - 1e-6;
+        for (int it = 0; it < 50; ++it) {
+            const double fp = slope(th);
+            if (std::fabs(fp) < 1e-12) break;
+            double next = th - (value(th) - target) / fp;
+            next = next < 0.0 ? 0.0 : (next > pi ? pi : next);
+            const bool done = std::fabs(next - th) < 1e-12;
+            th = next;
+            if (done) break;
+        }
+        return th;
+    }
+};
+struct Rt8Law {  // radial factor (1 + k1 r^2 + k2 r^4 + k3 r^6) / (1 + k4 r^2 + k5 r^4 + k6 r^6)   (camera.rs:170-178)
+    double k[6];
+    explicit Rt8Law(const float* d) { for (int i = 0; i < 6; ++i) k[i] = d ? (double)d[i] : 0.0; }
+    double radial(double r) const {
+        const double r2 = r * r, r4 = r2 * r2, r6 = r4 * r2;
+        return (1.0 + k[0] * r2 + k[1] * r4 + k[2] * r6) / (1.0 + k[3] * r2 + k[4] * r4 + k[5] * r6);
+    }
+    // fixed-point r <- r_d / radial(r)   (camera.rs:182-198)
+    double undistort(double r_d) const {
+        double r = r_d;
+        for (int it = 0; it < 30; ++it) {
+            const double f = radial(r);
+            if (std::fabs(f) < 1e-12) break;
+            const double rn = r_d / f;
+            const bool done = std::fabs(rn - r) < 1e-12;
+            r = rn;
+            if (done) break;
+        }
+        return r;
+    }
+};
+}  // namespace
+
+double bh_fov_to_focal(double fov, uint32_t pixels, uint32_t model, const float* dist) {
+    const double half = fov / 2.0, r_pix = (double)pixels / 2.0;
+    switch (model) {
+        case BH_CAMERA_PINHOLE: return r_pix / std::tan(half);
+        case BH_CAMERA_KANNALA_BRANDT_4:
+        case BH_CAMERA_THIN_PRISM_FISHEYE: return r_pix / Kb4Law(dist).value(half);
+        case BH_CAMERA_RADIAL_TANGENTIAL_8: { const double r = std::tan(half); return r_pix / (r * Rt8Law(dist).radial(r)); }
+        default: return std::nan("");
+    }
+}
+
+double bh_focal_to_fov(double focal, uint32_t pixels, uint32_t model, const float* dist) {
+    const double r_norm = ((double)pixels / 2.0) / focal;
+    switch (model) {
+        case BH_CAMERA_PINHOLE: return 2.0 * std::atan(r_norm);
+        case BH_CAMERA_KANNALA_BRANDT_4:
+        case BH_CAMERA_THIN_PRISM_FISHEYE: return 2.0 * Kb4Law(dist).invert(r_norm);
+        case BH_CAMERA_RADIAL_TANGENTIAL_8: return 2.0 * std::atan(Rt8Law(dist).undistort(r_norm));
+        default: return std::nan("");
+    }
+}
+
+// brush-render/src/camera.rs:63-101,200-254, render.rs:70-71; glam 0.30 Affine3A/Mat3A restated in f32.
+int bh_camera_setup_model(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u, float center_v,
+                          uint32_t img_w, uint32_t img_h, uint32_t model, const float* dist, BhCamera* out) {
+    if (!pos || !rot_xyzw || !out || img_w == 0 || img_h == 0 || model > BH_CAMERA_THIN_PRISM_FISHEYE) return BH_ERR_INVALID_ARG;
     const float x = rot_xyzw[0], y = rot_xyzw[1], z = rot_xyzw[2], w = rot_xyzw[3];
     const float x2 = x + x, y2 = y + y, z2 = z + z;
     const float xx = x * x2, xy = x * y2, xz = x * z2;
@@ -253,21 +331,42 @@ int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, doubl
         const float ip = (c0[i] * pos[0] + c1[i] * pos[1]) + c2[i] * pos[2];
         out->vm[9 + i] = -ip;
     }
-    out->fx = (float)(((double)img_w / 2.0) / std::tan(fov_x / 2.0));
-    out->fy = (float)(((double)img_h / 2.0) / std::tan(fov_y / 2.0));
+    out->model = model;
+    for (int i = 0; i < 8; ++i) out->dist[i] = (model != BH_CAMERA_PINHOLE && dist) ? dist[i] : 0.0f;
+    out->fx = (float)bh_fov_to_focal(fov_x, img_w, model, out->dist);
+    out->fy = (float)bh_fov_to_focal(fov_y, img_h, model, out->dist);
     out->cx = center_u * (float)img_w;
     out->cy = center_v * (float)img_h;
+    // calculate_jacobian_clamp_limits (camera.rs:200-254): image edges +-15 %, in normalised coordinates
     const float wf = (float)img_w, hf = (float)img_h;
-    out->lim_pos_x = (1.15f * wf - out->cx) / out->fx;
-    out->lim_pos_y = (1.15f * hf - out->cy) / out->fy;
-    out->lim_neg_x = (-0.15f * wf - out->cx) / out->fx;
-    out->lim_neg_y = (-0.15f * hf - out->cy) / out->fy;
+    float lim[4] = {(1.15f * wf - out->cx) / out->fx, (1.15f * hf - out->cy) / out->fy,
+                    (-0.15f * wf - out->cx) / out->fx, (-0.15f * hf - out->cy) / out->fy};
+    if (model == BH_CAMERA_RADIAL_TANGENTIAL_8) {
+        // the clamp bounds the UNDISTORTED coordinate: invert the radial law at each edge
+        const Rt8Law law(out->dist);
+        for (float& e : lim) {
+            const float mag = (float)law.undistort(std::fabs((double)e));
+            e = (e != e) ? e : (std::signbit(e) ? -mag : mag);  // * f32::signum(edge)
+        }
+    } else if (model != BH_CAMERA_PINHOLE) {
+        for (float& e : lim) e = 0.0f;  // fisheye Jacobians are not clamped
+    }
+    out->lim_pos_x = lim[0]; out->lim_pos_y = lim[1]; out->lim_neg_x = lim[2]; out->lim_neg_y = lim[3];
+    // render.rs:70-71 (f32)
+    const float full = hypotf((float)fov_x, (float)fov_y) * 1.05f;
+    const float cap = 2.0f * 3.14159265358979323846f - 1e-6f;
+    out->half_max_render_fov = (full < cap ? full : cap) * 0.5f;
     out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2];
     out->img_w = img_w;
     out->img_h = img_h;
     out->tile_row_begin = 0;
     out->tile_row_end = 0;
     return 0;
+}
+
+int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u, float center_v,
+                    uint32_t img_w, uint32_t img_h, BhCamera* out) {
+    return bh_camera_setup_model(pos, rot_xyzw, fov_x, fov_y, center_u, center_v, img_w, img_h, BH_CAMERA_PINHOLE, nullptr, out);
 }
 
 // ---- forward -------------------------------------------------------------------
@@ -278,6 +377,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (!cam || !out || !background) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null argument");
     if (cam->img_w == 0 || cam->img_h == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "Can't render images with 0 size.");  // render.rs:50-53
     if (sh_degree > 4) return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    if (cam->model > BH_CAMERA_THIN_PRISM_FISHEYE) return set_error(ctx, BH_ERR_INVALID_ARG, "unknown camera model");
     if (cam->img_w > 16368 || cam->img_h > 16368) return set_error(ctx, BH_ERR_UNSUPPORTED, "images larger than 16368 px per side are not supported (tile grid <= 1023 x 1023)");
     if (n > 0 && (!transforms || !sh_coeffs || !raw_opacities)) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null splat tensor");
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");

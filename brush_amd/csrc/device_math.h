@@ -218,6 +218,9 @@ struct ViewUniforms {
     float cam_x, cam_y, cam_z;
     uint32_t img_w, img_h, tile_bw, tile_bh;
     uint32_t tile_y0, tile_y1;  // tile-row window [y0, y1) rendered by this call (0, tile_bh = whole image)
+    uint32_t model;             // BH_CAMERA_*
+    float dist[8];              // distortion parameters of the model
+    float half_fov;             // view-angle cull bound of the non-pinhole models
 };
 BH_DEV Mat3 view_rotation(const ViewUniforms& u) { return Mat3{u.vm[0], u.vm[1], u.vm[2], u.vm[3], u.vm[4], u.vm[5], u.vm[6], u.vm[7], u.vm[8]}; }
 BH_DEV Vec3A view_translation(const ViewUniforms& u) { return Vec3A{u.vm[9], u.vm[10], u.vm[11]}; }
@@ -242,18 +245,6 @@ BH_DEV Mat2x3 jacobian_pinhole(Vec3A p, const ViewUniforms& u) {
     j.c1 = Vec2{0.0f, dy};
     j.c2 = Vec2{-dx * clamped_x, -dy * clamped_y};
     return j;
-}
-
-// helpers.rs:145-175
-BH_DEV Sym2 calc_cov2d(Vec3A scl, Quat quat, Vec3A mean_c, const ViewUniforms& u) {
-    const Mat3 ns = mul_diag(mul_mat3(view_rotation(u), quat_to_mat3(quat)), scl);
-    const Mat2x3 jac = jacobian_pinhole(mean_c, u);
-    const Mat2x3 v = mul_mat3(jac, ns);
-    const Sym2 raw = gram_matrix(v);
-    const float lim = 1.0e18f;
-    const float max_abs = sym2_max_abs(raw);
-    const float scale_down = max_abs > lim ? lim / max_abs : 1.0f;
-    return sym2_scale(raw, scale_down);
 }
 
 // helpers.rs:180-195

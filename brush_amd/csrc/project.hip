@@ -12,6 +12,7 @@
 // per-splat depth key (0xFFFFFFFF when culled) in place and lets the stable depth
 // sort do the compaction: no per-splat atomics, deterministic tie order (by id).
 #include "context.h"
+#include "device_camera.h"
 #include "device_sh.h"
 
 namespace bh {
@@ -89,7 +90,7 @@ BH_DEV void flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my
 // ---------------------------------------------------------------------------
 // K1: project_forward  (kernels/project_forward.rs:22-125)
 // ---------------------------------------------------------------------------
-template <bool MIP>
+template <bool MIP, bool PINHOLE>
 __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ raw_opacities,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts, float* __restrict__ max_radius,
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         do {
             const Vec3A mean_c = world_to_cam(v3(tr[0], tr[1], tr[2]), u);
             if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) break;
-            if (mean_c.z < 0.01f) break;
+            if (!in_front_of_camera<PINHOLE>(mean_c, u)) break;  // project_forward.rs:47-61
             const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
             if (!finite3(scl)) break;
             const Quat qu = Quat{tr[3], tr[4], tr[5], tr[6]};
@@ -119,12 +120,12 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             const float raw_opac = raw_opacities[gid];
             if (!is_finite_f32(raw_opac)) break;
             const Quat q = qnormalize(qu);
-            const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+            const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
             float filter_comp;
             const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
             const float opac = sigmoid(raw_opac) * filter_comp;
             if (!sym2_finite(cov)) break;
-            project_pinhole(mean_c, u, mx, my);
+            project_point<PINHOLE>(mean_c, u, mx, my);
             if (!(opac >= 1.0f / 255.0f)) break;
             pt = bh_logf(opac * 255.0f);
             conic = sym2_inverse(cov);
@@ -178,10 +179,15 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
     if (n == 0) return 0;
     const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     auto* c64 = reinterpret_cast<unsigned long long*>(counters);
-    if (mip)
-        hipLaunchKernelGGL(project_forward_kernel<true>, grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    const bool pinhole = u.model == CAM_PINHOLE;
+    if (mip && pinhole)
+        hipLaunchKernelGGL((project_forward_kernel<true, true>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    else if (pinhole)
+        hipLaunchKernelGGL((project_forward_kernel<false, true>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    else if (mip)
+        hipLaunchKernelGGL((project_forward_kernel<true, false>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
     else
-        hipLaunchKernelGGL(project_forward_kernel<false>, grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+        hipLaunchKernelGGL((project_forward_kernel<false, false>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
     BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
     return 0;
 }
@@ -189,7 +195,7 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
 // ---------------------------------------------------------------------------
 // K4: project_visible  (kernels/project_visible.rs:23-88)
 // ---------------------------------------------------------------------------
-template <bool MIP, int DEG>
+template <bool MIP, int DEG, bool PINHOLE>
 __global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(
     ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ coeffs,
     const float* __restrict__ raw_opacities, const uint32_t* __restrict__ global_from_compact_gid,
@@ -202,13 +208,13 @@ __global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(
     const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
     const Quat q = qnormalize(Quat{tr[3], tr[4], tr[5], tr[6]});
     const Vec3A mean_c = world_to_cam(mean, u);
-    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
     float filter_comp;
     const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
     const float opac = sigmoid(raw_opacities[gid]) * filter_comp;
     const Sym2 conic = sym2_inverse(cov);
     float mx, my;
-    project_pinhole(mean_c, u, mx, my);
+    project_point<PINHOLE>(mean_c, u, mx, my);
     const Vec3A v = normalize(sub(mean, camera_pos(u)));
     constexpr int C = (DEG + 1) * (DEG + 1);
     const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
@@ -225,16 +231,16 @@ __global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(
     o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
 }
 
-template <bool MIP>
+template <bool MIP, bool PINHOLE>
 static int launch_pv_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
                          const float* ro, const uint32_t* gid, float* projected) {
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_visible_kernel<MIP, 0>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 1: hipLaunchKernelGGL((project_visible_kernel<MIP, 1>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 2: hipLaunchKernelGGL((project_visible_kernel<MIP, 2>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 3: hipLaunchKernelGGL((project_visible_kernel<MIP, 3>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 4: hipLaunchKernelGGL((project_visible_kernel<MIP, 4>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 0: hipLaunchKernelGGL((project_visible_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 1: hipLaunchKernelGGL((project_visible_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 2: hipLaunchKernelGGL((project_visible_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 3: hipLaunchKernelGGL((project_visible_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
+        case 4: hipLaunchKernelGGL((project_visible_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_visible_kernel");
@@ -245,8 +251,11 @@ int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool
                            const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                            float* projected) {
     if (nv == 0) return 0;
-    return mip ? launch_pv_deg<true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
-               : launch_pv_deg<false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
+    if (u.model == CAM_PINHOLE)
+        return mip ? launch_pv_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
+                   : launch_pv_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
+    return mip ? launch_pv_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
+               : launch_pv_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
 }
 
 // ---------------------------------------------------------------------------
@@ -366,7 +375,7 @@ BH_DEV Vec3A projection_vjp_pinhole(const Mat2x3& jac, Vec3A mean_c, Sym3 cov_c,
     return Vec3A{v_mx, v_my, v_mz};
 }
 
-template <bool MIP, int DEG>
+template <bool MIP, int DEG, bool PINHOLE>
 __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ sh_coeffs,
     const float* __restrict__ raw_opac, const uint32_t* __restrict__ global_from_compact_gid,
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     const Vec3A mean_c = world_to_cam(mean, u);
     const Mat3 r = quat_to_mat3(q);
     const Mat3 m = mul_diag(r, scl);
-    const Sym2 raw_cov = calc_cov2d(scl, q, mean_c, u);
+    const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
     float filter_comp;
     const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
     const float os = sigmoid(raw_opac[gid]);
@@ -411,8 +420,13 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     const Sym3 covar = outer_product_self(m);
     const Mat3 view_rot = view_rotation(u);
     const Sym3 cov_c = congruence(covar, view_rot);
-    const Mat2x3 jac = jacobian_pinhole(mean_c, u);
-    const Vec3A v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, Vec2{g[0], g[1]});
+    const Mat2x3 jac = project_jacobian<PINHOLE>(mean_c, u);
+    const Vec2 v_xy = Vec2{g[0], g[1]};
+    Vec3A v_mean_c;  // camera_model/mod.rs:86-125
+    if (PINHOLE) v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, v_xy);
+    else if (u.model == CAM_KB4) v_mean_c = projection_vjp_kb4(jac, mean_c, cov_c, u, v_cov2d, v_xy, u.dist);
+    else if (u.model == CAM_RT8) v_mean_c = projection_vjp_rt8(mean_c, cov_c, u, v_cov2d, v_xy, u.dist);
+    else v_mean_c = projection_vjp_tpf(jac, mean_c, cov_c, u, v_cov2d, v_xy, u.dist);
     const Sym3 vcc = transpose_congruence_sym2(jac, v_cov2d);
     const Vec3A v_mean = add(transpose_mul_vec3(view_rot, v_mean_c), v_mean_from_sh);
     const Mat3 v_m = sym3_mul_mat3(sym3_scale(transpose_congruence(vcc, view_rot), 2.0f), m);
@@ -425,16 +439,16 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     vt[7] = v_scale.x; vt[8] = v_scale.y; vt[9] = v_scale.z;
 }
 
-template <bool MIP>
+template <bool MIP, bool PINHOLE>
 static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
                          const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr) {
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_backward_kernel");
@@ -446,8 +460,11 @@ int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, boo
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
                             float* v_refine) {
     if (nv == 0) return 0;
-    return mip ? launch_pb_deg<true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
-               : launch_pb_deg<false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
+    if (u.model == CAM_PINHOLE)
+        return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
+                   : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
+    return mip ? launch_pb_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
+               : launch_pb_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
 }
 
 }  // namespace bh

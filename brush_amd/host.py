@@ -109,6 +109,23 @@ def _f32c(t, device):
 # ---------------------------------------------------------------------------
 # Camera (brush-render/src/camera.rs)
 # ---------------------------------------------------------------------------
+def _model_and_dist(camera_model, dist):
+    c = Camera(camera_model=camera_model, dist=tuple(dist or ()))
+    return c.model_id(), c._dist8()
+
+
+def fov_to_focal(fov, pixels, camera_model="pinhole", dist=None):
+    """camera.rs:85-101 (f64): focal such that pixels/2 = focal * lens_law(fov/2)."""
+    m, d = _model_and_dist(camera_model, dist)
+    return _ffi.load().bh_fov_to_focal(float(fov), int(pixels), m, d)
+
+
+def focal_to_fov(focal, pixels, camera_model="pinhole", dist=None):
+    """camera.rs:104-118 (f64)."""
+    m, d = _model_and_dist(camera_model, dist)
+    return _ffi.load().bh_focal_to_fov(float(focal), int(pixels), m, d)
+
+
 @dataclass
 class Camera:
     position: Tuple[float, float, float] = (0.0, 0.0, 0.0)
@@ -116,6 +133,21 @@ class Camera:
     fov_x: float = 1.0
     fov_y: float = 1.0
     center_uv: Tuple[float, float] = (0.5, 0.5)
+    # CameraModel (kernels/camera_model/mod.rs:31-38): "pinhole" | "kb4" | "rt8" | "tpf" (or the BH_CAMERA_* id)
+    # with its distortion parameters in the reference's struct order (see include/brush_hip.h)
+    camera_model: object = "pinhole"
+    dist: Tuple[float, ...] = ()
+
+    def model_id(self):
+        ids = {"pinhole": _ffi.CAMERA_PINHOLE, "kb4": _ffi.CAMERA_KANNALA_BRANDT_4, "rt8": _ffi.CAMERA_RADIAL_TANGENTIAL_8,
+               "tpf": _ffi.CAMERA_THIN_PRISM_FISHEYE}
+        return ids[self.camera_model] if isinstance(self.camera_model, str) else int(self.camera_model)
+
+    def _dist8(self):
+        d = (C.c_float * 8)()
+        for i, v in enumerate(self.dist):
+            d[i] = float(v)
+        return d
 
     def is_valid(self):
         vals = list(self.position) + list(self.rotation) + [self.fov_x, self.fov_y] + list(self.center_uv)
@@ -129,21 +161,13 @@ class Camera:
         cam = _ffi.BhCamera()
         pos = (C.c_float * 3)(*self.position)
         rot = (C.c_float * 4)(*self.rotation)
-        rc = _ffi.load().bh_camera_setup(pos, rot, float(self.fov_x), float(self.fov_y), float(self.center_uv[0]),
-                                         float(self.center_uv[1]), w, h, C.byref(cam))
+        rc = _ffi.load().bh_camera_setup_model(pos, rot, float(self.fov_x), float(self.fov_y), float(self.center_uv[0]),
+                                               float(self.center_uv[1]), w, h, self.model_id(), self._dist8(), C.byref(cam))
         if rc != 0:
-            raise BrushHipError("bh_camera_setup failed (%d): image size must be non-zero" % rc)
+            raise BrushHipError("bh_camera_setup_model failed (%d): image size must be non-zero, camera model known" % rc)
         if tile_rows is not None:
             cam.tile_row_begin, cam.tile_row_end = int(tile_rows[0]), int(tile_rows[1])
         return cam
-
-
-def fov_to_focal(fov, pixels):  # camera.rs:85-101 (pinhole)
-    return (pixels / 2.0) / math.tan(fov / 2.0)
-
-
-def focal_to_fov(focal, pixels):  # camera.rs:104-120 (pinhole)
-    return 2.0 * math.atan((pixels / 2.0) / focal)
 
 
 # ---------------------------------------------------------------------------

@@ -17,8 +17,10 @@
  *   bh_adam_step        <- AdamScaled::step                   brush-train/src/adam_scaled.rs:75-147
  *   bh_gather_stats     <- RefineRecord::gather_stats         brush-train/src/stats.rs:40-50
  *   bh_train_step       <- SplatTrainer::step                 brush-train/src/train.rs:176-429
- *   bh_camera_setup     <- Camera::{build_pinhole_params, world_to_local},
- *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-101,200-254
+ *   bh_camera_setup[_model] <- Camera::{build_pinhole_params, world_to_local}, fov_to_focal,
+ *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-254
+ *                          (+ kernels/camera_model/{pinhole,kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs: pinhole, Kannala-Brandt 4, radial-tangential 8,
+ *                          thin-prism fisheye projection / Jacobian / VJP inside the project kernels)
  *
  * Conventions (following the reference's only C ABI, apps/brush-c/src/lib.rs:109-163):
  *   - every function returns 0 on success, <0 on error; nothing throws or
@@ -63,8 +65,21 @@ enum {
     BH_FLAG_SMOOTH_CUTOFF = 4  /* RasterPass::BackwardSmoothCutoff (test-only C^1 alpha cutoff) */
 };
 
+/* Camera models = CameraModel (brush-render/src/kernels/camera_model/mod.rs:31-38).  The reference
+ * bakes the distortion parameters into the kernels at JIT time (#[comptime]); here they are data
+ * in BhCamera.dist, in the field order of the reference's parameter structs:
+ *   BH_CAMERA_KANNALA_BRANDT_4     k1 k2 k3 k4                       (kannala_brandt_4.rs:10-16)
+ *   BH_CAMERA_RADIAL_TANGENTIAL_8  k1 k2 k3 k4 k5 k6 p1 p2           (radial_tangential_8.rs:12-22)
+ *   BH_CAMERA_THIN_PRISM_FISHEYE   k1 k2 k3 k4 (kb4) p1 p2 sx1 sy1   (thin_prism_fisheye.rs:24-31) */
+enum {
+    BH_CAMERA_PINHOLE = 0,
+    BH_CAMERA_KANNALA_BRANDT_4 = 1,
+    BH_CAMERA_RADIAL_TANGENTIAL_8 = 2,
+    BH_CAMERA_THIN_PRISM_FISHEYE = 3
+};
+
 /* Host-side view uniforms = ProjectUniforms (kernels/types.rs:53-81) without the
- * per-launch counters.  Pinhole only (the other camera models are SURVEY §8f). */
+ * per-launch counters. */
 typedef struct BhCamera {
     float vm[12]; /* world-to-camera 3x4, column-major: col0(x,y,z) col1 col2 translation */
     float fx, fy, cx, cy;
@@ -76,6 +91,9 @@ typedef struct BhCamera {
      * (SURVEY.md 8e): splats are binned only into the window's tiles and only the window's
      * pixels of out_img are written; per-tile splat lists are identical to a full render. */
     uint32_t tile_row_begin, tile_row_end;
+    uint32_t model;            /* BH_CAMERA_* */
+    float dist[8];             /* distortion parameters of `model` (unused entries 0) */
+    float half_max_render_fov; /* fisheye/distorted models cull on the view angle (render.rs:70-71, project_forward.rs:53-61) */
 } BhCamera;
 
 /* Forward outputs = RenderOutput + RenderAuxInner (render_aux.rs:17-68) and the
@@ -115,6 +133,16 @@ const char* bh_version(void);
 /* pos[3], rot_xyzw[4] (glam order), fov in radians (f64 like camera.rs), centre in uv. */
 int bh_camera_setup(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u,
                     float center_v, uint32_t img_w, uint32_t img_h, BhCamera* out /*host*/);
+/* Same with a camera model: focal from fov through the model's radial law (camera.rs:85-101), the
+ * Jacobian clamp limits of the model (camera.rs:200-254; RT8 inverts its radial law, the fisheye
+ * models are not clamped), the view-angle cull bound.  dist: host [8] in the order documented at
+ * BH_CAMERA_* (NULL = all zero). */
+int bh_camera_setup_model(const float* pos, const float* rot_xyzw, double fov_x, double fov_y, float center_u,
+                          float center_v, uint32_t img_w, uint32_t img_h, uint32_t model, const float* dist /*host[8]*/,
+                          BhCamera* out /*host*/);
+/* fov_to_focal / focal_to_fov (camera.rs:85-118), f64 like the reference; NaN on an unknown model. */
+double bh_fov_to_focal(double fov, uint32_t pixels, uint32_t model, const float* dist /*host[8]*/);
+double bh_focal_to_fov(double focal, uint32_t pixels, uint32_t model, const float* dist /*host[8]*/);
 
 /* ---- render ---------------------------------------------------------------- */
 int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uint32_t sh_degree,

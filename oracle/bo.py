@@ -25,7 +25,22 @@ class BoCamera(C.Structure):
         ("lim_neg_x", C.c_float), ("lim_neg_y", C.c_float),
         ("cam_pos", C.c_float * 3),
         ("img_w", C.c_uint32), ("img_h", C.c_uint32),
+        ("model", C.c_uint32), ("dist", C.c_float * 8), ("half_max_render_fov", C.c_float),
     ]
+
+
+# kernels/camera_model/mod.rs:31-38
+CAM_PINHOLE, CAM_KB4, CAM_RT8, CAM_TPF = 0, 1, 2, 3
+_MODEL_IDS = {"pinhole": CAM_PINHOLE, "kb4": CAM_KB4, "rt8": CAM_RT8, "tpf": CAM_TPF}
+
+
+def _model_args(model, dist):
+    m = _MODEL_IDS[model] if isinstance(model, str) else int(model)
+    d = np.zeros(8, np.float32)
+    if dist is not None:
+        dd = np.asarray(dist, np.float32).reshape(-1)
+        d[: dd.size] = dd
+    return m, d
 
 
 def build(force=False):
@@ -51,6 +66,11 @@ def lib():
         L.bo_powi.restype = C.c_float; L.bo_powi.argtypes = [C.c_float, C.c_int]
         L.bo_camera_setup.restype = None
         L.bo_camera_setup.argtypes = [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BoCamera)]
+        L.bo_camera_setup_model.restype = None
+        L.bo_camera_setup_model.argtypes = [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(BoCamera)]
+        for nm in ("bo_focal_to_fov_model", "bo_fov_to_focal_model"):
+            getattr(L, nm).restype = C.c_double
+            getattr(L, nm).argtypes = [C.c_double, C.c_uint32, C.c_uint32, fp]
         L.bo_focal_to_fov.restype = C.c_double; L.bo_focal_to_fov.argtypes = [C.c_double, C.c_uint32]
         L.bo_fov_to_focal.restype = C.c_double; L.bo_fov_to_focal.argtypes = [C.c_double, C.c_uint32]
         L.bo_render_create.restype = C.c_void_p
@@ -92,13 +112,27 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def camera(pos=(0.0, 0.0, 0.0), rot_xyzw=(0.0, 0.0, 0.0, 1.0), fov_x=1.0, fov_y=1.0, center_uv=(0.5, 0.5), img_w=64, img_h=64):
-    """brush-render/src/camera.rs Camera -> kernel uniforms (oracle restatement)."""
+def camera(pos=(0.0, 0.0, 0.0), rot_xyzw=(0.0, 0.0, 0.0, 1.0), fov_x=1.0, fov_y=1.0, center_uv=(0.5, 0.5), img_w=64, img_h=64,
+           model="pinhole", dist=None):
+    """brush-render/src/camera.rs Camera -> kernel uniforms (oracle restatement).  `model` is
+    "pinhole" | "kb4" (dist k1..k4) | "rt8" (k1 k2 k3 k4 k5 k6 p1 p2) | "tpf" (k1..k4 p1 p2 sx1 sy1)."""
     cam = BoCamera()
     p = f32(pos)
     r = f32(rot_xyzw)
-    lib().bo_camera_setup(_fp(p), _fp(r), float(fov_x), float(fov_y), float(center_uv[0]), float(center_uv[1]), int(img_w), int(img_h), C.byref(cam))
+    m, d = _model_args(model, dist)
+    lib().bo_camera_setup_model(_fp(p), _fp(r), float(fov_x), float(fov_y), float(center_uv[0]), float(center_uv[1]), int(img_w), int(img_h),
+                                m, _fp(d), C.byref(cam))
     return cam
+
+
+def fov_to_focal(fov, pixels, model="pinhole", dist=None):
+    m, d = _model_args(model, dist)
+    return lib().bo_fov_to_focal_model(float(fov), int(pixels), m, _fp(d))
+
+
+def focal_to_fov(focal, pixels, model="pinhole", dist=None):
+    m, d = _model_args(model, dist)
+    return lib().bo_focal_to_fov_model(float(focal), int(pixels), m, _fp(d))
 
 
 _GETTERS = {

@@ -287,7 +287,15 @@ struct BoCamera {
     float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y;
     float cam_pos[3];
     uint32_t img_w, img_h;
+    // kernels/camera_model/mod.rs:31-38 CameraModel (comptime in the reference, data here):
+    //   0 Pinhole | 1 KannalaBrandt4 dist = k1..k4 | 2 RadialTangential8 dist = k1 k2 k3 k4 k5 k6 p1 p2
+    //   | 3 ThinPrismFisheye dist = k1..k4 (kb4) p1 p2 sx1 sy1
+    uint32_t model;
+    float dist[8];
+    float half_max_render_fov;  // render.rs:70-71
 };
+
+enum { BO_CAM_PINHOLE = 0, BO_CAM_KB4 = 1, BO_CAM_RT8 = 2, BO_CAM_TPF = 3 };
 
 enum { BO_FLAG_MIP = 1, BO_FLAG_BWD_INFO = 2, BO_FLAG_SMOOTH_CUTOFF = 4 };
 
@@ -297,12 +305,92 @@ float bo_calc_sigma(float px, float py, float c00, float c01, float c11, float x
     return calc_sigma(px, py, Sym2{c00, c01, c11}, x, y);
 }
 
-// brush-render/src/camera.rs:63-101,200-254 + render.rs:72-91 (pinhole).
+// ---- camera.rs:85-198: fov <-> focal per camera model (all f64) ----------------
+static double kb4_d(double theta, const float* k) {  // camera.rs:120-128
+    const double t2 = theta * theta;
+    const double t3 = t2 * theta;
+    const double t5 = t3 * t2;
+    const double t7 = t5 * t2;
+    const double t9 = t7 * t2;
+    return theta + (double)k[0] * t3 + (double)k[1] * t5 + (double)k[2] * t7 + (double)k[3] * t9;
+}
+static double kb4_dd_dtheta(double theta, const float* k) {  // camera.rs:131-142
+    const double t2 = theta * theta;
+    const double t4 = t2 * t2;
+    const double t6 = t4 * t2;
+    const double t8 = t6 * t2;
+    return 1.0 + 3.0 * (double)k[0] * t2 + 5.0 * (double)k[1] * t4 + 7.0 * (double)k[2] * t6 + 9.0 * (double)k[3] * t8;
+}
+static double kb4_invert_d(double target, const float* k) {  // camera.rs:145-167
+    const double PI = 3.14159265358979323846;
+    if (target <= 0.0) return 0.0;
+    double theta = std::min(target, PI - 1e-6);
+    for (int it = 0; it < 50; ++it) {
+        const double f = kb4_d(theta, k) - target;
+        const double fp = kb4_dd_dtheta(theta, k);
+        if (std::fabs(fp) < 1e-12) break;
+        const double step = f / fp;
+        const double next = std::min(std::max(theta - step, 0.0), PI);
+        if (std::fabs(next - theta) < 1e-12) { theta = next; break; }
+        theta = next;
+    }
+    return theta;
+}
+static double rt8_radial(double r, const float* d) {  // camera.rs:170-178 (d = k1 k2 k3 k4 k5 k6 ..)
+    const double r2 = r * r;
+    const double r4 = r2 * r2;
+    const double r6 = r4 * r2;
+    const double num = 1.0 + (double)d[0] * r2 + (double)d[1] * r4 + (double)d[2] * r6;
+    const double den = 1.0 + (double)d[3] * r2 + (double)d[4] * r4 + (double)d[5] * r6;
+    return num / den;
+}
+static double rt8_undistort_radius(double r_d, const float* d) {  // camera.rs:182-198
+    double r = r_d;
+    for (int it = 0; it < 30; ++it) {
+        const double factor = rt8_radial(r, d);
+        if (std::fabs(factor) < 1e-12) break;
+        const double r_new = r_d / factor;
+        if (std::fabs(r_new - r) < 1e-12) { r = r_new; break; }
+        r = r_new;
+    }
+    return r;
+}
+// camera.rs:85-101
+double bo_fov_to_focal_model(double fov, uint32_t pixels, uint32_t model, const float* dist) {
+    const double half_fov = fov / 2.0;
+    const double r_pix = (double)pixels / 2.0;
+    double projected;
+    switch (model) {
+        case BO_CAM_KB4: projected = kb4_d(half_fov, dist); break;
+        case BO_CAM_RT8: { const double r = std::tan(half_fov); projected = r * rt8_radial(r, dist); break; }
+        case BO_CAM_TPF: projected = kb4_d(half_fov, dist); break;
+        default: projected = std::tan(half_fov);
+    }
+    return r_pix / projected;
+}
+// camera.rs:104-118
+double bo_focal_to_fov_model(double focal, uint32_t pixels, uint32_t model, const float* dist) {
+    const double r_pix = (double)pixels / 2.0;
+    const double r_norm = r_pix / focal;
+    double half_fov;
+    switch (model) {
+        case BO_CAM_KB4: half_fov = kb4_invert_d(r_norm, dist); break;
+        case BO_CAM_RT8: half_fov = std::atan(rt8_undistort_radius(r_norm, dist)); break;
+        case BO_CAM_TPF: half_fov = kb4_invert_d(r_norm, dist); break;
+        default: half_fov = std::atan(r_norm);
+    }
+    return 2.0 * half_fov;
+}
+double bo_focal_to_fov(double focal, uint32_t pixels) { return bo_focal_to_fov_model(focal, pixels, BO_CAM_PINHOLE, nullptr); }
+double bo_fov_to_focal(double fov, uint32_t pixels) { return bo_fov_to_focal_model(fov, pixels, BO_CAM_PINHOLE, nullptr); }
+
+// brush-render/src/camera.rs:63-101,200-254 + render.rs:70-91.
 // glam (un-vendored dependency, 0.30.x): Affine3A::from_rotation_translation,
 // Mat3A::from_quat, Affine3A::inverse restated in f32.
 // `rot` is glam order (x, y, z, w).
-void bo_camera_setup(const float pos[3], const float rot_xyzw[4], double fov_x, double fov_y,
-                     float center_u, float center_v, uint32_t img_w, uint32_t img_h, BoCamera* out) {
+void bo_camera_setup_model(const float pos[3], const float rot_xyzw[4], double fov_x, double fov_y,
+                           float center_u, float center_v, uint32_t img_w, uint32_t img_h, uint32_t model,
+                           const float* dist, BoCamera* out) {
     const float x = rot_xyzw[0], y = rot_xyzw[1], z = rot_xyzw[2], w = rot_xyzw[3];
     const float x2 = x + x, y2 = y + y, z2 = z + z;
     const float xx = x * x2, xy = x * y2, xz = x * z2;
@@ -328,26 +416,42 @@ void bo_camera_setup(const float pos[3], const float rot_xyzw[4], double fov_x, 
     out->vm[3] = c1.x; out->vm[4] = c1.y; out->vm[5] = c1.z;
     out->vm[6] = c2.x; out->vm[7] = c2.y; out->vm[8] = c2.z;
     out->vm[9] = -ip.x; out->vm[10] = -ip.y; out->vm[11] = -ip.z;
+    out->model = model;
+    for (int i = 0; i < 8; ++i) out->dist[i] = (model != BO_CAM_PINHOLE && dist) ? dist[i] : 0.0f;
     // camera.rs:85-101 (f64), camera.rs:49-54 (cast to f32)
-    const double fxd = ((double)img_w / 2.0) / std::tan(fov_x / 2.0);
-    const double fyd = ((double)img_h / 2.0) / std::tan(fov_y / 2.0);
-    out->fx = (float)fxd;
-    out->fy = (float)fyd;
+    out->fx = (float)bo_fov_to_focal_model(fov_x, img_w, model, out->dist);
+    out->fy = (float)bo_fov_to_focal_model(fov_y, img_h, model, out->dist);
     out->cx = center_u * (float)img_w;
     out->cy = center_v * (float)img_h;
-    // camera.rs:221-226
+    // camera.rs:200-254
     const float wf = (float)img_w, hf = (float)img_h;
-    out->lim_pos_x = (1.15f * wf - out->cx) / out->fx;
-    out->lim_pos_y = (1.15f * hf - out->cy) / out->fy;
-    out->lim_neg_x = (-0.15f * wf - out->cx) / out->fx;
-    out->lim_neg_y = (-0.15f * hf - out->cy) / out->fy;
+    out->lim_pos_x = out->lim_pos_y = out->lim_neg_x = out->lim_neg_y = 0.0f;
+    if (model == BO_CAM_PINHOLE) {
+        out->lim_pos_x = (1.15f * wf - out->cx) / out->fx;
+        out->lim_pos_y = (1.15f * hf - out->cy) / out->fy;
+        out->lim_neg_x = (-0.15f * wf - out->cx) / out->fx;
+        out->lim_neg_y = (-0.15f * hf - out->cy) / out->fy;
+    } else if (model == BO_CAM_RT8) {
+        auto undistort = [&](float edge) {
+            const float sgn = std::isnan(edge) ? edge : (std::signbit(edge) ? -1.0f : 1.0f);  // f32::signum
+            return (float)rt8_undistort_radius(std::fabs((double)edge), out->dist) * sgn;
+        };
+        out->lim_pos_x = undistort((1.15f * wf - out->cx) / out->fx);
+        out->lim_pos_y = undistort((1.15f * hf - out->cy) / out->fy);
+        out->lim_neg_x = undistort((-0.15f * wf - out->cx) / out->fx);
+        out->lim_neg_y = undistort((-0.15f * hf - out->cy) / out->fy);
+    }
+    // render.rs:70-71
+    const float two_pi = 2.0f * 3.14159265358979323846f;
+    out->half_max_render_fov = std::fmin(hypotf((float)fov_x, (float)fov_y) * 1.05f, two_pi - 1e-6f) * 0.5f;
     out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2];
     out->img_w = img_w; out->img_h = img_h;
 }
 
-// camera.rs:104-120 (pinhole)
-double bo_focal_to_fov(double focal, uint32_t pixels) { return 2.0 * std::atan(((double)pixels / 2.0) / focal); }
-double bo_fov_to_focal(double fov, uint32_t pixels) { return ((double)pixels / 2.0) / std::tan(fov / 2.0); }
+void bo_camera_setup(const float pos[3], const float rot_xyzw[4], double fov_x, double fov_y,
+                     float center_u, float center_v, uint32_t img_w, uint32_t img_h, BoCamera* out) {
+    bo_camera_setup_model(pos, rot_xyzw, fov_x, fov_y, center_u, center_v, img_w, img_h, BO_CAM_PINHOLE, nullptr, out);
+}
 
 }  // extern "C"
 
@@ -379,6 +483,9 @@ struct Uniforms {
     float lim_pos_x, lim_pos_y, lim_neg_x, lim_neg_y;
     Vec3A cam_pos;
     uint32_t img_w, img_h, tile_bw, tile_bh;
+    uint32_t model;   // BO_CAM_*
+    float dist[8];
+    float half_max_render_fov;
 };
 
 Uniforms make_uniforms(const BoCamera& c) {
@@ -391,6 +498,9 @@ Uniforms make_uniforms(const BoCamera& c) {
     u.img_w = c.img_w; u.img_h = c.img_h;
     u.tile_bw = (c.img_w + TILE_WIDTH - 1) / TILE_WIDTH;  // render.rs:30-35
     u.tile_bh = (c.img_h + TILE_WIDTH - 1) / TILE_WIDTH;
+    u.model = c.model;
+    for (int i = 0; i < 8; ++i) u.dist[i] = c.dist[i];
+    u.half_max_render_fov = c.half_max_render_fov;
     return u;
 }
 
@@ -418,10 +528,514 @@ inline Mat2x3 jacobian_pinhole(Vec3A p, const Uniforms& u) {
     return j;
 }
 
+// atan2 for the fisheye models (kannala_brandt_4.rs:37,85; project_forward.rs:57): a fixed
+// Cephes-style atanf polynomial with explicit fma, restated identically by the HIP kernels so the
+// cull decision and the tile assignment stay bit-reproducible (WGSL leaves atan2 precision open).
+inline float bo_atanf_pos(float x) {  // x >= 0 (or NaN)
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -1.0f / x; }
+    else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    const float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = fmaf(p, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    return y0 + fmaf(p * z, x, x);
+}
+inline float bo_atan2f_impl(float y, float x) {
+    if (x != x || y != y) return x + y;
+    if (y == 0.0f) return (x < 0.0f || (x == 0.0f && std::signbit(x))) ? (std::signbit(y) ? -3.14159265358979323846f : 3.14159265358979323846f) : y;
+    const float ay = fabsf(y), ax = fabsf(x);
+    float a;
+    if (ax == INFINITY && ay == INFINITY) a = 0.7853981633974483f;
+    else a = bo_atanf_pos(ay / ax);          // ax == 0 -> +inf -> pi/2
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return y < 0.0f ? -a : a;
+}
+
+// ---- camera_model/kannala_brandt_4.rs ----------------------------------------------------
+// :19-53
+inline void project_kb4(Vec3A point, const Uniforms& u, const float* kk, float& ou, float& ov) {
+    const float x = point.x, y = point.y, z = point.z;
+    const float fx = u.fx, fy = u.fy, cx = u.cx, cy = u.cy;
+    const float k1 = kk[0], k2 = kk[1], k3 = kk[2], k4 = kk[3];
+    const float inv_z = 1.0f / z;
+    const float pinhole_u = fx * x * inv_z + cx;
+    const float pinhole_v = fy * y * inv_z + cy;
+    const float r = sqrtf(x * x + y * y);
+    const float theta = bo_atan2f_impl(r, z);
+    const float theta2 = theta * theta;
+    const float theta4 = theta2 * theta2;
+    const float theta6 = theta2 * theta4;
+    const float theta8 = theta4 * theta4;
+    const float d = theta * (1.0f + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+    const float inv_r = 1.0f / r;
+    const float fisheye_u = fx * (d * x * inv_r) + cx;
+    const float fisheye_v = fy * (d * y * inv_r) + cy;
+    const bool near_axis = r < 1e-6f;
+    ou = near_axis ? pinhole_u : fisheye_u;
+    ov = near_axis ? pinhole_v : fisheye_v;
+}
+// :57-152
+inline Mat2x3 jacobian_kb4(Vec3A point, const Uniforms& u, const float* kk) {
+    const float fx = u.fx, fy = u.fy;
+    const float k1 = kk[0], k2 = kk[1], k3 = kk[2], k4 = kk[3];
+    const float x = point.x, y = point.y, z = point.z;
+    const float inv_z = 1.0f / z;
+    const float x2 = x * x, y2 = y * y, xy = x * y;
+    const float r2 = x2 + y2;
+    const float r = sqrtf(r2);
+    const float inv_r = 1.0f / r;
+    const float inv_r3 = inv_r * inv_r * inv_r;
+    const float rho2 = r2 + z * z;
+    const float inv_rho2 = 1.0f / rho2;
+    const float inv_rho2_r = inv_rho2 * inv_r;
+    const float theta = bo_atan2f_impl(r, z);
+    const float theta2 = theta * theta;
+    const float theta4 = theta2 * theta2;
+    const float theta6 = theta4 * theta2;
+    const float theta8 = theta4 * theta4;
+    const float d = theta * (1.0f + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+    const float dd_dtheta = 1.0f + 3.0f * k1 * theta2 + 5.0f * k2 * theta4 + 7.0f * k3 * theta6 + 9.0f * k4 * theta8;
+    const float dth_dx = x * z * inv_rho2_r;
+    const float dth_dy = y * z * inv_rho2_r;
+    const float dth_dz = -r * inv_rho2;
+    const float dd_dx = dd_dtheta * dth_dx;
+    const float dd_dy = dd_dtheta * dth_dy;
+    const float dd_dz = dd_dtheta * dth_dz;
+    const float xr = x * inv_r;
+    const float dxr_dx = y2 * inv_r3;
+    const float dxr_dy = -xy * inv_r3;
+    const float du_dx = fx * (dd_dx * xr + d * dxr_dx);
+    const float du_dy = fx * (dd_dy * xr + d * dxr_dy);
+    const float du_dz = fx * (dd_dz * xr);
+    const float yr = y * inv_r;
+    const float dyr_dx = -xy * inv_r3;
+    const float dyr_dy = x2 * inv_r3;
+    const float dv_dx = fy * (dd_dx * yr + d * dyr_dx);
+    const float dv_dy = fy * (dd_dy * yr + d * dyr_dy);
+    const float dv_dz = fy * (dd_dz * yr);
+    const bool near_axis = r < 1e-6f;
+    const float dx = fx * inv_z;
+    const float dy = fy * inv_z;
+    const float pinhole_du_dz = -dx * x * inv_z;
+    const float pinhole_dv_dz = -dy * y * inv_z;
+    Mat2x3 j;
+    j.c0 = {near_axis ? dx : du_dx, near_axis ? 0.0f : dv_dx};
+    j.c1 = {near_axis ? 0.0f : du_dy, near_axis ? dy : dv_dy};
+    j.c2 = {near_axis ? pinhole_du_dz : du_dz, near_axis ? pinhole_dv_dz : dv_dz};
+    return j;
+}
+// :154-337
+inline Vec3A projection_vjp_kb4(const Mat2x3& jac, Vec3A mean_c, Sym3 cov_c, const Uniforms& u, Sym2 v_cov2d, Vec2 v_mean2d,
+                                const float* kk) {
+    const float fx = u.fx, fy = u.fy;
+    const float k1 = kk[0], k2 = kk[1], k3 = kk[2], k4 = kk[3];
+    const float mx = mean_c.x, my = mean_c.y, mz = mean_c.z;
+    const float r2 = mx * mx + my * my;
+    const float r = std::fmax(sqrtf(r2), 1.0e-8f);
+    const float rho2 = r2 + mz * mz;
+    const float theta = bo_atan2f_impl(r, mz);
+    const float th2 = theta * theta;
+    const float th4 = th2 * th2;
+    const float th6 = th4 * th2;
+    const float th8 = th4 * th4;
+    const float theta_d = theta * (1.0f + k1 * th2 + k2 * th4 + k3 * th6 + k4 * th8);
+    const float p1 = 1.0f + 3.0f * k1 * th2 + 5.0f * k2 * th4 + 7.0f * k3 * th6 + 9.0f * k4 * th8;
+    const float p2 = 6.0f * k1 * theta + 20.0f * k2 * theta * th2 + 42.0f * k3 * theta * th4 + 72.0f * k4 * theta * th6;
+    const float inv_r = 1.0f / r;
+    const float inv_r3 = inv_r * inv_r * inv_r;
+    const float inv_r5 = inv_r3 * inv_r * inv_r;
+    const float inv_rho2 = 1.0f / rho2;
+    const float inv_rho2_sq = inv_rho2 * inv_rho2;
+    const float inv_rho2_r = inv_rho2 * inv_r;
+    const float dth_x = mx * mz * inv_rho2_r;
+    const float dth_y = my * mz * inv_rho2_r;
+    const float dth_z = -r * inv_rho2;
+    const float xr = mx * inv_r;
+    const float yr = my * inv_r;
+    const float dxr_x = my * my * inv_r3;
+    const float dxr_y = -mx * my * inv_r3;
+    const float dyr_x = dxr_y;
+    const float dyr_y = mx * mx * inv_r3;
+    const float dg_x = p1 * dth_x;
+    const float dg_y = p1 * dth_y;
+    const float dg_z = p1 * dth_z;
+    float v_mx = dot(v_mean2d, jac.c0);
+    float v_my = dot(v_mean2d, jac.c1);
+    float v_mz = dot(v_mean2d, jac.c2);
+    const Mat2x3 tmp = sym2_mul_mat2x3(v_cov2d, jac);
+    const float vj_u0 = 2.0f * dot(row0(tmp), s3row0(cov_c));
+    const float vj_u1 = 2.0f * dot(row0(tmp), s3row1(cov_c));
+    const float vj_u2 = 2.0f * dot(row0(tmp), s3row2(cov_c));
+    const float vj_v0 = 2.0f * dot(row1(tmp), s3row0(cov_c));
+    const float vj_v1 = 2.0f * dot(row1(tmp), s3row1(cov_c));
+    const float vj_v2 = 2.0f * dot(row1(tmp), s3row2(cov_c));
+    const float three_r2_z2 = 3.0f * r2 + mz * mz;
+    const float r2_minus_z2 = r2 - mz * mz;
+    const float h_th_00 = mz * (r2 * rho2 - mx * mx * three_r2_z2) * inv_r3 * inv_rho2_sq;
+    const float h_th_11 = mz * (r2 * rho2 - my * my * three_r2_z2) * inv_r3 * inv_rho2_sq;
+    const float h_th_01 = -mx * my * mz * three_r2_z2 * inv_r3 * inv_rho2_sq;
+    const float h_th_02 = mx * r2_minus_z2 * inv_r * inv_rho2_sq;
+    const float h_th_12 = my * r2_minus_z2 * inv_r * inv_rho2_sq;
+    const float h_th_22 = 2.0f * mz * r * inv_rho2_sq;
+    const float two_x2_my2 = 2.0f * mx * mx - my * my;
+    const float two_y2_mx2 = 2.0f * my * my - mx * mx;
+    const float h_xr_00 = -3.0f * mx * my * my * inv_r5;
+    const float h_xr_01 = my * two_x2_my2 * inv_r5;
+    const float h_xr_11 = mx * two_y2_mx2 * inv_r5;
+    const float h_yr_00 = my * two_x2_my2 * inv_r5;
+    const float h_yr_01 = mx * two_y2_mx2 * inv_r5;
+    const float h_yr_11 = -3.0f * mx * mx * my * inv_r5;
+    {   // (j,k) = (0,0)
+        const float d2g = p2 * dth_x * dth_x + p1 * h_th_00;
+        const float d_ju = fx * (d2g * xr + dg_x * dxr_x + dg_x * dxr_x + theta_d * h_xr_00);
+        const float d_jv = fy * (d2g * yr + dg_x * dyr_x + dg_x * dyr_x + theta_d * h_yr_00);
+        v_mx += vj_u0 * d_ju + vj_v0 * d_jv;
+    }
+    {   // (1,0)
+        const float d2g = p2 * dth_y * dth_x + p1 * h_th_01;
+        const float d_ju = fx * (d2g * xr + dg_y * dxr_x + dg_x * dxr_y + theta_d * h_xr_01);
+        const float d_jv = fy * (d2g * yr + dg_y * dyr_x + dg_x * dyr_y + theta_d * h_yr_01);
+        v_mx += vj_u1 * d_ju + vj_v1 * d_jv;
+    }
+    {   // (2,0)
+        const float d2g = p2 * dth_z * dth_x + p1 * h_th_02;
+        const float d_ju = fx * (d2g * xr + dg_x * 0.0f + dg_z * dxr_x);
+        const float d_jv = fy * (d2g * yr + dg_x * 0.0f + dg_z * dyr_x);
+        v_mx += vj_u2 * d_ju + vj_v2 * d_jv;
+    }
+    {   // (0,1)
+        const float d2g = p2 * dth_x * dth_y + p1 * h_th_01;
+        const float d_ju = fx * (d2g * xr + dg_x * dxr_y + dg_y * dxr_x + theta_d * h_xr_01);
+        const float d_jv = fy * (d2g * yr + dg_x * dyr_y + dg_y * dyr_x + theta_d * h_yr_01);
+        v_my += vj_u0 * d_ju + vj_v0 * d_jv;
+    }
+    {   // (1,1)
+        const float d2g = p2 * dth_y * dth_y + p1 * h_th_11;
+        const float d_ju = fx * (d2g * xr + dg_y * dxr_y + dg_y * dxr_y + theta_d * h_xr_11);
+        const float d_jv = fy * (d2g * yr + dg_y * dyr_y + dg_y * dyr_y + theta_d * h_yr_11);
+        v_my += vj_u1 * d_ju + vj_v1 * d_jv;
+    }
+    {   // (2,1)
+        const float d2g = p2 * dth_z * dth_y + p1 * h_th_12;
+        const float d_ju = fx * (d2g * xr + dg_y * 0.0f + dg_z * dxr_y);
+        const float d_jv = fy * (d2g * yr + dg_y * 0.0f + dg_z * dyr_y);
+        v_my += vj_u2 * d_ju + vj_v2 * d_jv;
+    }
+    {   // (0,2)
+        const float d2g = p2 * dth_x * dth_z + p1 * h_th_02;
+        const float d_ju = fx * (d2g * xr + dg_z * dxr_x + dg_x * 0.0f);
+        const float d_jv = fy * (d2g * yr + dg_z * dyr_x + dg_x * 0.0f);
+        v_mz += vj_u0 * d_ju + vj_v0 * d_jv;
+    }
+    {   // (1,2)
+        const float d2g = p2 * dth_y * dth_z + p1 * h_th_12;
+        const float d_ju = fx * (d2g * xr + dg_z * dxr_y + dg_y * 0.0f);
+        const float d_jv = fy * (d2g * yr + dg_z * dyr_y + dg_y * 0.0f);
+        v_mz += vj_u1 * d_ju + vj_v1 * d_jv;
+    }
+    {   // (2,2)
+        const float d2g = p2 * dth_z * dth_z + p1 * h_th_22;
+        const float d_ju = fx * (d2g * xr);
+        const float d_jv = fy * (d2g * yr);
+        v_mz += vj_u2 * d_ju + vj_v2 * d_jv;
+    }
+    return {v_mx, v_my, v_mz};
+}
+
+// ---- camera_model/radial_tangential_8.rs --------------------------------------------------
+// dist = k1 k2 k3 k4 k5 k6 p1 p2.  :23-67
+inline void project_rt8(Vec3A point, const Uniforms& u, const float* dd, float& ou, float& ov) {
+    const float fx = u.fx, fy = u.fy, cx = u.cx, cy = u.cy;
+    const float k1 = dd[0], k2 = dd[1], k3 = dd[2], k4 = dd[3], k5 = dd[4], k6 = dd[5], p1 = dd[6], p2 = dd[7];
+    const float x = point.x, y = point.y, z = point.z;
+    const float x_ = x / z;
+    const float y_ = y / z;
+    const float x_2 = x_ * x_;
+    const float y_2 = y_ * y_;
+    const float r2 = x_2 + y_2;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float d = (1.0f + k1 * r2 + k2 * r4 + k3 * r6) / (1.0f + k4 * r2 + k5 * r4 + k6 * r6);
+    const float x_y_ = x_ * y_;
+    const float x__ = x_ * d + 2.0f * p1 * x_y_ + p2 * (r2 + 2.0f * x_2);
+    const float y__ = y_ * d + 2.0f * p2 * x_y_ + p1 * (r2 + 2.0f * y_2);
+    ou = fx * x__ + cx;
+    ov = fy * y__ + cy;
+}
+// :69-149
+inline Mat2x3 jacobian_rt8(Vec3A point, const Uniforms& u, const float* dd) {
+    const float fx = u.fx, fy = u.fy;
+    const float k1 = dd[0], k2 = dd[1], k3 = dd[2], k4 = dd[3], k5 = dd[4], k6 = dd[5], p1 = dd[6], p2 = dd[7];
+    const float x = point.x, y = point.y, z = point.z;
+    const float inv_z = 1.0f / z;
+    const float inv_z2 = inv_z * inv_z;
+    const float x_n = clampf(x * inv_z, u.lim_neg_x, u.lim_pos_x);
+    const float y_n = clampf(y * inv_z, u.lim_neg_y, u.lim_pos_y);
+    const float xc = x_n * z;
+    const float yc = y_n * z;
+    const float r2 = x_n * x_n + y_n * y_n;
+    const float r4 = r2 * r2;
+    const float r6 = r4 * r2;
+    const float n_poly = 1.0f + k1 * r2 + k2 * r4 + k3 * r6;
+    const float dn_poly = 1.0f + k4 * r2 + k5 * r4 + k6 * r6;
+    const float np_poly = k1 + 2.0f * k2 * r2 + 3.0f * k3 * r4;
+    const float dnp_poly = k4 + 2.0f * k5 * r2 + 3.0f * k6 * r4;
+    const float inv_dn = 1.0f / dn_poly;
+    const float inv_dn2 = inv_dn * inv_dn;
+    const float r_val = n_poly * inv_dn;
+    const float rp_val = (np_poly * dn_poly - n_poly * dnp_poly) * inv_dn2;
+    const float d00 = r_val + 2.0f * x_n * x_n * rp_val + 2.0f * p1 * y_n + 6.0f * p2 * x_n;
+    const float d01 = 2.0f * x_n * y_n * rp_val + 2.0f * p1 * x_n + 2.0f * p2 * y_n;
+    const float d10 = d01;
+    const float d11 = r_val + 2.0f * y_n * y_n * rp_val + 6.0f * p1 * y_n + 2.0f * p2 * x_n;
+    const float du_dx = fx * d00 * inv_z;
+    const float du_dy = fx * d01 * inv_z;
+    const float du_dz = -fx * (d00 * xc + d01 * yc) * inv_z2;
+    const float dv_dx = fy * d10 * inv_z;
+    const float dv_dy = fy * d11 * inv_z;
+    const float dv_dz = -fy * (d10 * xc + d11 * yc) * inv_z2;
+    Mat2x3 j;
+    j.c0 = {du_dx, dv_dx};
+    j.c1 = {du_dy, dv_dy};
+    j.c2 = {du_dz, dv_dz};
+    return j;
+}
+// :151-377
+inline Vec3A projection_vjp_rt8(Vec3A mean_c, Sym3 cov_c, const Uniforms& u, Sym2 v_cov2d, Vec2 v_mean2d, const float* dd) {
+    const float fx = u.fx, fy = u.fy;
+    const float k1 = dd[0], k2 = dd[1], k3 = dd[2], k4 = dd[3], k5 = dd[4], k6 = dd[5], p1 = dd[6], p2 = dd[7];
+    const float lim_pos_x = u.lim_pos_x, lim_pos_y = u.lim_pos_y, lim_neg_x = u.lim_neg_x, lim_neg_y = u.lim_neg_y;
+    const float mx = mean_c.x, my = mean_c.y, mz = mean_c.z;
+    const float inv_z = 1.0f / mz;
+    const float mx_rz_raw = mx * inv_z;
+    const float my_rz_raw = my * inv_z;
+    const float mx_rz = clampf(mx_rz_raw, lim_neg_x, lim_pos_x);
+    const float my_rz = clampf(my_rz_raw, lim_neg_y, lim_pos_y);
+    const bool in_x = mx_rz_raw <= lim_pos_x && mx_rz_raw >= lim_neg_x;
+    const bool in_y = my_rz_raw <= lim_pos_y && my_rz_raw >= lim_neg_y;
+    const float xc = mx_rz * mz;
+    const float yc = my_rz * mz;
+    const float inv_z2 = inv_z * inv_z;
+    const float inv_z3 = inv_z2 * inv_z;
+    const float x = xc * inv_z;
+    const float y = yc * inv_z;
+    const float r2 = x * x + y * y;
+    const float r4 = r2 * r2;
+    const float n_poly = 1.0f + k1 * r2 + k2 * r4 + k3 * r2 * r4;
+    const float dn_poly = 1.0f + k4 * r2 + k5 * r4 + k6 * r2 * r4;
+    const float np_poly = k1 + 2.0f * k2 * r2 + 3.0f * k3 * r4;
+    const float dnp_poly = k4 + 2.0f * k5 * r2 + 3.0f * k6 * r4;
+    const float npp_poly = 2.0f * k2 + 6.0f * k3 * r2;
+    const float dnpp_poly = 2.0f * k5 + 6.0f * k6 * r2;
+    const float inv_dn = 1.0f / dn_poly;
+    const float inv_dn2 = inv_dn * inv_dn;
+    const float inv_dn3 = inv_dn2 * inv_dn;
+    const float rr = n_poly * inv_dn;
+    const float rrp = (np_poly * dn_poly - n_poly * dnp_poly) * inv_dn2;
+    const float rrpp = (npp_poly * dn_poly * dn_poly - 2.0f * np_poly * dn_poly * dnp_poly - n_poly * dnpp_poly * dn_poly +
+                        2.0f * n_poly * dnp_poly * dnp_poly) * inv_dn3;
+    const float rx = 2.0f * x * rrp;
+    const float ry = 2.0f * y * rrp;
+    const float rpx = 2.0f * x * rrpp;
+    const float rpy = 2.0f * y * rrpp;
+    const float d00 = rr + 2.0f * x * x * rrp + 2.0f * p1 * y + 6.0f * p2 * x;
+    const float d01 = 2.0f * x * y * rrp + 2.0f * p1 * x + 2.0f * p2 * y;
+    const float d10 = d01;
+    const float d11 = rr + 2.0f * y * y * rrp + 6.0f * p1 * y + 2.0f * p2 * x;
+    const float js00 = fx * d00 * inv_z;
+    const float js01 = fx * d01 * inv_z;
+    const float js02 = -fx * (d00 * xc + d01 * yc) * inv_z2;
+    const float js10 = fy * d10 * inv_z;
+    const float js11 = fy * d11 * inv_z;
+    const float js12 = -fy * (d10 * xc + d11 * yc) * inv_z2;
+    const float je00 = in_x ? js00 : 0.0f;
+    const float je10 = in_x ? js10 : 0.0f;
+    const float je01 = in_y ? js01 : 0.0f;
+    const float je11 = in_y ? js11 : 0.0f;
+    const float je02 = (in_x ? 0.0f : mx_rz * js00) + (in_y ? 0.0f : my_rz * js01) + js02;
+    const float je12 = (in_x ? 0.0f : mx_rz * js10) + (in_y ? 0.0f : my_rz * js11) + js12;
+    float v_mx = je00 * v_mean2d.x + je10 * v_mean2d.y;
+    float v_my = je01 * v_mean2d.x + je11 * v_mean2d.y;
+    float v_mz = je02 * v_mean2d.x + je12 * v_mean2d.y;
+    Mat2x3 je;
+    je.c0 = {je00, je10};
+    je.c1 = {je01, je11};
+    je.c2 = {je02, je12};
+    const Mat2x3 tmp = sym2_mul_mat2x3(v_cov2d, je);
+    const float ve_u0 = 2.0f * dot(row0(tmp), s3row0(cov_c));
+    const float ve_u1 = 2.0f * dot(row0(tmp), s3row1(cov_c));
+    const float ve_u2 = 2.0f * dot(row0(tmp), s3row2(cov_c));
+    const float ve_v0 = 2.0f * dot(row1(tmp), s3row0(cov_c));
+    const float ve_v1 = 2.0f * dot(row1(tmp), s3row1(cov_c));
+    const float ve_v2 = 2.0f * dot(row1(tmp), s3row2(cov_c));
+    const float vs_u0 = in_x ? ve_u0 : mx_rz * ve_u2;
+    const float vs_v0 = in_x ? ve_v0 : mx_rz * ve_v2;
+    const float vs_u1 = in_y ? ve_u1 : my_rz * ve_u2;
+    const float vs_v1 = in_y ? ve_v1 : my_rz * ve_v2;
+    const float vs_u2 = ve_u2;
+    const float vs_v2 = ve_v2;
+    const float dd00_dx = rx + 4.0f * x * rrp + 2.0f * x * x * rpx + 6.0f * p2;
+    const float dd00_dy = ry + 2.0f * x * x * rpy + 2.0f * p1;
+    const float dd01_dx = 2.0f * y * rrp + 2.0f * x * y * rpx + 2.0f * p1;
+    const float dd01_dy = 2.0f * x * rrp + 2.0f * x * y * rpy + 2.0f * p2;
+    const float dd10_dx = dd01_dx;
+    const float dd10_dy = dd01_dy;
+    const float dd11_dx = rx + 2.0f * y * y * rpx + 2.0f * p2;
+    const float dd11_dy = ry + 4.0f * y * rrp + 2.0f * y * y * rpy + 6.0f * p1;
+    const float dd00_dxc = dd00_dx * inv_z;
+    const float dd00_dyc = dd00_dy * inv_z;
+    const float dd00_dz = -(xc * dd00_dx + yc * dd00_dy) * inv_z2;
+    const float dd01_dxc = dd01_dx * inv_z;
+    const float dd01_dyc = dd01_dy * inv_z;
+    const float dd01_dz = -(xc * dd01_dx + yc * dd01_dy) * inv_z2;
+    const float dd10_dxc = dd10_dx * inv_z;
+    const float dd10_dyc = dd10_dy * inv_z;
+    const float dd10_dz = -(xc * dd10_dx + yc * dd10_dy) * inv_z2;
+    const float dd11_dxc = dd11_dx * inv_z;
+    const float dd11_dyc = dd11_dy * inv_z;
+    const float dd11_dz = -(xc * dd11_dx + yc * dd11_dy) * inv_z2;
+    const float djs00_dxc = fx * dd00_dxc * inv_z;
+    const float djs00_dyc = fx * dd00_dyc * inv_z;
+    const float djs00_dz = fx * (dd00_dz * inv_z - d00 * inv_z2);
+    const float djs01_dxc = fx * dd01_dxc * inv_z;
+    const float djs01_dyc = fx * dd01_dyc * inv_z;
+    const float djs01_dz = fx * (dd01_dz * inv_z - d01 * inv_z2);
+    const float djs10_dxc = fy * dd10_dxc * inv_z;
+    const float djs10_dyc = fy * dd10_dyc * inv_z;
+    const float djs10_dz = fy * (dd10_dz * inv_z - d10 * inv_z2);
+    const float djs11_dxc = fy * dd11_dxc * inv_z;
+    const float djs11_dyc = fy * dd11_dyc * inv_z;
+    const float djs11_dz = fy * (dd11_dz * inv_z - d11 * inv_z2);
+    const float djs02_dxc = -fx * (dd00_dxc * xc + d00 + dd01_dxc * yc) * inv_z2;
+    const float djs02_dyc = -fx * (dd00_dyc * xc + dd01_dyc * yc + d01) * inv_z2;
+    const float djs02_dz = -fx * ((dd00_dz * xc + dd01_dz * yc) * inv_z2 - 2.0f * (d00 * xc + d01 * yc) * inv_z3);
+    const float djs12_dxc = -fy * (dd10_dxc * xc + d10 + dd11_dxc * yc) * inv_z2;
+    const float djs12_dyc = -fy * (dd10_dyc * xc + dd11_dyc * yc + d11) * inv_z2;
+    const float djs12_dz = -fy * ((dd10_dz * xc + dd11_dz * yc) * inv_z2 - 2.0f * (d10 * xc + d11 * yc) * inv_z3);
+    const float c_xc = vs_u0 * djs00_dxc + vs_u1 * djs01_dxc + vs_u2 * djs02_dxc + vs_v0 * djs10_dxc + vs_v1 * djs11_dxc + vs_v2 * djs12_dxc;
+    const float c_yc = vs_u0 * djs00_dyc + vs_u1 * djs01_dyc + vs_u2 * djs02_dyc + vs_v0 * djs10_dyc + vs_v1 * djs11_dyc + vs_v2 * djs12_dyc;
+    const float c_z = vs_u0 * djs00_dz + vs_u1 * djs01_dz + vs_u2 * djs02_dz + vs_v0 * djs10_dz + vs_v1 * djs11_dz + vs_v2 * djs12_dz;
+    if (in_x) v_mx += c_xc;
+    if (in_y) v_my += c_yc;
+    v_mz += c_z;
+    if (!in_x) v_mz += mx_rz * c_xc;
+    if (!in_y) v_mz += my_rz * c_yc;
+    return {v_mx, v_my, v_mz};
+}
+
+// ---- camera_model/thin_prism_fisheye.rs ---------------------------------------------------
+// dist = k1..k4 (kb4) p1 p2 sx1 sy1.  :34-58
+struct TpPolys { float nu, nv, dnu_dx, dnu_dy, dnv_dx, dnv_dy; };
+inline TpPolys thin_prism_polys(float x, float y, const float* dd) {
+    const float p1 = dd[4], p2 = dd[5], sx1 = dd[6], sy1 = dd[7];
+    const float x2 = x * x, y2 = y * y, xy = x * y;
+    const float r2 = x2 + y2;
+    TpPolys t;
+    t.nu = 2.0f * p1 * xy + p2 * (3.0f * x2 + y2) + sx1 * r2;
+    t.nv = 2.0f * p2 * xy + p1 * (x2 + 3.0f * y2) + sy1 * r2;
+    t.dnu_dx = 2.0f * (p1 * y + (3.0f * p2 + sx1) * x);
+    t.dnu_dy = 2.0f * (p1 * x + (p2 + sx1) * y);
+    t.dnv_dx = 2.0f * (p2 * y + (p1 + sy1) * x);
+    t.dnv_dy = 2.0f * (p2 * x + (3.0f * p1 + sy1) * y);
+    return t;
+}
+// :60-78
+inline void project_tpf(Vec3A point, const Uniforms& u, const float* dd, float& ou, float& ov) {
+    float u_kb4, v_kb4;
+    project_kb4(point, u, dd, u_kb4, v_kb4);
+    const float inv_z = 1.0f / point.z;
+    const float inv_z2 = inv_z * inv_z;
+    const TpPolys t = thin_prism_polys(point.x, point.y, dd);
+    ou = u_kb4 + u.fx * t.nu * inv_z2;
+    ov = v_kb4 + u.fy * t.nv * inv_z2;
+}
+// :80-112
+inline Mat2x3 jacobian_tpf(Vec3A point, const Uniforms& u, const float* dd) {
+    const Mat2x3 kj = jacobian_kb4(point, u, dd);
+    const float fx = u.fx, fy = u.fy;
+    const float inv_z = 1.0f / point.z;
+    const float inv_z2 = inv_z * inv_z;
+    const float inv_z3 = inv_z2 * inv_z;
+    const TpPolys t = thin_prism_polys(point.x, point.y, dd);
+    const float add_du_dx = fx * t.dnu_dx * inv_z2;
+    const float add_du_dy = fx * t.dnu_dy * inv_z2;
+    const float add_du_dz = -2.0f * fx * t.nu * inv_z3;
+    const float add_dv_dx = fy * t.dnv_dx * inv_z2;
+    const float add_dv_dy = fy * t.dnv_dy * inv_z2;
+    const float add_dv_dz = -2.0f * fy * t.nv * inv_z3;
+    Mat2x3 j;
+    j.c0 = {kj.c0.x + add_du_dx, kj.c0.y + add_dv_dx};
+    j.c1 = {kj.c1.x + add_du_dy, kj.c1.y + add_dv_dy};
+    j.c2 = {kj.c2.x + add_du_dz, kj.c2.y + add_dv_dz};
+    return j;
+}
+// :114-203
+inline Vec3A projection_vjp_tpf(const Mat2x3& jac, Vec3A mean_c, Sym3 cov_c, const Uniforms& u, Sym2 v_cov2d, Vec2 v_mean2d,
+                                const float* dd) {
+    const Vec3A kb4_grad = projection_vjp_kb4(jac, mean_c, cov_c, u, v_cov2d, v_mean2d, dd);
+    const float fx = u.fx, fy = u.fy;
+    const float p1 = dd[4], p2 = dd[5], sx1 = dd[6], sy1 = dd[7];
+    const float mx = mean_c.x, my = mean_c.y, mz = mean_c.z;
+    const float inv_z = 1.0f / mz;
+    const float inv_z2 = inv_z * inv_z;
+    const float inv_z3 = inv_z2 * inv_z;
+    const float inv_z4 = inv_z2 * inv_z2;
+    const TpPolys t = thin_prism_polys(mx, my, dd);
+    const float d2nu_dxx = 6.0f * p2 + 2.0f * sx1;
+    const float d2nu_dyy = 2.0f * p2 + 2.0f * sx1;
+    const float d2nu_dxy = 2.0f * p1;
+    const float d2nv_dxx = 2.0f * p1 + 2.0f * sy1;
+    const float d2nv_dyy = 6.0f * p1 + 2.0f * sy1;
+    const float d2nv_dxy = 2.0f * p2;
+    const float h_u_00 = d2nu_dxx * inv_z2;
+    const float h_u_01 = d2nu_dxy * inv_z2;
+    const float h_u_11 = d2nu_dyy * inv_z2;
+    const float h_u_02 = -2.0f * t.dnu_dx * inv_z3;
+    const float h_u_12 = -2.0f * t.dnu_dy * inv_z3;
+    const float h_u_22 = 6.0f * t.nu * inv_z4;
+    const float h_v_00 = d2nv_dxx * inv_z2;
+    const float h_v_01 = d2nv_dxy * inv_z2;
+    const float h_v_11 = d2nv_dyy * inv_z2;
+    const float h_v_02 = -2.0f * t.dnv_dx * inv_z3;
+    const float h_v_12 = -2.0f * t.dnv_dy * inv_z3;
+    const float h_v_22 = 6.0f * t.nv * inv_z4;
+    const Mat2x3 tmp = sym2_mul_mat2x3(v_cov2d, jac);
+    const float vj_u0 = 2.0f * dot(row0(tmp), s3row0(cov_c));
+    const float vj_u1 = 2.0f * dot(row0(tmp), s3row1(cov_c));
+    const float vj_u2 = 2.0f * dot(row0(tmp), s3row2(cov_c));
+    const float vj_v0 = 2.0f * dot(row1(tmp), s3row0(cov_c));
+    const float vj_v1 = 2.0f * dot(row1(tmp), s3row1(cov_c));
+    const float vj_v2 = 2.0f * dot(row1(tmp), s3row2(cov_c));
+    const float v_mx = fx * (vj_u0 * h_u_00 + vj_u1 * h_u_01 + vj_u2 * h_u_02) + fy * (vj_v0 * h_v_00 + vj_v1 * h_v_01 + vj_v2 * h_v_02);
+    const float v_my = fx * (vj_u0 * h_u_01 + vj_u1 * h_u_11 + vj_u2 * h_u_12) + fy * (vj_v0 * h_v_01 + vj_v1 * h_v_11 + vj_v2 * h_v_12);
+    const float v_mz = fx * (vj_u0 * h_u_02 + vj_u1 * h_u_12 + vj_u2 * h_u_22) + fy * (vj_v0 * h_v_02 + vj_v1 * h_v_12 + vj_v2 * h_v_22);
+    return {kb4_grad.x + v_mx, kb4_grad.y + v_my, kb4_grad.z + v_mz};
+}
+
+// ---- camera_model/mod.rs:49-125 dispatch ----------------------------------------------------
+inline void project_model(Vec3A p, const Uniforms& u, float& ox, float& oy) {
+    switch (u.model) {
+        case BO_CAM_KB4: project_kb4(p, u, u.dist, ox, oy); break;
+        case BO_CAM_RT8: project_rt8(p, u, u.dist, ox, oy); break;
+        case BO_CAM_TPF: project_tpf(p, u, u.dist, ox, oy); break;
+        default: project_pinhole(p, u, ox, oy);
+    }
+}
+inline Mat2x3 jacobian_model(Vec3A p, const Uniforms& u) {
+    switch (u.model) {
+        case BO_CAM_KB4: return jacobian_kb4(p, u, u.dist);
+        case BO_CAM_RT8: return jacobian_rt8(p, u, u.dist);
+        case BO_CAM_TPF: return jacobian_tpf(p, u, u.dist);
+        default: return jacobian_pinhole(p, u);
+    }
+}
+
 // helpers.rs:145-175
 inline Sym2 calc_cov2d(Vec3A scl, Quat quat, Vec3A mean_c, const Uniforms& u) {
     const Mat3 ns = mul_diag(mul_mat3(u.view_rot, quat_to_mat3(quat)), scl);
-    const Mat2x3 jac = jacobian_pinhole(mean_c, u);
+    const Mat2x3 jac = jacobian_model(mean_c, u);
     const Mat2x3 v = mul_mat3(jac, ns);
     const Sym2 raw = gram_matrix(v);
     const float lim = 1.0e18f;
@@ -737,7 +1351,13 @@ inline bool project_forward_one(const float* tr, float raw_opac, const Uniforms&
                                 float& depth, uint32_t& tiles_hit, float& radius) {
     const Vec3A mean_c = world_to_cam(v3(tr[0], tr[1], tr[2]), u);
     if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) return false;
-    if (mean_c.z < 0.01f) return false;
+    if (u.model == BO_CAM_PINHOLE) {  // project_forward.rs:47-61
+        if (mean_c.z < 0.01f) return false;
+    } else {
+        const float r = sqrtf(mean_c.x * mean_c.x + mean_c.y * mean_c.y);
+        const float theta = bo_atan2f_impl(r, mean_c.z);
+        if (theta > u.half_max_render_fov) return false;
+    }
     const Vec3A scl = v3(bo_expf_impl(tr[7]), bo_expf_impl(tr[8]), bo_expf_impl(tr[9]));  // helpers.rs:329-335
     if (!finite3(scl)) return false;
     const Quat qu = {tr[3], tr[4], tr[5], tr[6]};
@@ -751,7 +1371,7 @@ inline bool project_forward_one(const float* tr, float raw_opac, const Uniforms&
     const float opac = sigmoid(raw_opac) * filter_comp;
     if (!sym2_finite(cov)) return false;
     float mx, my;
-    project_pinhole(mean_c, u, mx, my);
+    project_model(mean_c, u, mx, my);
     if (!(opac >= 1.0f / 255.0f)) return false;
     const float pt = bo_logf_impl(opac * 255.0f);
     const Sym2 conic = sym2_inverse(cov);
@@ -781,7 +1401,7 @@ inline void project_visible_one(const float* tr, const float* coeffs, float raw_
     const float opac = sigmoid(raw_opac) * filter_comp;
     const Sym2 conic = sym2_inverse(cov);
     float mx, my;
-    project_pinhole(mean_c, u, mx, my);
+    project_model(mean_c, u, mx, my);
     const Vec3A v = normalize(sub(mean, u.cam_pos));
     const Vec3A raw = sh_coeffs_to_color(coeffs, sh_degree, v);
     const float cr = raw.x + 0.5f, cg = raw.y + 0.5f, cb = raw.z + 0.5f;
@@ -1221,8 +1841,15 @@ void project_backward(Render& R, const float* transforms, const float* sh, const
         const Sym2 v_cov2d = inverse2x2_vjp(conic_inv, v_inv);
         const Sym3 covar = outer_product_self(m);
         const Sym3 cov_c = congruence(covar, u.view_rot);
-        const Mat2x3 jac = jacobian_pinhole(mean_c, u);
-        const Vec3A v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, Vec2{rg[0], rg[1]});
+        const Mat2x3 jac = jacobian_model(mean_c, u);
+        const Vec2 v_xy = {rg[0], rg[1]};
+        Vec3A v_mean_c;  // camera_model/mod.rs:86-125
+        switch (u.model) {
+            case BO_CAM_KB4: v_mean_c = projection_vjp_kb4(jac, mean_c, cov_c, u, v_cov2d, v_xy, u.dist); break;
+            case BO_CAM_RT8: v_mean_c = projection_vjp_rt8(mean_c, cov_c, u, v_cov2d, v_xy, u.dist); break;
+            case BO_CAM_TPF: v_mean_c = projection_vjp_tpf(jac, mean_c, cov_c, u, v_cov2d, v_xy, u.dist); break;
+            default: v_mean_c = projection_vjp_pinhole(jac, mean_c, cov_c, u, v_cov2d, v_xy);
+        }
         const Sym3 vcc = transpose_congruence_sym2(jac, v_cov2d);
         const Vec3A v_mean = add(transpose_mul_vec3(u.view_rot, v_mean_c), v_mean_from_sh);
         const Mat3 v_m = sym3_mul_mat3(sym3_scale(transpose_congruence(vcc, u.view_rot), 2.0f), m);

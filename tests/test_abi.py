@@ -46,6 +46,37 @@ def test_camera_setup_matches_oracle_host_math():
                 assert va == vb, f
 
 
+def test_camera_setup_model_and_fov_laws_match_oracle_host_math():
+    """bh_camera_setup_model / bh_fov_to_focal / bh_focal_to_fov (product host code) vs the oracle's
+    restatement of camera.rs:85-254 for every camera model; plus the reference's own round trips
+    (crates/brush-render/src/tests/mod.rs:711-790) on the product functions."""
+    import brush_amd as ba
+    from oracle import bo
+    import util
+    for lens, (model, dist) in util.REF_LENSES.items():
+        p = dict(pos=(0.3, -0.2, 1.5), rot_xyzw=util.quat_from_axis_angle((0.3, -1.0, 0.2), 1.1), fov_x=1.1, fov_y=0.7,
+                 center_uv=(0.45, 0.55), model=model, dist=dist)
+        a = util.hip_camera(ba, p).uniforms((640, 360))
+        b = bo.camera(img_w=640, img_h=360, **p)
+        assert a.model == b.model != 0
+        for f, _ in b._fields_:
+            va, vb = getattr(a, f), getattr(b, f)
+            assert (list(va) == list(vb)) if hasattr(va, "__len__") else (va == vb), (lens, f)
+        for fov in (0.3, 1.0, 2.0):
+            assert ba.fov_to_focal(fov, 1024, model, dist) == bo.fov_to_focal(fov, 1024, model, dist)
+        for focal in (200.0, 900.0):
+            assert ba.focal_to_fov(focal, 1920, model, dist) == bo.focal_to_fov(focal, 1920, model, dist)
+    assert abs(ba.fov_to_focal(ba.focal_to_fov(800.0, 1920), 1920) - 800.0) < 1e-9
+    z4 = (0.0, 0.0, 0.0, 0.0)
+    assert abs(ba.focal_to_fov(300.0, 1024, "kb4", z4) - 1024 / 300.0) < 1e-9
+    k = (-0.01, 0.003, -0.0005, 0.00002)
+    assert abs(ba.fov_to_focal(ba.focal_to_fov(280.0, 1024, "kb4", k), 1024, "kb4", k) - 280.0) < 1e-6
+    r = (-0.2, 0.05, -0.001, 0.0, 0.0, 0.0, 0.0, 0.0)
+    assert abs(ba.fov_to_focal(ba.focal_to_fov(900.0, 1920, "rt8", r), 1920, "rt8", r) - 900.0) < 1e-6
+    t = k + (1e-3, -2e-3, 5e-4, -5e-4)
+    assert abs(ba.fov_to_focal(ba.focal_to_fov(280.0, 1024, "tpf", t), 1024, "tpf", t) - 280.0) < 1e-6
+
+
 def test_null_and_bad_arguments_return_errors_not_crashes():
     """apps/brush-c/tests/integration.rs:120-183 convention: bad args -> error code."""
     import ctypes as C
@@ -56,6 +87,7 @@ def test_null_and_bad_arguments_return_errors_not_crashes():
     pos = (C.c_float * 3)(0, 0, 0)
     rot = (C.c_float * 4)(0, 0, 0, 1)
     assert lib.bh_camera_setup(pos, rot, 1.0, 1.0, 0.5, 0.5, 0, 10, C.byref(cam)) < 0
+    assert lib.bh_camera_setup_model(pos, rot, 1.0, 1.0, 0.5, 0.5, 10, 10, 7, None, C.byref(cam)) < 0  # unknown model
     assert lib.bh_sync(None) < 0
     assert lib.bh_render_forward(None, None, 0, 0, None, None, None, None, 0, None) < 0
     assert lib.bh_last_error(None) == b"null context"
