@@ -71,6 +71,7 @@ class BhTrainState(C.Structure):
         ("m1_opac", C.c_void_p), ("m2_opac", C.c_void_p),
         ("refine_weight_norm", C.c_void_p), ("vis_weight", C.c_void_p), ("max_screen_size", C.c_void_p),
         ("step_count", C.c_uint32),
+        ("min_scale", C.c_void_p),
     ]
 
 
@@ -128,6 +129,9 @@ SYMBOLS = {
     "bh_refine_plan_flags": (C.c_void_p, [C.c_void_p, C.c_int]),
     "bh_refine_apply": (C.c_int, [C.c_void_p, C.POINTER(BhRefineConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainState)]),
     "bh_splat_bounds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bh_fold_min_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bh_fold_min_scale_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bh_compute_min_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, fp, C.c_uint32, C.c_float, C.c_void_p]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
     "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),

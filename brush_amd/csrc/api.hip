@@ -611,6 +611,35 @@ int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, f
     return launch_gather_stats(ctx, refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, n);
 }
 
+// ---- Mip-Splatting 3D filter ---------------------------------------------------------
+int bh_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw_opacities, const float* min_scale, uint32_t n,
+                      float* out_transforms, float* out_raw_opacities) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (n > 0 && (!transforms || !raw_opacities || !min_scale || !out_transforms || !out_raw_opacities))
+        return set_error(ctx, BH_ERR_INVALID_ARG, "fold_min_scale: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_fold_min_scale(ctx, transforms, raw_opacities, min_scale, n, out_transforms, out_raw_opacities);
+}
+
+int bh_fold_min_scale_backward(bh_ctx* ctx, const float* transforms, const float* raw_opacities, const float* min_scale, uint32_t n,
+                               float* v_transforms, float* v_raw_opacities) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (n > 0 && (!transforms || !raw_opacities || !min_scale || !v_transforms || !v_raw_opacities))
+        return set_error(ctx, BH_ERR_INVALID_ARG, "fold_min_scale_backward: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_fold_min_scale_backward(ctx, transforms, raw_opacities, min_scale, n, v_transforms, v_raw_opacities);
+}
+
+int bh_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const float* view_cams, uint32_t num_views, float factor,
+                         float* out) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    // train.rs:107-109: disabled (factor <= 0) or no cameras -> there is no floor; the caller keeps min_scale = NULL
+    if (!(factor > 0.0f) || num_views == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "compute_min_scale: needs factor > 0 and at least one view camera");
+    if (!view_cams || (n > 0 && (!transforms || !out))) return set_error(ctx, BH_ERR_INVALID_ARG, "compute_min_scale: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_compute_min_scale(ctx, transforms, n, view_cams, num_views, factor, out);
+}
+
 }  // extern "C"
 
 // ---- training step -------------------------------------------------------------
@@ -639,12 +668,25 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* grads = exch + n;
     float* s_refine = grads + grad_count;
 
+    // ---- Mip-Splatting 3D filter: render fold_min_scale(params) (bwd/burn_glue.rs:260-270)
+    const float* r_transforms = st->transforms;
+    const float* r_raw_opac = st->raw_opacities;
+    if (st->min_scale && n > 0) {
+        ProfScope ps(ctx, "FoldMinScale");
+        auto* ft = (float*)ensure(ctx, SLOT_FOLDED_TRANSFORMS, (size_t)n * 10 * 4);
+        auto* fo = (float*)ensure(ctx, SLOT_FOLDED_RAW_OPAC, (size_t)n * 4);
+        if (!ft || !fo) return BH_ERR_OOM;
+        BH_TRY(launch_fold_min_scale(ctx, st->transforms, st->raw_opacities, st->min_scale, n, ft, fo));
+        r_transforms = ft;
+        r_raw_opac = fo;
+    }
+
     // ---- forward (train.rs:211-215); `visible` lands directly in the exchange buffer
     BhRenderOut ro;
     const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
     ctx->ext_visible = s_visible;
     ctx->ext_max_radius = s_radius;
-    const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, st->transforms, st->sh_coeffs, st->raw_opacities,
+    const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
     ctx->ext_visible = nullptr;
     ctx->ext_max_radius = nullptr;
@@ -681,7 +723,11 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* g_tr = grads;
     float* g_sh = grads + (size_t)n * 10;
     float* g_op = g_sh + (size_t)n * 3 * C;
-    BH_TRY(bh_render_backward(ctx, v_output, st->transforms, st->sh_coeffs, st->raw_opacities, g_tr, g_sh, g_op, s_refine));
+    BH_TRY(bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine));
+    if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
+        ProfScope ps(ctx, "FoldMinScaleBackward");
+        BH_TRY(launch_fold_min_scale_backward(ctx, st->transforms, st->raw_opacities, st->min_scale, n, g_tr, g_op));
+    }
     // ---- multi-GPU exchange (not in the reference: SURVEY.md §8e) — one SUM over the leading floats
     const bool tile_mode = batch->image_hook != nullptr;
     if (hook) {
@@ -706,7 +752,15 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     // ---- visibility-gated noise on the means (train.rs:389-416)
     if (batch->noise_samples && cfg->mean_noise_weight > 0.0f) {
         ProfScope ps(ctx, "MeanNoise");
-        BH_TRY(launch_mean_noise(ctx, st->transforms, st->raw_opacities, s_visible, batch->noise_samples, n,
+        // the gate reads splats.opacities() of the UPDATED parameters (train.rs:389), i.e. through the fold when a floor is set
+        const float* gate_opac = st->raw_opacities;
+        if (st->min_scale && n > 0) {
+            auto* ft = (float*)ctx->slots[SLOT_FOLDED_TRANSFORMS].ptr;
+            auto* fo = (float*)ctx->slots[SLOT_FOLDED_RAW_OPAC].ptr;
+            BH_TRY(launch_fold_min_scale(ctx, st->transforms, st->raw_opacities, st->min_scale, n, ft, fo));
+            gate_opac = fo;
+        }
+        BH_TRY(launch_mean_noise(ctx, st->transforms, gate_opac, s_visible, batch->noise_samples, n,
                                  (float)lr_mean * cfg->mean_noise_weight, cfg->median_scene_scale));
     }
     stats->num_visible = ro.num_visible;

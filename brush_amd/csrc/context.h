@@ -49,6 +49,8 @@ enum Slot : int {
     SLOT_MISC,
     SLOT_REFINE,             // refine plan: control block + 10 x [N] u32
     SLOT_REFINE_BOUNDS,      // percentile bounds: keys / sorted keys / indices
+    SLOT_FOLDED_TRANSFORMS,  // train step with a 3D-filter floor: folded [N,10] / [N]
+    SLOT_FOLDED_RAW_OPAC,
     SLOT_COUNT
 };
 
@@ -178,5 +180,12 @@ int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weigh
                         const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
 int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible,
                       const float* samples, uint64_t n, float noise_scale, float clamp_abs);
+
+// filter3d.hip — Mip-Splatting 3D filter (scale floor): fold, its VJP, the floor itself
+int launch_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw_opac, const float* min_scale, uint32_t n,
+                          float* out_transforms, float* out_raw_opac);
+int launch_fold_min_scale_backward(bh_ctx* ctx, const float* transforms, const float* raw_opac, const float* min_scale, uint32_t n,
+                                   float* v_transforms, float* v_raw_opac);
+int launch_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const float* view_cams, uint32_t k, float factor, float* out);
 
 }  // namespace bh

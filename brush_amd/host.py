@@ -189,8 +189,10 @@ class Splats:
     """transforms [N,10] = means(3) quat wxyz(4) log-scales(3); sh_coeffs [N,C,3];
     raw_opacities [N] (logits)."""
 
-    def __init__(self, transforms, sh_coeffs, raw_opacities, render_mip=False, device=None):
+    def __init__(self, transforms, sh_coeffs, raw_opacities, render_mip=False, device=None, min_scale=None):
         device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # Splats::min_scale (gaussian_splats.rs:69-73): optional frozen per-splat world-space scale floor [N]
+        self.min_scale = None if min_scale is None else _f32c(min_scale, device).reshape(-1)
         self.transforms = _f32c(transforms, device).reshape(-1, 10)
         n = self.transforms.shape[0]
         self.sh_coeffs = _f32c(sh_coeffs, device).reshape(n, -1, 3) if n else _f32c(sh_coeffs, device).reshape(0, 1, 3)
@@ -220,7 +222,45 @@ class Splats:
         return self.transforms.device
 
     def clone(self):
-        return Splats(self.transforms.clone(), self.sh_coeffs.clone(), self.raw_opacities.clone(), self.render_mip, self.device)
+        return Splats(self.transforms.clone(), self.sh_coeffs.clone(), self.raw_opacities.clone(), self.render_mip, self.device,
+                      None if self.min_scale is None else self.min_scale.clone())
+
+    # ---- Mip-Splatting 3D filter (gaussian_splats.rs:188-256) ----
+    def with_min_scale(self, f):
+        """Attach a per-splat world-space scale floor [N] (Splats::with_min_scale)."""
+        f = _f32c(f, self.device).reshape(-1)
+        if f.numel() != self.num_splats():
+            raise ValueError("min_scale must have one entry per splat")
+        self.min_scale = f
+        return self
+
+    def folded(self, ctx=None):
+        """(transforms, raw_opacities) the renderer sees: fold_min_scale(params) when a floor is set
+        (gaussian_splats.rs:379-386), the raw parameters otherwise."""
+        if self.min_scale is None:
+            return self.transforms, self.raw_opacities
+        ctx = ctx or get_context(self.device)
+        ft, fo = torch.empty_like(self.transforms), torch.empty_like(self.raw_opacities)
+        ctx.check(ctx.lib.bh_fold_min_scale(ctx._h, _ptr(self.transforms), _ptr(self.raw_opacities), _ptr(self.min_scale), self.num_splats(),
+                                            _ptr(ft), _ptr(fo)))
+        return ft, fo
+
+    def opacities(self, ctx=None):
+        """Post-activation opacity incl. the floor's energy compensation (Splats::opacities)."""
+        return torch.sigmoid(self.folded(ctx)[1])
+
+    def scales(self, ctx=None):
+        """World-space scales sqrt(s^2 + f^2) (Splats::scales)."""
+        return torch.exp(self.folded(ctx)[0][:, 7:10])
+
+    def bake_min_scale(self, ctx=None):
+        """Permanently fold the floor into the raw parameters and clear it (Splats::bake_min_scale): in place."""
+        if self.min_scale is not None:
+            ctx = ctx or get_context(self.device)
+            ctx.check(ctx.lib.bh_fold_min_scale(ctx._h, _ptr(self.transforms), _ptr(self.raw_opacities), _ptr(self.min_scale), self.num_splats(),
+                                                _ptr(self.transforms), _ptr(self.raw_opacities)))
+            self.min_scale = None
+        return self
 
 
 @dataclass
@@ -259,9 +299,10 @@ def _forward(ctx, splats, camera, img_size, background, pass_):
     out = _ffi.BhRenderOut()
     bg = (C.c_float * 3)(*[float(b) for b in background])
     n = splats.num_splats()
-    ctx.check(ctx.lib.bh_render_forward(ctx._h, C.byref(cam), n, splats.sh_degree(), _ptr(splats.transforms), _ptr(splats.sh_coeffs),
-                                        _ptr(splats.raw_opacities), bg, flags, C.byref(out)))
-    return cam, out
+    r_t, r_o = splats.folded(ctx)  # gaussian_splats.rs:379-386: the 3D-filter floor is part of the splat
+    ctx.check(ctx.lib.bh_render_forward(ctx._h, C.byref(cam), n, splats.sh_degree(), _ptr(r_t), _ptr(splats.sh_coeffs),
+                                        _ptr(r_o), bg, flags, C.byref(out)))
+    return cam, out, (r_t, r_o)
 
 
 def _aux_from(out, n, w, h, device, copy):
@@ -296,7 +337,7 @@ def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), 
     w, h = int(img_size[0]), int(img_size[1])
     if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
         camera = camera.uniforms((w, h), tile_rows)
-    _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
+    _, out, _ = _forward(ctx, splats, camera, (w, h), background, pass_)
     if pass_.bwd_info():
         img = _view(out.out_img, (h, w, 4), torch.float32, splats.device)
     else:
@@ -317,7 +358,7 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     dev = splats.device
     if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
         camera = camera.uniforms((w, h), tile_rows)
-    _, out = _forward(ctx, splats, camera, (w, h), background, pass_)
+    _, out, (r_t, r_o) = _forward(ctx, splats, camera, (w, h), background, pass_)
     img = _view(out.out_img, (h, w, 4), torch.float32, dev).clone()
     aux = _aux_from(out, splats.num_splats(), w, h, dev, True)
     if callable(v_output):
@@ -328,8 +369,11 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     v_sh = torch.empty((n, c, 3), dtype=torch.float32, device=dev)
     v_op = torch.empty((n,), dtype=torch.float32, device=dev)
     v_rf = torch.empty((n,), dtype=torch.float32, device=dev)
-    ctx.check(ctx.lib.bh_render_backward(ctx._h, _ptr(v_output), _ptr(splats.transforms), _ptr(splats.sh_coeffs), _ptr(splats.raw_opacities),
+    ctx.check(ctx.lib.bh_render_backward(ctx._h, _ptr(v_output), _ptr(r_t), _ptr(splats.sh_coeffs), _ptr(r_o),
                                          _ptr(v_t), _ptr(v_sh), _ptr(v_op), _ptr(v_rf)))
+    if splats.min_scale is not None:  # chain through the fold (the autodiff of bwd/burn_glue.rs:260-270)
+        ctx.check(ctx.lib.bh_fold_min_scale_backward(ctx._h, _ptr(splats.transforms), _ptr(splats.raw_opacities), _ptr(splats.min_scale), n,
+                                                     _ptr(v_t), _ptr(v_op)))
     vc = _view(ctx.lib.bh_last_v_combined(ctx._h), (max(out.num_visible, 1), 10), torch.float32, dev).clone()
     return dict(img=img, aux=aux, v_transforms=v_t, v_sh_coeffs=v_sh, v_raw_opacities=v_op, v_refine_weight=v_rf, v_combined=vc)
 
@@ -548,6 +592,28 @@ class SplatTrainer:
         self.pg = process_group
         self._hook = None
         self.generator = None
+        self.view_cams = []  # [(centre xyz, focal px)] of the train views: enables the Mip-Splatting 3D filter
+
+    MIN_SCALE_FACTOR = 0.1       # train.rs:44
+    MIN_SCALE_FREEZE_FRAC = 0.9  # train.rs:37
+
+    def set_view_cams(self, view_cams):
+        """SplatTrainer::set_view_cams (train.rs:170-174): per train view (world centre (x,y,z), focal in px at
+        native resolution).  Empty disables the 3D filter."""
+        self.view_cams = [(tuple(float(v) for v in c), float(f)) for c, f in view_cams]
+
+    def compute_min_scale(self, splats, ctx=None):
+        """compute_min_scale (train.rs:102-125) -> [N] tensor, or None when there are no view cameras."""
+        if not self.view_cams or self.MIN_SCALE_FACTOR <= 0.0:
+            return None
+        ctx = ctx or self.ctx or get_context(splats.device)
+        k = len(self.view_cams)
+        vc = (C.c_float * (4 * k))()
+        for i, (c, f) in enumerate(self.view_cams):
+            vc[4 * i], vc[4 * i + 1], vc[4 * i + 2], vc[4 * i + 3] = c[0], c[1], c[2], f
+        out = torch.empty(splats.num_splats(), dtype=torch.float32, device=splats.device)
+        ctx.check(ctx.lib.bh_compute_min_scale(ctx._h, _ptr(splats.transforms), splats.num_splats(), vc, k, float(self.MIN_SCALE_FACTOR), _ptr(out)))
+        return out
 
     def _init_state(self, splats: Splats):
         dev = splats.device
@@ -616,6 +682,7 @@ class SplatTrainer:
         st.m1_opac, st.m2_opac = s["m1_o"].data_ptr(), s["m2_o"].data_ptr()
         st.refine_weight_norm, st.vis_weight, st.max_screen_size = s["refine_weight_norm"].data_ptr(), s["vis_weight"].data_ptr(), s["max_screen_size"].data_ptr()
         st.step_count = self.step_count
+        st.min_scale = splats.min_scale.data_ptr() if splats.min_scale is not None else None
         h, w = batch.img_size()
         b = _ffi.BhTrainBatch()
         b.camera = batch.camera if isinstance(batch.camera, _ffi.BhCamera) else batch.camera.uniforms((w, h))
@@ -685,6 +752,7 @@ class SplatTrainer:
         dev = splats.device
         if self.state is None:
             raise BrushHipError("Can only refine if refine stats are initialized")  # train.rs:445
+        splats.bake_min_scale(ctx)  # train.rs:433-437: refine manipulates the canonical (un-floored) params
         self.sync_refine_stats()
         if self.bounds is None:
             self.set_bounds(*splat_bounds(splats, ctx=ctx))
@@ -713,6 +781,11 @@ class SplatTrainer:
         ctx.check(ctx.lib.bh_refine_apply(ctx._h, C.byref(cfg), C.byref(st_in), C.byref(st_out)))
         self.state = ns
         self.set_bounds(*splat_bounds(new, ctx=ctx))  # train.rs:634
+        # train.rs:636-648: recompute the 3D-filter floor for the new positions / count unless frozen
+        if float(iter) / float(max(int(c.total_train_iters), 1)) < self.MIN_SCALE_FREEZE_FRAC:
+            f = self.compute_min_scale(new, ctx)
+            if f is not None:
+                new.with_min_scale(f)
         stats = RefineStats(rs.num_added, rs.num_split_oversized, rs.num_split_high_grad, rs.num_pruned, rs.num_pruned_non_finite,
                             rs.total_splats, rs.num_resampled)
         return new, stats

@@ -17,6 +17,8 @@
  *   bh_adam_step        <- AdamScaled::step                   brush-train/src/adam_scaled.rs:75-147
  *   bh_gather_stats     <- RefineRecord::gather_stats         brush-train/src/stats.rs:40-50
  *   bh_train_step       <- SplatTrainer::step                 brush-train/src/train.rs:176-429
+ *   bh_fold_min_scale[_backward] <- fold_min_scale (+ its autodiff)  brush-render/src/gaussian_splats.rs:86-111
+ *   bh_compute_min_scale <- compute_min_scale                brush-train/src/train.rs:102-125
  *   bh_camera_setup[_model] <- Camera::{build_pinhole_params, world_to_local}, fov_to_focal,
  *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-254
  *                          (+ kernels/camera_model/{pinhole,kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs: pinhole, Kannala-Brandt 4, radial-tangential 8,
@@ -199,6 +201,24 @@ int bh_adam_step(bh_ctx* ctx, float* param, const float* grad, float* m1, float*
 int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
                     const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
 
+/* ---- Mip-Splatting 3D filter (world-space scale floor) ------------------------ */
+/* fold_min_scale (brush-render/src/gaussian_splats.rs:86-111): scales -> sqrt(s^2 + f^2), opacity
+ * energy-compensated by sqrt(det1/det2) (clamped to [1e-6, 1-1e-6], returned as a logit).  The
+ * reference applies it in front of every render of a Splats with a floor (gaussian_splats.rs:379-386,
+ * bwd/burn_glue.rs:260-270) and to bake the floor into the parameters (Splats::bake_min_scale,
+ * gaussian_splats.rs:245-256: pass out == in).  transforms [N,10], raw_opac [N], min_scale [N]. */
+int bh_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw_opacities, const float* min_scale, uint32_t n,
+                      float* out_transforms, float* out_raw_opacities);
+/* Its VJP w.r.t. the learned log-scales / raw opacity (min_scale is a constant) — what burn's autodiff
+ * derives for the fold.  In place: v_transforms [N,10] and v_raw_opacities [N] hold the gradients w.r.t.
+ * the FOLDED tensors on entry and w.r.t. the raw parameters on return (columns 0..6 pass through). */
+int bh_fold_min_scale_backward(bh_ctx* ctx, const float* transforms, const float* raw_opacities, const float* min_scale, uint32_t n,
+                               float* v_transforms, float* v_raw_opacities);
+/* compute_min_scale (brush-train/src/train.rs:102-125): out[i] = sqrt(factor) * min_v |mean_i - centre_v| / max(focal_v, 1e-6).
+ * view_cams: host [num_views,4] = camera centre xyz + focal length in pixels at native resolution. */
+int bh_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const float* view_cams /*host*/, uint32_t num_views,
+                         float factor, float* out /*[N]*/);
+
 /* ---- training step ---------------------------------------------------------- */
 /* TrainConfig subset that defines step() (brush-train/src/config.rs:7-132). */
 typedef struct BhTrainConfig {
@@ -229,6 +249,11 @@ typedef struct BhTrainState {
     float* m1_opac; float* m2_opac;             /* [N] each */
     float* refine_weight_norm; float* vis_weight; float* max_screen_size; /* [N] each */
     uint32_t step_count; /* number of steps already taken (host; incremented by the call) */
+    /* Splats::min_scale (gaussian_splats.rs:69-73): optional frozen per-splat world-space scale floor [N]
+     * (Mip-Splatting 3D filter), NULL = none.  bh_train_step renders fold_min_scale(params) and chains the
+     * gradients back to the raw parameters; refine bakes it (train.rs:437) and the caller recomputes it
+     * with bh_compute_min_scale afterwards (train.rs:636-648). */
+    const float* min_scale;
 } BhTrainState;
 
 /* Image hook: called (if non-NULL) after the forward render and before the loss with the

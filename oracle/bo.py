@@ -96,6 +96,12 @@ def lib():
         L.bo_gather_stats.restype = None
         L.bo_gather_stats.argtypes = [fp, fp, fp, fp, fp, fp, C.c_uint64]
         L.bo_num_threads.restype = C.c_int
+        L.bo_fold_min_scale.restype = None
+        L.bo_fold_min_scale.argtypes = [fp, fp, fp, C.c_uint64, fp, fp]
+        L.bo_fold_min_scale_backward.restype = None
+        L.bo_fold_min_scale_backward.argtypes = [fp, fp, fp, C.c_uint64, fp, fp]
+        L.bo_compute_min_scale.restype = None
+        L.bo_compute_min_scale.argtypes = [fp, C.c_uint64, fp, C.c_uint32, C.c_float, fp]
         _lib = L
     return _lib
 
@@ -248,6 +254,31 @@ def adam_step(param, grad, m1, m2, lr, t, col_scale=None, reduce_m2=False, beta1
     g = f32(grad)
     cs = f32(col_scale) if col_scale is not None else None
     lib().bo_adam_step(_fp(param), _fp(g), _fp(m1), _fp(m2), rows, row_len, _fp(cs) if cs is not None else None, lr, t, int(reduce_m2), beta1, beta2, eps)
+
+
+def fold_min_scale(transforms, raw_opac, min_scale):
+    """gaussian_splats.rs:86-111 -> (folded transforms [N,10], folded raw opacity [N])."""
+    t, o, f = f32(transforms).reshape(-1, 10), f32(raw_opac).reshape(-1), f32(min_scale).reshape(-1)
+    ot, oo = np.empty_like(t), np.empty_like(o)
+    lib().bo_fold_min_scale(_fp(t), _fp(o), _fp(f), t.shape[0], _fp(ot), _fp(oo))
+    return ot, oo
+
+
+def fold_min_scale_backward(transforms, raw_opac, min_scale, v_folded_transforms, v_folded_raw_opac):
+    """Chain gradients w.r.t. the folded tensors back to the raw parameters -> (v_transforms, v_raw_opac)."""
+    t, o, f = f32(transforms).reshape(-1, 10), f32(raw_opac).reshape(-1), f32(min_scale).reshape(-1)
+    vt, vo = f32(v_folded_transforms).reshape(-1, 10).copy(), f32(v_folded_raw_opac).reshape(-1).copy()
+    lib().bo_fold_min_scale_backward(_fp(t), _fp(o), _fp(f), t.shape[0], _fp(vt), _fp(vo))
+    return vt, vo
+
+
+def compute_min_scale(transforms, view_cams, factor=0.1):
+    """brush-train/src/train.rs:102-125; view_cams [K,4] = centre xyz + focal px."""
+    t = f32(transforms).reshape(-1, 10)
+    vc = f32(view_cams).reshape(-1, 4)
+    out = np.empty(t.shape[0], np.float32)
+    lib().bo_compute_min_scale(_fp(t), t.shape[0], _fp(vc), vc.shape[0], float(factor), _fp(out))
+    return out
 
 
 def num_threads():

@@ -2197,6 +2197,80 @@ void bo_gather_stats(float* refine_weight_norm, float* vis_weight, float* max_sc
     }
 }
 
+// ---- Mip-Splatting 3D smoothing filter -------------------------------------------------------
+// fold_min_scale, brush-render/src/gaussian_splats.rs:86-111 (burn elementwise ops restated in
+// their order; exp / ln are the fixed polynomials, sigmoid is 1/(1+exp(-x))).  out may alias in.
+void bo_fold_min_scale(const float* transforms, const float* raw_opac, const float* f, uint64_t n, float* out_transforms,
+                       float* out_raw_opac) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* tr = transforms + i * 10;
+        float* o = out_transforms + i * 10;
+        float s2[3], s2f[3];
+        const float f2 = f[i] * f[i];
+        for (int k = 0; k < 3; ++k) {
+            s2[k] = bo_expf_impl(tr[7 + k] * 2.0f);
+            s2f[k] = s2[k] + f2;
+        }
+        for (int k = 0; k < 7; ++k) o[k] = tr[k];
+        for (int k = 0; k < 3; ++k) o[7 + k] = bo_logf_impl(s2f[k]) * 0.5f;
+        const float det1 = s2[0] * s2[1] * s2[2];
+        const float det2 = s2f[0] * s2f[1] * s2f[2];
+        const float coef = sqrtf(det1 / det2);
+        const float opac = clampf(sigmoid(raw_opac[i]) * coef, 1e-6f, 1.0f - 1e-6f);
+        out_raw_opac[i] = bo_logf_impl(opac / (-opac + 1.0f));
+    }
+}
+
+// VJP of the fold w.r.t. the learned log-scales and raw opacity (f is a constant): what burn's
+// autodiff derives from the ops above.  In place: on entry v_transforms[:,7:10] / v_raw_opac are the
+// gradients w.r.t. the FOLDED tensors, on return w.r.t. the raw parameters; other columns pass through.
+//   new_log_k = 0.5 ln(a_k + f^2), a_k = exp(2 l_k):   d new_log_k / d l_k = a_k / (a_k + f^2) =: w_k
+//   coef = sqrt(prod a_k / prod (a_k + f^2)):           d coef / d l_k = coef (1 - w_k)
+//   raw' = logit(clamp(sigmoid(raw) coef)):             d raw'/d pre = 1 / (opac (1 - opac)) inside the clamp, 0 outside
+void bo_fold_min_scale_backward(const float* transforms, const float* raw_opac, const float* f, uint64_t n, float* v_transforms,
+                                float* v_raw_opac) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* tr = transforms + i * 10;
+        float* vt = v_transforms + i * 10;
+        float s2[3], s2f[3], w[3];
+        const float f2 = f[i] * f[i];
+        for (int k = 0; k < 3; ++k) {
+            s2[k] = bo_expf_impl(tr[7 + k] * 2.0f);
+            s2f[k] = s2[k] + f2;
+            w[k] = s2[k] / s2f[k];
+        }
+        const float det1 = s2[0] * s2[1] * s2[2];
+        const float det2 = s2f[0] * s2f[1] * s2f[2];
+        const float coef = sqrtf(det1 / det2);
+        const float sg = sigmoid(raw_opac[i]);
+        const float pre = sg * coef;
+        const bool inside = pre >= 1e-6f && pre <= 1.0f - 1e-6f;
+        const float opac = clampf(pre, 1e-6f, 1.0f - 1e-6f);
+        const float v_pre = inside ? v_raw_opac[i] / (opac * (1.0f - opac)) : 0.0f;
+        v_raw_opac[i] = v_pre * coef * sg * (1.0f - sg);
+        const float v_coef_coef = v_pre * sg * coef;
+        for (int k = 0; k < 3; ++k) vt[7 + k] = vt[7 + k] * w[k] + v_coef_coef * (1.0f - w[k]);
+    }
+}
+
+// compute_min_scale, brush-train/src/train.rs:102-125: f_i = sqrt(factor) * min_v(|mean_i - c_v| / max(focal_v, 1e-6)).
+// view_cams: [k,4] = centre xyz, focal in px.
+void bo_compute_min_scale(const float* transforms, uint64_t n, const float* view_cams, uint32_t k, float factor, float* out) {
+    const float sf = sqrtf(factor);
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* m = transforms + i * 10;
+        float best = 0.0f;
+        for (uint32_t v = 0; v < k; ++v) {
+            const float* c = view_cams + (size_t)v * 4;
+            const float dx = m[0] - c[0], dy = m[1] - c[1], dz = m[2] - c[2];
+            const float dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ratio = dist / std::fmax(c[3], 1e-6f);
+            best = v == 0 ? ratio : std::fmin(best, ratio);
+        }
+        out[i] = best * sf;
+    }
+}
+
 int bo_num_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();

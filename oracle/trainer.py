@@ -15,7 +15,7 @@ class OracleTrainer:
         self.state = None
 
     def step(self, scene, cam, gt_packed, background, has_alpha=False, alpha_is_mask=False, noise=None,
-             extra_grads=None, world=1, dry_run=False):
+             extra_grads=None, world=1, dry_run=False, min_scale=None):
         bo, c = self.bo, self.cfg
         tr, sh, op = scene["transforms"], scene["sh"], scene["raw_opac"]
         n, C = tr.shape[0], sh.shape[1]
@@ -26,7 +26,9 @@ class OracleTrainer:
         self.step_count += 1
         h, w = cam.img_h, cam.img_w
         flags = bo.FLAG_BWD_INFO | (bo.FLAG_MIP if c.render_mip else 0)
-        R = bo.Render().forward(cam, tr, sh, op, bg=background, flags=flags)
+        # Mip-Splatting 3D filter: the renderer sees fold_min_scale(params) (bwd/burn_glue.rs:260-270)
+        r_tr, r_op = (tr, op) if min_scale is None else bo.fold_min_scale(tr, op, min_scale)
+        R = bo.Render().forward(cam, r_tr, sh, r_op, bg=background, flags=flags)
         img = R.image()
         ssim_on = c.ssim_weight > 0
         l1_w, ssim_w = (1.0 - c.ssim_weight, -c.ssim_weight) if ssim_on else (1.0, 0.0)
@@ -50,6 +52,9 @@ class OracleTrainer:
         g_tr = R.get("v_transforms").reshape(n, 10).copy()
         g_sh = R.get("v_coeffs").reshape(n, C * 3).copy()
         g_op = R.get("v_raw_opac").reshape(n, 1).copy()
+        if min_scale is not None:  # chain through the fold
+            g_tr, g_o1 = bo.fold_min_scale_backward(tr, op, min_scale, g_tr, g_op.reshape(n))
+            g_op = g_o1.reshape(n, 1)
         refine, vis, radius = R.get("v_refine").copy(), R.get("visible").copy(), R.get("max_radius").copy()
         if dry_run:  # this rank's raw gradients only (data-parallel tests); no state change
             self.step_count -= 1
@@ -76,7 +81,8 @@ class OracleTrainer:
         op2 = op.reshape(n, 1)
         bo.adam_step(op2, g_op, st["m1_o"], st["m2_o"], np.float32(c.lr_opac), t)
         if noise is not None and c.mean_noise_weight > 0:
-            sig = 1.0 / (1.0 + np.exp(-op.astype(np.float64)))
+            gate_op = op if min_scale is None else bo.fold_min_scale(tr, op, min_scale)[1]  # splats.opacities(), train.rs:389
+            sig = 1.0 / (1.0 + np.exp(-gate_op.astype(np.float64)))
             wgt = np.clip((1.0 - sig) ** 150, 0, 1) * np.minimum(vis, 1.0)
             wm = (wgt * (np.float32(lr_mean) * c.mean_noise_weight)).astype(np.float32)
             tr[:, :3] += np.clip(noise * wm[:, None], -self.median, self.median).astype(np.float32)
