@@ -12,6 +12,8 @@ Names and argument meaning follow the reference (paths under
     radix_argsort     brush-sort/src/lib.rs:16
     prefix_sum        brush-prefix-sum/src/lib.rs:11
     image_loss        brush-loss/src/lib.rs:1075-1104
+    splat_to_ply / load_splat_from_ply   brush-serde/src/export.rs:179-204, import.rs:166-330 (plain PLY)
+    BatchUploader / SceneLoader          brush-dataset/src/scene.rs:97-136, scene_loader.rs:59-174
     SplatTrainer      brush-train/src/train.rs:140-429 (step) and :431-893 (refine)
 
 torch is used only for device memory, streams and torch.distributed; every
@@ -21,5 +23,6 @@ from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
     render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
+    splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader,
 )
 from ._ffi import BrushHipError  # noqa: F401

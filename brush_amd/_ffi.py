@@ -101,6 +101,11 @@ class BhTrainStats(C.Structure):
     _fields_ = [("num_visible", C.c_uint32), ("num_intersections", C.c_uint32), ("lr_mean", C.c_double), ("loss", C.c_float)]
 
 
+class BhPlyInfo(C.Structure):
+    _fields_ = [("num_splats", C.c_uint64), ("sh_degree", C.c_uint32), ("row_floats", C.c_uint32), ("body_offset", C.c_uint64),
+                ("render_mode", C.c_int32), ("has_up_axis", C.c_int32), ("up_axis", C.c_float * 3)]
+
+
 GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 IMAGE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 
@@ -132,6 +137,17 @@ SYMBOLS = {
     "bh_fold_min_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bh_fold_min_scale_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "bh_compute_min_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, fp, C.c_uint32, C.c_float, C.c_void_p]),
+    "bh_splat_to_ply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, fp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bh_ply_parse_header": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(BhPlyInfo)]),
+    "bh_splats_from_ply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bh_uploader_create": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "bh_uploader_destroy": (None, [C.c_void_p]),
+    "bh_uploader_last_error": (C.c_char_p, [C.c_void_p]),
+    "bh_uploader_begin": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "bh_uploader_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "bh_uploader_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    "bh_uploader_acquire": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "bh_uploader_release": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
     "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),

@@ -51,6 +51,7 @@ enum Slot : int {
     SLOT_REFINE_BOUNDS,      // percentile bounds: keys / sorted keys / indices
     SLOT_FOLDED_TRANSFORMS,  // train step with a 3D-filter floor: folded [N,10] / [N]
     SLOT_FOLDED_RAW_OPAC,
+    SLOT_PLY_ROWS,           // PLY body being packed / unpacked
     SLOT_COUNT
 };
 

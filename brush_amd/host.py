@@ -379,6 +379,58 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
 
 
 # ---------------------------------------------------------------------------
+# PLY at the edges (brush-serde)
+# ---------------------------------------------------------------------------
+def splat_to_ply(splats: Splats, up_axis=None, ctx: Optional[Context] = None) -> bytes:
+    """splat_to_ply (brush-serde/src/export.rs:179-204): the INRIA-layout binary PLY, rows packed on the
+    device (3D-filter floor baked, quaternions normalised, SH permuted to [channel][coeff])."""
+    ctx = ctx or get_context(splats.device)
+    n = splats.num_splats()
+    up = (C.c_float * 3)(*[float(v) for v in up_axis]) if up_axis is not None else None
+    need = C.c_uint64(0)
+    args = (_ptr(splats.transforms), _ptr(splats.sh_coeffs), _ptr(splats.raw_opacities),
+            _ptr(splats.min_scale) if splats.min_scale is not None else None, n, splats.sh_degree(), int(splats.render_mip), up)
+    ctx.check(ctx.lib.bh_splat_to_ply(ctx._h, *args, None, 0, C.byref(need)))
+    buf = (C.c_char * need.value)()
+    ctx.check(ctx.lib.bh_splat_to_ply(ctx._h, *args, buf, need.value, C.byref(need)))
+    return bytes(buf)
+
+
+@dataclass
+class ParseMetadata:
+    """brush-serde/src/import.rs:19-24"""
+    up_axis: Optional[Tuple[float, float, float]]
+    render_mode: Optional[str]
+    total_splats: int
+    sh_degree: int
+
+
+def ply_parse_header(data: bytes) -> ParseMetadata:
+    """Header of a splat PLY (host only; no GPU needed)."""
+    info = _ffi.BhPlyInfo()
+    rc = _ffi.load().bh_ply_parse_header(data, len(data), C.byref(info))
+    if rc != 0:
+        raise BrushHipError("unsupported PLY (%d): only binary_little_endian float vertex rows are read" % rc if rc == -5 else "malformed PLY (%d)" % rc)
+    return ParseMetadata(tuple(info.up_axis) if info.has_up_axis else None, {0: "default", 1: "mip"}.get(info.render_mode), int(info.num_splats),
+                         int(info.sh_degree))
+
+
+def load_splat_from_ply(data: bytes, device=None, render_mip=None, ctx: Optional[Context] = None):
+    """load_splat_from_ply + SplatData::into_splats (import.rs:166-170, 57-75) -> (Splats, ParseMetadata).
+    render_mip None = take the file's SplatRenderMode comment (default mode when absent)."""
+    meta = ply_parse_header(data)
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or get_context(device)
+    n, c = meta.total_splats, (meta.sh_degree + 1) ** 2
+    tr = torch.empty((n, 10), dtype=torch.float32, device=device)
+    sh = torch.empty((n, c, 3), dtype=torch.float32, device=device)
+    op = torch.empty((n,), dtype=torch.float32, device=device)
+    ctx.check(ctx.lib.bh_splats_from_ply(ctx._h, data, len(data), _ptr(tr), _ptr(sh), _ptr(op)))
+    mip = (meta.render_mode == "mip") if render_mip is None else bool(render_mip)
+    return Splats(tr, sh, op, mip, device), meta
+
+
+# ---------------------------------------------------------------------------
 # primitives
 # ---------------------------------------------------------------------------
 def _as_u32(t, device):
@@ -561,6 +613,169 @@ class TrainStepStats:
     num_intersections: int
     lr_mean: float
     loss: float
+
+
+class BatchUploader:
+    """Ring of pinned staging slots + a copy stream that turns decoded host images into packed rgba8
+    device batches while the previous batch trains (bh_uploader_*: view_to_packed_data of
+    brush-dataset/src/scene.rs:97-136 on the device, the hand-off of scene_loader.rs:59-174)."""
+
+    def __init__(self, max_pixels, slots=3, ctx: Optional[Context] = None):
+        self.ctx = ctx or get_context()
+        self.lib = self.ctx.lib
+        self._h = C.c_void_p(self.lib.bh_uploader_create(self.ctx._h, int(max_pixels), int(slots)))
+        if not self._h:
+            raise BrushHipError("bh_uploader_create failed (max_pixels > 0, 2 <= slots <= 16, enough pinned memory)")
+        self.max_pixels, self.slots = int(max_pixels), int(slots)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bh_uploader_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise BrushHipError("uploader error %d: %s" % (rc, self.lib.bh_uploader_last_error(self._h).decode()))
+        return rc
+
+    def map(self, nbytes):
+        """-> (slot, writable uint8 numpy view of the slot's pinned buffer): decode straight into it, then commit()."""
+        import numpy as np
+        p = C.c_void_p()
+        slot = self._check(self.lib.bh_uploader_begin(self._h, int(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        return slot, np.frombuffer(buf, dtype=np.uint8)
+
+    def commit(self, slot, w, h, channels, premultiply):
+        self._check(self.lib.bh_uploader_commit(self._h, int(slot), int(w), int(h), int(channels), int(bool(premultiply))))
+
+    def submit(self, img_u8, premultiply=True):
+        """img_u8: C-contiguous uint8 [H,W,3] or [H,W,4] host array.  `premultiply` applies to RGBA views
+        (AlphaMode::Transparent); returns the slot index."""
+        import numpy as np
+        a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        if a.ndim != 3 or a.shape[2] not in (3, 4):
+            raise ValueError("image must be [H,W,3] or [H,W,4] uint8")
+        h, w, c = a.shape
+        return self._check(self.lib.bh_uploader_submit(self._h, a.ctypes.data_as(C.c_void_p), w, h, c, int(bool(premultiply) and c == 4)))
+
+    def acquire(self, slot):
+        """-> (packed int32 [H,W] device tensor aliasing the slot, has_alpha).  Work queued on the ctx stream
+        afterwards is ordered behind the upload; call release(slot) once the step that reads it is queued."""
+        p, w, h, ha = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_int()
+        self._check(self.lib.bh_uploader_acquire(self._h, int(slot), C.byref(p), C.byref(w), C.byref(h), C.byref(ha)))
+        return _view(p.value, (int(h.value), int(w.value)), torch.int32, self.ctx.device), bool(ha.value)
+
+    def release(self, slot):
+        self._check(self.lib.bh_uploader_release(self._h, int(slot)))
+
+
+class SceneLoader:
+    """SceneLoader (brush-dataset/src/scene_loader.rs:59-174): an endless shuffled stream of SceneBatch over
+    a list of views, prefetched by a loader thread through a BatchUploader so the H2D copy + packing of the
+    next views overlap the current train step.
+
+    views: sequence of (image, Camera[, alpha_is_mask]) with image a uint8 [H,W,3|4] array or a callable
+    returning one (the decode).  Shuffling: every epoch is a seeded Fisher-Yates permutation (SplitMix64) of
+    this rank's views — the reference's order comes from rand::StdRng inside racing loader tasks and is not
+    reproducible, so only the "every view once per epoch" property is kept.  `rank`/`world` shard the view
+    list for data-parallel training (view i belongs to rank i % world)."""
+
+    def __init__(self, views, seed=0, uploader: Optional[BatchUploader] = None, slots=3, rank=0, world=1, ctx: Optional[Context] = None):
+        import queue
+        import threading
+        self.views = [v for i, v in enumerate(views) if i % world == rank]
+        if not self.views:
+            raise ValueError("Need at least one view in dataset")  # scene_loader.rs:130
+        self._own_uploader = uploader is None
+        if uploader is None:
+            mp = 0
+            for v in self.views:
+                img = v[0]() if callable(v[0]) else v[0]
+                mp = max(mp, img.shape[0] * img.shape[1])
+            uploader = BatchUploader(mp, slots, ctx)
+        self.up = uploader
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._q = queue.Queue(maxsize=max(1, self.up.slots - 1))  # slots in flight = queued + the one being trained on
+        self._stop = threading.Event()
+        self._held = None
+        self._thread = threading.Thread(target=self._run, name="brush-hip-loader", daemon=True)
+        self._thread.start()
+
+    @staticmethod
+    def _splitmix(state):
+        state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return state, z ^ (z >> 31)
+
+    def epoch_order(self, epoch):
+        """The view order of `epoch` (deterministic in seed, epoch and the shard)."""
+        n = len(self.views)
+        order = list(range(n))
+        st = (self._seed ^ (0xD1B54A32D192ED03 * (epoch + 1))) & 0xFFFFFFFFFFFFFFFF
+        for i in range(n - 1, 0, -1):
+            st, r = self._splitmix(st)
+            j = r % (i + 1)
+            order[i], order[j] = order[j], order[i]
+        return order
+
+    def _run(self):
+        import queue
+        epoch = 0
+        try:
+            while not self._stop.is_set():
+                for idx in self.epoch_order(epoch):
+                    view = self.views[idx]
+                    img = view[0]() if callable(view[0]) else view[0]
+                    mask = bool(view[2]) if len(view) > 2 else False
+                    # wait for a free place in the queue BEFORE mapping a slot, so a mapped slot is never parked
+                    while not self._stop.is_set() and self._q.full():
+                        self._stop.wait(0.0005)
+                    if self._stop.is_set():
+                        return
+                    slot = self.up.submit(img, premultiply=not mask)
+                    self._q.put((slot, idx, view[1], mask))
+                epoch += 1
+        except Exception as e:  # surface loader failures to the consumer ("Scene loader failed to load an image")
+            try:
+                self._q.put(e, timeout=1.0)
+            except queue.Full:
+                pass
+
+    def next_batch(self):
+        """-> SceneBatch (its img_packed aliases an uploader slot that stays valid until the NEXT next_batch call).
+        Call after queuing the train step of the previous batch: that is what releases its slot."""
+        if self._held is not None:
+            self.up.release(self._held)
+            self._held = None
+        item = self._q.get()
+        if isinstance(item, Exception):
+            raise BrushHipError("Scene loader failed to load an image: %r" % (item,))
+        slot, idx, cam, mask = item
+        packed, has_alpha = self.up.acquire(slot)
+        self._held = slot
+        b = SceneBatch(packed, cam, has_alpha=has_alpha, alpha_is_mask=mask)
+        b.view_index = idx
+        return b
+
+    def close(self):
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:
+            pass
+        self._thread.join(timeout=5.0)
+        if self._own_uploader:
+            self.up.close()
 
 
 class SplatTrainer:

@@ -19,6 +19,9 @@
  *   bh_train_step       <- SplatTrainer::step                 brush-train/src/train.rs:176-429
  *   bh_fold_min_scale[_backward] <- fold_min_scale (+ its autodiff)  brush-render/src/gaussian_splats.rs:86-111
  *   bh_compute_min_scale <- compute_min_scale                brush-train/src/train.rs:102-125
+ *   bh_uploader_*       <- view_to_packed_data + the SceneLoader hand-off   brush-dataset/src/scene.rs:97-136, scene_loader.rs:59-174
+ *   bh_splat_to_ply     <- splat_to_ply                       brush-serde/src/export.rs:86-204
+ *   bh_ply_parse_header / bh_splats_from_ply <- load_splat_from_ply (plain PLY)  brush-serde/src/import.rs:166-330
  *   bh_camera_setup[_model] <- Camera::{build_pinhole_params, world_to_local}, fov_to_focal,
  *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-254
  *                          (+ kernels/camera_model/{pinhole,kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs: pinhole, Kannala-Brandt 4, radial-tangential 8,
@@ -334,6 +337,60 @@ int bh_refine_apply(bh_ctx* ctx, const BhRefineConfig* cfg /*host*/, const BhTra
 /* get_splat_bounds / bounds_from_pos (brush-train/src/splat_init.rs:130-160): per-axis percentile
  * box of the means ([N,10] transforms, columns 0..2), non-finite values ignored; blocking. */
 int bh_splat_bounds(bh_ctx* ctx, const float* transforms, uint32_t n, float percentile, float* center /*host[3]*/, float* extent /*host[3]*/);
+
+/* ---- PLY at the edges (brush-serde) -------------------------------------------- */
+/* splat_to_ply (brush-serde/src/export.rs:179-204): the INRIA-layout binary_little_endian PLY Brush writes —
+ * header comments "Exported from Brush", "Vertical axis: ...", "SH degree: d", "SplatRenderMode: mip|default";
+ * per splat x y z scale_0..2 opacity rot_0..3 (normalised) f_dc_0..2 f_rest_0..3(C-1)-1 ([channel][coeff]).
+ * min_scale (nullable): the 3D-filter floor is baked into the written scales / opacity (export.rs:183).
+ * The rows are packed on the device and arrive in `out` with one D2H copy.  out == NULL: size query
+ * (*written = bytes needed).  Blocking.  up_axis: host [3] or NULL ("Vertical axis: y"). */
+int bh_splat_to_ply(bh_ctx* ctx, const float* transforms, const float* sh_coeffs, const float* raw_opacities, const float* min_scale,
+                    uint32_t n, uint32_t sh_degree, int render_mip, const float* up_axis /*host*/, void* out /*host*/, uint64_t cap,
+                    uint64_t* written /*host*/);
+
+/* What parse_ply learns from the header (brush-serde/src/import.rs:172-277). */
+typedef struct BhPlyInfo {
+    uint64_t num_splats;
+    uint32_t sh_degree;   /* from the number of f_dc_/f_rest_ properties */
+    uint32_t row_floats;  /* properties per vertex row */
+    uint64_t body_offset; /* first byte after end_header */
+    int32_t render_mode;  /* -1 unknown, 0 default, 1 mip ("SplatRenderMode:" comment) */
+    int32_t has_up_axis;
+    float up_axis[3];     /* "Vertical axis:" comment: x -> +X, y -> -Y, z -> -Z, or three numbers */
+} BhPlyInfo;
+/* Host only.  BH_ERR_UNSUPPORTED for files this build does not read (ascii / big-endian, non-float
+ * vertex properties, SuperSplat-compressed chunks); BH_ERR_INVALID_ARG for malformed ones. */
+int bh_ply_parse_header(const void* bytes /*host*/, uint64_t len, BhPlyInfo* info /*host*/);
+/* load_splat_from_ply + SplatData::into_splats (import.rs:166-170, 57-75): one H2D copy of the body, columns
+ * scattered on the device; absent properties take the reference's defaults (rotation 1,0,0,0; log-scale -4;
+ * SH DC 0.5; raw opacity 0).  Outputs sized from bh_ply_parse_header: transforms [N,10], sh_coeffs
+ * [N,(d+1)^2,3], raw_opacities [N].  Blocking. */
+int bh_splats_from_ply(bh_ctx* ctx, const void* bytes /*host*/, uint64_t len, float* transforms, float* sh_coeffs, float* raw_opacities);
+
+/* ---- host image -> packed device batch (brush-dataset) ---------------------------- */
+/* SceneBatch::img_packed producer: view_to_packed_data (brush-dataset/src/scene.rs:97-136) moved to the
+ * device behind a ring of pinned staging slots and a copy stream, replacing the depth-4 channel + wgpu
+ * staging upload of scene_loader.rs:59-174.  The decoded RGB8 / RGBA8 bytes cross PCIe unpacked (3 or 4
+ * B/pixel); widening (a = 255), byte-space premultiply ((c*a + 127) / 255, AlphaMode::Transparent) and
+ * packing run in a kernel on the copy stream while the previous batch trains.
+ *
+ * Threads: begin / commit / submit may be called from ONE loader thread, acquire / release from the thread
+ * that owns `ctx` (internally locked).  Life of a slot: begin -> (fill pinned bytes) -> commit -> acquire
+ * (the ctx stream waits for the upload on the device; no host block) -> queue the train step -> release
+ * (an event on the ctx stream; begin blocks on it only when the ring wraps onto a still-busy slot). */
+typedef struct bh_uploader bh_uploader;
+bh_uploader* bh_uploader_create(bh_ctx* ctx, uint64_t max_pixels, uint32_t num_slots /*2..16*/);
+void bh_uploader_destroy(bh_uploader* up);
+const char* bh_uploader_last_error(bh_uploader* up);
+/* Map the next slot: returns its index (>= 0) and the pinned host buffer to decode into (`bytes` <= 4*max_pixels). */
+int bh_uploader_begin(bh_uploader* up, uint64_t bytes, void** pinned /*host out*/);
+/* Queue H2D + pack of a mapped slot. channels 3 = RGB8, 4 = RGBA8 (tightly packed rows). */
+int bh_uploader_commit(bh_uploader* up, int slot, uint32_t w, uint32_t h, uint32_t channels, int premultiply);
+/* begin + memcpy + commit for pixels that already live elsewhere; returns the slot index. */
+int bh_uploader_submit(bh_uploader* up, const uint8_t* pixels /*host*/, uint32_t w, uint32_t h, uint32_t channels, int premultiply);
+int bh_uploader_acquire(bh_uploader* up, int slot, const uint32_t** packed /*device [H,W] rgba8*/, uint32_t* w, uint32_t* h, int* has_alpha);
+int bh_uploader_release(bh_uploader* up, int slot);
 
 /* ---- profiling --------------------------------------------------------------- */
 /* on = 1: every pipeline stage is bracketed by HIP events on the ctx stream (costs ~0.1 ms of host
