@@ -393,7 +393,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
     auto* isect_counts = (uint32_t*)ensure(ctx, SLOT_ISECT_COUNTS, npad * 4);
     auto* max_radius = ctx->ext_max_radius ? ctx->ext_max_radius : (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
-    if (!counters || !depth_keys || !isect_counts || !max_radius) return BH_ERR_OOM;
+    auto* proj_by_gid = (float*)ensure(ctx, SLOT_PROJECTED_BY_GID, npad * 9 * 4);
+    if (!counters || !depth_keys || !isect_counts || !max_radius || !proj_by_gid) return BH_ERR_OOM;
 
     auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
     auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
@@ -404,7 +405,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         {
             ProfScope ps(ctx, "ProjectSplats");
             BH_HIP(ctx, hipMemsetAsync(counters, 0, 16, ctx->stream));
-            BH_TRY(launch_project_forward(ctx, u, n, mip, transforms, raw_opacities, depth_keys, isect_counts, max_radius, counters));
+            BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
+                                          proj_by_gid, counters));
         }
         // the one mid-pipeline readback (render.rs:146-168).  The depth sort covers all n splats
         // and needs neither count, so it is queued behind the copy BEFORE the host waits: the GPU
@@ -446,7 +448,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         }
         {
             ProfScope ps(ctx, "ProjectVisible");
-            BH_TRY(launch_project_visible(ctx, u, nv, mip, sh_degree, transforms, sh_coeffs, raw_opacities, gfc, projected));
+            BH_TRY(launch_project_visible(ctx, nv, proj_by_gid, gfc, projected));
         }
         if (ni > 0) {
             {

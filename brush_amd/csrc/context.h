@@ -52,6 +52,7 @@ enum Slot : int {
     SLOT_FOLDED_TRANSFORMS,  // train step with a 3D-filter floor: folded [N,10] / [N]
     SLOT_FOLDED_RAW_OPAC,
     SLOT_PLY_ROWS,           // PLY body being packed / unpacked
+    SLOT_PROJECTED_BY_GID,   // [N,9] projected records at their splat id (visible splats only)
     SLOT_COUNT
 };
 
@@ -133,12 +134,10 @@ ViewUniforms make_uniforms(const BhCamera& c);
 
 // ---- launchers (each in its own TU) --------------------------------------------
 // project.hip
-int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, const float* transforms,
-                           const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           uint32_t* counters);
-int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
-                           const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
-                           float* projected);
+int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
+                           const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
+                           float* projected_by_gid, uint32_t* counters);
+int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
                          const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,

@@ -90,11 +90,15 @@ BH_DEV void flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my
 // ---------------------------------------------------------------------------
 // K1: project_forward  (kernels/project_forward.rs:22-125)
 // ---------------------------------------------------------------------------
-template <bool MIP, bool PINHOLE>
+// The projected record of a visible splat (project_visible.rs:23-88: xy, conic, alpha, colour) is computed
+// here too and stored at its splat id: every term but the colour is needed for the cull anyway, so the
+// reference's second per-splat pass (K4: re-read transforms / opacity / SH through the depth permutation —
+// three random gathers — and redo the projection) shrinks to a 36-byte row gather.
+template <bool MIP, bool PINHOLE, int DEG>
 __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
-    ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ raw_opacities,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts, float* __restrict__ max_radius,
-    unsigned long long* __restrict__ counters) {
+    ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ coeffs,
+    const float* __restrict__ raw_opacities, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts,
+    float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
@@ -103,13 +107,15 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     uint32_t key = 0xFFFFFFFFu;
     float radius = 0.0f;
     bool visible = false;
-    float mx = 0.0f, my = 0.0f, pt = 0.0f;
+    float mx = 0.0f, my = 0.0f, pt = 0.0f, opac = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
+    Vec3A mean = v3(0.0f, 0.0f, 0.0f);
     if (gid < n) {
         const float* tr = transforms + (size_t)gid * 10;
         do {
-            const Vec3A mean_c = world_to_cam(v3(tr[0], tr[1], tr[2]), u);
+            mean = v3(tr[0], tr[1], tr[2]);
+            const Vec3A mean_c = world_to_cam(mean, u);
             if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) break;
             if (!in_front_of_camera<PINHOLE>(mean_c, u)) break;  // project_forward.rs:47-61
             const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
             float filter_comp;
             const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
-            const float opac = sigmoid(raw_opac) * filter_comp;
+            opac = sigmoid(raw_opac) * filter_comp;
             if (!sym2_finite(cov)) break;
             project_point<PINHOLE>(mean_c, u, mx, my);
             if (!(opac >= 1.0f / 255.0f)) break;
@@ -143,6 +149,22 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             key = f2u(mean_c.z);
             visible = true;
         } while (false);
+    }
+    if (visible) {  // project_visible.rs:56-87
+        const Vec3A v = normalize(sub(mean, camera_pos(u)));
+        constexpr int C = (DEG + 1) * (DEG + 1);
+        const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
+        const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
+        float* o = projected_by_gid + (size_t)gid * 9;
+        o[0] = mx;
+        o[1] = my;
+        o[2] = conic.c00;
+        o[3] = conic.c01;
+        o[4] = conic.c11;
+        o[5] = opac;
+        o[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
+        o[7] = clampf(is_finite_f32(cgc) ? cgc : 0.0f, -100.0f, 100.0f);
+        o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
     }
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
@@ -173,89 +195,56 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     }
 }
 
-int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, const float* transforms,
-                           const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           uint32_t* counters) {
-    if (n == 0) return 0;
+template <bool MIP, bool PINHOLE>
+static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_t deg, const float* t, const float* sh, const float* ro,
+                         uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64) {
     const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    auto* c64 = reinterpret_cast<unsigned long long*>(counters);
-    const bool pinhole = u.model == CAM_PINHOLE;
-    if (mip && pinhole)
-        hipLaunchKernelGGL((project_forward_kernel<true, true>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
-    else if (pinhole)
-        hipLaunchKernelGGL((project_forward_kernel<false, true>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
-    else if (mip)
-        hipLaunchKernelGGL((project_forward_kernel<true, false>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
-    else
-        hipLaunchKernelGGL((project_forward_kernel<false, false>), grid, block, 0, ctx->stream, u, n, transforms, raw_opac, depth_keys, isect_counts, max_radius, c64);
+    switch (deg) {
+        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
+    }
     BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// K4: project_visible  (kernels/project_visible.rs:23-88)
-// ---------------------------------------------------------------------------
-template <bool MIP, int DEG, bool PINHOLE>
-__global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(
-    ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ coeffs,
-    const float* __restrict__ raw_opacities, const uint32_t* __restrict__ global_from_compact_gid,
-    float* __restrict__ projected) {
-    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
-    if (cg >= nv) return;
-    const uint32_t gid = global_from_compact_gid[cg];
-    const float* tr = transforms + (size_t)gid * 10;
-    const Vec3A mean = v3(tr[0], tr[1], tr[2]);
-    const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
-    const Quat q = qnormalize(Quat{tr[3], tr[4], tr[5], tr[6]});
-    const Vec3A mean_c = world_to_cam(mean, u);
-    const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
-    float filter_comp;
-    const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
-    const float opac = sigmoid(raw_opacities[gid]) * filter_comp;
-    const Sym2 conic = sym2_inverse(cov);
-    float mx, my;
-    project_point<PINHOLE>(mean_c, u, mx, my);
-    const Vec3A v = normalize(sub(mean, camera_pos(u)));
-    constexpr int C = (DEG + 1) * (DEG + 1);
-    const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
-    const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
-    float* o = projected + (size_t)cg * 9;
-    o[0] = mx;
-    o[1] = my;
-    o[2] = conic.c00;
-    o[3] = conic.c01;
-    o[4] = conic.c11;
-    o[5] = opac;
-    o[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
-    o[7] = clampf(is_finite_f32(cgc) ? cgc : 0.0f, -100.0f, 100.0f);
-    o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
+int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
+                           const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
+                           float* projected_by_gid, uint32_t* counters) {
+    if (n == 0) return 0;
+    auto* c64 = reinterpret_cast<unsigned long long*>(counters);
+    const bool pinhole = u.model == CAM_PINHOLE;
+    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
+    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
+    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
+    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
 }
 
-template <bool MIP, bool PINHOLE>
-static int launch_pv_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
-                         const float* ro, const uint32_t* gid, float* projected) {
-    const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    switch (deg) {
-        case 0: hipLaunchKernelGGL((project_visible_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 1: hipLaunchKernelGGL((project_visible_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 2: hipLaunchKernelGGL((project_visible_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 3: hipLaunchKernelGGL((project_visible_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        case 4: hipLaunchKernelGGL((project_visible_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, projected); break;
-        default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
-    }
+// ---------------------------------------------------------------------------
+// K4: project_visible  (kernels/project_visible.rs:23-88) — here: the records K1 stored by splat id,
+// permuted into depth order.  One thread per output float: coalesced 4-byte stores, the nine reads of
+// a row fall in one or two 64-byte sectors.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_WG) void project_visible_kernel(uint32_t nv, const float* __restrict__ projected_by_gid,
+                                                                 const uint32_t* __restrict__ global_from_compact_gid,
+                                                                 float* __restrict__ projected) {
+    const uint32_t e = blockIdx.x * PROJ_WG + threadIdx.x;
+    if (e >= nv * 9u) return;
+    const uint32_t cg = e / 9u, j = e - cg * 9u;
+    projected[e] = projected_by_gid[(size_t)global_from_compact_gid[cg] * 9 + j];
+}
+
+int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected) {
+    if (nv == 0) return 0;
+    const uint64_t total = (uint64_t)nv * 9u;
+    if (total > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32/9 visible splats");
+    hipLaunchKernelGGL(project_visible_kernel, dim3((unsigned)((total + PROJ_WG - 1) / PROJ_WG)), dim3(PROJ_WG), 0, ctx->stream, nv,
+                       projected_by_gid, gid, projected);
     BH_LAUNCH_CHECK(ctx, "project_visible_kernel");
     return 0;
-}
-
-int launch_project_visible(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
-                           const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
-                           float* projected) {
-    if (nv == 0) return 0;
-    if (u.model == CAM_PINHOLE)
-        return mip ? launch_pv_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
-                   : launch_pv_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
-    return mip ? launch_pv_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected)
-               : launch_pv_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, projected);
 }
 
 // ---------------------------------------------------------------------------
