@@ -468,7 +468,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets));
     }
     {
-        if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, npad * 4, ctx->stream));
+        if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) * 4, ctx->stream));
         ProfScope ps(ctx, "Rasterize");
         BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
                                 bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible));
@@ -525,10 +525,9 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
         if (n > 0) {
             // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
-            const bool fused = v_sh_coeffs == v_transforms + (size_t)n * 10 && v_raw_opacities == v_sh_coeffs + (size_t)n * C * 3;
-            if (fused && v_refine_weight == v_raw_opacities + n) {
+            if (ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats) {
                 // the train step's exchange buffer: one fill instead of four
-                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * (10 + 3 * C + 2) * 4, ctx->stream));
+                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, ctx->ext_grad_floats * 4, ctx->stream));
             } else {
                 BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
                 BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
@@ -659,16 +658,17 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     st->step_count += 1;  // train.rs:183
     const uint32_t step = st->step_count;
 
-    // ---- the exchange buffer: visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | v_refine[N].
-    // One buffer = one collective per step for a multi-GPU caller (see bh_grad_hook).
-    const size_t grad_count = (size_t)n * (10 + 3 * C + 1);
-    const size_t exch_count = (size_t)n * (10 + 3 * C + 3);
-    auto* exch = (float*)ensure(ctx, SLOT_GRADS, (exch_count ? exch_count : 1) * 4);
+    // ---- the exchange buffer: visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | v_refine[N], every section
+    // starting on a 16-byte boundary (padded to a multiple of 4 floats; the padding stays zero) so the update kernel
+    // can move it with 128-bit accesses whatever N is.  One buffer = one collective per step for a multi-GPU caller.
+    auto pad4 = [](size_t x) { return (x + 3) & ~(size_t)3; };
+    const size_t o_tr = pad4(n), o_sh = o_tr + pad4((size_t)n * 10), o_op = o_sh + pad4((size_t)n * 3 * C), o_ref = o_op + pad4(n);
+    const size_t exch_count = o_ref + pad4(n);
+    auto* exch = (float*)ensure(ctx, SLOT_GRADS, (exch_count ? exch_count : 4) * 4);
     auto* s_radius = (float*)ensure(ctx, SLOT_STATS, (size_t)(n ? n : 1) * 4);
     if (!exch || !s_radius) return BH_ERR_OOM;
     float* s_visible = exch;
-    float* grads = exch + n;
-    float* s_refine = grads + grad_count;
+    float* s_refine = exch + o_ref;
 
     // ---- Mip-Splatting 3D filter: render fold_min_scale(params) (bwd/burn_glue.rs:260-270)
     const float* r_transforms = st->transforms;
@@ -687,6 +687,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     BhRenderOut ro;
     const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
     ctx->ext_visible = s_visible;
+    ctx->ext_visible_floats = o_tr;  // the forward clears the section incl. its padding
     ctx->ext_max_radius = s_radius;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
@@ -722,10 +723,15 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output));
 
     // ---- backward (train.rs:278)
-    float* g_tr = grads;
-    float* g_sh = grads + (size_t)n * 10;
-    float* g_op = g_sh + (size_t)n * 3 * C;
-    BH_TRY(bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine));
+    float* g_tr = exch + o_tr;
+    float* g_sh = exch + o_sh;
+    float* g_op = exch + o_op;
+    ctx->ext_grad_begin = g_tr;              // one zero-fill of the whole gradient span (padding included)
+    ctx->ext_grad_floats = exch_count - o_tr;
+    const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
+    ctx->ext_grad_begin = nullptr;
+    ctx->ext_grad_floats = 0;
+    BH_TRY(brc);
     if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
         ProfScope ps(ctx, "FoldMinScaleBackward");
         BH_TRY(launch_fold_min_scale_backward(ctx, st->transforms, st->raw_opacities, st->min_scale, n, g_tr, g_op));
@@ -734,7 +740,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const bool tile_mode = batch->image_hook != nullptr;
     if (hook) {
         ProfScope ps(ctx, "GradExchange");
-        const uint64_t sum_count = tile_mode ? (uint64_t)exch_count : (uint64_t)n + grad_count;
+        const uint64_t sum_count = tile_mode ? (uint64_t)exch_count : (uint64_t)o_ref;
         const int rc = hook(hook_user, exch, sum_count);
         if (rc != 0) return set_error(ctx, BH_ERR_STATE, "gradient hook failed");
     }

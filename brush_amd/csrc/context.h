@@ -94,6 +94,9 @@ struct bh_ctx {
     BhRenderOut last{};
     float* ext_visible = nullptr;     // train step: the forward writes visible / max_radius here (stats buffer)
     float* ext_max_radius = nullptr;
+    size_t ext_visible_floats = 0;    // floats to clear at ext_visible (its section of the exchange buffer incl. padding)
+    float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
+    size_t ext_grad_floats = 0;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;

@@ -157,6 +157,10 @@ struct UpdateArgs {
     float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
 };
 
+// VEC: every tensor base is 16-byte aligned -> 128-bit loads / stores (a block's region starts at a multiple of
+// 256 rows, so it is aligned whenever the tensor is; a float4 may straddle two rows, rows/columns are resolved per
+// component).  The element arithmetic is identical either way.
+template <bool VEC>
 __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     float* __restrict__ transforms, float* __restrict__ m1_t, float* __restrict__ m2_t, const float* __restrict__ g_t,
     float* __restrict__ sh, float* __restrict__ m1_sh, float* __restrict__ m2_sh, const float* __restrict__ g_sh,
@@ -171,15 +175,25 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
     float* s_g = s_dyn;                       // [ADAM_ROWS][row_len + 1]
     float* s_v = s_dyn + ADAM_ROWS * pitch;   // [ADAM_ROWS]
+    const float rcp_len = 1.0f / (float)row_len;
+    const uint32_t sh_count = nrows * row_len;
+    const uint64_t sh_base = row0 * row_len;
     // ---- SH gradients -> LDS (coalesced), issued first so the loads overlap the work below
     {
-        const uint32_t count = nrows * row_len;
-        const uint64_t base = row0 * row_len;
-        const float rcp_len = 1.0f / (float)row_len;
-        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
-            const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);  // e / row_len, exact for e < 2^16
-            const uint32_t c = e - r * row_len;
-            s_g[r * pitch + c] = g_sh[base + e] * u.gscale;
+        const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
+        for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+            const float4 g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ee = e + k;
+                const uint32_t r = (uint32_t)(((float)ee + 0.5f) * rcp_len);  // ee / row_len, exact for ee < 2^16
+                s_g[r * pitch + (ee - r * row_len)] = gv[k] * u.gscale;
+            }
+        }
+        for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
+            const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
+            s_g[r * pitch + (e - r * row_len)] = g_sh[sh_base + e] * u.gscale;
         }
     }
     // ---- statistics + opacity: one splat per thread
@@ -203,18 +217,41 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     {
         const uint32_t count = nrows * 10u;
         const uint64_t base = row0 * 10u;
-        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+        auto one = [&](float g_raw, float m1v, float m2v, float pv, uint32_t e, float& o_m1, float& o_m2, float& o_p) {
             const uint32_t c = e - ((e * 52429u) >> 19) * 10u;  // e % 10 (e < 2560)
-            const uint64_t i = base + e;
-            const float g = g_t[i] * u.gscale;
-            float mm1 = a.first ? g * a.f1 : m1_t[i] * a.beta1 + g * a.f1;
+            const float g = g_raw * u.gscale;
+            const float mm1 = a.first ? g * a.f1 : m1v * a.beta1 + g * a.f1;
             const float gsq = g * g;
-            const float mm2 = a.first ? gsq * a.f2 : m2_t[i] * a.beta2 + gsq * a.f2;
-            m1_t[i] = mm1;
-            m2_t[i] = mm2;
-            float p = transforms[i];
-            adam_elem(p, g, mm1, mm2, a, u.tab_t[c] * 1.0f);
-            transforms[i] = p;
+            const float mm2 = a.first ? gsq * a.f2 : m2v * a.beta2 + gsq * a.f2;
+            o_m1 = mm1;
+            o_m2 = mm2;
+            float p = pv;
+            float m1c = mm1;
+            adam_elem(p, g, m1c, mm2, a, u.tab_t[c] * 1.0f);
+            o_p = p;
+        };
+        const uint32_t vec_end = VEC ? (count & ~3u) : 0u;
+        for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+            const uint64_t i = base + e;
+            const float4 g4 = *reinterpret_cast<const float4*>(&g_t[i]);
+            float4 m14 = *reinterpret_cast<const float4*>(&m1_t[i]);
+            float4 m24 = *reinterpret_cast<const float4*>(&m2_t[i]);
+            float4 p4 = *reinterpret_cast<const float4*>(&transforms[i]);
+            one(g4.x, m14.x, m24.x, p4.x, e, m14.x, m24.x, p4.x);
+            one(g4.y, m14.y, m24.y, p4.y, e + 1, m14.y, m24.y, p4.y);
+            one(g4.z, m14.z, m24.z, p4.z, e + 2, m14.z, m24.z, p4.z);
+            one(g4.w, m14.w, m24.w, p4.w, e + 3, m14.w, m24.w, p4.w);
+            *reinterpret_cast<float4*>(&m1_t[i]) = m14;
+            *reinterpret_cast<float4*>(&m2_t[i]) = m24;
+            *reinterpret_cast<float4*>(&transforms[i]) = p4;
+        }
+        for (uint32_t e = vec_end + threadIdx.x; e < count; e += OPT_WG) {
+            const uint64_t i = base + e;
+            float o1, o2, op;
+            one(g_t[i], m1_t[i], m2_t[i], transforms[i], e, o1, o2, op);
+            m1_t[i] = o1;
+            m2_t[i] = o2;
+            transforms[i] = op;
         }
     }
     // ---- SH: per-row second moment (adam_scaled.rs:99-104,152-165), row sums in index order
@@ -231,19 +268,34 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     }
     __syncthreads();
     {
-        const uint32_t count = nrows * row_len;
-        const uint64_t base = row0 * row_len;
-        const float rcp_len = 1.0f / (float)row_len;
-        for (uint32_t e = threadIdx.x; e < count; e += OPT_WG) {
+        auto one = [&](float m1v, float pv, uint32_t e, float& o_m1, float& o_p) {
             const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
             const uint32_t c = e - r * row_len;
-            const uint64_t i = base + e;
             const float gi = s_g[r * pitch + c];
-            float mm1 = a.first ? gi * a.f1 : m1_sh[i] * a.beta1 + gi * a.f1;
-            m1_sh[i] = mm1;
-            float p = sh[i];
+            float mm1 = a.first ? gi * a.f1 : m1v * a.beta1 + gi * a.f1;
+            o_m1 = mm1;
+            float p = pv;
             adam_elem(p, gi, mm1, s_v[r], a, u.tab_sh[c] * u.lr_sh);
-            sh[i] = p;
+            o_p = p;
+        };
+        const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
+        for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+            const uint64_t i = sh_base + e;
+            float4 m14 = *reinterpret_cast<const float4*>(&m1_sh[i]);
+            float4 p4 = *reinterpret_cast<const float4*>(&sh[i]);
+            one(m14.x, p4.x, e, m14.x, p4.x);
+            one(m14.y, p4.y, e + 1, m14.y, p4.y);
+            one(m14.z, p4.z, e + 2, m14.z, p4.z);
+            one(m14.w, p4.w, e + 3, m14.w, p4.w);
+            *reinterpret_cast<float4*>(&m1_sh[i]) = m14;
+            *reinterpret_cast<float4*>(&sh[i]) = p4;
+        }
+        for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
+            const uint64_t i = sh_base + e;
+            float o1, op;
+            one(m1_sh[i], sh[i], e, o1, op);
+            m1_sh[i] = o1;
+            sh[i] = op;
         }
     }
 }
@@ -270,14 +322,23 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             raised = true;
         }
     }
     const unsigned nb = (unsigned)(((uint64_t)n + ADAM_ROWS - 1) / ADAM_ROWS);
-    hipLaunchKernelGGL(train_update_kernel, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
-                       st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
-                       st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
+    const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
+    bool vec = true;
+    for (const void* q : vec_ptrs) vec = vec && ((uintptr_t)q & 15u) == 0;
+    if (vec)
+        hipLaunchKernelGGL(train_update_kernel<true>, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
+                           st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
+                           st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
+    else
+        hipLaunchKernelGGL(train_update_kernel<false>, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
+                           st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
+                           st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
     BH_LAUNCH_CHECK(ctx, "train_update_kernel");
     return 0;
 }

@@ -288,8 +288,9 @@ typedef struct BhTrainStats {
  * non-NULL) after the backward and before the statistics / Adam update with the step's ONE
  * exchange buffer on the ctx stream:
  *     visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | refine_weight[N]
+ * (each section padded with zeros to a multiple of 4 floats, so all of them are 16-byte aligned).
  * The caller must SUM the first `sum_count` floats over its ranks, in place:
- *   - data parallel over cameras: sum_count = N*(1 + 10 + 3C + 1) — the per-view visible flags and the
+ *   - data parallel over cameras: sum_count = everything before refine_weight — the per-view visible flags and the
  *     gradients (scaled by `grad_scale` = 1/K inside the update).  refine_weight stays local: the
  *     RefineRecord keeps running MAXima (refine_weight_norm, max_screen_size), which a caller reduces
  *     over ranks with MAX once, before refine — not every step.  vis_weight counts views.
