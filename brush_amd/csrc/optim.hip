@@ -4,6 +4,8 @@
 // train.rs:389-416.  The reference expresses these as a few dozen burn tensor ops
 // (fused opportunistically by burn-fusion); here each is ONE pass over HBM:
 // 28 B/element for Adam (p,g,m,v read; p,m,v written), the floor for the update.
+#include <cstdlib>
+
 #include "context.h"
 
 namespace bh {
@@ -160,7 +162,8 @@ struct UpdateArgs {
 // VEC: every tensor base is 16-byte aligned -> 128-bit loads / stores (a block's region starts at a multiple of
 // 256 rows, so it is aligned whenever the tensor is; a float4 may straddle two rows, rows/columns are resolved per
 // component).  The element arithmetic is identical either way.
-template <bool VEC>
+// ROWS: splats per block (multiple of 4, <= OPT_WG) — fewer for long SH rows keeps more blocks resident per CU.
+template <bool VEC, int ROWS>
 __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     float* __restrict__ transforms, float* __restrict__ m1_t, float* __restrict__ m2_t, const float* __restrict__ g_t,
     float* __restrict__ sh, float* __restrict__ m1_sh, float* __restrict__ m2_sh, const float* __restrict__ g_sh,
@@ -170,11 +173,11 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     UpdateArgs u) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const AdamArgs& a = u.a;
-    const uint64_t row0 = (uint64_t)blockIdx.x * ADAM_ROWS;
-    const uint32_t nrows = (uint32_t)((uint64_t)u.n - row0 < (uint64_t)ADAM_ROWS ? (uint64_t)u.n - row0 : (uint64_t)ADAM_ROWS);
+    const uint64_t row0 = (uint64_t)blockIdx.x * (uint32_t)ROWS;
+    const uint32_t nrows = (uint32_t)((uint64_t)u.n - row0 < (uint64_t)(uint32_t)ROWS ? (uint64_t)u.n - row0 : (uint64_t)(uint32_t)ROWS);
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
-    float* s_g = s_dyn;                       // [ADAM_ROWS][row_len + 1]
-    float* s_v = s_dyn + ADAM_ROWS * pitch;   // [ADAM_ROWS]
+    float* s_g = s_dyn;                       // [rows][row_len + 1]
+    float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
@@ -318,27 +321,22 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
     for (int i = 0; i < 10; ++i) u.tab_t[i] = tab_t[i];
     for (uint32_t k = 0; k < 75; ++k) u.tab_sh[k] = (k / 3 == 0) ? 1.0f : sh_rest_scale;
-    const size_t lds = ((size_t)ADAM_ROWS * (u.sh_len + 1) + ADAM_ROWS) * sizeof(float);
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            BH_HIP(ctx, hipFuncSetAttribute((const void*)train_update_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
-    }
-    const unsigned nb = (unsigned)(((uint64_t)n + ADAM_ROWS - 1) / ADAM_ROWS);
+    // splats per block: ~13 KB of LDS-staged SH gradients keeps >= 8 blocks resident per CU (measured at 1 M splats:
+    // SH degree 3: 0.368 ms @256, 0.300 @128, 0.290 @64, 0.327 @32; degree 0 is best at 256)
+    const uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
+    const size_t lds = ((size_t)rows * (u.sh_len + 1) + rows) * sizeof(float);
+    const unsigned nb = (unsigned)(((uint64_t)n + rows - 1) / rows);
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
     bool vec = true;
     for (const void* q : vec_ptrs) vec = vec && ((uintptr_t)q & 15u) == 0;
-    if (vec)
-        hipLaunchKernelGGL(train_update_kernel<true>, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
-                           st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
-                           st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
-    else
-        hipLaunchKernelGGL(train_update_kernel<false>, dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,
-                           st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, g_o,
-                           st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u);
+#define BH_LAUNCH_UPDATE(V, R)                                                                                                          \
+    hipLaunchKernelGGL((train_update_kernel<V, R>), dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,         \
+                       st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, \
+                       g_o, st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u)
+    if (rows == 256u) { if (vec) BH_LAUNCH_UPDATE(true, 256); else BH_LAUNCH_UPDATE(false, 256); }
+    else if (rows == 128u) { if (vec) BH_LAUNCH_UPDATE(true, 128); else BH_LAUNCH_UPDATE(false, 128); }
+    else { if (vec) BH_LAUNCH_UPDATE(true, 64); else BH_LAUNCH_UPDATE(false, 64); }
+#undef BH_LAUNCH_UPDATE
     BH_LAUNCH_CHECK(ctx, "train_update_kernel");
     return 0;
 }

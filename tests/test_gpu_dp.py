@@ -81,10 +81,10 @@ def test_two_rank_step_matches_oracle_mean_gradient(oracle_lib):
                                                  synth.synthetic_gt_packed(W, H, seed=4), (0.1, 0.2, 0.3), dry_run=True)
     ot.step(sc, bo.camera(**_cam_params(0)), synth.synthetic_gt_packed(W, H, seed=3), (0.1, 0.2, 0.3), extra_grads=[g1], world=2)
     tr, sh, op = o0[0]
-    assert np.abs(tr[:, 3:7] - sc["transforms"][:, 3:7]).max() <= 0.02 * cfg.lr_rotation
-    assert np.abs(tr[:, 7:10] - sc["transforms"][:, 7:10]).max() <= 0.02 * cfg.lr_scale
-    assert np.abs(op - sc["raw_opac"]).max() <= 0.02 * cfg.lr_opac
-    assert np.abs(sh - sc["sh"]).max() <= 0.02 * cfg.lr_coeffs_dc
+    util.assert_adam_close(tr[:, 3:7], sc["transforms"][:, 3:7], cfg.lr_rotation, 1, "rotation")
+    util.assert_adam_close(tr[:, 7:10], sc["transforms"][:, 7:10], cfg.lr_scale, 1, "scale")
+    util.assert_adam_close(op, sc["raw_opac"], cfg.lr_opac, 1, "opacity")
+    util.assert_adam_close(sh, sc["sh"], cfg.lr_coeffs_dc, 1, "sh")
     # and it is NOT the single-view update: the second view changed something
     single = util.OracleTrainer(bo, cfg, 2.0)
     sc1 = _scene()

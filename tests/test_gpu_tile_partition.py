@@ -128,12 +128,13 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
         losses.append(trainer.stats().loss)
     assert np.allclose(r0[4], losses, rtol=1e-6, atol=1e-7)      # same image -> same loss
     tr = spl.transforms.cpu().numpy()
-    assert np.abs(r0[1][:, 3:7] - tr[:, 3:7]).max() <= 0.02 * cfg.lr_rotation * 2
-    assert np.abs(r0[1][:, 7:10] - tr[:, 7:10]).max() <= 0.02 * cfg.lr_scale * 2
-    assert np.abs(r0[3] - spl.raw_opacities.cpu().numpy()).max() <= 0.02 * cfg.lr_opac * 2
-    assert np.abs(r0[2] - spl.sh_coeffs.cpu().numpy()).max() <= 0.02 * cfg.lr_coeffs_dc * 2
+    util.assert_adam_close(r0[1][:, 3:7], tr[:, 3:7], cfg.lr_rotation, 2, "rotation")
+    util.assert_adam_close(r0[1][:, 7:10], tr[:, 7:10], cfg.lr_scale, 2, "scale")
+    util.assert_adam_close(r0[3], spl.raw_opacities.cpu().numpy(), cfg.lr_opac, 2, "opacity")
+    util.assert_adam_close(r0[2], spl.sh_coeffs.cpu().numpy(), cfg.lr_coeffs_dc, 2, "sh")
     assert np.mean(r0[5] != trainer.state["vis_weight"].cpu().numpy()) <= 2e-3
-    assert np.array_equal(r0[6], trainer.state["max_screen_size"].cpu().numpy())
+    # step 2 renders parameters that already carry step 1's Adam rounding differences: close, not identical
+    assert np.allclose(r0[6], trainer.state["max_screen_size"].cpu().numpy(), rtol=5e-3, atol=1e-6)
     # the refine weight is a per-pixel sum: the strips' partial sums add up to the single-GPU value
     ref_norm = trainer.state["refine_weight_norm"].cpu().numpy()
     assert np.abs(r0[7] - ref_norm).max() <= 1e-3 * ref_norm.max() + 1e-12

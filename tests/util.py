@@ -152,3 +152,15 @@ from oracle.trainer import OracleTrainer  # noqa: E402,F401
 def packed_from_rgba(rgba_u8):
     a = rgba_u8.astype(np.uint32)
     return (a[..., 0] | (a[..., 1] << 8) | (a[..., 2] << 16) | (a[..., 3] << 24)).astype(np.uint32)
+
+
+def assert_adam_close(a, b, lr, steps=1, what="", extra_abs=0.0):
+    """Parameters after `steps` Adam steps computed two ways (HIP vs oracle, 2 ranks vs 1, ...).  Adam's update is
+    lr * m / (sqrt(v) + 1e-15): where a gradient is summation-order noise (|g| ~ 1e-14) its sign, hence a full +-lr
+    step, is arbitrary; everywhere else the two must agree to a small fraction of the learning rate.  So: at most
+    0.1 % of the entries may differ by more than 2 % of the accumulated lr, none by more than the +-lr flips allow."""
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    tol = 0.02 * lr * steps + extra_abs
+    frac = float(np.mean(d > tol))
+    assert frac <= 1e-3, (what, "fraction beyond 2%% of lr: %.2e" % frac, float(d.max()))
+    assert float(d.max()) <= 2.1 * lr * steps + extra_abs, (what, float(d.max()))
