@@ -27,16 +27,28 @@ constexpr int PROJ_WAVES = PROJ_WG / 64;
 // (helpers.rs:204-223, map_gaussians.rs:46-72): a wave then runs as long as its
 // largest splat.  Here a wave flattens the boxes of its 64 splats into one
 // candidate list (wave prefix sum of the box areas), and lane l tests candidates
-// l, l+64, ...: every lane is busy whatever the size distribution.  A candidate
-// finds its splat with a 6-step search over the 64 prefix sums in LDS.  The
-// per-(splat, tile) test is the same inlined will_primitive_contribute for both
+// l, l+64, ...: every lane is busy whatever the size distribution.
+//
+// Which splat owns candidate c?  The splats with a non-empty box are compacted to
+// ranks 0..K-1 (their parameters are stored in LDS by RANK); rank r owns the
+// candidates [start_r, start_r + area_r), and the starts are strictly increasing.
+// One step covers the 64 consecutive candidates base..base+63, so
+//     owner(base + l) = A + popcount(marks & lanes<=l) - 1
+// with A = number of ranks that start before `base` (a running scalar) and `marks`
+// the 64-bit mask of the starts that fall inside this step — built by the owning
+// lanes dropping one byte each into a 64-byte LDS strip that the wave reads back
+// with a ballot.  That is ONE LDS round trip per step where a binary search over
+// the prefix sums took six dependent ones (the walk is latency-, not ALU-bound).
+// The per-(splat, tile) test is the same inlined will_primitive_contribute for both
 // kernels, so count and emit cannot disagree.
 // ---------------------------------------------------------------------------
 struct WalkLds {
-    uint32_t end[64];     // inclusive prefix sum of box areas
-    uint32_t count[64];   // hits per splat (K1) / emit cursor (K5)
-    float mx[64], my[64], c00[64], c01[64], c11[64], pt[64], rcp_w[64];
-    uint32_t box[64];     // min_x | min_y << 10 | width << 20   (tile grids up to 1023 x 1023)
+    uint32_t count[64];   // by rank: hits per splat (K1) / emit cursor (K5)
+    float mx[64], my[64], c00[64], c01[64], c11[64], pt[64], rcp_w[64];   // by rank
+    uint32_t box[64];     // by rank: min_x | min_y << 10 | width << 20   (tile grids up to 1023 x 1023)
+    uint32_t start[64];   // by rank: first candidate of the splat
+    uint32_t lane_of[64]; // by rank: the lane (splat slot) it came from
+    uint8_t flags[64];    // scratch strip for the per-step start marks
 };
 
 BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
@@ -48,43 +60,60 @@ BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-// first index o in [0,63] with end[o] > c   (requires c < end[63])
-BH_DEV uint32_t walk_owner(const uint32_t* end, uint32_t c) {
-    uint32_t lo = 0;
-#pragma unroll
-    for (uint32_t step = 32; step > 0; step >>= 1)
-        if (end[lo + step - 1] <= c) lo += step;
-    return lo;
-}
-
-// Visits every (splat, tile) candidate of the wave; calls on_hit(owner_lane, tile_x, tile_y)
-// for the contributing ones.  `nb` = box area of this lane's splat (0 = none).
+// Visits every (splat, tile) candidate of the wave; calls on_hit(rank, tile_x, tile_y) for the
+// contributing ones.  `nb` = box area of this lane's splat (0 = none).  Returns this lane's rank
+// (valid when nb > 0): per-splat results are read back from w.count[rank].
 template <class OnHit>
-BH_DEV void flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
-                           OnHit on_hit) {
+BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
+                               OnHit on_hit) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
+    const uint32_t start = incl - nb;
+    const bool nz = nb > 0u;
+    const unsigned long long nzmask = __ballot(nz);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(nzmask & below);
     const uint32_t bb_w = bb.max_x - bb.min_x;
-    w.end[lane] = incl;
-    w.count[lane] = 0;
-    w.mx[lane] = mx; w.my[lane] = my;
-    w.c00[lane] = conic.c00; w.c01[lane] = conic.c01; w.c11[lane] = conic.c11;
-    w.pt[lane] = pt;
-    w.rcp_w[lane] = 1.0f / (float)(bb_w ? bb_w : 1u);
-    w.box[lane] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
-    __syncthreads();
-    const uint32_t tot = w.end[63];
-    for (uint32_t c = lane; c < tot; c += 64) {
-        const uint32_t o = walk_owner(w.end, c);
-        const uint32_t i = c - (o ? w.end[o - 1] : 0u);
-        const uint32_t box = w.box[o];
-        const uint32_t bw = box >> 20;
-        // i / bw via float: exact for boxes up to 1023 tiles high (error <= rows * 2^-23 << 0.5 / bw)
-        const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[o]);
-        const uint32_t tx = (box & 1023u) + (i - row * bw);
-        const uint32_t ty = ((box >> 10) & 1023u) + row;
-        if (will_primitive_contribute(tx, ty, w.mx[o], w.my[o], Sym2{w.c00[o], w.c01[o], w.c11[o]}, w.pt[o])) on_hit(o, tx, ty);
+    if (nz) {
+        w.count[rank] = 0;
+        w.mx[rank] = mx; w.my[rank] = my;
+        w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
+        w.pt[rank] = pt;
+        w.rcp_w[rank] = 1.0f / (float)bb_w;
+        w.box[rank] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
+        w.start[rank] = start;
+        w.lane_of[rank] = (uint32_t)lane;
     }
-    __syncthreads();
+    // The lanes of one wave talk to each other through LDS below.  In hardware a wave's LDS operations retire in
+    // order, so no s_barrier is needed — but the COMPILER reasons per lane and would forward a lane's own store to
+    // its later load: a wavefront-scope fence (no instructions, only an ordering point) and volatile accesses to the
+    // mark strip keep every cross-lane read a real load.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    volatile uint8_t* flags = w.flags;
+    const uint32_t tot = __shfl(incl, 63);
+    const unsigned long long le = below | (1ull << lane);
+    uint32_t before = 0;  // ranks that start before `base` (wave-uniform)
+    for (uint32_t base = 0; base < tot; base += 64) {
+        // marks: which of the 64 candidates of this step is the first tile of a splat
+        flags[lane] = 0;
+        const uint32_t rel = start - base;   // wraps for starts before base -> fails the range test
+        if (nz && rel < 64u) flags[rel] = 1;
+        const unsigned long long marks = __ballot(flags[lane] != 0);
+        const uint32_t c = base + (uint32_t)lane;
+        if (c < tot) {
+            const uint32_t r = before + (uint32_t)__popcll(marks & le) - 1u;
+            const uint32_t i = c - w.start[r];
+            const uint32_t box = w.box[r];
+            const uint32_t bw = box >> 20;
+            // i / bw via float: exact for boxes up to 1023 tiles high (error <= rows * 2^-23 << 0.5 / bw)
+            const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[r]);
+            const uint32_t tx = (box & 1023u) + (i - row * bw);
+            const uint32_t ty = ((box >> 10) & 1023u) + row;
+            if (will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
+        }
+        before += (uint32_t)__popcll(marks);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the callers read w.count[] of other lanes' hits next
+    return rank;
 }
 
 // ---------------------------------------------------------------------------
@@ -169,8 +198,8 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
-    flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t o, uint32_t, uint32_t) { atomicAdd(&w.count[o], 1u); });
-    const uint32_t tiles_hit = w.count[lane];
+    const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); });
+    const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
     if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
@@ -275,21 +304,24 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
     }
     WalkLds& w = s_walk[wave];
-    uint32_t* wbase = s_base[wave];
-    wbase[lane] = base;
+    uint32_t* wbase = s_base[wave];   // by rank, like the walk's own arrays
+    {
+        const unsigned long long nzmask = __ballot(nb > 0u);
+        if (nb > 0u) wbase[__popcll(nzmask & ((1ull << lane) - 1ull))] = base;
+    }
     const uint32_t cg0 = cg - (uint32_t)lane;
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
-    flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t o, uint32_t tx, uint32_t ty) {
-        const uint32_t k = atomicAdd(&w.count[o], 1u);
-        const uint32_t idx = wbase[o] + k;
+    const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
+        const uint32_t k = atomicAdd(&w.count[r], 1u);
+        const uint32_t idx = wbase[r] + k;
         tile_id_from_isect[idx] = tx + ty * tile_bw;
-        compact_gid_from_isect[idx] = cg0 + o;
+        compact_gid_from_isect[idx] = cg0 + w.lane_of[r];
     });
     // map_gaussians.rs:73-79: pad any leftover budget (cannot happen here: the count
     // and the emit walk are the same inlined function with the same flags).
     const uint32_t sentinel = tile_bw * tile_bh;
-    for (uint32_t k = w.count[lane]; k < pf_count; ++k) {
+    for (uint32_t k = nb ? w.count[wrank] : 0u; k < pf_count; ++k) {
         tile_id_from_isect[base + k] = sentinel;
         compact_gid_from_isect[base + k] = cg;
     }
