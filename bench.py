@@ -78,9 +78,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    # BH_FORCE_PG=1: build the RCCL process group even for one rank (developer smoke test of the exchange-hook path on a 1-GPU box)
+    if world > 1 or os.environ.get("BH_FORCE_PG") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
         pg = dist.group.WORLD
 
@@ -113,7 +117,7 @@ def main():
         return loader.next_batch() if loader is not None else batch
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -140,7 +144,7 @@ def main():
     ctx.profile(0)
     st = trainer.stats()
 
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,7 +202,7 @@ def main():
         print(json.dumps(out))
     if loader is not None:
         loader.close()
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 
