@@ -3,6 +3,7 @@
 // forward pipeline (render.rs:37-314), the backward (bwd/render_bwd.rs:21-171)
 // and SplatTrainer::step (brush-train/src/train.rs:176-429).
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -433,7 +434,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* isect_gids = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS, nipad * 4);
     auto* tile_ids_sorted = (uint32_t*)ensure(ctx, SLOT_TILE_IDS_SORTED, nipad * 4);
     auto* isect_gids_sorted = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS_SORTED, nipad * 4);
-    auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, (size_t)num_tiles * 2 * 4);
+    // [T,2] offsets | 8*16 work-class counters | [8][16][ceil(T/8)] class lists (longest-first tile order of the backward)
+    const size_t lpt_words = 8 * 16 + (size_t)8 * 16 * ((num_tiles + 7) / 8);
+    auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     const size_t pixels = (size_t)u.img_w * u.img_h;
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
@@ -470,8 +473,13 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     {
         if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) * 4, ctx->stream));
         ProfScope ps(ctx, "Rasterize");
+        // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
+        const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
+        const float class_width = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
+        ctx->lpt = (bwd_info && getenv("BH_NO_LPT") == nullptr) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
         BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
-                                bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible));
+                                bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible, ctx->lpt,
+                                class_width < 8.0f ? 8.0f : class_width));
     }
 
     BhRenderOut r{};
@@ -540,7 +548,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "RasterizeBackwards", /*dominant=*/true);
         if (r.num_intersections > 0)
             BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
-                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined));
+                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, ctx->lpt));
     }
     {
         ProfScope ps(ctx, "ProjectBackwards");

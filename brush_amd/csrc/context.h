@@ -98,6 +98,7 @@ struct bh_ctx {
     float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
     size_t ext_grad_floats = 0;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
+    uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;
 };
@@ -155,12 +156,14 @@ int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t
 // rasterize.hip
 int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
                         uint32_t* tile_offsets);
+// lpt: the longest-first tile order scratch (8*16 counters directly behind tile_offsets, then the class lists); NULL = index order
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,
-                     const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible);
+                     const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
+                     uint32_t* lpt, float class_width);
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
-                              const float* out_img, const float* v_output, float* v_combined);
+                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt);
 // loss.hip
 int launch_image_loss_forward(bh_ctx* ctx, const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h,
                               uint32_t w, const BhLossConfig& cfg, float* loss_map);

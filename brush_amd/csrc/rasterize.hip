@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
 
 int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
                         uint32_t* tile_offsets) {
-    BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, (size_t)num_tiles * 2 * 4, ctx->stream));
+    // the 8 x 16 work-class counters of the backward's tile order sit right behind the table: one fill clears both
+    BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
     if (num_isect == 0) return 0;
     hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 255) / 256), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets);
     BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");
@@ -60,7 +61,20 @@ struct RasterUniforms {
     uint32_t tile_bw, num_tiles, img_w, img_h;  // num_tiles = tiles of the rendered window
     uint32_t tile_begin;                        // first tile id of the window
     float bg_r, bg_g, bg_b;
+    float rcp_class_width;                      // work classes of the backward's longest-first tile order (see LPT below)
 };
+
+// ---- longest-first tile order for the backward ------------------------------------------------------------
+// A tile is one wave and the chip holds only ~8 waves per SIMD over the whole launch (8160 tiles at 1080p), so
+// WHICH tiles share a SIMD decides the makespan: in index order the slowest SIMD carries ~10 % (up to ~40 % per
+// wave slot) more blended splats than the mean at the bench workload (scripts/tile_work_hist.py).  The forward
+// learns every tile's exact backward work (its list end is shrunk to the last useful splat, rasterize.rs:183-189),
+// so it files the tile, per XCD band, into one of LPT_CLASSES work classes (an atomic append), and the backward
+// maps block j of an XCD to that band's j-th tile in DESCENDING class order: heavy tiles start first, light ones
+// fill the tail.  The band structure (each XCD keeps a contiguous range of tiles for its L2) is unchanged.
+constexpr uint32_t LPT_CLASSES = 16;
+// layout of the LPT scratch: [8 * LPT_CLASSES] counters (zeroed with tile_offsets), then [8][LPT_CLASSES][per] tile lists
+BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return (num_tiles + 7u) / 8u; }
 
 // One staged splat = 12 floats (48 B, 16-B aligned rows):
 //   [0..3] x y c00 c01   [4..7] c11 alpha max(r,0) max(g,0)   [8] max(b,0)
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
                                                       const uint32_t* __restrict__ global_from_compact,
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
-                                                      float* __restrict__ visible) {
+                                                      float* __restrict__ visible, uint32_t* __restrict__ lpt) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
     const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
     if (local_tile >= u.num_tiles) return;
@@ -241,13 +255,24 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         }
     }
     // rasterize.rs:183-189: shrink the tile's end to one past the last useful splat
-    if (BWD_INFO && lane == 0) tile_offsets[tile * 2 + 1] = last_useful;
+    if (BWD_INFO && lane == 0) {
+        tile_offsets[tile * 2 + 1] = last_useful;
+        if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
+            const uint32_t work = last_useful - range_lo;
+            const uint32_t cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
+            const uint32_t list = (blockIdx.x & 7u) * LPT_CLASSES + cls;
+            const uint32_t pos = atomicAdd(&lpt[list], 1u);
+            lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
+        }
+    }
 }
 
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,
-                     const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible) {
+                     const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
+                     uint32_t* lpt, float class_width) {
     RasterUniforms u;
+    u.rcp_class_width = 1.0f / (class_width > 1.0f ? class_width : 1.0f);
     u.tile_bw = vu.tile_bw;
     u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
     u.tile_begin = vu.tile_bw * vu.tile_y0;
@@ -257,11 +282,11 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     const dim3 grid(nblocks), block(64);
     if (bwd_info && smooth)
-        hipLaunchKernelGGL((rasterize_kernel<true, true>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible);
+        hipLaunchKernelGGL((rasterize_kernel<true, true>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
     else if (bwd_info)
-        hipLaunchKernelGGL((rasterize_kernel<true, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible);
+        hipLaunchKernelGGL((rasterize_kernel<true, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
     else
-        hipLaunchKernelGGL((rasterize_kernel<false, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible);
+        hipLaunchKernelGGL((rasterize_kernel<false, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
     BH_LAUNCH_CHECK(ctx, "rasterize_kernel");
     return 0;
 }
@@ -303,10 +328,30 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
                                                                const float* __restrict__ v_output,
-                                                               float* __restrict__ v_combined) {
+                                                               float* __restrict__ v_combined, const uint32_t* __restrict__ lpt) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
-    if (local_tile >= u.num_tiles) return;
+    uint32_t local_tile;
+    if (lpt) {
+        // block j of XCD x takes the j-th tile of band x in descending work-class order (wave-uniform scalar code)
+        const uint32_t xcd = blockIdx.x & 7u;
+        uint32_t j = blockIdx.x >> 3;
+        const uint32_t* cnt = lpt + xcd * LPT_CLASSES;
+        uint32_t cls = LPT_CLASSES;
+        bool found = false;
+#pragma unroll
+        for (uint32_t c = LPT_CLASSES; c-- > 0u;) {
+            const uint32_t k = cnt[c];
+            if (!found) {
+                if (j < k) { cls = c; found = true; }
+                else j -= k;
+            }
+        }
+        if (!found) return;  // more blocks than tiles in this band
+        local_tile = lpt[8u * LPT_CLASSES + (xcd * LPT_CLASSES + cls) * lpt_band_tiles(u.num_tiles) + j];
+    } else {
+        local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+        if (local_tile >= u.num_tiles) return;
+    }
     const uint32_t tile = u.tile_begin + local_tile;
     const uint32_t range_lo = tile_offsets[tile * 2];
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
@@ -449,8 +494,9 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
 
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
-                              const float* out_img, const float* v_output, float* v_combined) {
+                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt) {
     RasterUniforms u;
+    u.rcp_class_width = 1.0f;
     u.tile_bw = vu.tile_bw;
     u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
     u.tile_begin = vu.tile_bw * vu.tile_y0;
@@ -460,9 +506,9 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     const dim3 grid(nblocks), block(64);
     if (smooth)
-        hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined);
+        hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
     else
-        hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined);
+        hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
     BH_LAUNCH_CHECK(ctx, "rasterize_backward_kernel");
     return 0;
 }
