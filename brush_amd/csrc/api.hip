@@ -166,15 +166,6 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         return nullptr;
     }
     std::memset(ctx->host_counters, 0, 64);
-    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->side_begin, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();  // no side stream: the train step zero-fills in line
-        if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-        if (ctx->side_begin) (void)hipEventDestroy(ctx->side_begin);
-        ctx->side_stream = nullptr;
-        ctx->side_begin = ctx->side_done = nullptr;
-    }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipHostFree(ctx->host_counters);
@@ -195,12 +186,6 @@ void bh_destroy(bh_ctx* ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
-    if (ctx->side_stream) {
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
-        (void)hipEventDestroy(ctx->side_begin);
-        (void)hipEventDestroy(ctx->side_done);
-    }
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -486,13 +471,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets));
     }
     {
-        if (bwd_info && ctx->prezeroed && ctx->ext_visible) {
-            // cleared on the side stream while the sorts ran: from here on the main stream is ordered behind those fills
-            BH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-            ctx->prezero_waited = true;
-        } else if (bwd_info) {
-            BH_HIP(ctx, hipMemsetAsync(visible, 0, ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) * 4, ctx->stream));
-        }
+        if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) * 4, ctx->stream));
         ProfScope ps(ctx, "Rasterize");
         // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
         const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
@@ -549,9 +528,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     const size_t nvpad = nv ? nv : 1;
     auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4);
     if (!v_combined) return BH_ERR_OOM;
-    if (ctx->prezeroed && ctx->prezero_waited && ctx->ext_grad_begin == v_transforms) {
-        // the train step cleared v_combined and the whole exchange buffer on the side stream (already waited for)
-    } else {
+    {
         ProfScope ps(ctx, "ZeroGradBuffers");
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
         if (n > 0) {
@@ -700,20 +677,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     if (!exch || !s_radius) return BH_ERR_OOM;
     float* s_visible = exch;
     float* s_refine = exch + o_ref;
-    // zero-fill of the whole exchange buffer and of v_combined (sized for every splat visible) on the side stream:
-    // it starts once the previous step has consumed the buffers and overlaps K1 and the launch-bound depth sort
-    ctx->prezeroed = false;
-    ctx->prezero_waited = false;
-    if (ctx->side_stream && n > 0 && getenv("BH_NO_SIDE_FILL") == nullptr) {
-        auto* vc = (float*)ensure(ctx, SLOT_V_COMBINED, (size_t)n * 10 * 4);
-        if (!vc) return BH_ERR_OOM;
-        BH_HIP(ctx, hipEventRecord(ctx->side_begin, ctx->stream));
-        BH_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_begin, 0));
-        BH_HIP(ctx, hipMemsetAsync(exch, 0, exch_count * 4, ctx->side_stream));
-        BH_HIP(ctx, hipMemsetAsync(vc, 0, (size_t)n * 10 * 4, ctx->side_stream));
-        BH_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
-        ctx->prezeroed = true;
-    }
 
     // ---- Mip-Splatting 3D filter: render fold_min_scale(params) (bwd/burn_glue.rs:260-270)
     const float* r_transforms = st->transforms;
@@ -776,7 +739,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
-    ctx->prezeroed = false;
     BH_TRY(brc);
     if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
         ProfScope ps(ctx, "FoldMinScaleBackward");

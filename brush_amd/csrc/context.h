@@ -98,12 +98,6 @@ struct bh_ctx {
     float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
     size_t ext_grad_floats = 0;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
-    // train step: the step's zero-fills (exchange buffer + v_combined) run on a side stream, under the launch-latency
-    // bound depth sort, instead of on the critical path
-    hipStream_t side_stream = nullptr;
-    hipEvent_t side_begin = nullptr, side_done = nullptr;
-    bool prezeroed = false;           // the exchange buffer and v_combined were cleared by the side stream for this step
-    bool prezero_waited = false;      // the main stream already waits on side_done
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;
