@@ -143,6 +143,11 @@ def main():
     stages.update(dominant)   # the dominant kernel's duration is the one measured inside the timed region
     ctx.profile(0)
     st = trainer.stats()
+    # how much of the per-tile lists the blend kernels actually consume before every pixel saturates (outside the
+    # timed region): the forward shrinks each tile's list end to its last useful splat
+    _, aux = ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
+    to = aux.tile_offsets.to(torch.int64)
+    isect_blended = int((to[:, 1] - to[:, 0]).clamp(min=0).sum().item())
 
     if pg is not None:
         import torch.distributed as dist
@@ -194,7 +199,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "rasterize_backward_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "note": "blend kernels are ALU/atomic bound, not HBM bound (DESIGN.md §5); G pixel-splat evals/s upper bound = %.1f" % (256.0 * ni / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0)},
+                         "intersections_blended": isect_blended,
+                         "note": "achieved = SURVEY 8d algorithmic bytes (80*I + 32*P, every listed intersection) / measured duration; the kernel "
+                                 "stops each tile when all its pixels saturate and blends only %d of the %d listed intersections (%.1f %%), so it is "
+                                 "VALU-issue bound, not HBM bound (DESIGN.md §5): %.2f ns per blended (splat, tile), %.1f G pixel-splat evaluations/s"
+                                 % (isect_blended, ni, 100.0 * isect_blended / max(ni, 1), (dom_ms * 1e6 / max(isect_blended, 1)),
+                                    256.0 * isect_blended / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0)},
             "stages": stage_out,
         }
         if world == 1 and not args.no_cpu_baseline:

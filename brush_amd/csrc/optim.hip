@@ -323,7 +323,11 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     for (uint32_t k = 0; k < 75; ++k) u.tab_sh[k] = (k / 3 == 0) ? 1.0f : sh_rest_scale;
     // splats per block: ~13 KB of LDS-staged SH gradients keeps >= 8 blocks resident per CU (measured at 1 M splats:
     // SH degree 3: 0.368 ms @256, 0.300 @128, 0.290 @64, 0.327 @32; degree 0 is best at 256)
-    const uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
+    uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
+    if (const char* e = getenv("BH_UPDATE_ROWS")) {  // developer knob (A/B measurements): 64 | 128 | 256
+        const int r = atoi(e);
+        if (r == 64 || r == 128 || r == 256) rows = (uint32_t)r;
+    }
     const size_t lds = ((size_t)rows * (u.sh_len + 1) + rows) * sizeof(float);
     const unsigned nb = (unsigned)(((uint64_t)n + rows - 1) / rows);
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
