@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--workload", default="1m_1080p")
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
+                    help="N>1 gradient exchange: 'torch' = torch.distributed all_reduce (backend nccl = RCCL) from the exchange hook; "
+                         "'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in bh_train_step); the "
+                         "unique id travels through a torch TCPStore on MASTER_ADDR:MASTER_PORT+1")
     ap.add_argument("--feed", choices=["resident", "loader"], default="resident",
                     help="'resident' (the headline): the GT batch is already in HBM when the timed region starts; 'loader': every step "
                          "takes a fresh 1080p RGB8 host image through SceneLoader/BatchUploader (pinned ring + copy stream + device "
@@ -70,6 +74,11 @@ def main():
                          "'tiles' = ONE view partitioned by strips of tile rows (strong scaling, BASELINE.json configs[4])")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: keep the real stdout aside and point fd 1 at stderr, so that banners
+    # printed by native libraries (RCCL prints its version to stdout when a communicator is created) cannot join it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +114,15 @@ def main():
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
     batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
     ctx = ba.get_context(dev)
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=pg, ctx=ctx, partition=args.parallel)
+    native = args.comm == "native" and not tile_mode and (world > 1 or os.environ.get("BH_FORCE_PG") == "1")
+    if native:
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29517")) + 1, world, rank == 0)
+        if rank == 0:
+            store.set("bh_comm_id", ba.Context.comm_unique_id())
+        ctx.comm_init(rank, world, store.get("bh_comm_id"))
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
+                              native_comm=native)
 
     loader = None
     if args.feed == "loader":
@@ -192,7 +209,7 @@ def main():
             "data": "synthetic" if loader is None else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
                        "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (RCCL all-gather of strips + all-reduce of gradients)" % world if tile_mode else
-                                       "dp%d over cameras (RCCL all-reduce of gradients)" % world) if world > 1 else "single GPU"},
+                                       "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else "")) if world > 1 else "single GPU"},
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),
@@ -209,7 +226,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cp, w, h)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if loader is not None:
         loader.close()
     if pg is not None:

@@ -148,6 +148,13 @@ SYMBOLS = {
     "bh_uploader_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "bh_uploader_acquire": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "bh_uploader_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "bh_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "bh_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bh_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bh_comm_world": (C.c_int, [C.c_void_p]),
+    "bh_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bh_allreduce_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bh_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
     "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),

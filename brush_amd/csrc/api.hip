@@ -186,6 +186,7 @@ void bh_destroy(bh_ctx* ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
+    if (ctx->comm) (void)bh_comm_destroy(ctx);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -751,6 +752,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         const uint64_t sum_count = tile_mode ? (uint64_t)exch_count : (uint64_t)o_ref;
         const int rc = hook(hook_user, exch, sum_count);
         if (rc != 0) return set_error(ctx, BH_ERR_STATE, "gradient hook failed");
+    } else if (ctx->comm && ctx->comm_world > 1) {
+        // no hook but a communicator (bh_comm_init): the library sums the exchange buffer itself over RCCL
+        ProfScope ps(ctx, "GradExchange");
+        BH_TRY(comm_allreduce(ctx, exch, tile_mode ? (uint64_t)exch_count : (uint64_t)o_ref, false));
     }
     // ---- refine statistics (train.rs:280-298) + optimizer (train.rs:300-381): one launch
     const double decay = std::pow(cfg->lr_mean_end / cfg->lr_mean, 1.0 / (double)cfg->total_train_iters);

@@ -98,6 +98,8 @@ struct bh_ctx {
     float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
     size_t ext_grad_floats = 0;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
+    void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
+    int comm_rank = 0, comm_world = 1;
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bh::Profiler prof;
@@ -193,5 +195,8 @@ int launch_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw
 int launch_fold_min_scale_backward(bh_ctx* ctx, const float* transforms, const float* raw_opac, const float* min_scale, uint32_t n,
                                    float* v_transforms, float* v_raw_opac);
 int launch_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const float* view_cams, uint32_t k, float factor, float* out);
+
+// comm.hip — in-place all-reduce of `count` floats over the ctx's RCCL communicator, on the ctx stream
+int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);
 
 }  // namespace bh

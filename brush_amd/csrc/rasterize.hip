@@ -147,8 +147,13 @@ BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float
 // ---------------------------------------------------------------------------
 // K16: rasterize (kernels/rasterize.rs:27-190)
 // ---------------------------------------------------------------------------
+#ifdef BH_FWD_WAVES  // measurement-only: cap the forward's occupancy (waves per SIMD)
+#define BH_FWD_ATTR __attribute__((amdgpu_waves_per_eu(BH_FWD_WAVES, BH_FWD_WAVES)))
+#else
+#define BH_FWD_ATTR
+#endif
 template <bool BWD_INFO, bool SMOOTH>
-__global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+__global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
                                                       const uint32_t* __restrict__ global_from_compact,
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,

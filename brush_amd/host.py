@@ -55,6 +55,32 @@ class Context:
     def sync(self):
         self.check(self.lib.bh_sync(self._h))
 
+    # ---- RCCL inside the library (bh_comm_*): for hosts without torch.distributed ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: call on rank 0, hand the 128 bytes to every rank (file, socket, TCPStore ...)."""
+        buf = (C.c_char * 128)()
+        rc = _ffi.load().bh_comm_unique_id(buf)
+        if rc != 0:
+            raise BrushHipError("bh_comm_unique_id failed (%d): RCCL not loadable" % rc)
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id: bytes):
+        self.check(self.lib.bh_comm_init(self._h, int(rank), int(world), unique_id))
+
+    def comm_destroy(self):
+        self.check(self.lib.bh_comm_destroy(self._h))
+
+    def comm_world(self):
+        return int(self.lib.bh_comm_world(self._h))
+
+    def allreduce_sum(self, t: torch.Tensor):
+        """In place, asynchronous on the ctx stream; t: contiguous float32 device tensor."""
+        self.check(self.lib.bh_allreduce_sum_f32(self._h, _ptr(t), t.numel()))
+
+    def allreduce_max(self, t: torch.Tensor):
+        self.check(self.lib.bh_allreduce_max_f32(self._h, _ptr(t), t.numel()))
+
     def profile(self, on=True):
         """True/1: HIP events around every stage; 2: only around the dominant kernel; False/0: off."""
         self.check(self.lib.bh_profile_enable(self._h, int(on)))
@@ -790,12 +816,17 @@ class SplatTrainer:
     rank-local until `sync_refine_stats()` (called by `refine`) MAX-reduces them."""
 
     def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
-                 partition: str = "cameras"):
+                 partition: str = "cameras", native_comm: bool = False):
         """partition (only with a process_group): "cameras" = data parallel, every rank its own view,
         mean gradient; "tiles" = every rank renders a strip of tile rows of the SAME view, strips are
         all-gathered before the loss and the partial gradients summed."""
         if partition not in ("cameras", "tiles"):
             raise ValueError("partition must be 'cameras' or 'tiles'")
+        # native_comm: the ctx carries an RCCL communicator (Context.comm_init) and bh_train_step all-reduces the
+        # exchange buffer itself — no torch.distributed, no callback (data parallel over cameras only)
+        if native_comm and (process_group is not None or partition != "cameras"):
+            raise ValueError("native_comm excludes process_group and supports partition='cameras' only")
+        self.native_comm = bool(native_comm)
         self.partition = partition
         self._img_hook = None
         self.bounds = None  # (center, extent); None = unit box scaled by median_scene_scale (set by refine / set_bounds)
@@ -923,6 +954,8 @@ class SplatTrainer:
             b.noise_samples = ns.data_ptr()
         stats = _ffi.BhTrainStats()
         hook, scale = None, 1.0
+        if self.native_comm:
+            scale = 1.0 / ctx.comm_world()
         if self.pg is not None:
             if self._hook is None:
                 self._hook = self._make_hook(dev)
@@ -951,6 +984,10 @@ class SplatTrainer:
         Needed once before refine, not per step (brush_amd/parallel.py)."""
         if self.pg is not None and self.state is not None:
             allreduce_refine_maxima(self.state["refine_weight_norm"], self.state["max_screen_size"], self.pg)
+        elif self.native_comm and self.state is not None:
+            ctx = self.ctx or get_context(self.state["refine_weight_norm"].device)
+            ctx.allreduce_max(self.state["refine_weight_norm"])
+            ctx.allreduce_max(self.state["max_screen_size"])
 
     def set_bounds(self, center, extent):
         self.bounds = (tuple(float(x) for x in center), tuple(float(x) for x in extent))

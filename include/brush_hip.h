@@ -299,6 +299,21 @@ typedef struct BhTrainStats {
  * One buffer = one collective per step.  Return 0. */
 typedef int (*bh_grad_hook)(void* user, float* exchange, uint64_t sum_count);
 
+/* ---- collectives inside the library (optional) --------------------------------- */
+/* For a host without a collective layer of its own (the Rust pipeline): one RCCL communicator per
+ * ctx, one process per GPU.  RCCL is bound at run time (dlopen) — nothing here is needed, or loaded, on one GPU.
+ * rank 0 calls bh_comm_unique_id and hands the 128 bytes to every rank by its own means (env, file, socket);
+ * every rank calls bh_comm_init.  With a communicator of world > 1 attached and hook == NULL, bh_train_step
+ * all-reduces its exchange buffer itself (pass grad_scale = 1/world for the mean over the ranks' views).
+ * All collectives are in place and asynchronous on the ctx stream. */
+int bh_comm_unique_id(void* out_id /*host, 128 bytes*/);
+int bh_comm_init(bh_ctx* ctx, int rank, int world, const void* unique_id /*host, 128 bytes*/);
+int bh_comm_destroy(bh_ctx* ctx);
+int bh_comm_world(bh_ctx* ctx); /* 1 without a communicator */
+int bh_allreduce_sum_f32(bh_ctx* ctx, float* buf, uint64_t count);
+int bh_allreduce_max_f32(bh_ctx* ctx, float* buf, uint64_t count); /* e.g. RefineRecord maxima before refine */
+int bh_allgather_bytes(bh_ctx* ctx, const void* send, void* recv /*world * bytes_per_rank*/, uint64_t bytes_per_rank); /* e.g. image strips */
+
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);

@@ -8,10 +8,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/brush_amd/variants; mkdir -p $OUT/obj_$NAME
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function $EXTRA"
 cd $ROOT/brush_amd/csrc
-for f in api project sort scan rasterize loss loss_fused optim refine; do
+for f in api project sort scan rasterize loss loss_fused optim refine filter3d ply upload comm; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OUT/obj_$NAME/*.o -o $OUT/libbrush_hip_$NAME.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OUT/obj_$NAME/*.o -ldl -o $OUT/libbrush_hip_$NAME.so
 rm -rf $OUT/obj_$NAME
 echo built $OUT/libbrush_hip_$NAME.so
