@@ -1,0 +1,466 @@
+// brush_hip.hpp — C++17 host-side mirror of Brush's operator surface over the C ABI of libbrush_hip.so.
+//
+// The reference's host language is Rust (not available in this image); where the reference is compiled code
+// the host side above the C ABI is C++: this header restates, with the reference's names and argument
+// meaning, what a Brush host sees (paths relative to /root/reference/crates/):
+//
+//   brush_hip::Camera            brush-render/src/camera.rs:12-58          (+ CameraModel, kernels/camera_model/mod.rs:31-38)
+//   brush_hip::Splats            brush-render/src/gaussian_splats.rs:62-256 (transforms / sh_coeffs / raw_opacities / min_scale)
+//   brush_hip::RasterPass        brush-render/src/gaussian_splats.rs:28-48
+//   brush_hip::render_splats     brush-render/src/gaussian_splats.rs:365-446 -> (image, RenderAux)
+//   brush_hip::render_splats_bwd brush-render/src/bwd/burn_glue.rs:223-311   (+ RenderBackwards::backward :121-182)
+//   brush_hip::radix_argsort     brush-sort/src/lib.rs:16,  brush_hip::prefix_sum  brush-prefix-sum/src/lib.rs:11
+//   brush_hip::SplatTrainer      brush-train/src/train.rs:140-893           (step, refine, set_view_cams)
+//   brush_hip::splat_to_ply / load_splat_from_ply   brush-serde/src/export.rs:179-204, import.rs:166-170
+//
+// Errors are exceptions (brush_hip::Error carrying bh_last_error) where the reference panics.  Device memory is
+// owned by DeviceBuffer<T> (hipMalloc/hipFree); nothing here computes — every operation is one C-ABI call.
+// tests/cpp/test_host.cpp runs the reference-style checks through this header on the MI355X.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "brush_hip.h"
+
+namespace brush_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error("brush_hip error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(BH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---- device memory -------------------------------------------------------------------------------------------
+template <class T>
+class DeviceBuffer {
+  public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t n) { resize(n); }
+    explicit DeviceBuffer(const std::vector<T>& host) { upload(host); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void resize(size_t n) {
+        release();
+        if (n) hip_check(hipMalloc((void**)&p_, n * sizeof(T)), "hipMalloc");
+        n_ = n;
+    }
+    void upload(const std::vector<T>& host) {
+        if (host.size() != n_) resize(host.size());
+        if (n_) hip_check(hipMemcpy(p_, host.data(), n_ * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+    }
+    std::vector<T> download() const {
+        std::vector<T> out(n_);
+        if (n_) hip_check(hipMemcpy(out.data(), p_, n_ * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+        return out;
+    }
+    void zero() { if (n_) hip_check(hipMemset(p_, 0, n_ * sizeof(T)), "hipMemset"); }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+
+  private:
+    void release() { if (p_) (void)hipFree(p_); p_ = nullptr; n_ = 0; }
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+template <class T>
+std::vector<T> download(const T* dev, size_t n) {
+    std::vector<T> out(n);
+    if (n) hip_check(hipMemcpy(out.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    return out;
+}
+
+// ---- context: one per thread / per GPU (brush-async/src/lib.rs:1-17) ---------------------------------------
+class Context {
+  public:
+    explicit Context(int device = 0) : h_(bh_create(device, nullptr, /*own_stream=*/1)) {
+        if (!h_) throw Error(BH_ERR_HIP, "bh_create failed: no HIP device " + std::to_string(device));
+    }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ~Context() { bh_destroy(h_); }
+    bh_ctx* get() const { return h_; }
+    void check(int rc) const { if (rc != 0) throw Error(rc, bh_last_error(h_)); }
+    void sync() const { check(bh_sync(h_)); }
+
+  private:
+    bh_ctx* h_;
+};
+
+// ---- Camera (camera.rs:12-58) ------------------------------------------------------------------------------------
+enum class CameraModel : uint32_t {
+    Pinhole = BH_CAMERA_PINHOLE,
+    KannalaBrandt4 = BH_CAMERA_KANNALA_BRANDT_4,
+    RadialTangential8 = BH_CAMERA_RADIAL_TANGENTIAL_8,
+    ThinPrismFisheye = BH_CAMERA_THIN_PRISM_FISHEYE
+};
+
+struct Camera {
+    double fov_x = 1.0, fov_y = 1.0;
+    float center_uv[2] = {0.5f, 0.5f};
+    float position[3] = {0.0f, 0.0f, 0.0f};
+    float rotation[4] = {0.0f, 0.0f, 0.0f, 1.0f};  // glam order x, y, z, w
+    CameraModel camera_model = CameraModel::Pinhole;
+    float dist[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // the model's parameter struct in field order (brush_hip.h)
+
+    bool is_valid() const {  // camera.rs:41-47
+        bool ok = std::isfinite(fov_x) && std::isfinite(fov_y) && std::isfinite(center_uv[0]) && std::isfinite(center_uv[1]);
+        for (float v : position) ok = ok && std::isfinite(v);
+        for (float v : rotation) ok = ok && std::isfinite(v);
+        return ok;
+    }
+    // kernel uniforms for an (img_w, img_h) render: focal from fov through the lens law, view matrix, clamp limits
+    BhCamera uniforms(uint32_t img_w, uint32_t img_h) const {
+        BhCamera cam{};
+        const int rc = bh_camera_setup_model(position, rotation, fov_x, fov_y, center_uv[0], center_uv[1], img_w, img_h,
+                                             (uint32_t)camera_model, dist, &cam);
+        if (rc != 0) throw Error(rc, "Can't render images with 0 size.");  // render.rs:50-53
+        return cam;
+    }
+};
+inline double fov_to_focal(double fov, uint32_t pixels, CameraModel m = CameraModel::Pinhole, const float* dist = nullptr) {
+    return bh_fov_to_focal(fov, pixels, (uint32_t)m, dist);
+}
+inline double focal_to_fov(double focal, uint32_t pixels, CameraModel m = CameraModel::Pinhole, const float* dist = nullptr) {
+    return bh_focal_to_fov(focal, pixels, (uint32_t)m, dist);
+}
+
+// ---- Splats (gaussian_splats.rs:62-256) --------------------------------------------------------------------
+inline uint32_t sh_degree_from_coeffs(uint32_t coeffs) {  // sh.rs
+    uint32_t d = 0;
+    while ((d + 1) * (d + 1) < coeffs) ++d;
+    if ((d + 1) * (d + 1) != coeffs || d > 4) throw Error(BH_ERR_INVALID_ARG, "sh_coeffs must have (d+1)^2 coefficients, d <= 4");
+    return d;
+}
+
+struct Splats {
+    DeviceBuffer<float> transforms;     // [N,10] means(3) quat wxyz(4) log-scales(3)
+    DeviceBuffer<float> sh_coeffs;      // [N,C,3]
+    DeviceBuffer<float> raw_opacities;  // [N] logits
+    std::optional<DeviceBuffer<float>> min_scale;  // [N] Mip-Splatting 3D-filter floor
+    bool render_mip = false;
+
+    static Splats from_host(const std::vector<float>& transforms, const std::vector<float>& sh, const std::vector<float>& raw_opac,
+                            bool render_mip = false) {
+        const size_t n = raw_opac.size();
+        if (transforms.size() != n * 10 || (n && sh.size() % (3 * n) != 0)) throw Error(BH_ERR_INVALID_ARG, "Splats: transforms [N,10], sh [N,C,3], raw_opacities [N]");
+        Splats s;
+        s.transforms.upload(transforms);
+        s.sh_coeffs.upload(sh);
+        s.raw_opacities.upload(raw_opac);
+        s.render_mip = render_mip;
+        (void)s.sh_degree();
+        return s;
+    }
+    uint32_t num_splats() const { return (uint32_t)raw_opacities.size(); }
+    uint32_t num_coeffs() const { return num_splats() ? (uint32_t)(sh_coeffs.size() / (3 * (size_t)num_splats())) : 1u; }
+    uint32_t sh_degree() const { return sh_degree_from_coeffs(num_coeffs()); }
+    Splats& with_min_scale(DeviceBuffer<float> f) {  // gaussian_splats.rs:188-194
+        if (f.size() != num_splats()) throw Error(BH_ERR_INVALID_ARG, "min_scale must have one entry per splat");
+        min_scale = std::move(f);
+        return *this;
+    }
+    // Splats::bake_min_scale (gaussian_splats.rs:245-256): fold the floor into the raw parameters, in place
+    Splats& bake_min_scale(const Context& ctx) {
+        if (min_scale) {
+            ctx.check(bh_fold_min_scale(ctx.get(), transforms.data(), raw_opacities.data(), min_scale->data(), num_splats(), transforms.data(),
+                                        raw_opacities.data()));
+            ctx.sync();  // the floor buffer is freed next
+            min_scale.reset();
+        }
+        return *this;
+    }
+};
+
+// ---- RasterPass / render (gaussian_splats.rs:28-48, 365-446) ---------------------------------------------------
+enum class RasterPass { Forward, Backward, BackwardSmoothCutoff };
+inline bool bwd_info(RasterPass p) { return p != RasterPass::Forward; }
+
+struct RenderAux {  // render_aux.rs:17-68: host scalars + ctx-owned device pointers (valid until the next render on the ctx)
+    BhRenderOut raw{};
+    uint32_t img_w = 0, img_h = 0, num_splats = 0;
+    uint32_t num_visible() const { return raw.num_visible; }
+    uint32_t num_intersections() const { return raw.num_intersections; }
+    std::vector<float> image() const { return download(raw.out_img, (size_t)img_w * img_h * 4); }             // [H,W,4] f32
+    std::vector<uint32_t> image_packed() const { return download(raw.out_img_packed, (size_t)img_w * img_h); }  // [H,W] rgba8
+    void validate() const {  // render_aux.rs:30-45
+        if (raw.num_visible > num_splats) throw Error(BH_ERR_STATE, "num_visible exceeds the splat count");
+    }
+};
+
+namespace detail {
+struct Folded {  // what the renderer sees: fold_min_scale(params) when a floor is set (gaussian_splats.rs:379-386)
+    const float* t;
+    const float* o;
+    DeviceBuffer<float> ft, fo;
+};
+inline Folded fold(const Context& ctx, const Splats& s) {
+    Folded f{s.transforms.data(), s.raw_opacities.data(), {}, {}};
+    if (s.min_scale) {
+        f.ft.resize(s.transforms.size());
+        f.fo.resize(s.raw_opacities.size());
+        ctx.check(bh_fold_min_scale(ctx.get(), s.transforms.data(), s.raw_opacities.data(), s.min_scale->data(), s.num_splats(), f.ft.data(), f.fo.data()));
+        f.t = f.ft.data();
+        f.o = f.fo.data();
+    }
+    return f;
+}
+inline uint32_t flags_of(const Splats& s, RasterPass pass) {
+    return (s.render_mip ? BH_FLAG_MIP : 0u) | (bwd_info(pass) ? BH_FLAG_BWD_INFO : 0u) |
+           (pass == RasterPass::BackwardSmoothCutoff ? BH_FLAG_SMOOTH_CUTOFF : 0u);
+}
+}  // namespace detail
+
+inline RenderAux render_splats(const Context& ctx, const Splats& splats, const Camera& camera, uint32_t img_w, uint32_t img_h,
+                               const float background[3], RasterPass pass = RasterPass::Forward) {
+    const BhCamera cam = camera.uniforms(img_w, img_h);
+    const detail::Folded f = detail::fold(ctx, splats);
+    RenderAux aux;
+    aux.img_w = img_w; aux.img_h = img_h; aux.num_splats = splats.num_splats();
+    ctx.check(bh_render_forward(ctx.get(), &cam, splats.num_splats(), splats.sh_degree(), f.t, splats.sh_coeffs.data(), f.o, background,
+                                detail::flags_of(splats, pass), &aux.raw));
+    ctx.sync();  // the folded temporaries die with this scope
+    return aux;
+}
+
+struct SplatGrads {  // SplatGrads + the refine weight (bwd/burn_glue.rs:184-193, 165-180)
+    DeviceBuffer<float> v_transforms, v_sh_coeffs, v_raw_opacities, v_refine_weight;
+};
+
+// forward (Backward pass flags) + backward for a given dL/d(out_img) [H,W,4] on the device
+inline std::pair<RenderAux, SplatGrads> render_splats_bwd(const Context& ctx, const Splats& splats, const Camera& camera, uint32_t img_w,
+                                                          uint32_t img_h, const float background[3], const float* v_output,
+                                                          RasterPass pass = RasterPass::Backward) {
+    if (!bwd_info(pass)) throw Error(BH_ERR_INVALID_ARG, "render_splats_bwd requires a Backward variant");  // bwd/burn_glue.rs:281-284
+    const BhCamera cam = camera.uniforms(img_w, img_h);
+    const detail::Folded f = detail::fold(ctx, splats);
+    RenderAux aux;
+    aux.img_w = img_w; aux.img_h = img_h; aux.num_splats = splats.num_splats();
+    const uint32_t n = splats.num_splats();
+    ctx.check(bh_render_forward(ctx.get(), &cam, n, splats.sh_degree(), f.t, splats.sh_coeffs.data(), f.o, background,
+                                detail::flags_of(splats, pass), &aux.raw));
+    SplatGrads g;
+    g.v_transforms.resize((size_t)n * 10);
+    g.v_sh_coeffs.resize(splats.sh_coeffs.size());
+    g.v_raw_opacities.resize(n);
+    g.v_refine_weight.resize(n);
+    ctx.check(bh_render_backward(ctx.get(), v_output, f.t, splats.sh_coeffs.data(), f.o, g.v_transforms.data(), g.v_sh_coeffs.data(),
+                                 g.v_raw_opacities.data(), g.v_refine_weight.data()));
+    if (splats.min_scale)  // chain through the fold (the autodiff of bwd/burn_glue.rs:260-270)
+        ctx.check(bh_fold_min_scale_backward(ctx.get(), splats.transforms.data(), splats.raw_opacities.data(), splats.min_scale->data(), n,
+                                             g.v_transforms.data(), g.v_raw_opacities.data()));
+    ctx.sync();
+    return {std::move(aux), std::move(g)};
+}
+
+// ---- primitives --------------------------------------------------------------------------------------------------
+inline void radix_argsort(const Context& ctx, const DeviceBuffer<uint32_t>& keys, const DeviceBuffer<uint32_t>& vals, uint32_t bits,
+                          DeviceBuffer<uint32_t>& out_keys, DeviceBuffer<uint32_t>& out_vals) {
+    if (keys.size() != vals.size()) throw Error(BH_ERR_INVALID_ARG, "Input keys and values must have the same number of elements");  // brush-sort/src/lib.rs:21-33
+    if (bits > 32) throw Error(BH_ERR_INVALID_ARG, "Can only sort up to 32 bits");
+    out_keys.resize(keys.size());
+    out_vals.resize(keys.size());
+    ctx.check(bh_radix_argsort(ctx.get(), keys.data(), vals.data(), (uint32_t)keys.size(), bits, out_keys.data(), out_vals.data()));
+    ctx.sync();  // the ctx owns a non-blocking stream: DeviceBuffer::download (default stream) must not overtake it
+}
+inline void prefix_sum(const Context& ctx, const DeviceBuffer<uint32_t>& in, DeviceBuffer<uint32_t>& out) {
+    out.resize(in.size());
+    ctx.check(bh_prefix_sum(ctx.get(), in.data(), (uint32_t)in.size(), out.data()));
+    ctx.sync();
+}
+
+// ---- PLY (brush-serde) -------------------------------------------------------------------------------------------
+inline std::vector<uint8_t> splat_to_ply(const Context& ctx, const Splats& s, const float* up_axis = nullptr) {
+    uint64_t need = 0;
+    const float* f = s.min_scale ? s.min_scale->data() : nullptr;
+    ctx.check(bh_splat_to_ply(ctx.get(), s.transforms.data(), s.sh_coeffs.data(), s.raw_opacities.data(), f, s.num_splats(), s.sh_degree(),
+                              s.render_mip ? 1 : 0, up_axis, nullptr, 0, &need));
+    std::vector<uint8_t> out(need);
+    ctx.check(bh_splat_to_ply(ctx.get(), s.transforms.data(), s.sh_coeffs.data(), s.raw_opacities.data(), f, s.num_splats(), s.sh_degree(),
+                              s.render_mip ? 1 : 0, up_axis, out.data(), need, &need));
+    return out;
+}
+inline std::pair<Splats, BhPlyInfo> load_splat_from_ply(const Context& ctx, const std::vector<uint8_t>& bytes) {
+    BhPlyInfo info{};
+    const int rc = bh_ply_parse_header(bytes.data(), bytes.size(), &info);
+    if (rc != 0) throw Error(rc, rc == BH_ERR_UNSUPPORTED ? "unsupported PLY variant" : "malformed PLY");
+    Splats s;
+    const size_t n = info.num_splats, c = (size_t)(info.sh_degree + 1) * (info.sh_degree + 1);
+    s.transforms.resize(n * 10);
+    s.sh_coeffs.resize(n * c * 3);
+    s.raw_opacities.resize(n);
+    s.render_mip = info.render_mode == 1;
+    ctx.check(bh_splats_from_ply(ctx.get(), bytes.data(), bytes.size(), s.transforms.data(), s.sh_coeffs.data(), s.raw_opacities.data()));
+    return {std::move(s), info};
+}
+
+// ---- training (brush-train) ---------------------------------------------------------------------------------------
+struct TrainConfig {  // config.rs:7-132 subset, same defaults
+    uint32_t total_train_iters = 30000;
+    double lr_mean = 2e-5, lr_mean_end = 2e-7, lr_coeffs_dc = 2e-3, lr_opac = 0.012, lr_scale = 5e-3, lr_rotation = 2e-3;
+    float lr_coeffs_sh_scale = 10.0f, ssim_weight = 0.2f, match_alpha_weight = 0.1f, mean_noise_weight = 50.0f;
+    float background_color[3] = {0.0f, 0.0f, 0.0f};
+    bool render_mip = false;
+    uint32_t max_splats = 10000000, refine_every = 200, growth_stop_iter = 15000;
+    float growth_grad_threshold = 0.0025f, growth_select_fraction = 0.25f, split_at_screen_size = 0.5f, opac_decay = 0.004f;
+};
+
+struct SceneBatch {  // brush-dataset/src/scene.rs:139-147
+    const uint32_t* img_packed = nullptr;  // device [H,W] rgba8
+    uint32_t img_w = 0, img_h = 0;
+    bool has_alpha = false, alpha_is_mask = false;
+    Camera camera;
+};
+
+struct TrainStepStats { uint32_t num_visible, num_intersections; double lr_mean; float loss; };
+
+class SplatTrainer {
+  public:
+    SplatTrainer(const Context& ctx, TrainConfig config, float median_scene_scale = 1.0f) : ctx_(ctx), cfg_(config), median_(median_scene_scale) {}
+
+    void set_view_cams(std::vector<float> centre_xyz_focal /*[K,4]*/) { view_cams_ = std::move(centre_xyz_focal); }  // train.rs:170-174
+    uint32_t step_count() const { return step_count_; }
+
+    // SplatTrainer::step (train.rs:176-429): forward, L1+SSIM (+alpha) loss, backward, statistics, Adam, optional noise.
+    // `noise_samples`: device [N,3] N(0,1) or null; `background`: the colour actually used this step.
+    TrainStepStats step(const SceneBatch& batch, Splats& splats, const float* noise_samples = nullptr, const float* background = nullptr) {
+        ensure_state(splats);
+        BhTrainConfig c = c_config(splats);
+        BhTrainState st = c_state(splats);
+        BhTrainBatch b{};
+        b.camera = batch.camera.uniforms(batch.img_w, batch.img_h);
+        b.gt_packed = batch.img_packed;
+        b.has_alpha = batch.has_alpha;
+        b.alpha_is_mask = batch.alpha_is_mask;
+        for (int k = 0; k < 3; ++k) b.background[k] = background ? background[k] : cfg_.background_color[k];
+        b.noise_samples = noise_samples;
+        BhTrainStats stats{};
+        ctx_.check(bh_train_step(ctx_.get(), &c, &st, &b, nullptr, nullptr, 1.0f, &stats));
+        step_count_ = st.step_count;
+        ctx_.sync();  // delivers stats.loss
+        return {stats.num_visible, stats.num_intersections, stats.lr_mean, stats.loss};
+    }
+
+    // SplatTrainer::refine (train.rs:431-663); `seed` replaces rand::rng().  Replaces `splats` and the optimizer state.
+    BhRefineStats refine(uint32_t iter, Splats& splats, uint64_t seed) {
+        if (!have_state_) throw Error(BH_ERR_STATE, "Can only refine if refine stats are initialized");  // train.rs:445
+        splats.bake_min_scale(ctx_);
+        if (!have_bounds_) update_bounds(splats);
+        BhRefineConfig rc{};
+        rc.iter = iter;
+        rc.total_train_iters = cfg_.total_train_iters ? cfg_.total_train_iters : 1;
+        rc.growth_stop_iter = cfg_.growth_stop_iter < cfg_.total_train_iters ? cfg_.growth_stop_iter : cfg_.total_train_iters;
+        rc.max_splats = cfg_.max_splats;
+        rc.growth_grad_threshold = cfg_.growth_grad_threshold;
+        rc.growth_select_fraction = cfg_.growth_select_fraction;
+        rc.split_at_screen_size = cfg_.split_at_screen_size;
+        rc.opac_decay = cfg_.opac_decay;
+        for (int k = 0; k < 3; ++k) { rc.bounds_center[k] = center_[k]; rc.bounds_extent[k] = extent_[k]; }
+        rc.seed = seed;
+        BhTrainState in = c_state(splats);
+        BhRefineStats rs{};
+        ctx_.check(bh_refine_plan(ctx_.get(), &rc, &in, &rs));
+        const size_t n2 = rs.total_splats, c3 = (size_t)splats.num_coeffs() * 3;
+        Splats out;
+        out.render_mip = splats.render_mip;
+        out.transforms.resize(n2 * 10);
+        out.sh_coeffs.resize(n2 * c3);
+        out.raw_opacities.resize(n2);
+        State ns;
+        ns.alloc(n2, c3);
+        BhTrainState o = in;
+        o.n = (uint32_t)n2;
+        o.transforms = out.transforms.data(); o.sh_coeffs = out.sh_coeffs.data(); o.raw_opacities = out.raw_opacities.data();
+        ns.fill(o);
+        o.min_scale = nullptr;
+        ctx_.check(bh_refine_apply(ctx_.get(), &rc, &in, &o));
+        ctx_.sync();
+        splats = std::move(out);
+        state_ = std::move(ns);
+        update_bounds(splats);  // train.rs:634
+        if ((float)iter / (float)rc.total_train_iters < 0.9f && !view_cams_.empty()) {  // train.rs:636-648, MIN_SCALE_FREEZE_FRAC
+            DeviceBuffer<float> f(splats.num_splats());
+            ctx_.check(bh_compute_min_scale(ctx_.get(), splats.transforms.data(), splats.num_splats(), view_cams_.data(),
+                                            (uint32_t)(view_cams_.size() / 4), 0.1f, f.data()));
+            splats.with_min_scale(std::move(f));
+        }
+        return rs;
+    }
+
+  private:
+    struct State {
+        DeviceBuffer<float> m1_t, m2_t, m1_sh, m2_sh, m1_o, m2_o, refine_weight_norm, vis_weight, max_screen_size;
+        void alloc(size_t n, size_t c3) {
+            m1_t.resize(n * 10); m2_t.resize(n * 10); m1_sh.resize(n * c3); m2_sh.resize(n); m1_o.resize(n); m2_o.resize(n);
+            refine_weight_norm.resize(n); vis_weight.resize(n); max_screen_size.resize(n);
+        }
+        void zero() { for (auto* b : {&m1_t, &m2_t, &m1_sh, &m2_sh, &m1_o, &m2_o, &refine_weight_norm, &vis_weight, &max_screen_size}) b->zero(); }
+        void fill(BhTrainState& s) {
+            s.m1_transforms = m1_t.data(); s.m2_transforms = m2_t.data(); s.m1_sh = m1_sh.data(); s.m2_sh = m2_sh.data();
+            s.m1_opac = m1_o.data(); s.m2_opac = m2_o.data();
+            s.refine_weight_norm = refine_weight_norm.data(); s.vis_weight = vis_weight.data(); s.max_screen_size = max_screen_size.data();
+        }
+    };
+    void ensure_state(const Splats& s) {
+        if (have_state_ && state_.m2_o.size() == s.num_splats()) return;
+        state_.alloc(s.num_splats(), (size_t)s.num_coeffs() * 3);
+        state_.zero();
+        have_state_ = true;
+    }
+    void update_bounds(const Splats& s) {  // get_splat_bounds (train.rs:124-133), BOUND_PERCENTILE 0.8; median_size = 2 * median extent
+        ctx_.check(bh_splat_bounds(ctx_.get(), s.transforms.data(), s.num_splats(), 0.8f, center_, extent_));
+        float e[3] = {extent_[0], extent_[1], extent_[2]};
+        if (e[0] > e[1]) std::swap(e[0], e[1]);
+        if (e[1] > e[2]) std::swap(e[1], e[2]);
+        if (e[0] > e[1]) std::swap(e[0], e[1]);
+        median_ = e[1] * 2.0f;
+        have_bounds_ = true;
+    }
+    BhTrainConfig c_config(const Splats& s) const {
+        BhTrainConfig c{};
+        c.lr_mean = cfg_.lr_mean; c.lr_mean_end = cfg_.lr_mean_end; c.total_train_iters = cfg_.total_train_iters;
+        c.lr_coeffs_dc = cfg_.lr_coeffs_dc; c.lr_coeffs_sh_scale = cfg_.lr_coeffs_sh_scale; c.lr_opac = cfg_.lr_opac;
+        c.lr_scale = cfg_.lr_scale; c.lr_rotation = cfg_.lr_rotation; c.ssim_weight = cfg_.ssim_weight;
+        c.match_alpha_weight = cfg_.match_alpha_weight; c.mean_noise_weight = cfg_.mean_noise_weight;
+        for (int k = 0; k < 3; ++k) c.background[k] = cfg_.background_color[k];
+        c.median_scene_scale = median_;
+        c.render_mip = (cfg_.render_mip || s.render_mip) ? 1 : 0;
+        return c;
+    }
+    BhTrainState c_state(Splats& s) {
+        BhTrainState st{};
+        st.n = s.num_splats(); st.sh_degree = s.sh_degree();
+        st.transforms = s.transforms.data(); st.sh_coeffs = s.sh_coeffs.data(); st.raw_opacities = s.raw_opacities.data();
+        state_.fill(st);
+        st.step_count = step_count_;
+        st.min_scale = s.min_scale ? s.min_scale->data() : nullptr;
+        return st;
+    }
+    const Context& ctx_;
+    TrainConfig cfg_;
+    float median_;
+    State state_;
+    bool have_state_ = false, have_bounds_ = false;
+    float center_[3] = {0, 0, 0}, extent_[3] = {1, 1, 1};
+    uint32_t step_count_ = 0;
+    std::vector<float> view_cams_;
+};
+
+}  // namespace brush_hip
