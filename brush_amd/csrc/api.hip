@@ -560,6 +560,13 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     return 0;
 }
 
+int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out) {
+    if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    if (!ctx->have_forward) return set_error(ctx, BH_ERR_STATE, "no forward render on this context yet");
+    *out = ctx->last;
+    return 0;
+}
+
 const float* bh_last_v_combined(bh_ctx* ctx) { return ctx ? (const float*)ctx->slots[SLOT_V_COMBINED].ptr : nullptr; }
 
 // ---- primitives ----------------------------------------------------------------

@@ -839,6 +839,11 @@ class SplatTrainer:
         self._hook = None
         self.generator = None
         self.view_cams = []  # [(centre xyz, focal px)] of the train views: enables the Mip-Splatting 3D filter
+        # partition == "tiles": strips are re-cut every `rebalance_every` steps so that every rank gets the same number of
+        # blended intersections (the backward's work), measured on the previous frame ("balance by
+        # intersection count, not rows"); 0 keeps equal-height strips
+        self.rebalance_every = 8
+        self._row_weights = None
 
     MIN_SCALE_FACTOR = 0.1       # train.rs:44
     MIN_SCALE_FREEZE_FRAC = 0.9  # train.rs:37
@@ -897,7 +902,7 @@ class SplatTrainer:
             try:
                 img = _view(img_ptr, (int(h), int(w), 4), torch.float32, dev)
                 import torch.distributed as dist
-                allgather_strips(img, int(r0), int(r1), pg, spans=strip_spans_px(int(h), dist.get_world_size(pg)))
+                allgather_strips(img, int(r0), int(r1), pg, spans=strip_spans_px(int(h), dist.get_world_size(pg), self._row_weights))
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1
@@ -935,7 +940,7 @@ class SplatTrainer:
         tiles = self.pg is not None and self.partition == "tiles"
         if tiles:
             import torch.distributed as dist
-            rows = tile_rows_for_rank((h + 15) // 16, dist.get_rank(self.pg), dist.get_world_size(self.pg))
+            rows = tile_rows_for_rank((h + 15) // 16, dist.get_rank(self.pg), dist.get_world_size(self.pg), self._row_weights)
             cam = _ffi.BhCamera()
             C.memmove(C.byref(cam), C.byref(b.camera), C.sizeof(cam))
             cam.tile_row_begin, cam.tile_row_end = rows
@@ -965,7 +970,20 @@ class SplatTrainer:
         self.step_count = st.step_count
         self._last_stats = stats
         self._keep = (gt, ns)
+        if tiles and self.rebalance_every > 0 and self.step_count % self.rebalance_every == 0:
+            self._measure_row_weights(ctx, (h + 15) // 16, (w + 15) // 16, dev)
         return splats, stats
+
+    def _measure_row_weights(self, ctx, tile_bh, tile_bw, dev):
+        """Per tile row: intersections this frame actually blended (the lists' shrunk ends), summed over the ranks'
+        strips -> the weights of the next cut.  One small readback + one [tile_bh] all-reduce every rebalance_every steps."""
+        import torch.distributed as dist
+        out = _ffi.BhRenderOut()
+        ctx.check(ctx.lib.bh_last_render_out(ctx._h, C.byref(out)))
+        to = _view(out.tile_offsets, (tile_bh * tile_bw, 2), torch.int32, dev).to(torch.int64)
+        per_row = (to[:, 1] - to[:, 0]).clamp(min=0).view(tile_bh, tile_bw).sum(1).to(torch.float32)
+        dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
+        self._row_weights = [float(x) + 1.0 for x in per_row.tolist()]  # +1: empty rows still cost a launch slot
 
     def _train_state(self, splats, s):
         st = _ffi.BhTrainState()

@@ -161,6 +161,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
 int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
                        const float* raw_opacities, float* v_transforms /*[N,10]*/, float* v_sh_coeffs /*[N,C,3]*/,
                        float* v_raw_opacities /*[N]*/, float* v_refine_weight /*[N]*/);
+/* The BhRenderOut of the last forward on this ctx (also the one inside bh_train_step); BH_ERR_STATE if there is none. */
+int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out /*host*/);
 /* [Nv,10] rasterize-backward accumulator of the last bh_render_backward (RasterizeGrads). */
 const float* bh_last_v_combined(bh_ctx* ctx);
 

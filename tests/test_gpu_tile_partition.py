@@ -75,7 +75,7 @@ def test_strip_gradients_sum_to_the_full_gradients(dev):
         assert float((v - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-12, k
 
 
-def _worker(rank, world, port, q, partition):
+def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -87,15 +87,16 @@ def _worker(rank, world, port, q, partition):
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
     trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, partition=partition)
+    trainer.rebalance_every = rebalance_every
     batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
     losses = []
-    for _ in range(2):
+    for _ in range(steps):
         trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
         losses.append(trainer.stats().loss)
     trainer.sync_refine_stats()  # max_screen_size is strip-local until refine asks for it
     q.put((rank, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(), losses,
            trainer.state["vis_weight"].cpu().numpy(), trainer.state["max_screen_size"].cpu().numpy(),
-           trainer.state["refine_weight_norm"].cpu().numpy()))
+           trainer.state["refine_weight_norm"].cpu().numpy(), trainer._row_weights))
     dist.destroy_process_group()
 
 
@@ -113,7 +114,8 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
         p.join(timeout=60)
         assert p.exitcode == 0
     r0, r1 = res
-    for a, b in zip(r0[1:], r1[1:]):  # replicas identical
+    assert r0[8] is None                     # 2 steps < rebalance_every: equal-height strips throughout
+    for a, b in zip(r0[1:8], r1[1:8]):  # replicas identical
         assert np.array_equal(np.asarray(a), np.asarray(b))
     # single-GPU reference on this process
     sc, cp, w, h = _problem(n=4000, w=160, h=112)
@@ -138,3 +140,45 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
     # the refine weight is a per-pixel sum: the strips' partial sums add up to the single-GPU value
     ref_norm = trainer.state["refine_weight_norm"].cpu().numpy()
     assert np.abs(r0[7] - ref_norm).max() <= 1e-3 * ref_norm.max() + 1e-12
+
+
+def test_strips_rebalanced_by_blended_intersections(dev):
+    """strips are cut by intersection count, not rows.  With rebalance_every = 1 the second and third
+    steps run on strips re-cut from the previous frame's blended-intersection counts per tile row; the result still
+    equals the single-GPU trajectory (strip composition is exact for ANY cut) and both ranks agree on the weights."""
+    import brush_amd as ba
+    from brush_amd.parallel import tile_rows_for_rank
+    world, steps = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tiles", 1, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r0[8] is not None and r0[8] == r1[8] and len(r0[8]) == 7          # 112 px = 7 tile rows, same weights on both ranks
+    cuts = [tile_rows_for_rank(7, r, world, r0[8]) for r in range(world)]
+    assert cuts[0][0] == 0 and cuts[0][1] == cuts[1][0] and cuts[1][1] == 7
+    loads = [sum(r0[8][b:e]) for b, e in cuts]
+    assert max(loads) <= 0.75 * sum(loads)                                     # neither rank carries most of the work
+    for a, b in zip(r0[1:8], r1[1:8]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    sc, cp, w, h = _problem(n=4000, w=160, h=112)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
+    cfg = ba.TrainConfig()
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=2.0)
+    batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
+    losses = []
+    for _ in range(steps):
+        trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        losses.append(trainer.stats().loss)
+    assert np.allclose(r0[4], losses, rtol=1e-5, atol=1e-7)
+    tr = spl.transforms.cpu().numpy()
+    util.assert_adam_close(r0[1][:, 3:7], tr[:, 3:7], cfg.lr_rotation, steps, "rotation")
+    util.assert_adam_close(r0[1][:, 7:10], tr[:, 7:10], cfg.lr_scale, steps, "scale")
+    util.assert_adam_close(r0[3], spl.raw_opacities.cpu().numpy(), cfg.lr_opac, steps, "opacity")
