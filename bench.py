@@ -65,6 +65,9 @@ def main():
                     help="N>1 gradient exchange: 'torch' = torch.distributed all_reduce (backend nccl = RCCL) from the exchange hook; "
                          "'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in bh_train_step); the "
                          "unique id travels through a torch TCPStore on MASTER_ADDR:MASTER_PORT+1")
+    ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse",
+                    help="N>1, cameras: 'sparse' = mask-keyed exchange (visible flags, then only the gradient rows of splats some rank "
+                         "saw; dense fallback above half of the scene), 'dense' = one all-reduce of the whole exchange buffer")
     ap.add_argument("--feed", choices=["resident", "loader"], default="resident",
                     help="'resident' (the headline): the GT batch is already in HBM when the timed region starts; 'loader': every step "
                          "takes a fresh 1080p RGB8 host image through SceneLoader/BatchUploader (pinned ring + copy stream + device "
@@ -122,7 +125,7 @@ def main():
             store.set("bh_comm_id", ba.Context.comm_unique_id())
         ctx.comm_init(rank, world, store.get("bh_comm_id"))
     trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
-                              native_comm=native)
+                              native_comm=native, sparse_exchange=args.exchange == "sparse")
 
     loader = None
     if args.feed == "loader":
@@ -210,6 +213,7 @@ def main():
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
                        "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (RCCL all-gather of strips + all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else "")) if world > 1 else "single GPU"},
+            "exchange": ({"mode": args.exchange, "rows_last_step": st.exchange_rows, "rows_total": n} if pg is not None or native else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),

@@ -93,12 +93,13 @@ class BhTrainBatch(C.Structure):
     _fields_ = [
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
         ("background", C.c_float * 3), ("noise_samples", C.c_void_p),
-        ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p),
+        ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p), ("exchange_mode", C.c_int32),
     ]
 
 
 class BhTrainStats(C.Structure):
-    _fields_ = [("num_visible", C.c_uint32), ("num_intersections", C.c_uint32), ("lr_mean", C.c_double), ("loss", C.c_float)]
+    _fields_ = [("num_visible", C.c_uint32), ("num_intersections", C.c_uint32), ("lr_mean", C.c_double), ("loss", C.c_float),
+                ("exchange_rows", C.c_uint32)]
 
 
 class BhPlyInfo(C.Structure):

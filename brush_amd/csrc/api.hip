@@ -754,15 +754,46 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     }
     // ---- multi-GPU exchange (not in the reference: SURVEY.md §8e) — one SUM over the leading floats
     const bool tile_mode = batch->image_hook != nullptr;
-    if (hook) {
+    stats->exchange_rows = 0;
+    if (hook || (ctx->comm && ctx->comm_world > 1)) {
         ProfScope ps(ctx, "GradExchange");
-        const uint64_t sum_count = tile_mode ? (uint64_t)exch_count : (uint64_t)o_ref;
-        const int rc = hook(hook_user, exch, sum_count);
-        if (rc != 0) return set_error(ctx, BH_ERR_STATE, "gradient hook failed");
-    } else if (ctx->comm && ctx->comm_world > 1) {
-        // no hook but a communicator (bh_comm_init): the library sums the exchange buffer itself over RCCL
-        ProfScope ps(ctx, "GradExchange");
-        BH_TRY(comm_allreduce(ctx, exch, tile_mode ? (uint64_t)exch_count : (uint64_t)o_ref, false));
+        // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
+        auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
+            if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
+            return comm_allreduce(ctx, p, cnt, false);
+        };
+        if (tile_mode) {
+            BH_TRY(sum_over_ranks(exch, (uint64_t)exch_count));
+        } else if (batch->exchange_mode == 1 && n > 0) {
+            // mask-keyed exchange (exchange.hip): flags first, then only the rows some rank saw
+            const uint32_t c3 = 3 * C, k = 11 + c3;
+            BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
+            auto* mask = (uint32_t*)ensure(ctx, SLOT_EXCH_MASK, (size_t)n * 4);
+            auto* incl = (uint32_t*)ensure(ctx, SLOT_EXCH_INCL, (size_t)n * 4);
+            auto* idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
+            auto* compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * k * 4);
+            if (!mask || !incl || !idx || !compact) return BH_ERR_OOM;
+            BH_TRY(launch_union_mask(ctx, s_visible, n, mask));
+            BH_TRY(prefix_sum(ctx, mask, nullptr, n, incl, false));
+            auto* hc = reinterpret_cast<uint32_t*>(ctx->host_counters);
+            BH_HIP(ctx, hipMemcpyAsync(hc + 8, incl + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+            BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+            BH_TRY(launch_union_index(ctx, mask, incl, n, idx));   // needs no count: queued before the host waits
+            BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+            const uint32_t rows = hc[8];
+            if (rows == 0) {
+                // no rank saw any splat: every gradient row is zero everywhere, nothing to send (same decision on all ranks)
+            } else if ((uint64_t)rows * 2 <= n) {
+                BH_TRY(launch_exchange_rows(ctx, true, idx, rows, c3, g_tr, g_sh, g_op, compact));
+                BH_TRY(sum_over_ranks(compact, (uint64_t)rows * k));
+                BH_TRY(launch_exchange_rows(ctx, false, idx, rows, c3, g_tr, g_sh, g_op, compact));
+                stats->exchange_rows = rows;
+            } else {
+                BH_TRY(sum_over_ranks(exch + o_tr, (uint64_t)(o_ref - o_tr)));
+            }
+        } else {
+            BH_TRY(sum_over_ranks(exch, (uint64_t)o_ref));
+        }
     }
     // ---- refine statistics (train.rs:280-298) + optimizer (train.rs:300-381): one launch
     const double decay = std::pow(cfg->lr_mean_end / cfg->lr_mean, 1.0 / (double)cfg->total_train_iters);

@@ -639,6 +639,7 @@ class TrainStepStats:
     num_intersections: int
     lr_mean: float
     loss: float
+    exchange_rows: int = 0  # mask-keyed exchange: gradient rows sent this step (0 = the dense block)
 
 
 class BatchUploader:
@@ -816,7 +817,7 @@ class SplatTrainer:
     rank-local until `sync_refine_stats()` (called by `refine`) MAX-reduces them."""
 
     def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
-                 partition: str = "cameras", native_comm: bool = False):
+                 partition: str = "cameras", native_comm: bool = False, sparse_exchange: bool = True):
         """partition (only with a process_group): "cameras" = data parallel, every rank its own view,
         mean gradient; "tiles" = every rank renders a strip of tile rows of the SAME view, strips are
         all-gathered before the loss and the partial gradients summed."""
@@ -827,6 +828,9 @@ class SplatTrainer:
         if native_comm and (process_group is not None or partition != "cameras"):
             raise ValueError("native_comm excludes process_group and supports partition='cameras' only")
         self.native_comm = bool(native_comm)
+        # data parallel over cameras: exchange only the gradient rows of splats some rank saw (BhTrainBatch.exchange_mode 1,
+        # brush_amd/csrc/exchange.hip); False = one dense all-reduce of the whole exchange buffer
+        self.sparse_exchange = bool(sparse_exchange)
         self.partition = partition
         self._img_hook = None
         self.bounds = None  # (center, extent); None = unit box scaled by median_scene_scale (set by refine / set_bounds)
@@ -958,6 +962,7 @@ class SplatTrainer:
             ns = _f32c(noise_samples, dev).reshape(-1, 3)
             b.noise_samples = ns.data_ptr()
         stats = _ffi.BhTrainStats()
+        b.exchange_mode = 1 if (self.sparse_exchange and not tiles and (self.pg is not None or self.native_comm)) else 0
         hook, scale = None, 1.0
         if self.native_comm:
             scale = 1.0 / ctx.comm_world()
@@ -1064,4 +1069,4 @@ class SplatTrainer:
         """Resolve the stats of the last step (synchronises)."""
         (ctx or self.ctx or get_context()).sync()
         s = self._last_stats
-        return TrainStepStats(s.num_visible, s.num_intersections, s.lr_mean, s.loss)
+        return TrainStepStats(s.num_visible, s.num_intersections, s.lr_mean, s.loss, s.exchange_rows)

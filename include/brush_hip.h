@@ -277,6 +277,13 @@ typedef struct BhTrainBatch {
     const float* noise_samples; /* [N,3] N(0,1) device, or NULL = no noise */
     bh_image_hook image_hook;   /* NULL unless the frame is tile-partitioned over ranks */
     void* image_hook_user;
+    /* Data parallel over cameras only.  0: one SUM over visible | gradients (dense).  1: mask-keyed — the hook (or the
+     * library's communicator) is called for the visible flags first, then for a compact block holding only the gradient
+     * rows of the splats some rank saw (their union is known from the summed flags and identical on every rank); falls
+     * back to the dense block when that union exceeds half of the scene.  The result equals mode 0 up to the summation
+     * order inside the collective; per view only the splats that reached a pixel carry a gradient, so the message is
+     * typically several times smaller.  Costs one more 4-byte readback per step. */
+    int32_t exchange_mode;
 } BhTrainBatch;
 
 typedef struct BhTrainStats {
@@ -284,6 +291,7 @@ typedef struct BhTrainStats {
     double lr_mean;
     float loss; /* written by the next bh_sync on this ctx (the struct must stay alive until then);
                    0 until then, and only the most recent step's stats are completed */
+    uint32_t exchange_rows; /* exchange_mode 1: gradient rows in the compact block this step (0 = dense block was sent) */
 } BhTrainStats;
 
 /* Exchange hook (multi-GPU callers; not in the reference, which is single-GPU): called (if
@@ -298,7 +306,8 @@ typedef struct BhTrainStats {
  *     over ranks with MAX once, before refine — not every step.  vis_weight counts views.
  *   - one frame partitioned by tile rows (image_hook set): sum_count = the whole buffer — the refine
  *     weight is a per-pixel sum, so the strips' partial sums add; `visible` is clamped to 1 afterwards.
- * One buffer = one collective per step.  Return 0. */
+ * One buffer = one collective per step (BhTrainBatch.exchange_mode 0; mode 1 calls the hook twice: for the leading visible
+ * section, then for a compact scratch block — the contract is always "sum `sum_count` floats at `exchange`").  Return 0. */
 typedef int (*bh_grad_hook)(void* user, float* exchange, uint64_t sum_count);
 
 /* ---- collectives inside the library (optional) --------------------------------- */
