@@ -768,17 +768,15 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
             // mask-keyed exchange (exchange.hip): flags first, then only the rows some rank saw
             const uint32_t c3 = 3 * C, k = 11 + c3;
             BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
-            auto* mask = (uint32_t*)ensure(ctx, SLOT_EXCH_MASK, (size_t)n * 4);
-            auto* incl = (uint32_t*)ensure(ctx, SLOT_EXCH_INCL, (size_t)n * 4);
+            const uint32_t nblk = (n + 4095u) / 4096u;
+            auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
             auto* idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
             auto* compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * k * 4);
-            if (!mask || !incl || !idx || !compact) return BH_ERR_OOM;
-            BH_TRY(launch_union_mask(ctx, s_visible, n, mask));
-            BH_TRY(prefix_sum(ctx, mask, nullptr, n, incl, false));
+            if (!blocks || !idx || !compact) return BH_ERR_OOM;
+            BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, idx));
             auto* hc = reinterpret_cast<uint32_t*>(ctx->host_counters);
-            BH_HIP(ctx, hipMemcpyAsync(hc + 8, incl + (n - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+            BH_HIP(ctx, hipMemcpyAsync(hc + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
             BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
-            BH_TRY(launch_union_index(ctx, mask, incl, n, idx));   // needs no count: queued before the host waits
             BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
             const uint32_t rows = hc[8];
             if (rows == 0) {

@@ -52,8 +52,7 @@ enum Slot : int {
     SLOT_FOLDED_TRANSFORMS,  // train step with a 3D-filter floor: folded [N,10] / [N]
     SLOT_FOLDED_RAW_OPAC,
     SLOT_PLY_ROWS,           // PLY body being packed / unpacked
-    SLOT_EXCH_MASK,          // mask-keyed gradient exchange: union mask / its scan / rank -> splat / compact rows
-    SLOT_EXCH_INCL,
+    SLOT_EXCH_BLOCKS,        // mask-keyed gradient exchange: per-block counts (+ total) / rank -> splat / compact rows
     SLOT_EXCH_IDX,
     SLOT_EXCH_COMPACT,
     SLOT_PROJECTED_BY_GID,   // [N,9] projected records at their splat id (visible splats only)
@@ -204,8 +203,8 @@ int launch_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, c
 int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);
 
 // exchange.hip — compaction kernels of the mask-keyed gradient exchange
-int launch_union_mask(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* mask);
-int launch_union_index(bh_ctx* ctx, const uint32_t* mask, const uint32_t* incl, uint32_t n, uint32_t* idx);
+int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* block_scratch /*[n/4096+2]*/, uint32_t* count_dev,
+                       uint32_t* idx);
 int launch_exchange_rows(bh_ctx* ctx, bool gather, const uint32_t* idx, uint32_t count, uint32_t c3, float* g_tr, float* g_sh, float* g_op,
                          float* compact);
 

@@ -4,7 +4,7 @@
 // that view (visible[] = 1; ~10 % of the rows at the 1 M / 1080p bench workload), so instead of all-reducing the dense
 // [N, 11 + 3C] gradient block every step, bh_train_step (BhTrainBatch.exchange_mode = 1)
 //   1. sums the visible flags over the ranks (needed anyway: vis_weight counts views)      — 4 B per splat
-//   2. takes U = { i : summed visible > 0 } — identical on every rank — ranks it with the scan,
+//   2. takes U = { i : summed visible > 0 } — identical on every rank — and lists it in ascending order (count / spine / place),
 //   3. gathers the rows of U into a compact [|U|, 11 + 3C] block, sums THAT, scatters it back.
 // Rows outside U are zero on every rank, so the dense buffer ends up exactly as a dense all-reduce would leave it
 // (up to the summation order inside the collective).  When U is more than half of the scene the dense block is summed
@@ -15,16 +15,83 @@ namespace bh {
 
 constexpr int EX_WG = 256;
 
-__global__ __launch_bounds__(EX_WG) void union_mask_kernel(const float* __restrict__ visible_sum, uint32_t n, uint32_t* __restrict__ mask) {
-    const uint32_t i = blockIdx.x * EX_WG + threadIdx.x;
-    if (i < n) mask[i] = visible_sum[i] > 0.0f ? 1u : 0u;
+// ---- rank -> splat id of the union, in three launches (count per 4096-splat block, spine over the block counts, place)
+constexpr int EX_EPT = 16;
+constexpr int EX_TILE = EX_WG * EX_EPT;
+
+BH_DEV uint32_t ex_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
 }
 
-// idx[rank] = splat id, for the splats of U (rank = inclusive scan of the mask - 1)
-__global__ __launch_bounds__(EX_WG) void union_index_kernel(const uint32_t* __restrict__ mask, const uint32_t* __restrict__ incl, uint32_t n,
+__global__ __launch_bounds__(EX_WG) void union_count_kernel(const float* __restrict__ visible_sum, uint32_t n, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t s_w[EX_WG / 64];
+    const uint32_t base = blockIdx.x * EX_TILE;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < EX_EPT; ++j) {
+        const uint32_t i = base + j * EX_WG + threadIdx.x;
+        if (i < n) acc += visible_sum[i] > 0.0f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// one block: block_counts <- exclusive prefix, total -> total_out[0]   (nb = N / 4096: a few hundred to a few thousand)
+__global__ __launch_bounds__(EX_WG) void union_spine_kernel(uint32_t* __restrict__ block_counts, uint32_t nb, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t s_w[EX_WG / 64];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += EX_WG) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_counts[i] : 0u;
+        const uint32_t incl = ex_wave_incl_scan(v, lane);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t ofs = s_carry, tot = 0;
+#pragma unroll
+        for (int w = 0; w < EX_WG / 64; ++w) { ofs += w < wave ? s_w[w] : 0u; tot += s_w[w]; }
+        if (i < nb) block_counts[i] = ofs + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total_out[0] = s_carry;
+}
+
+// idx[rank] = splat id: thread t owns the 16 consecutive splats base + 16 t .. (ascending ids -> ascending ranks)
+__global__ __launch_bounds__(EX_WG) void union_place_kernel(const float* __restrict__ visible_sum, uint32_t n, const uint32_t* __restrict__ block_offsets,
                                                            uint32_t* __restrict__ idx) {
-    const uint32_t i = blockIdx.x * EX_WG + threadIdx.x;
-    if (i < n && mask[i]) idx[incl[i] - 1u] = i;
+    __shared__ uint32_t s_w[EX_WG / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * EX_TILE + threadIdx.x * EX_EPT;
+    uint32_t bits = 0, cnt = 0;
+#pragma unroll
+    for (int j = 0; j < EX_EPT; ++j) {
+        const uint32_t i = first + j;
+        const bool f = i < n && visible_sum[i] > 0.0f;
+        bits |= f ? (1u << j) : 0u;
+        cnt += f ? 1u : 0u;
+    }
+    const uint32_t incl = ex_wave_incl_scan(cnt, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t ofs = block_offsets[blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < EX_WG / 64; ++w) ofs += w < wave ? s_w[w] : 0u;
+    uint32_t r = ofs + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < EX_EPT; ++j)
+        if (bits & (1u << j)) idx[r++] = first + j;
 }
 
 // compact[r, :] <-> (v_transforms[i, 0:10] | v_sh[i, 0:3C] | v_raw_opac[i]),  i = idx[r].  One thread per float of the
@@ -42,17 +109,16 @@ __global__ __launch_bounds__(EX_WG) void exchange_rows_kernel(const uint32_t* __
     else *dense = compact[e];
 }
 
-int launch_union_mask(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* mask) {
+// idx[0..count) = ids of the splats whose summed visible flag is > 0, ascending; *count_dev = their number
+int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* block_scratch, uint32_t* count_dev, uint32_t* idx) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(union_mask_kernel, dim3((n + EX_WG - 1) / EX_WG), dim3(EX_WG), 0, ctx->stream, visible_sum, n, mask);
-    BH_LAUNCH_CHECK(ctx, "union_mask_kernel");
-    return 0;
-}
-
-int launch_union_index(bh_ctx* ctx, const uint32_t* mask, const uint32_t* incl, uint32_t n, uint32_t* idx) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(union_index_kernel, dim3((n + EX_WG - 1) / EX_WG), dim3(EX_WG), 0, ctx->stream, mask, incl, n, idx);
-    BH_LAUNCH_CHECK(ctx, "union_index_kernel");
+    const uint32_t nb = (n + EX_TILE - 1) / EX_TILE;
+    hipLaunchKernelGGL(union_count_kernel, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch);
+    BH_LAUNCH_CHECK(ctx, "union_count_kernel");
+    hipLaunchKernelGGL(union_spine_kernel, dim3(1), dim3(EX_WG), 0, ctx->stream, block_scratch, nb, count_dev);
+    BH_LAUNCH_CHECK(ctx, "union_spine_kernel");
+    hipLaunchKernelGGL(union_place_kernel, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch, idx);
+    BH_LAUNCH_CHECK(ctx, "union_place_kernel");
     return 0;
 }
 

@@ -890,9 +890,15 @@ class SplatTrainer:
         pg = self.pg
         world = dist.get_world_size(pg)
 
+        views = {}  # device pointer -> flat float32 view of the longest range summed there so far (only [:count] is touched)
+
         def hook(_user, exch_ptr, sum_count):
             try:
-                allreduce_exchange(_view(exch_ptr, (int(sum_count),), torch.float32, dev), int(sum_count), pg)
+                cnt = int(sum_count)
+                t = views.get(exch_ptr)
+                if t is None or t.numel() < cnt:
+                    t = views[exch_ptr] = _view(exch_ptr, (cnt,), torch.float32, dev)
+                allreduce_exchange(t, cnt, pg)
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1
