@@ -719,6 +719,32 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         if (batch->image_hook(batch->image_hook_user, ro.out_img, H, W, r0, r1) != 0) return set_error(ctx, BH_ERR_STATE, "image hook failed");
     }
 
+    // ---- multi-GPU exchange, part 1 (mask-keyed mode, exchange.hip): the visible flags are final after the forward, so
+    // they are summed, the union of contributing splats is listed and its size starts travelling to the host NOW —
+    // the loss and the backward hide the collective's latency and the readback, and the host finds the count ready
+    const bool tile_mode = batch->image_hook != nullptr;
+    const bool exchanging = hook || (ctx->comm && ctx->comm_world > 1);
+    // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
+    auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
+        if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
+        return comm_allreduce(ctx, p, cnt, false);
+    };
+    const bool keyed = exchanging && !tile_mode && batch->exchange_mode == 1 && n > 0;
+    uint32_t* union_idx = nullptr;
+    float* compact = nullptr;
+    if (keyed) {
+        ProfScope ps(ctx, "FlagExchange");
+        const uint32_t nblk = (n + 4095u) / 4096u;
+        auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
+        union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
+        compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * (11 + 3 * C) * 4);
+        if (!blocks || !union_idx || !compact) return BH_ERR_OOM;
+        BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
+        BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
+        BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+    }
+
     // ---- loss (train.rs:227-260)
     const bool ssim_on = cfg->ssim_weight > 0.0f;
     BhLossConfig lc{};
@@ -752,39 +778,23 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         ProfScope ps(ctx, "FoldMinScaleBackward");
         BH_TRY(launch_fold_min_scale_backward(ctx, st->transforms, st->raw_opacities, st->min_scale, n, g_tr, g_op));
     }
-    // ---- multi-GPU exchange (not in the reference: SURVEY.md §8e) — one SUM over the leading floats
-    const bool tile_mode = batch->image_hook != nullptr;
+    // ---- multi-GPU exchange, part 2 (not in the reference: SURVEY.md §8e)
     stats->exchange_rows = 0;
-    if (hook || (ctx->comm && ctx->comm_world > 1)) {
+    if (exchanging) {
         ProfScope ps(ctx, "GradExchange");
-        // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
-        auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
-            if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
-            return comm_allreduce(ctx, p, cnt, false);
-        };
         if (tile_mode) {
             BH_TRY(sum_over_ranks(exch, (uint64_t)exch_count));
-        } else if (batch->exchange_mode == 1 && n > 0) {
-            // mask-keyed exchange (exchange.hip): flags first, then only the rows some rank saw
+        } else if (keyed) {
+            // only the gradient rows of splats some rank saw (the count was requested right after the forward)
             const uint32_t c3 = 3 * C, k = 11 + c3;
-            BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
-            const uint32_t nblk = (n + 4095u) / 4096u;
-            auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
-            auto* idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
-            auto* compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * k * 4);
-            if (!blocks || !idx || !compact) return BH_ERR_OOM;
-            BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, idx));
-            auto* hc = reinterpret_cast<uint32_t*>(ctx->host_counters);
-            BH_HIP(ctx, hipMemcpyAsync(hc + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
-            BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
             BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
-            const uint32_t rows = hc[8];
+            const uint32_t rows = reinterpret_cast<uint32_t*>(ctx->host_counters)[8];
             if (rows == 0) {
                 // no rank saw any splat: every gradient row is zero everywhere, nothing to send (same decision on all ranks)
             } else if ((uint64_t)rows * 2 <= n) {
-                BH_TRY(launch_exchange_rows(ctx, true, idx, rows, c3, g_tr, g_sh, g_op, compact));
+                BH_TRY(launch_exchange_rows(ctx, true, union_idx, rows, c3, g_tr, g_sh, g_op, compact));
                 BH_TRY(sum_over_ranks(compact, (uint64_t)rows * k));
-                BH_TRY(launch_exchange_rows(ctx, false, idx, rows, c3, g_tr, g_sh, g_op, compact));
+                BH_TRY(launch_exchange_rows(ctx, false, union_idx, rows, c3, g_tr, g_sh, g_op, compact));
                 stats->exchange_rows = rows;
             } else {
                 BH_TRY(sum_over_ranks(exch + o_tr, (uint64_t)(o_ref - o_tr)));
