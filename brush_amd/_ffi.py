@@ -93,7 +93,7 @@ class BhTrainBatch(C.Structure):
     _fields_ = [
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
         ("background", C.c_float * 3), ("noise_samples", C.c_void_p),
-        ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p), ("exchange_mode", C.c_int32),
+        ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p), ("exchange_mode", C.c_int32), ("strip_loss", C.c_int32),
     ]
 
 

@@ -20,6 +20,9 @@ int launch_image_loss_backward_strided(bh_ctx* ctx, const float* pred, uint32_t 
 
 int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
                             bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output);
+int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                                   bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
+                                   float* v_output);
 
 int set_error(bh_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
@@ -762,7 +765,15 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
-    BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output));
+    if (batch->image_hook && batch->strip_loss) {
+        // one frame over several ranks: the hook delivered only the 21-px halos; loss and dL/dimg for this rank's strip
+        // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
+        const ViewUniforms wu = make_uniforms(batch->camera);
+        BH_TRY(launch_image_loss_fused_window(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, wu.tile_y0, wu.tile_y1,
+                                              loss_dev, v_output));
+    } else {
+        BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output));
+    }
 
     // ---- backward (train.rs:278)
     float* g_tr = exch + o_tr;

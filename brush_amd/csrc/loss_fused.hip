@@ -55,6 +55,7 @@ struct FusedArgs {
     float bg[3];
     int composite, mask, alpha_match;
     float dl_rgb, dl_alpha;
+    uint32_t ty_base;  // first tile row this launch covers (blockIdx.y is relative to it): strip-wise loss
     Taps taps;
 };
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
     __shared__ float2 s_tile[3][SH * SH];          // (pred, gt_eff) per colour plane
     __shared__ float s_h[3][SH * LB * 5];          // horizontally blurred moments
     __shared__ float s_red[LB * LB / 64];
-    const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
+    const int tx0 = blockIdx.x * LB, ty0 = (blockIdx.y + a.ty_base) * LB;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * LB + lx;
     for (int i = rank; i < SH * SH; i += LB * LB) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((rank & 63) == 0) s_red[rank >> 6] = acc;
     __syncthreads();
-    if (rank == 0) block_sums[blockIdx.y * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (rank == 0) block_sums[(blockIdx.y + a.ty_base) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
                                                                      float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
     __shared__ float4 s_part[3][SH * SH];      // chain * (dmu1, dsigma1, dsigma12, -)
     __shared__ float4 s_h2[3][SH * LB];
-    const int tx0 = blockIdx.x * LB, ty0 = blockIdx.y * LB;
+    const int tx0 = blockIdx.x * LB, ty0 = (blockIdx.y + a.ty_base) * LB;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * LB + lx;
     for (int i = rank; i < SH * SH; i += LB * LB) {
@@ -294,14 +295,24 @@ __global__ __launch_bounds__(256) void loss_block_sum_kernel(const float* __rest
     if (threadIdx.x == 0) out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
-// loss scalar -> loss_out[0];  dloss/d(out_img) -> v_output [H,W,4] (fully overwritten)
-int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
-                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output) {
-    const dim3 grid((w + LB - 1) / LB, (h + LB - 1) / LB), block(LB, LB);
+// loss scalar -> loss_out[0];  dloss/d(out_img) -> v_output [H,W,4].
+// Whole image: tile_y0 = 0, tile_y1 = ceil(h/16), v_output fully overwritten.
+// Strip-wise (one frame partitioned over ranks): the caller owns tile rows [tile_y0, tile_y1) and has
+// valid image rows for one more tile row plus the 5-px SSIM halo on each side (21 px).  Pass A then also runs on the two
+// neighbouring tile rows (pass B blurs the SSIM partials of rows up to 5 px outside the strip), pass B and the loss sum on
+// the strip only: loss_out is this strip's share of the mean (the ranks' shares add up), v_output is written for the
+// strip's pixels.  Image-border zero padding is unchanged.
+int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                                   bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
+                                   float* v_output) {
+    const uint32_t gx = (w + LB - 1) / LB, gy = (h + LB - 1) / LB;
+    if (tile_y1 > gy) tile_y1 = gy;
+    if (tile_y0 >= tile_y1) return set_error(ctx, BH_ERR_INVALID_ARG, "image loss: empty tile-row window");
+    const uint32_t a0 = tile_y0 > 0 ? tile_y0 - 1 : 0, a1 = tile_y1 < gy ? tile_y1 + 1 : gy;  // pass A window
+    const dim3 block(LB, LB);
     const size_t hw = (size_t)h * w;
-    const int nb = (int)(grid.x * grid.y);
     auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));
-    auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)nb * sizeof(float));
+    auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)gx * gy * sizeof(float));
     if (!partials || !block_sums) return BH_ERR_OOM;
     FusedArgs a;
     a.h = h; a.w = w;
@@ -312,17 +323,25 @@ int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* 
     a.taps = gauss_taps();
     {
         ProfScope ps(ctx, "ImageLoss");
-        hipLaunchKernelGGL(loss_fused_forward_kernel, grid, block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a);
+        a.ty_base = a0;
+        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, a1 - a0), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
-        hipLaunchKernelGGL(loss_block_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, block_sums, nb, loss_out);
+        // the strip's own tiles only (block_sums is indexed by absolute tile row)
+        hipLaunchKernelGGL(loss_block_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, block_sums + (size_t)tile_y0 * gx, (int)((tile_y1 - tile_y0) * gx), loss_out);
         BH_LAUNCH_CHECK(ctx, "loss_block_sum_kernel");
     }
     {
         ProfScope ps(ctx, "ImageLossBackward");
-        hipLaunchKernelGGL(loss_fused_backward_kernel, grid, block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
+        a.ty_base = tile_y0;
+        hipLaunchKernelGGL(loss_fused_backward_kernel, dim3(gx, tile_y1 - tile_y0), block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_backward_kernel");
     }
     return 0;
+}
+
+int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output) {
+    return launch_image_loss_fused_window(ctx, img_hwc4, gt, h, w, cfg, alpha_match, dl_rgb, dl_alpha, 0, (h + LB - 1) / LB, loss_out, v_output);
 }
 
 }  // namespace bh

@@ -14,7 +14,8 @@ import torch
 
 from . import _ffi
 from ._ffi import BrushHipError
-from .parallel import allreduce_exchange, allreduce_refine_maxima, allgather_strips, strip_spans_px, tile_rows_for_rank
+from .parallel import (allreduce_exchange, allreduce_refine_maxima, allgather_strips, exchange_strip_halos, strip_spans_px,
+                       strips_allow_halo_loss, tile_rows_for_rank)
 
 
 # ---------------------------------------------------------------------------
@@ -848,6 +849,11 @@ class SplatTrainer:
         # intersection count, not rows"); 0 keeps equal-height strips
         self.rebalance_every = 8
         self._row_weights = None
+        # partition == "tiles": evaluate the loss strip-wise (each rank on its own rows, 21-px halos from the neighbours)
+        # instead of all-gathering the frame and computing the whole loss everywhere; TrainStepStats.loss is then this
+        # rank's share of the frame's loss (reduce_loss() sums the shares)
+        self.strip_loss = True
+        self._strip_loss_now = False
 
     MIN_SCALE_FACTOR = 0.1       # train.rs:44
     MIN_SCALE_FREEZE_FRAC = 0.9  # train.rs:37
@@ -912,7 +918,11 @@ class SplatTrainer:
             try:
                 img = _view(img_ptr, (int(h), int(w), 4), torch.float32, dev)
                 import torch.distributed as dist
-                allgather_strips(img, int(r0), int(r1), pg, spans=strip_spans_px(int(h), dist.get_world_size(pg), self._row_weights))
+                spans = strip_spans_px(int(h), dist.get_world_size(pg), self._row_weights)
+                if self._strip_loss_now:
+                    exchange_strip_halos(img, spans, dist.get_rank(pg), pg)
+                else:
+                    allgather_strips(img, int(r0), int(r1), pg, spans=spans)
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1
@@ -958,6 +968,8 @@ class SplatTrainer:
             if self._img_hook is None:
                 self._img_hook = self._make_image_hook(dev)
             b.image_hook = C.cast(self._img_hook, C.c_void_p)
+            self._strip_loss_now = bool(self.strip_loss) and strips_allow_halo_loss(strip_spans_px(h, dist.get_world_size(self.pg), self._row_weights))
+            b.strip_loss = int(self._strip_loss_now)
         gt = _as_u32(batch.img_packed, dev)
         b.gt_packed = gt.data_ptr()
         b.has_alpha, b.alpha_is_mask = int(batch.has_alpha), int(batch.alpha_is_mask)
@@ -1070,6 +1082,16 @@ class SplatTrainer:
         stats = RefineStats(rs.num_added, rs.num_split_oversized, rs.num_split_high_grad, rs.num_pruned, rs.num_pruned_non_finite,
                             rs.total_splats, rs.num_resampled)
         return new, stats
+
+    def reduce_loss(self, stats: "TrainStepStats") -> float:
+        """Tile-partitioned frame with the strip-wise loss: every rank holds its strip's share of the frame's loss;
+        this sums the shares (a collective: call it on every rank).  Otherwise returns stats.loss."""
+        if self.pg is not None and self.partition == "tiles" and self._strip_loss_now:
+            import torch.distributed as dist
+            t = torch.tensor([stats.loss], dtype=torch.float64, device=self.state["m2_o"].device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            return float(t.item())
+        return stats.loss
 
     def stats(self, ctx=None) -> TrainStepStats:
         """Resolve the stats of the last step (synchronises)."""

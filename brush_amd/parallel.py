@@ -109,3 +109,36 @@ def allgather_strips(img: torch.Tensor, row_begin_px: int, row_end_px: int, grou
     for r, (b, e) in enumerate(spans):
         if r != dist.get_rank(group):
             flat[b:e] = recv[r, : (e - b) * row_elems].view(e - b, row_elems)
+
+
+STRIP_HALO_PX = 21  # one 16-px tile row + the 5-px reach of the 11-tap SSIM window (brush_amd/csrc/loss_fused.hip)
+
+
+def exchange_strip_halos(img: torch.Tensor, spans, rank: int, group=None, halo: int = STRIP_HALO_PX):
+    """In place on img [H,W,C]: fetch the `halo` pixel rows just above and just below this rank's strip from the
+    neighbouring ranks (strip-wise loss, SURVEY.md §8e: "exchange 5 rows with neighbours" — 21 here because the loss
+    kernels work in whole tile rows).  One all_gather_into_tensor of [2, halo, W, C] per rank instead of the whole
+    image.  Every strip must be at least `halo` rows tall (callers fall back to allgather_strips otherwise)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    h = img.shape[0]
+    b, e = spans[rank]
+    send = torch.zeros((2, halo) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device)
+    send[0, : min(halo, e - b)] = img[b: min(b + halo, e)]
+    send[1, halo - min(halo, e - b):] = img[max(e - halo, b): e]
+    recv = torch.empty(world * send.numel(), dtype=img.dtype, device=img.device)
+    dist.all_gather_into_tensor(recv, send.view(-1), group=group)
+    recv = recv.view((world,) + tuple(send.shape))
+    if rank > 0:                       # rows [b - halo, b) = the last rows of the strip above
+        k = min(halo, b)
+        img[b - k: b] = recv[rank - 1, 1, halo - k:]
+    if rank < world - 1 and e < h:     # rows [e, e + halo) = the first rows of the strip below
+        k = min(halo, h - e, spans[rank + 1][1] - spans[rank + 1][0])
+        img[e: e + k] = recv[rank + 1, 0, :k]
+
+
+def strips_allow_halo_loss(spans, halo: int = STRIP_HALO_PX):
+    """The strip-wise loss needs every neighbour to own at least `halo` rows (else a halo would span two ranks)."""
+    return all(e - b >= halo for b, e in spans)

@@ -263,7 +263,8 @@ typedef struct BhTrainState {
 
 /* Image hook: called (if non-NULL) after the forward render and before the loss with the
  * ctx-owned out_img [H,W,4]; a tile-partitioned caller all-gathers the strips of the other
- * ranks into it (pixel rows [row_begin_px, row_end_px) are this rank's).  Return 0. */
+ * ranks into it (pixel rows [row_begin_px, row_end_px) are this rank's) — or, with
+ * BhTrainBatch.strip_loss, just the 21 rows on either side of its strip.  Return 0. */
 typedef int (*bh_image_hook)(void* user, float* out_img, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px);
 
 typedef struct BhTrainBatch {
@@ -284,6 +285,11 @@ typedef struct BhTrainBatch {
      * order inside the collective; per view only the splats that reached a pixel carry a gradient, so the message is
      * typically several times smaller.  Costs one more 4-byte readback per step. */
     int32_t exchange_mode;
+    /* Tile-partitioned frame only (image_hook set).  0: the hook all-gathers the whole image and every rank evaluates the
+     * loss on all of it.  1: strip-wise loss — the hook only has to deliver the image rows within 21 px (one tile row + the
+     * 5-px SSIM window) above and below this rank's strip; the loss kernels run on the strip (pass A one tile row wider),
+     * BhTrainStats.loss is the strip's share of the frame's mean loss (sum the ranks' values). */
+    int32_t strip_loss;
 } BhTrainBatch;
 
 typedef struct BhTrainStats {

@@ -106,6 +106,44 @@ def test_allgather_strips_world2():
         assert spans == [(0, 80), (80, 150)]
 
 
+def _halo_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brush_amd.parallel import STRIP_HALO_PX, exchange_strip_halos, strip_spans_px, strips_allow_halo_loss
+    h, w = 150, 23   # 10 tile rows over 3 ranks: strips of 4 / 3 / 3 tile rows, the last cut to 22 px by the image edge
+    full = torch.arange(h * w * 4, dtype=torch.float32).reshape(h, w, 4)
+    spans = strip_spans_px(h, world)
+    b, e = spans[rank]
+    img = torch.full((h, w, 4), -1.0)
+    img[b:e] = full[b:e]
+    exchange_strip_halos(img, spans, rank)
+    lo, hi = max(b - STRIP_HALO_PX, 0), min(e + STRIP_HALO_PX, h)
+    ok = bool(torch.equal(img[lo:hi], full[lo:hi]))                       # strip + both halos hold the frame's rows
+    untouched = bool((img[:lo] == -1).all() and (img[hi:] == -1).all())   # nothing else was written
+    q.put((rank, ok, untouched, spans, strips_allow_halo_loss(spans)))
+    dist.destroy_process_group()
+
+
+def test_strip_halo_exchange_world3():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ok, untouched, spans, allowed in res:
+        assert ok and untouched and allowed
+        assert spans == [(0, 64), (64, 112), (112, 150)]
+    from brush_amd.parallel import strips_allow_halo_loss
+    assert not strips_allow_halo_loss([(0, 16), (16, 112)])    # a 1-tile-row strip cannot serve a 21-px halo
+
+
 def test_tile_row_partition_properties():
     from brush_amd.parallel import tile_rows_for_rank
     for tile_bh in (1, 7, 68, 135):

@@ -75,7 +75,7 @@ def test_strip_gradients_sum_to_the_full_gradients(dev):
         assert float((v - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-12, k
 
 
-def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2):
+def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_loss=True):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -88,25 +88,32 @@ def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2):
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
     trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, partition=partition)
     trainer.rebalance_every = rebalance_every
+    trainer.strip_loss = strip_loss
     batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
-    losses = []
+    losses, shares = [], []
     for _ in range(steps):
         trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
-        losses.append(trainer.stats().loss)
+        st = trainer.stats()
+        shares.append((st.loss, trainer._strip_loss_now))
+        losses.append(trainer.reduce_loss(st))     # strip-wise loss: the ranks' shares sum to the frame's loss
     trainer.sync_refine_stats()  # max_screen_size is strip-local until refine asks for it
     q.put((rank, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(), losses,
            trainer.state["vis_weight"].cpu().numpy(), trainer.state["max_screen_size"].cpu().numpy(),
-           trainer.state["refine_weight_norm"].cpu().numpy(), trainer._row_weights))
+           trainer.state["refine_weight_norm"].cpu().numpy(), trainer._row_weights, shares))
     dist.destroy_process_group()
 
 
-def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
+@pytest.mark.parametrize("strip_loss", [True, False])
+def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev, strip_loss):
+    """strip_loss: each rank evaluates L1 + SSIM on its own strip after fetching 21-px halos from its neighbour (no
+    whole-image all-gather); otherwise every rank gathers the frame and evaluates the whole loss.  Both must follow the
+    single-GPU trajectory."""
     import brush_amd as ba
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tiles")) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tiles", 8, 2, strip_loss)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
@@ -115,6 +122,11 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev):
         assert p.exitcode == 0
     r0, r1 = res
     assert r0[8] is None                     # 2 steps < rebalance_every: equal-height strips throughout
+    if strip_loss:   # both strips (64 and 48 px) are taller than the halo: the strip-wise path ran, each rank holds a share
+        assert all(on for _, on in r0[9]) and all(on for _, on in r1[9])
+        assert all(0.0 < a[0] and 0.0 < b[0] and abs(a[0] - b[0]) > 1e-6 for a, b in zip(r0[9], r1[9]))
+    else:
+        assert not any(on for _, on in r0[9]) and [a[0] for a in r0[9]] == [b[0] for b in r1[9]]
     for a, b in zip(r0[1:8], r1[1:8]):  # replicas identical
         assert np.array_equal(np.asarray(a), np.asarray(b))
     # single-GPU reference on this process
