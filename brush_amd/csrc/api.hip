@@ -19,10 +19,20 @@ int launch_image_loss_backward_strided(bh_ctx* ctx, const float* pred, uint32_t 
                                        const BhLossConfig& cfg, float* dl_dpred);
 
 int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
-                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output);
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host = nullptr);
 int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
                                    bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
-                                   float* v_output);
+                                   float* v_output, float* loss_host = nullptr);
+
+// grid-stride clear of two float4 spans in one launch
+__global__ __launch_bounds__(256) void zero_two_kernel(float4* __restrict__ a, size_t na, float4* __restrict__ b, size_t nb) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += stride) {
+        if (i < na) a[i] = z;
+        else b[i - na] = z;
+    }
+}
 
 int set_error(bh_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->last_error = msg;
@@ -162,13 +172,13 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         }
         ctx->owns_stream = true;
     }
-    if (hipHostMalloc((void**)&ctx->host_counters, 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&ctx->host_counters, bh::HOST_COUNTERS_BYTES, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return nullptr;
     }
-    std::memset(ctx->host_counters, 0, 64);
+    std::memset(ctx->host_counters, 0, bh::HOST_COUNTERS_BYTES);
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipHostFree(ctx->host_counters);
@@ -394,7 +404,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const uint32_t num_tiles = u.tile_bw * u.tile_bh;
     const size_t npad = n ? n : 1;
 
-    auto* counters = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 16);
+    // two counter pairs: K1 accumulates into one and clears the other for the next forward (no fill launch)
+    constexpr size_t counter_set_bytes = COUNTER_SLOTS * 16, counter_set_words = COUNTER_SLOTS * 4;
+    auto* counter_pairs = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 2 * counter_set_bytes);
+    uint32_t* counters = counter_pairs ? counter_pairs + counter_set_words * (ctx->counter_phase & 1u) : nullptr;
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
     auto* isect_counts = (uint32_t*)ensure(ctx, SLOT_ISECT_COUNTS, npad * 4);
     auto* max_radius = ctx->ext_max_radius ? ctx->ext_max_radius : (float*)ensure(ctx, SLOT_MAX_RADIUS, npad * 4);
@@ -404,20 +417,35 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
     auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
     if (!gfc || !depths_sorted) return BH_ERR_OOM;
+    // [T,2] offsets | 8*16 work-class counters | [8][16][ceil(T/8)] class lists (longest-first tile order of the backward)
+    const size_t lpt_words = 8 * 16 + (size_t)8 * 16 * ((num_tiles + 7) / 8);
+    auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
+    auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
+    if (!tile_offsets || !visible) return BH_ERR_OOM;
+    const size_t visible_words = bwd_info ? ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) : 0;
 
     uint32_t nv = 0, ni = 0;
     if (n > 0) {
         {
             ProfScope ps(ctx, "ProjectSplats");
-            BH_HIP(ctx, hipMemsetAsync(counters, 0, 16, ctx->stream));
+            if (!ctx->counters_ready) BH_HIP(ctx, hipMemsetAsync(counter_pairs, 0, 2 * counter_set_bytes, ctx->stream));
+            ctx->counters_ready = false;
+            ForwardPrep prep;
+            prep.next_counters = reinterpret_cast<unsigned long long*>(counter_pairs + counter_set_words * ((ctx->counter_phase & 1u) ^ 1u));
+            prep.visible = visible_words ? reinterpret_cast<uint32_t*>(visible) : nullptr;
+            prep.visible_words = (uint32_t)visible_words;
+            prep.tile_table = tile_offsets;
+            prep.tile_words = num_tiles * 2 + 8 * 16;
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
-                                          proj_by_gid, counters));
+                                          proj_by_gid, counters, prep));
+            ctx->counter_phase ^= 1u;
+            ctx->counters_ready = true;
         }
         // the one mid-pipeline readback (render.rs:146-168).  The depth sort covers all n splats
         // and needs neither count, so it is queued behind the copy BEFORE the host waits: the GPU
         // sorts while the host reads the counts, sizes the buffers and queues the rest.
-        auto* hc = reinterpret_cast<unsigned long long*>(ctx->host_counters);
-        BH_HIP(ctx, hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+        auto* hslots = reinterpret_cast<unsigned long long*>(ctx->host_counters + 16);
+        BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_set_bytes, hipMemcpyDeviceToHost, ctx->stream));
         BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
         {
             ProfScope ps(ctx, "DepthSort");
@@ -426,9 +454,14 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
         }
         BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+        unsigned long long hc[2] = {0ull, 0ull};
+        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { hc[0] += hslots[2 * k]; hc[1] += hslots[2 * k + 1]; }
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
         nv = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
+    } else {   // no K1 to clear them on the way
+        BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
+        if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
     }
 
     const size_t nvpad = nv ? nv : 1, nipad = ni ? ni : 1;
@@ -438,14 +471,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* isect_gids = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS, nipad * 4);
     auto* tile_ids_sorted = (uint32_t*)ensure(ctx, SLOT_TILE_IDS_SORTED, nipad * 4);
     auto* isect_gids_sorted = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS_SORTED, nipad * 4);
-    // [T,2] offsets | 8*16 work-class counters | [8][16][ceil(T/8)] class lists (longest-first tile order of the backward)
-    const size_t lpt_words = 8 * 16 + (size_t)8 * 16 * ((num_tiles + 7) / 8);
-    auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     const size_t pixels = (size_t)u.img_w * u.img_h;
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
-    auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
-    if (!cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted ||
-        !tile_offsets || !out_img || !visible)
+    if (!cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted || !out_img)
         return BH_ERR_OOM;
 
     if (nv > 0) {
@@ -472,11 +500,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     }
     {
         ProfScope ps(ctx, "GetTileOffsets");
-        BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets));
+        BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets, /*pre_zeroed=*/true));   // K1 cleared the table (or a fill did, for n == 0)
     }
     {
-        if (bwd_info) BH_HIP(ctx, hipMemsetAsync(visible, 0, ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) * 4, ctx->stream));
-        ProfScope ps(ctx, "Rasterize");
+        ProfScope ps(ctx, "Rasterize");   // `visible` was cleared by K1 as well
         // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
         const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
         const float class_width = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
@@ -530,14 +557,23 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     const BhRenderOut& r = ctx->last;
     const uint32_t n = ctx->n, nv = r.num_visible, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
     const size_t nvpad = nv ? nv : 1;
-    auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4);
+    auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4 + 16);   // + room to clear whole float4s
     if (!v_combined) return BH_ERR_OOM;
     {
         ProfScope ps(ctx, "ZeroGradBuffers");
+        const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
+        if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
+            // the train step: v_combined and the exchange buffer's gradient span cleared by ONE launch (hipMemsetAsync
+            // spends two or three launches on them, each ~5 us of latency beyond the bytes)
+            const size_t na = (nvpad * 10 + 3) / 4, nb = ctx->ext_grad_floats / 4;
+            hipLaunchKernelGGL(zero_two_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(v_combined), na,
+                               reinterpret_cast<float4*>(v_transforms), nb);
+            BH_LAUNCH_CHECK(ctx, "zero_two_kernel");
+        } else {
         BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
         if (n > 0) {
             // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
-            if (ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats) {
+            if (one_span) {
                 // the train step's exchange buffer: one fill instead of four
                 BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, ctx->ext_grad_floats * 4, ctx->stream));
             } else {
@@ -546,6 +582,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
                 BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
                 BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
             }
+        }
         }
     }
     {
@@ -762,6 +799,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     auto* v_output = (float*)ensure(ctx, SLOT_V_OUTPUT, hw * 16);
     auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
     if (!v_output || !loss_dev) return BH_ERR_OOM;
+    // the loss scalar goes straight into pinned host memory (bh_sync hands it to stats->loss): no copy launch
+    float* loss_host = reinterpret_cast<float*>(ctx->host_counters) + 15;
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
@@ -770,9 +809,9 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
         const ViewUniforms wu = make_uniforms(batch->camera);
         BH_TRY(launch_image_loss_fused_window(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, wu.tile_y0, wu.tile_y1,
-                                              loss_dev, v_output));
+                                              loss_dev, v_output, loss_host));
     } else {
-        BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output));
+        BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host));
     }
 
     // ---- backward (train.rs:278)
@@ -844,9 +883,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     stats->num_visible = ro.num_visible;
     stats->num_intersections = ro.num_intersections;
     stats->lr_mean = lr_mean;
-    // device -> pinned staging (truly asynchronous: a copy into the caller's pageable struct would
+    // the loss kernel wrote the scalar into pinned staging (a copy into the caller's pageable struct would
     // stall the host until the whole step has run); bh_sync moves it into stats->loss
-    BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<float*>(ctx->host_counters) + 15, loss_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending_loss_dst = &stats->loss;
     stats->loss = 0.0f;
     return 0;

@@ -16,7 +16,7 @@ namespace bh {
 // training loop performs no hipMalloc/hipFree (the reference allocates ~20
 // buffers per render, render.rs:104-268).
 enum Slot : int {
-    SLOT_COUNTERS = 0,       // [4] u32: num_visible, num_intersections
+    SLOT_COUNTERS = 0,       // 2 (ping-pong) x [COUNTER_SLOTS][2] u64: partial num_visible, num_intersections
     SLOT_DEPTH_KEYS,         // [N] u32 depth bits / sentinel
     SLOT_ISECT_COUNTS,       // [N] u32
     SLOT_MAX_RADIUS,         // [N] f32
@@ -86,8 +86,10 @@ struct bh_ctx {
     bool owns_stream = false;
     std::string last_error;
     bh::Buffer slots[bh::SLOT_COUNT];
-    uint32_t* host_counters = nullptr;  // pinned [4]
+    uint32_t* host_counters = nullptr;  // pinned, HOST_COUNTERS_BYTES
     hipEvent_t readback_ev = nullptr;   // marks the count readback of the forward (the depth sort is queued behind it)
+    bool counters_ready = false;        // the counter pair the next forward accumulates into is known to be zero
+    uint32_t counter_phase = 0;         // which half of SLOT_COUNTERS that is
     // state of the last forward (what RenderBackwards saves, bwd/burn_glue.rs:336-371)
     bool have_forward = false;
     BhCamera cam{};
@@ -143,9 +145,21 @@ ViewUniforms make_uniforms(const BhCamera& c);
 
 // ---- launchers (each in its own TU) --------------------------------------------
 // project.hip
+// K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
+constexpr uint32_t COUNTER_SLOTS = 128;
+constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_SLOTS * 16;   // [16] u32 scalars (loss, refine, exchange rows) | the counter slots
+
+// Buffers K1 clears on the way (every splat thread stores a few zeros: three fill launches fewer per forward).
+struct ForwardPrep {
+    unsigned long long* next_counters = nullptr;  // the idle half of the counter ping-pong, cleared for the next forward
+    uint32_t* visible = nullptr;                  // visible flags (K16 sets them), or NULL
+    uint32_t visible_words = 0;
+    uint32_t* tile_table = nullptr;               // tile_offsets + the work-class counters behind it
+    uint32_t tile_words = 0;
+};
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters);
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
                          const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
@@ -160,7 +174,7 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive);
 // rasterize.hip
 int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
-                        uint32_t* tile_offsets);
+                        uint32_t* tile_offsets, bool pre_zeroed = false);
 // lpt: the longest-first tile order scratch (8*16 counters directly behind tile_offsets, then the class lists); NULL = index order
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,

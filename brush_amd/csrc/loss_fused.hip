@@ -56,6 +56,12 @@ struct FusedArgs {
     int composite, mask, alpha_match;
     float dl_rgb, dl_alpha;
     uint32_t ty_base;  // first tile row this launch covers (blockIdx.y is relative to it): strip-wise loss
+    // pass B's first block also adds up pass A's per-block loss partials (a separate one-block launch costs 9 us of
+    // latency; here the sum rides beside 2000 other blocks)
+    const float* sum_src;
+    int sum_n;
+    float* loss_out;   // device scalar
+    float* loss_host;  // pinned host scalar or NULL: the train step's loss lands there without a copy launch
     Taps taps;
 };
 
@@ -210,6 +216,20 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
     const int tx0 = blockIdx.x * LB, ty0 = (blockIdx.y + a.ty_base) * LB;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * LB + lx;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {   // block-uniform
+        __shared__ float s_w[4];
+        float acc = 0.0f;
+        for (int i = rank; i < a.sum_n; i += LB * LB) acc += a.sum_src[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if ((rank & 63) == 0) s_w[rank >> 6] = acc;
+        __syncthreads();
+        if (rank == 0) {
+            const float total = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            a.loss_out[0] = total;
+            if (a.loss_host) a.loss_host[0] = total;
+        }
+    }
     for (int i = rank; i < SH * SH; i += LB * LB) {
         const int r = i / SH, q = i - r * SH;
         const int y = ty0 + r - HALO, x = tx0 + q - HALO;
@@ -284,17 +304,6 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
     *reinterpret_cast<float4*>(&v_output[p * 4]) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
-__global__ __launch_bounds__(256) void loss_block_sum_kernel(const float* __restrict__ block_sums, int nb, float* __restrict__ out) {
-    __shared__ float s_w[4];
-    float acc = 0.0f;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += block_sums[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
-
 // loss scalar -> loss_out[0];  dloss/d(out_img) -> v_output [H,W,4].
 // Whole image: tile_y0 = 0, tile_y1 = ceil(h/16), v_output fully overwritten.
 // Strip-wise (one frame partitioned over ranks): the caller owns tile rows [tile_y0, tile_y1) and has
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void loss_block_sum_kernel(const float* __rest
 // strip's pixels.  Image-border zero padding is unchanged.
 int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
                                    bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
-                                   float* v_output) {
+                                   float* v_output, float* loss_host) {
     const uint32_t gx = (w + LB - 1) / LB, gy = (h + LB - 1) / LB;
     if (tile_y1 > gy) tile_y1 = gy;
     if (tile_y0 >= tile_y1) return set_error(ctx, BH_ERR_INVALID_ARG, "image loss: empty tile-row window");
@@ -324,15 +333,18 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
     {
         ProfScope ps(ctx, "ImageLoss");
         a.ty_base = a0;
+        a.sum_src = nullptr; a.sum_n = 0; a.loss_out = nullptr; a.loss_host = nullptr;
         hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, a1 - a0), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
-        // the strip's own tiles only (block_sums is indexed by absolute tile row)
-        hipLaunchKernelGGL(loss_block_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, block_sums + (size_t)tile_y0 * gx, (int)((tile_y1 - tile_y0) * gx), loss_out);
-        BH_LAUNCH_CHECK(ctx, "loss_block_sum_kernel");
     }
     {
         ProfScope ps(ctx, "ImageLossBackward");
         a.ty_base = tile_y0;
+        // the loss = the strip's own tiles only (block_sums is indexed by absolute tile row)
+        a.sum_src = block_sums + (size_t)tile_y0 * gx;
+        a.sum_n = (int)((tile_y1 - tile_y0) * gx);
+        a.loss_out = loss_out;
+        a.loss_host = loss_host;
         hipLaunchKernelGGL(loss_fused_backward_kernel, dim3(gx, tile_y1 - tile_y0), block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_backward_kernel");
     }
@@ -340,8 +352,8 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
 }
 
 int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
-                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output) {
-    return launch_image_loss_fused_window(ctx, img_hwc4, gt, h, w, cfg, alpha_match, dl_rgb, dl_alpha, 0, (h + LB - 1) / LB, loss_out, v_output);
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host) {
+    return launch_image_loss_fused_window(ctx, img_hwc4, gt, h, w, cfg, alpha_match, dl_rgb, dl_alpha, 0, (h + LB - 1) / LB, loss_out, v_output, loss_host);
 }
 
 }  // namespace bh

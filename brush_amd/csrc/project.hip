@@ -127,11 +127,15 @@ template <bool MIP, bool PINHOLE, int DEG>
 __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ coeffs,
     const float* __restrict__ raw_opacities, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts,
-    float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters) {
+    float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters, ForwardPrep prep) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
     const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
+    // housekeeping for the kernels behind this one (coalesced stores; nobody reads these buffers before K1 retires)
+    if (gid < prep.visible_words) prep.visible[gid] = 0u;
+    if (gid < prep.tile_words) prep.tile_table[gid] = 0u;
+    if (gid < 2u * COUNTER_SLOTS && prep.next_counters) prep.next_counters[gid] = 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t key = 0xFFFFFFFFu;
     float radius = 0.0f;
@@ -179,7 +183,11 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             visible = true;
         } while (false);
     }
+#ifdef BH_K1_NO_PROJ  // measurement-only variant
+    if (visible && mx == 123.456f) {
+#else
     if (visible) {  // project_visible.rs:56-87
+#endif
         const Vec3A v = normalize(sub(mean, camera_pos(u)));
         constexpr int C = (DEG + 1) * (DEG + 1);
         const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
@@ -198,14 +206,21 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
+#ifdef BH_K1_NO_WALK  // measurement-only variant
+    const uint32_t tiles_hit = nb;
+    (void)w;
+#else
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); });
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
+#endif
     if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
         max_radius[gid] = radius;
     }
-    // block totals -> two global atomics per block (the reference does two per splat)
+    // block totals -> two global atomics per block (the reference does two per splat), spread over COUNTER_SLOTS
+    // (visible, hits) pairs that the host adds up: 7814 atomics on ONE pair of addresses serialise at ~7 ns each on
+    // this chip (cross-XCD atomics execute at the memory side) and held the kernel's retirement back by 53 us
     const unsigned long long ball = __ballot(visible);
     uint32_t wave_hits = tiles_hit;
 #pragma unroll
@@ -219,21 +234,26 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         uint32_t v = 0, h = 0;
 #pragma unroll
         for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; }
-        if (v) atomicAdd(&counters[0], (unsigned long long)v);
-        if (h) atomicAdd(&counters[1], (unsigned long long)h);
+#ifdef BH_K1_NO_ATOMIC  // measurement-only variant
+        if (v == 0xFFFFFFFFu) counters[0] = h;
+#else
+        unsigned long long* slot = counters + 2u * (blockIdx.x & (COUNTER_SLOTS - 1u));
+        if (v) atomicAdd(&slot[0], (unsigned long long)v);
+        if (h) atomicAdd(&slot[1], (unsigned long long)h);
+#endif
     }
 }
 
 template <bool MIP, bool PINHOLE>
 static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_t deg, const float* t, const float* sh, const float* ro,
-                         uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64) {
+                         uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64, const ForwardPrep& prep) {
     const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
-        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
-        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
-        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
-        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64); break;
+        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
+        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
+        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
+        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
+        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
@@ -242,14 +262,28 @@ static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_
 
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters) {
-    if (n == 0) return 0;
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& want) {
+    // what the grid cannot cover (tiny scenes under a large tile table, n == 0) is cleared with plain fills
+    ForwardPrep prep = want;
+    const size_t covered = (size_t)((n + PROJ_WG - 1) / PROJ_WG) * PROJ_WG;
+    if (prep.visible && prep.visible_words > covered) {
+        BH_HIP(ctx, hipMemsetAsync(prep.visible, 0, (size_t)prep.visible_words * 4, ctx->stream));
+        prep.visible_words = 0;
+    }
+    if (prep.tile_table && prep.tile_words > covered) {
+        BH_HIP(ctx, hipMemsetAsync(prep.tile_table, 0, (size_t)prep.tile_words * 4, ctx->stream));
+        prep.tile_words = 0;
+    }
+    if (n == 0) {
+        if (prep.next_counters) BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SLOTS * 16, ctx->stream));
+        return 0;
+    }
     auto* c64 = reinterpret_cast<unsigned long long*>(counters);
     const bool pinhole = u.model == CAM_PINHOLE;
-    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
-    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
-    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
-    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64);
+    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
+    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
+    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
+    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,9 +45,10 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
 }
 
 int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
-                        uint32_t* tile_offsets) {
+                        uint32_t* tile_offsets, bool pre_zeroed) {
     // the 8 x 16 work-class counters of the backward's tile order sit right behind the table: one fill clears both
-    BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
+    // (pre_zeroed: the forward's K1 already did, project.hip ForwardPrep)
+    if (!pre_zeroed) BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
     if (num_isect == 0) return 0;
     hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 255) / 256), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets);
     BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");

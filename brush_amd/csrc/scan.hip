@@ -5,7 +5,9 @@
 // inclusive).  The reference runs a 512-wide Hillis-Steele per block with 18
 // barriers and a recursive block-sum pyramid (kernels.rs:20-73).  Here: 4096
 // elements per 256-thread block, 16 per thread in registers, wave64 shuffle scans,
-// one spine pass over the block sums: reduce -> spine -> apply (12 B/element).
+// one spine pass over the block sums: reduce -> spine -> apply (12 B/element).  Up to SELF_SPINE_MAX blocks
+// (4 M elements) the apply kernel sums the block totals in front of it itself — one coalesced load per
+// thread — and the one-block spine launch (5 us of pure latency on this chip) disappears: reduce -> apply.
 // The gather variant fuses `int_gather(intersect_counts, gid)` (render.rs:185).
 #include "context.h"
 
@@ -99,13 +101,24 @@ __global__ __launch_bounds__(SCAN_WG) void scan_spine_kernel(uint32_t* __restric
 // stride-17 (conflict-free) LDS access while the global side stays coalesced.
 BH_DEV uint32_t scan_pad(uint32_t e) { return e + (e >> 4); }
 
-template <bool GATHER, bool EXCLUSIVE>
+constexpr uint32_t SELF_SPINE_MAX = 4 * SCAN_WG;
+
+// SELF_SPINE: `sums` holds the raw block totals (gridDim.x <= SELF_SPINE_MAX); otherwise their exclusive prefix
+template <bool GATHER, bool EXCLUSIVE, bool SELF_SPINE>
 __global__ __launch_bounds__(SCAN_WG) void scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather,
                                                             uint32_t n, const uint32_t* __restrict__ sums,
                                                             uint32_t* __restrict__ out) {
     __shared__ uint32_t s_wave[SCAN_WG / 64];
     __shared__ uint32_t s_tile[SCAN_TILE + SCAN_TILE / 16];
     const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t ahead = 0;   // this thread's share of the totals of the blocks in front
+    if (SELF_SPINE) {
+#pragma unroll
+        for (uint32_t k = 0; k < SELF_SPINE_MAX / SCAN_WG; ++k) {
+            const uint32_t i = k * SCAN_WG + threadIdx.x;
+            if (i < blockIdx.x) ahead += sums[i];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < SCAN_EPT; ++j) {
         const uint32_t e = j * SCAN_WG + threadIdx.x;
@@ -122,7 +135,13 @@ __global__ __launch_bounds__(SCAN_WG) void scan_apply_kernel(const uint32_t* __r
         tsum += v[j];
     }
     uint32_t total;
-    uint32_t run = (sums ? sums[blockIdx.x] : 0u) + block_excl_scan(tsum, total, s_wave);
+    uint32_t carry;
+    if (SELF_SPINE) {
+        block_excl_scan(ahead, carry, s_wave);   // carry <- block-wide sum of `ahead`
+    } else {
+        carry = sums ? sums[blockIdx.x] : 0u;
+    }
+    uint32_t run = carry + block_excl_scan(tsum, total, s_wave);
 #pragma unroll
     for (int j = 0; j < SCAN_EPT; ++j) {
         const uint32_t o = EXCLUSIVE ? run : run + v[j];
@@ -147,13 +166,20 @@ static int scan_impl(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, ui
         if (!sums) return BH_ERR_OOM;
         hipLaunchKernelGGL(scan_reduce_kernel<GATHER>, dim3(nb), dim3(SCAN_WG), 0, ctx->stream, in, gather, n, sums);
         BH_LAUNCH_CHECK(ctx, "scan_reduce_kernel");
-        hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_WG), 0, ctx->stream, sums, nb);
-        BH_LAUNCH_CHECK(ctx, "scan_spine_kernel");
+        if (nb > SELF_SPINE_MAX) {
+            hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_WG), 0, ctx->stream, sums, nb);
+            BH_LAUNCH_CHECK(ctx, "scan_spine_kernel");
+        }
     }
-    if (exclusive)
-        hipLaunchKernelGGL((scan_apply_kernel<GATHER, true>), dim3(nb), dim3(SCAN_WG), 0, ctx->stream, in, gather, n, sums, out);
-    else
-        hipLaunchKernelGGL((scan_apply_kernel<GATHER, false>), dim3(nb), dim3(SCAN_WG), 0, ctx->stream, in, gather, n, sums, out);
+    const bool self_spine = nb > 1 && nb <= SELF_SPINE_MAX;
+    const dim3 grid(nb), block(SCAN_WG);
+    if (self_spine) {
+        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+    } else {
+        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+    }
     BH_LAUNCH_CHECK(ctx, "scan_apply_kernel");
     return 0;
 }

@@ -207,7 +207,10 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
                   uint32_t* out_keys, uint32_t* out_vals) {
     if (bits > 32) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: bits must be <= 32");
     if (n == 0) return 0;
+    // digits of equal width: 13-bit tile ids sort as 7 + 6 bits, not 8 + 5 — the wider a pass, the shorter the digit runs
+    // a block writes (4096 keys over 256 digits = 64-byte bursts; over 128 digits = 128-byte bursts)
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
+    const uint32_t base_w = bits / passes, wide = bits % passes;   // the first `wide` passes take one extra bit
     const uint32_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t bytes = (size_t)n * 4;
     // [256] digit totals followed by the [256][nblocks] table
@@ -241,9 +244,9 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
             dst_k = out_keys;
             dst_v = out_vals;
         }
-        const uint32_t shift = p * 8;
-        const uint32_t rem = bits - (shift < bits ? shift : bits);
-        const uint32_t mask = rem >= 8 ? 0xFFu : ((1u << rem) - 1u);
+        const uint32_t width = base_w + (p < wide ? 1u : 0u);
+        const uint32_t shift = p * base_w + (p < wide ? p : wide);
+        const uint32_t mask = (1u << width) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
         BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
         if (rowscan) {
