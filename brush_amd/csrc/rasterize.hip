@@ -26,20 +26,35 @@ namespace bh {
 // ---------------------------------------------------------------------------
 // K15: get_tile_offsets (get_tile_offset.rs:11-58)
 // ---------------------------------------------------------------------------
+// Four consecutive intersections per thread (one 16-byte load + the element in front of them).
 __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ tile_ids, uint32_t num_isect,
                                                           uint32_t num_tiles, uint32_t* __restrict__ tile_offsets) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= num_isect) return;
-    const uint32_t tid = tile_ids[i];
-    if (tid >= num_tiles) return;  // sentinel rows
-    if (i == num_isect - 1) tile_offsets[tid * 2 + 1] = i + 1;
-    if (i == 0) {
-        tile_offsets[tid * 2] = 0;
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4u;
+    if (i0 >= num_isect) return;
+    uint32_t t[4];
+    if (i0 + 4u <= num_isect) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&tile_ids[i0]);
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     } else {
-        const uint32_t prev = tile_ids[i - 1];
-        if (tid != prev) {
-            if (prev < num_tiles) tile_offsets[prev * 2 + 1] = i;
-            tile_offsets[tid * 2] = i;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) t[k] = i0 + k < num_isect ? tile_ids[i0 + k] : 0xFFFFFFFFu;
+    }
+    uint32_t prev = i0 > 0u ? tile_ids[i0 - 1u] : 0xFFFFFFFFu;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < num_isect) {
+            const uint32_t tid = t[k];
+            if (tid < num_tiles) {  // (sentinel rows are skipped)
+                if (i == num_isect - 1u) tile_offsets[tid * 2 + 1] = i + 1u;
+                if (i == 0u) {
+                    tile_offsets[tid * 2] = 0u;
+                } else if (tid != prev) {
+                    if (prev < num_tiles) tile_offsets[prev * 2 + 1] = i;
+                    tile_offsets[tid * 2] = i;
+                }
+            }
+            prev = tid;
         }
     }
 }
@@ -50,7 +65,7 @@ int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n
     // (pre_zeroed: the forward's K1 already did, project.hip ForwardPrep)
     if (!pre_zeroed) BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
     if (num_isect == 0) return 0;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 255) / 256), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 1023) / 1024), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets);
     BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");
     return 0;
 }

@@ -21,8 +21,10 @@ namespace bh {
 
 constexpr int SORT_WG = 256;
 constexpr int SORT_WAVES = SORT_WG / 64;
-constexpr int SORT_KPT = 16;                       // keys per thread
-constexpr int SORT_TILE = SORT_WG * SORT_KPT;      // 4096 keys per block
+// keys per thread: 16 (4096 keys per block) for large sorts; 8 for sorts of up to SMALL_SORT_MAX keys (the depth sort:
+// 1 M keys are only 245 blocks of 4096 on 256 CUs — each block is a serial latency chain with nothing to overlap;
+// 2048-key blocks halve the chain and put two of them on a CU)
+constexpr uint32_t SMALL_SORT_MAX = 2u << 20;
 constexpr int RADIX = 256;
 
 // `mask` is 0xFF except in the last pass, where it keeps only the bits still
@@ -41,12 +43,15 @@ BH_DEV unsigned long long match_digit(uint32_t d) {
 }
 
 // hist[digit * nblocks + block]
+// (electing one leader per digit group with 8 ballots instead of the LDS atomic was measured: tile sort 132 -> 155 us)
+template <int SORT_KPT>
 __global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
                                                             uint32_t mask, uint32_t nblocks, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_hist[SORT_WAVES][RADIX];
     const int tid = threadIdx.x, wave = tid >> 6;
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_WG) (&s_hist[0][0])[i] = 0;
     __syncthreads();
+    constexpr int SORT_TILE = SORT_WG * SORT_KPT;
     const uint32_t base = blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int k = 0; k < SORT_KPT; ++k) {
@@ -107,12 +112,13 @@ __global__ __launch_bounds__(SORT_WG) void radix_rowscan_kernel(uint32_t* __rest
     if (tid == 0) digit_totals[d] = run;
 }
 
-template <bool HAS_VALS>
+template <bool HAS_VALS, int SORT_KPT>
 __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                                uint32_t n, uint32_t shift, uint32_t mask, uint32_t nblocks,
                                                                const uint32_t* __restrict__ offsets,  // exclusive scan of hist
                                                                const uint32_t* __restrict__ digit_totals,  // row-scan mode: offsets are per-row, add the digit prefix
                                                                uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+    constexpr int SORT_TILE = SORT_WG * SORT_KPT;
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX];   // per-wave running digit counts -> wave bases
     __shared__ uint32_t s_dbase[RADIX];             // exclusive scan of block digit totals
     __shared__ uint32_t s_gofs[RADIX];              // global offset of (digit, block) minus s_dbase
@@ -211,7 +217,14 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
     // a block writes (4096 keys over 256 digits = 64-byte bursts; over 128 digits = 128-byte bursts)
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
     const uint32_t base_w = bits / passes, wide = bits % passes;   // the first `wide` passes take one extra bit
-    const uint32_t nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+    const bool small = n <= SMALL_SORT_MAX;
+    uint32_t kpt = small ? 8u : 16u;
+    if (const char* e = getenv("BH_SORT_KPT")) {   // developer knob (A/B measurements): 4 | 8 | 16
+        const int k = atoi(e);
+        if ((k == 4 && n <= (1u << 22)) || k == 8 || k == 16) kpt = (uint32_t)k;
+    }
+    const uint32_t tile = SORT_WG * kpt;
+    const uint32_t nblocks = (n + tile - 1) / tile;
     const size_t bytes = (size_t)n * 4;
     // [256] digit totals followed by the [256][nblocks] table
     uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * nblocks + RADIX) * 4);
@@ -247,7 +260,9 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
         const uint32_t width = base_w + (p < wide ? 1u : 0u);
         const uint32_t shift = p * base_w + (p < wide ? p : wide);
         const uint32_t mask = (1u << width) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
+        if (kpt == 4u) hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
+        else if (kpt == 8u) hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
+        else hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
         BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
         if (rowscan) {
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(SORT_WG), 0, ctx->stream, hist, nblocks, totals);
@@ -255,10 +270,18 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
         } else {
             BH_TRY(prefix_sum(ctx, hist, nullptr, RADIX * nblocks, hist, /*exclusive=*/true));
         }
-        if (src_v)
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, rowscan ? totals : nullptr, dst_k, dst_v);
-        else
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, rowscan ? totals : nullptr, dst_k, dst_v);
+        const uint32_t* tot = rowscan ? totals : nullptr;
+        const dim3 grid(nblocks), block(SORT_WG);
+        if (kpt == 4u) {
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+        } else if (kpt == 8u) {
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+        } else {
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+        }
         BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
         src_k = dst_k;
         src_v = dst_v;
