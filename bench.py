@@ -196,7 +196,9 @@ def main():
         dom_ms = stage_out.get(dom, {}).get("ms", 0.0)
         dom_bytes = sb[dom]
         achieved = dom_bytes / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes("rasterize_backward_kernel")
+        # the committed PMC passes were taken on the headline workload: no counter figure for any other
+        headline = args.workload == "1m_1080p" and args.sh_degree == 0 and not args.splats and not tile_mode
+        traffic, traffic_src = pmc_traffic_bytes("rasterize_backward_kernel") if headline else (None, None)
         out = {
             "metric": "train views/sec @ 1M Gaussians, 1080p (fwd + L1/SSIM loss + bwd + Adam per view)",
             "value": round((1 if tile_mode else world) * args.steps / dt, 3),

@@ -993,8 +993,11 @@ class SplatTrainer:
         self.step_count = st.step_count
         self._last_stats = stats
         self._keep = (gt, ns)
-        if tiles and self.rebalance_every > 0 and self.step_count % self.rebalance_every == 0:
-            self._measure_row_weights(ctx, (h + 15) // 16, (w + 15) // 16, dev)
+        if tiles and self.rebalance_every > 0:
+            if self.step_count % self.rebalance_every == 0:
+                self._measure_row_weights(ctx, (h + 15) // 16, (w + 15) // 16, dev)
+            elif self.step_count == 1:
+                self._warm_rebalance((h + 15) // 16, (w + 15) // 16, dev)
         return splats, stats
 
     def _measure_row_weights(self, ctx, tile_bh, tile_bw, dev):
@@ -1003,10 +1006,22 @@ class SplatTrainer:
         import torch.distributed as dist
         out = _ffi.BhRenderOut()
         ctx.check(ctx.lib.bh_last_render_out(ctx._h, C.byref(out)))
-        to = _view(out.tile_offsets, (tile_bh * tile_bw, 2), torch.int32, dev).to(torch.int64)
-        per_row = (to[:, 1] - to[:, 0]).clamp(min=0).view(tile_bh, tile_bw).sum(1).to(torch.float32)
+        per_row = self._rows_blended(_view(out.tile_offsets, (tile_bh * tile_bw, 2), torch.int32, dev), tile_bh, tile_bw)
         dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
         self._row_weights = [float(x) + 1.0 for x in per_row.tolist()]  # +1: empty rows still cost a launch slot
+
+    @staticmethod
+    def _rows_blended(tile_offsets, tile_bh, tile_bw):
+        to = tile_offsets.to(torch.int64)
+        return (to[:, 1] - to[:, 0]).clamp(min=0).view(tile_bh, tile_bw).sum(1).to(torch.float32)
+
+    def _warm_rebalance(self, tile_bh, tile_bw, dev):
+        """The first use of each torch kernel above loads its code object (~200 ms in total on ROCm): pay that in the
+        first step, not in the middle of training when the first re-cut happens."""
+        import torch.distributed as dist
+        per_row = self._rows_blended(torch.zeros((tile_bh * tile_bw, 2), dtype=torch.int32, device=dev), tile_bh, tile_bw)
+        dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
+        per_row.tolist()
 
     def _train_state(self, splats, s):
         st = _ffi.BhTrainState()
