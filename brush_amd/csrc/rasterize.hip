@@ -247,6 +247,12 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                     last_useful = batch_start + t + 1;
                 }
             }
+            // every pixel of the tile saturated: the rest of the batch (32 splats on average, ~45 VALU ops each just
+            // to fail the quadrant tests) cannot contribute.  Checked every 8th splat; the batch loop's own test ends the tile.
+            if ((t & 7u) == 7u) {
+                const bool still = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+                if (__ballot(still) == 0ull) break;
+            }
         }
         if (BWD_INFO) {
             // rasterize.rs:143-145: mark splats that touched at least one pixel
