@@ -481,14 +481,14 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             ProfScope ps(ctx, "PrefixSumGaussHits");
             BH_TRY(prefix_sum(ctx, isect_counts, gfc, nv, cum, false));
         }
-        {
+        if (ni == 0) {   // nothing to map: only the record gather is left (K5 does it on its way otherwise)
             ProfScope ps(ctx, "ProjectVisible");
             BH_TRY(launch_project_visible(ctx, nv, proj_by_gid, gfc, projected));
         }
         if (ni > 0) {
             {
                 ProfScope ps(ctx, "MapGaussiansToIntersect");
-                BH_TRY(launch_map_gaussians(ctx, nv, u, projected, cum, tile_ids, isect_gids));
+                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids));
             }
             {
                 ProfScope ps(ctx, "TileSort");

@@ -161,8 +161,8 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
                            float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
-int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
-                         const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
+                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,

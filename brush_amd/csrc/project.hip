@@ -313,8 +313,13 @@ int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_g
 // ---------------------------------------------------------------------------
 // K5: map_gaussians_to_intersect  (kernels/map_gaussians.rs:15-80)
 // ---------------------------------------------------------------------------
+// The kernel also IS K4 on its way: lane cg fetches its record from the by-splat-id table K1 filled (one 36-byte
+// gather through the depth permutation), uses it for the walk and stores it at row cg of `projected` — the compact,
+// depth-ordered table the blend kernels and the backward read (coalesced 36-byte rows).  A separate gather launch
+// (project_visible_kernel, still used when a frame has no intersections at all) cost 27 us.
 __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
-    uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected,
+    uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected_by_gid,
+    const uint32_t* __restrict__ global_from_compact_gid, float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
@@ -326,7 +331,13 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     TileBbox bb = TileBbox{0, 0, 0, 0};
     uint32_t base = 0, pf_count = 0, nb = 0;
     if (cg < nv) {
-        const float* p = projected + (size_t)cg * 9;
+        const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
+        float p[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p[k] = src[k];
+        float* dst = projected + (size_t)cg * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = p[k];
         xy_x = p[0]; xy_y = p[1];
         conic = Sym2{p[2], p[3], p[4]};
         pt = bh_logf(p[5] * 255.0f);
@@ -361,11 +372,12 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     }
 }
 
-int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected,
-                         const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids) {
+int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
+                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected, cum_tiles_hit, tile_ids, isect_gids);
+    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                       projected, cum_tiles_hit, tile_ids, isect_gids);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
 }

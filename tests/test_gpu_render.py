@@ -97,6 +97,27 @@ def test_odd_image_sizes_rotated_offcentre_camera(dev, oracle_lib, w, h):
     assert np.abs(img.cpu().numpy() - ref.image()).max() <= IMG_TOL
 
 
+def test_few_splats_under_a_large_tile_table(dev, oracle_lib):
+    """K1 clears the tile table and the visible flags on its way, one word per splat thread; with 40 splats under a
+    1920x1080 frame (16 448 table words) its grid cannot cover them and the launcher has to fall back to plain fills.
+    A dense render first leaves every table entry and flag dirty."""
+    import brush_amd as ba
+    w, h = 1920, 1080
+    cp = synth.default_camera_params(w, h)
+    dense = synth.make_scene(30000, 0x91, sh_degree=0, log_scale_range=(math.log(0.05), math.log(0.3)))
+    render_both(ba, oracle_lib, dev, dense, cp, w, h)
+    few = synth.make_scene(40, 0x92, sh_degree=0, log_scale_range=(math.log(0.05), math.log(0.4)))
+    for _ in range(2):   # twice: both halves of the counter ping-pong
+        img, aux, ref = render_both(ba, oracle_lib, dev, few, cp, w, h, bg=(0.1, 0.2, 0.3))
+        assert_stagewise_exact(aux, ref)
+        assert np.abs(img.cpu().numpy() - ref.image()).max() <= IMG_TOL
+    # and an empty scene right after a dirty one: no K1 at all, fills only
+    spl = ba.Splats(np.zeros((0, 10), np.float32), np.zeros((0, 1, 3), np.float32), np.zeros((0,), np.float32), device=dev)
+    img, aux = ba.render_splats(spl, util.hip_camera(ba, cp), (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward)
+    assert aux.num_visible == 0 and aux.num_intersections == 0 and float(img.abs().max()) == 0.0
+    assert int(aux.tile_offsets.to(torch.int64).abs().sum()) == 0
+
+
 def test_empty_render_and_zero_size(dev):
     """tests/mod.rs:20; render.rs:50-53 assert -> error."""
     import brush_amd as ba
