@@ -398,6 +398,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
     BH_HIP(ctx, hipSetDevice(ctx->device));
     ctx->have_forward = false;
+    ctx->vcombined_prezeroed = false;   // set below only by the kernels of THIS forward
+    ctx->grads_prezeroed = false;
     const bool mip = flags & BH_FLAG_MIP, bwd_info = flags & BH_FLAG_BWD_INFO, smooth = flags & BH_FLAG_SMOOTH_CUTOFF;
     const ViewUniforms u = make_uniforms(*cam);
     if (u.tile_y0 >= u.tile_y1 || u.tile_y1 > u.tile_bh) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_row window must satisfy begin < end <= ceil(img_h / 16)");
@@ -436,6 +438,13 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.visible_words = (uint32_t)visible_words;
             prep.tile_table = tile_offsets;
             prep.tile_words = num_tiles * 2 + 8 * 16;
+            ctx->grads_prezeroed = false;
+            if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
+                (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
+                prep.span = reinterpret_cast<float4*>(ctx->ext_grad_begin);   // the train step's gradient span
+                prep.span_f4 = (uint32_t)(ctx->ext_grad_floats / 4);
+                ctx->grads_prezeroed = true;
+            }
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
                                           proj_by_gid, counters, prep));
             ctx->counter_phase ^= 1u;
@@ -488,7 +497,15 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         if (ni > 0) {
             {
                 ProfScope ps(ctx, "MapGaussiansToIntersect");
-                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids));
+                // the backward's accumulator [nv,10] is cleared by K5 on its way (whole float4s: + 16 B of room)
+                float4* vc = nullptr;
+                ctx->vcombined_prezeroed = false;
+                if (bwd_info) {
+                    vc = (float4*)ensure(ctx, SLOT_V_COMBINED, (size_t)nv * 10 * 4 + 16);
+                    if (!vc) return BH_ERR_OOM;
+                    ctx->vcombined_prezeroed = true;
+                }
+                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u));
             }
             {
                 ProfScope ps(ctx, "TileSort");
@@ -561,28 +578,33 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     if (!v_combined) return BH_ERR_OOM;
     {
         ProfScope ps(ctx, "ZeroGradBuffers");
+        // what the forward's kernels cleared on their way (K5: v_combined; K1: the train step's gradient span) is done
         const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
+        const bool vc_done = ctx->vcombined_prezeroed, span_done = ctx->grads_prezeroed && one_span;
+        ctx->vcombined_prezeroed = false;
+        ctx->grads_prezeroed = false;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
-            // the train step: v_combined and the exchange buffer's gradient span cleared by ONE launch (hipMemsetAsync
-            // spends two or three launches on them, each ~5 us of latency beyond the bytes)
-            const size_t na = (nvpad * 10 + 3) / 4, nb = ctx->ext_grad_floats / 4;
-            hipLaunchKernelGGL(zero_two_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(v_combined), na,
-                               reinterpret_cast<float4*>(v_transforms), nb);
-            BH_LAUNCH_CHECK(ctx, "zero_two_kernel");
-        } else {
-        BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
-        if (n > 0) {
-            // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
-            if (one_span) {
-                // the train step's exchange buffer: one fill instead of four
-                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, ctx->ext_grad_floats * 4, ctx->stream));
-            } else {
-                BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
-                BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
-                BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
-                BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
+            // v_combined and the exchange buffer's gradient span cleared by ONE launch (hipMemsetAsync spends two or
+            // three launches on them, each ~5 us of latency beyond the bytes)
+            const size_t na = vc_done ? 0 : (nvpad * 10 + 3) / 4, nb = span_done ? 0 : ctx->ext_grad_floats / 4;
+            if (na + nb) {
+                hipLaunchKernelGGL(zero_two_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<float4*>(v_combined), na,
+                                   reinterpret_cast<float4*>(v_transforms), nb);
+                BH_LAUNCH_CHECK(ctx, "zero_two_kernel");
             }
-        }
+        } else {
+            if (!vc_done) BH_HIP(ctx, hipMemsetAsync(v_combined, 0, nvpad * 10 * 4, ctx->stream));
+            if (n > 0) {
+                // dense outputs are zero-filled; the kernel scatters compact -> global (render_bwd.rs:123-138)
+                if (one_span) {
+                    BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, ctx->ext_grad_floats * 4, ctx->stream));
+                } else {
+                    BH_HIP(ctx, hipMemsetAsync(v_transforms, 0, (size_t)n * 10 * 4, ctx->stream));
+                    BH_HIP(ctx, hipMemsetAsync(v_sh_coeffs, 0, (size_t)n * C * 3 * 4, ctx->stream));
+                    BH_HIP(ctx, hipMemsetAsync(v_raw_opacities, 0, (size_t)n * 4, ctx->stream));
+                    BH_HIP(ctx, hipMemsetAsync(v_refine_weight, 0, (size_t)n * 4, ctx->stream));
+                }
+            }
         }
     }
     {
@@ -745,10 +767,14 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_visible = s_visible;
     ctx->ext_visible_floats = o_tr;  // the forward clears the section incl. its padding
     ctx->ext_max_radius = s_radius;
+    ctx->ext_grad_begin = exch + o_tr;       // ... and the whole gradient span (padding included): K1 does both on its way
+    ctx->ext_grad_floats = exch_count - o_tr;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
     ctx->ext_visible = nullptr;
     ctx->ext_max_radius = nullptr;
+    ctx->ext_grad_begin = nullptr;
+    ctx->ext_grad_floats = 0;
     BH_TRY(frc);
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)

@@ -102,6 +102,9 @@ struct bh_ctx {
     size_t ext_visible_floats = 0;    // floats to clear at ext_visible (its section of the exchange buffer incl. padding)
     float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
     size_t ext_grad_floats = 0;
+    // cleared on the way by the forward's kernels (K1: the gradient span, K5: v_combined) -> the backward skips its fills;
+    // each flag is consumed by the next bh_render_backward
+    bool grads_prezeroed = false, vcombined_prezeroed = false;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
     int comm_rank = 0, comm_world = 1;
@@ -156,13 +159,16 @@ struct ForwardPrep {
     uint32_t visible_words = 0;
     uint32_t* tile_table = nullptr;               // tile_offsets + the work-class counters behind it
     uint32_t tile_words = 0;
+    float4* span = nullptr;                       // train step: the gradient span of the exchange buffer (grid-stride float4 clear)
+    uint32_t span_f4 = 0;
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
                            float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
-                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids);
+                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
+                         float4* zero_span = nullptr, uint32_t zero_f4 = 0);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,

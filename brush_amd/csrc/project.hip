@@ -136,6 +136,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     if (gid < prep.visible_words) prep.visible[gid] = 0u;
     if (gid < prep.tile_words) prep.tile_table[gid] = 0u;
     if (gid < 2u * COUNTER_SLOTS && prep.next_counters) prep.next_counters[gid] = 0ull;
+    for (uint32_t i = gid; i < prep.span_f4; i += gridDim.x * PROJ_WG) prep.span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t key = 0xFFFFFFFFu;
     float radius = 0.0f;
@@ -276,6 +277,7 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
     }
     if (n == 0) {
         if (prep.next_counters) BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SLOTS * 16, ctx->stream));
+        if (prep.span && prep.span_f4) BH_HIP(ctx, hipMemsetAsync(prep.span, 0, (size_t)prep.span_f4 * 16, ctx->stream));
         return 0;
     }
     auto* c64 = reinterpret_cast<unsigned long long*>(counters);
@@ -321,10 +323,12 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected_by_gid,
     const uint32_t* __restrict__ global_from_compact_gid, float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
-    uint32_t* __restrict__ compact_gid_from_isect) {
+    uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_base[PROJ_WAVES][64];
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
+    for (uint32_t i = cg; i < zero_f4; i += gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
@@ -373,11 +377,12 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
 }
 
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
-                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids) {
+                         float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
+                         float4* zero_span, uint32_t zero_f4) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                       projected, cum_tiles_hit, tile_ids, isect_gids);
+                       projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
 }
