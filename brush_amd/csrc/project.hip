@@ -116,6 +116,68 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
     return rank;
 }
 
+// The same walk for K5, emitting instead of counting.  The wave's 64 splats own ONE contiguous range of the output
+// (their slot ranges are consecutive: cum_tiles_hit is the prefix sum in exactly this order), and the walk visits the
+// candidates in (splat, tile) order — so the n-th hit of the wave simply goes to slot wave_base + n.  A ballot prefix
+// replaces the per-splat LDS cursor (an atomic with return per hit) and compacts the stores: lanes with a hit write
+// consecutive addresses.  Relies on K1 having counted with the same inlined test (it has: will_primitive_contribute).
+BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
+                                    uint32_t wave_base, uint32_t tile_bw, uint32_t cg0, uint32_t* __restrict__ tile_ids,
+                                    uint32_t* __restrict__ isect_gids) {
+    const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
+    const uint32_t start = incl - nb;
+    const bool nz = nb > 0u;
+    const unsigned long long nzmask = __ballot(nz);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(nzmask & below);
+    const uint32_t bb_w = bb.max_x - bb.min_x;
+    if (nz) {
+        w.mx[rank] = mx; w.my[rank] = my;
+        w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
+        w.pt[rank] = pt;
+        w.rcp_w[rank] = 1.0f / (float)bb_w;
+        w.box[rank] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
+        w.start[rank] = start;
+        w.lane_of[rank] = (uint32_t)lane;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // see flat_tile_walk
+    volatile uint8_t* flags = w.flags;
+    const uint32_t tot = __shfl(incl, 63);
+    const unsigned long long le = below | (1ull << lane);
+    uint32_t before = 0;   // ranks that start before `base` (wave-uniform)
+    uint32_t emitted = 0;  // hits of this wave so far (wave-uniform)
+    for (uint32_t base = 0; base < tot; base += 64) {
+        flags[lane] = 0;
+        const uint32_t rel = start - base;
+        if (nz && rel < 64u) flags[rel] = 1;
+        const unsigned long long marks = __ballot(flags[lane] != 0);
+        const uint32_t c = base + (uint32_t)lane;
+        bool hit = false;
+        uint32_t tile = 0, owner = 0;
+        if (c < tot) {
+            const uint32_t r = before + (uint32_t)__popcll(marks & le) - 1u;
+            const uint32_t i = c - w.start[r];
+            const uint32_t box = w.box[r];
+            const uint32_t bw = box >> 20;
+            const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[r]);
+            const uint32_t tx = (box & 1023u) + (i - row * bw);
+            const uint32_t ty = ((box >> 10) & 1023u) + row;
+            hit = will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
+            tile = tx + ty * tile_bw;
+            owner = cg0 + w.lane_of[r];
+        }
+        const unsigned long long hits = __ballot(hit);
+        if (hit) {
+            const uint32_t idx = wave_base + emitted + (uint32_t)__popcll(hits & below);
+            tile_ids[idx] = tile;
+            isect_gids[idx] = owner;
+        }
+        emitted += (uint32_t)__popcll(hits);
+        before += (uint32_t)__popcll(marks);
+    }
+    return emitted;
+}
+
 // ---------------------------------------------------------------------------
 // K1: project_forward  (kernels/project_forward.rs:22-125)
 // ---------------------------------------------------------------------------
@@ -325,7 +387,6 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
-    __shared__ uint32_t s_base[PROJ_WAVES][64];
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
     for (uint32_t i = cg; i < zero_f4; i += gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -353,27 +414,16 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
     }
     WalkLds& w = s_walk[wave];
-    uint32_t* wbase = s_base[wave];   // by rank, like the walk's own arrays
-    {
-        const unsigned long long nzmask = __ballot(nb > 0u);
-        if (nb > 0u) wbase[__popcll(nzmask & ((1ull << lane) - 1ull))] = base;
-    }
+    // first output slot of the wave = the slot range start of its first splat (lanes past nv hold nb = 0 and emit nothing)
     const uint32_t cg0 = cg - (uint32_t)lane;
+    const uint32_t wave_base = __shfl(base, 0);
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
-    const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
-        const uint32_t k = atomicAdd(&w.count[r], 1u);
-        const uint32_t idx = wbase[r] + k;
-        tile_id_from_isect[idx] = tx + ty * tile_bw;
-        compact_gid_from_isect[idx] = cg0 + w.lane_of[r];
-    });
-    // map_gaussians.rs:73-79: pad any leftover budget (cannot happen here: the count
-    // and the emit walk are the same inlined function with the same flags).
-    const uint32_t sentinel = tile_bw * tile_bh;
-    for (uint32_t k = nb ? w.count[wrank] : 0u; k < pf_count; ++k) {
-        tile_id_from_isect[base + k] = sentinel;
-        compact_gid_from_isect[base + k] = cg;
-    }
+    (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
+    // map_gaussians.rs:73-79 pads leftover budget with sentinel rows; it cannot happen here (K1's count and this walk
+    // are the same inlined test on the same values), and the compacted emit above relies on exactly that.
+    (void)pf_count;
+    (void)tile_bh;
 }
 
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
