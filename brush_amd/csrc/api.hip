@@ -136,11 +136,26 @@ ProfScope::ProfScope(bh_ctx* c, const char* name, bool dominant) : ctx(c) {
     idx = prof_index(c->prof, name);
     a = prof_event(c->prof);
     b = prof_event(c->prof);
+    if (c->prof.level == 2) {   // handed to the kernel launch inside the scope (Profiler::ext_a)
+        c->prof.ext_a = a;
+        c->prof.ext_b = b;
+        return;
+    }
     (void)hipEventRecord(a, c->stream);
 }
 ProfScope::~ProfScope() {
     if (!a) return;
-    (void)hipEventRecord(b, ctx->stream);
+    if (ctx->prof.level == 2) {
+        const bool used = ctx->prof.ext_a == nullptr;   // the launch took the events
+        ctx->prof.ext_a = ctx->prof.ext_b = nullptr;
+        if (!used) {   // nothing was launched inside the scope
+            ctx->prof.pool.push_back(a);
+            ctx->prof.pool.push_back(b);
+            return;
+        }
+    } else {
+        (void)hipEventRecord(b, ctx->stream);
+    }
     ctx->prof.pending.push_back({idx, a, b});
 }
 

@@ -76,6 +76,10 @@ struct Profiler {
     struct Pending { int idx; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
+    // level 2: the dominant kernel's launch carries its own (start, stop) events (hipExtLaunchKernelGGL): the times
+    // come from the dispatch packet itself, without the two barrier packets (~5.6 us of bubble each) that
+    // hipEventRecord puts in front of and behind the kernel
+    hipEvent_t ext_a = nullptr, ext_b = nullptr;
 };
 
 }  // namespace bh

@@ -19,6 +19,8 @@
 //     the spatially coherent part of `projected`.
 //   * exp() in the blend loops is exp_blend below (a base-2 polynomial shaped for the gfx950
 //     issue rates), restated identically by the oracle: images are bit-identical.
+#include <hip/hip_ext.h>
+
 #include "context.h"
 
 namespace bh {
@@ -532,7 +534,14 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
     const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     const dim3 grid(nblocks), block(64);
-    if (smooth)
+    // profiling level 2 (bench.py's timed region): the launch carries its own start / stop events (context.h)
+    hipEvent_t ea = ctx->prof.ext_a, eb = ctx->prof.ext_b;
+    ctx->prof.ext_a = ctx->prof.ext_b = nullptr;
+    if (ea && smooth)
+        hipExtLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+    else if (ea)
+        hipExtLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+    else if (smooth)
         hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
     else
         hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
