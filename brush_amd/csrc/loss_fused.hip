@@ -74,7 +74,7 @@ BH_DEV float gt_ch(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float* __restrict__ img /*[H,W,4]*/,
                                                                     const uint32_t* __restrict__ gt,
-                                                                    float* __restrict__ partials /*[H,W,3,4]*/,
+                                                                    float* __restrict__ partials /*[H,W,3,3]*/,
                                                                     float* __restrict__ block_sums, FusedArgs a) {
     __shared__ float2 s_tile[3][SH * SH];          // (pred, gt_eff) per colour plane
     __shared__ float s_h[3][SH * LB * 5];          // horizontally blurred moments
@@ -186,8 +186,12 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
             const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (inv_a - inv_b);
             const float ds1 = clamped ? 0.0f : -cd * inv_b;
             const float ds12 = clamped ? 0.0f : 2.0f * c_top * inv_ab;
-            // [H,W,3,4]: one 16-byte store per colour plane (and one 16-byte load per tap in pass B)
-            *reinterpret_cast<float4*>(&partials[(p * 3 + c) * 4]) = make_float4(dmu1 * chain, ds1 * chain, ds12 * chain, 0.0f);
+            // [H,W,3,3]: 36 bytes per pixel (a float4 per colour plane would move a third more bytes, and pass B reads every
+            // pixel 2.6 times through its halo)
+            float* o3 = &partials[(p * 3 + c) * 3];
+            o3[0] = dmu1 * chain;
+            o3[1] = ds1 * chain;
+            o3[2] = ds12 * chain;
         }
         if (a.alpha_match) {  // lib.rs:203-214
             const float pa = img[p * 4 + 3];
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
 // pass B
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
-                                                                     const float* __restrict__ partials /*[H,W,3,4]*/,
+                                                                     const float* __restrict__ partials /*[H,W,3,3]*/,
                                                                      float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
     __shared__ float4 s_part[3][SH * SH];      // chain * (dmu1, dsigma1, dsigma12, -)
     __shared__ float4 s_h2[3][SH * LB];
@@ -237,7 +241,10 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
         const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_part[c][i] = in ? *reinterpret_cast<const float4*>(&partials[(p * 3 + c) * 4]) : z;
+        for (int c = 0; c < 3; ++c) {
+            const float* q = &partials[(p * 3 + c) * 3];
+            s_part[c][i] = in ? make_float4(q[0], q[1], q[2], 0.0f) : z;
+        }
     }
     __syncthreads();
     for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
@@ -320,7 +327,7 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
     const uint32_t a0 = tile_y0 > 0 ? tile_y0 - 1 : 0, a1 = tile_y1 < gy ? tile_y1 + 1 : gy;  // pass A window
     const dim3 block(LB, LB);
     const size_t hw = (size_t)h * w;
-    auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));
+    auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));   // 9 floats per pixel used (the slot is shared with loss.hip's map)
     auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)gx * gy * sizeof(float));
     if (!partials || !block_sums) return BH_ERR_OOM;
     FusedArgs a;
