@@ -35,11 +35,13 @@ def stage_bytes(n, nv, ni, pixels, tiles, coeffs):
     """Algorithmic HBM bytes per stage (SURVEY.md §8d / DESIGN.md §5)."""
     c = coeffs
     return {
-        "ProjectSplats": 44 * n + 12 * n,
+        # K1 also stores the projected record by splat id and clears visible + the train step's gradient span on its way
+        "ProjectSplats": 44 * n + 12 * n + 36 * nv + 4 * n + (48 + 12 * c) * n,
         "DepthSort": 80 * n,
         "PrefixSumGaussHits": 12 * nv,
-        "ProjectVisible": (84 + 12 * c) * nv,
-        "MapGaussiansToIntersect": 32 * nv + 8 * ni,
+        "ProjectVisible": (84 + 12 * c) * nv,   # separate launch only for frames without intersections
+        # K5 also gathers the records into depth order (the former K4) and clears the backward's v_combined
+        "MapGaussiansToIntersect": 32 * nv + 8 * ni + 76 * nv + 40 * nv,
         "TileSort": 40 * ni,
         "GetTileOffsets": 4 * ni + 8 * tiles,
         "Rasterize": 44 * ni + 16 * pixels,
