@@ -69,6 +69,59 @@ def test_1m_1080p_properties(dev, scene_1m):
     assert torch.equal(packed, expect)
 
 
+def test_6m_4k_sh3_properties_and_step(dev):
+    """BASELINE.json configs[4] on one GPU (6 M splats, 3840x2160, SH degree 3): 168 M intersections take the sort
+    through its large-table paths (41 k blocks: generic scan of the [digit][block] table with a spine) and the scan /
+    counter / clear-on-the-way code through sizes no other test reaches.  Size-independent invariants, then one full
+    train step."""
+    import brush_amd as ba
+    sc, w, h = synth.config_scene("6m_4k", 3)
+    cp = synth.default_camera_params(w, h)
+    cam = util.hip_camera(ba, cp)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    n = spl.num_splats()
+    img, aux = ba.render_splats(spl, cam, (w, h), (0.2, 0.4, 0.6), ba.RasterPass.Backward)
+    aux.validate(n)
+    assert aux.num_visible > 5_000_000 and aux.num_intersections > 100_000_000
+    assert int(aux.cum_tiles_hit[-1].item()) == aux.num_intersections
+    assert int(aux.intersect_counts.long().sum().item()) == aux.num_intersections
+    tid = aux.tile_id_from_isect.long()
+    assert bool((tid[1:] >= tid[:-1]).all()) and int(tid.max().item()) < aux.tile_offsets.shape[0]
+    gid = aux.compact_gid_from_isect.long()
+    same_tile = tid[1:] == tid[:-1]
+    assert bool((gid[1:][same_tile] > gid[:-1][same_tile]).all()), "strict depth order inside every tile"
+    del same_tile
+    # every tile's [start, end) brackets exactly its ids (end = the forward's shrunk end <= the true end)
+    to = aux.tile_offsets.long()
+    counts = torch.bincount(tid, minlength=to.shape[0])
+    starts = torch.cumsum(counts, 0) - counts
+    nonempty = counts > 0
+    assert torch.equal(to[nonempty, 0], starts[nonempty]) and bool((to[:, 1] <= starts + counts).all()) and bool((to[:, 1] >= to[:, 0]).all())
+    dz = aux.depths_sorted
+    assert bool((dz[1:] >= dz[:-1]).all())
+    assert len(torch.unique(aux.global_from_compact_gid)) == aux.num_visible
+    a = img[..., 3]
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 and bool(torch.isfinite(img).all())
+    first = (aux.num_visible, aux.num_intersections, aux.compact_gid_from_isect.clone())
+    del tid, gid, counts, starts
+    img2, aux2 = ba.render_splats(spl, cam, (w, h), (0.2, 0.4, 0.6), ba.RasterPass.Backward)
+    assert (aux2.num_visible, aux2.num_intersections) == first[:2] and torch.equal(aux2.compact_gid_from_isect, first[2]) and torch.equal(img, img2)
+    del first, img2, aux2
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0)
+    batch = ba.SceneBatch(gt, cam)
+    before = spl.raw_opacities.clone()
+    losses = []
+    for _ in range(2):
+        trainer.step(batch, spl)
+        losses.append(trainer.stats().loss)
+    assert all(math.isfinite(x) and x > 0 for x in losses) and losses[1] < losses[0]
+    st = trainer.stats()
+    assert st.num_visible == aux.num_visible or st.num_visible > 5_000_000
+    assert bool(torch.isfinite(spl.transforms).all()) and bool(torch.isfinite(spl.sh_coeffs).all())
+    assert float((spl.raw_opacities - before).abs().max()) > 0.0
+
+
 def test_1080p_backward_vs_oracle_and_linearity(dev, oracle_lib):
     """Backward at full resolution on a 250 k sub-scene vs the oracle, plus linearity of the
     VJP in v_output (size-independent): bwd(a*v1 + b*v2) == a*bwd(v1) + b*bwd(v2)."""
