@@ -68,7 +68,7 @@ def main():
                          "'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in bh_train_step); the "
                          "unique id travels through a torch TCPStore on MASTER_ADDR:MASTER_PORT+1")
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse",
-                    help="N>1, cameras: 'sparse' = mask-keyed exchange (visible flags, then only the gradient rows of splats some rank "
+                    help="N>1 (cameras and tiles): 'sparse' = mask-keyed exchange (visible flags, then only the gradient rows of splats some rank "
                          "saw; dense fallback above half of the scene), 'dense' = one all-reduce of the whole exchange buffer")
     ap.add_argument("--feed", choices=["resident", "loader"], default="resident",
                     help="'resident' (the headline): the GT batch is already in HBM when the timed region starts; 'loader': every step "
@@ -215,7 +215,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if loader is None else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
-                       "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (RCCL all-gather of strips + all-reduce of gradients)" % world if tile_mode else
+                       "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else "")) if world > 1 else "single GPU"},
             "exchange": ({"mode": args.exchange, "rows_last_step": st.exchange_rows, "rows_total": n} if pg is not None or native else None),
             "fwd_ms": round(fwd_ms, 4),

@@ -810,7 +810,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
         return comm_allreduce(ctx, p, cnt, false);
     };
-    const bool keyed = exchanging && !tile_mode && batch->exchange_mode == 1 && n > 0;
+    const bool keyed = exchanging && batch->exchange_mode == 1 && n > 0;
     uint32_t* union_idx = nullptr;
     float* compact = nullptr;
     if (keyed) {
@@ -818,7 +818,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         const uint32_t nblk = (n + 4095u) / 4096u;
         auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
         union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
-        compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * (11 + 3 * C) * 4);
+        compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * (12 + 3 * C) * 4);
         if (!blocks || !union_idx || !compact) return BH_ERR_OOM;
         BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
         BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
@@ -873,23 +873,25 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     stats->exchange_rows = 0;
     if (exchanging) {
         ProfScope ps(ctx, "GradExchange");
-        if (tile_mode) {
-            BH_TRY(sum_over_ranks(exch, (uint64_t)exch_count));
-        } else if (keyed) {
-            // only the gradient rows of splats some rank saw (the count was requested right after the forward)
-            const uint32_t c3 = 3 * C, k = 11 + c3;
+        if (keyed) {
+            // only the gradient rows of splats some rank saw (the count was requested right after the forward).  One frame
+            // split over the ranks: the strips' refine weights are partial sums too and travel as one more column.
+            float* g_ref = tile_mode ? s_refine : nullptr;
+            const uint32_t c3 = 3 * C, k = 11 + c3 + (tile_mode ? 1u : 0u);
             BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
             const uint32_t rows = reinterpret_cast<uint32_t*>(ctx->host_counters)[8];
             if (rows == 0) {
                 // no rank saw any splat: every gradient row is zero everywhere, nothing to send (same decision on all ranks)
             } else if ((uint64_t)rows * 2 <= n) {
-                BH_TRY(launch_exchange_rows(ctx, true, union_idx, rows, c3, g_tr, g_sh, g_op, compact));
+                BH_TRY(launch_exchange_rows(ctx, true, union_idx, rows, c3, g_tr, g_sh, g_op, g_ref, compact));
                 BH_TRY(sum_over_ranks(compact, (uint64_t)rows * k));
-                BH_TRY(launch_exchange_rows(ctx, false, union_idx, rows, c3, g_tr, g_sh, g_op, compact));
+                BH_TRY(launch_exchange_rows(ctx, false, union_idx, rows, c3, g_tr, g_sh, g_op, g_ref, compact));
                 stats->exchange_rows = rows;
             } else {
-                BH_TRY(sum_over_ranks(exch + o_tr, (uint64_t)(o_ref - o_tr)));
+                BH_TRY(sum_over_ranks(exch + o_tr, (uint64_t)((tile_mode ? exch_count : o_ref) - o_tr)));
             }
+        } else if (tile_mode) {
+            BH_TRY(sum_over_ranks(exch, (uint64_t)exch_count));
         } else {
             BH_TRY(sum_over_ranks(exch, (uint64_t)o_ref));
         }

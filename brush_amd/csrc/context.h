@@ -230,6 +230,6 @@ int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);
 int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* block_scratch /*[n/4096+2]*/, uint32_t* count_dev,
                        uint32_t* idx);
 int launch_exchange_rows(bh_ctx* ctx, bool gather, const uint32_t* idx, uint32_t count, uint32_t c3, float* g_tr, float* g_sh, float* g_op,
-                         float* compact);
+                         float* g_ref /*NULL = no refine-weight column*/, float* compact);
 
 }  // namespace bh

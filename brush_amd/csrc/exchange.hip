@@ -94,17 +94,19 @@ __global__ __launch_bounds__(EX_WG) void union_place_kernel(const float* __restr
         if (bits & (1u << j)) idx[r++] = first + j;
 }
 
-// compact[r, :] <-> (v_transforms[i, 0:10] | v_sh[i, 0:3C] | v_raw_opac[i]),  i = idx[r].  One thread per float of the
-// compact block: coalesced on the compact side, row-contiguous on the dense side.
+// compact[r, :] <-> (v_transforms[i, 0:10] | v_sh[i, 0:3C] | v_raw_opac[i] [| refine_weight[i]]),  i = idx[r].  One thread
+// per float of the compact block: coalesced on the compact side, row-contiguous on the dense side.  The refine-weight
+// column exists only for the tile-partitioned frame (g_ref != NULL): its strips' partial sums add up, while
+// data-parallel views keep per-view maxima that are MAX-reduced before refine.
 template <bool GATHER>
 __global__ __launch_bounds__(EX_WG) void exchange_rows_kernel(const uint32_t* __restrict__ idx, uint32_t count, uint32_t c3,
-                                                             float* g_tr, float* g_sh, float* g_op, float* compact) {
-    const uint32_t k = 11u + c3;
+                                                             float* g_tr, float* g_sh, float* g_op, float* g_ref, float* compact) {
+    const uint32_t k = 11u + c3 + (g_ref ? 1u : 0u);
     const uint64_t e = (uint64_t)blockIdx.x * EX_WG + threadIdx.x;
     if (e >= (uint64_t)count * k) return;
     const uint32_t r = (uint32_t)(e / k), j = (uint32_t)(e - (uint64_t)r * k);
     const uint32_t i = idx[r];
-    float* dense = j < 10u ? &g_tr[(size_t)i * 10 + j] : (j < 10u + c3 ? &g_sh[(size_t)i * c3 + (j - 10u)] : &g_op[i]);
+    float* dense = j < 10u ? &g_tr[(size_t)i * 10 + j] : (j < 10u + c3 ? &g_sh[(size_t)i * c3 + (j - 10u)] : (j == 10u + c3 ? &g_op[i] : &g_ref[i]));
     if (GATHER) compact[e] = *dense;
     else *dense = compact[e];
 }
@@ -123,12 +125,12 @@ int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32
 }
 
 int launch_exchange_rows(bh_ctx* ctx, bool gather, const uint32_t* idx, uint32_t count, uint32_t c3, float* g_tr, float* g_sh, float* g_op,
-                         float* compact) {
+                         float* g_ref, float* compact) {
     if (count == 0) return 0;
-    const uint64_t total = (uint64_t)count * (11u + c3);
+    const uint64_t total = (uint64_t)count * (11u + c3 + (g_ref ? 1u : 0u));
     const dim3 grid((unsigned)((total + EX_WG - 1) / EX_WG)), block(EX_WG);
-    if (gather) hipLaunchKernelGGL(exchange_rows_kernel<true>, grid, block, 0, ctx->stream, idx, count, c3, g_tr, g_sh, g_op, compact);
-    else hipLaunchKernelGGL(exchange_rows_kernel<false>, grid, block, 0, ctx->stream, idx, count, c3, g_tr, g_sh, g_op, compact);
+    if (gather) hipLaunchKernelGGL(exchange_rows_kernel<true>, grid, block, 0, ctx->stream, idx, count, c3, g_tr, g_sh, g_op, g_ref, compact);
+    else hipLaunchKernelGGL(exchange_rows_kernel<false>, grid, block, 0, ctx->stream, idx, count, c3, g_tr, g_sh, g_op, g_ref, compact);
     BH_LAUNCH_CHECK(ctx, "exchange_rows_kernel");
     return 0;
 }

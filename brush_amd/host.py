@@ -829,7 +829,7 @@ class SplatTrainer:
         if native_comm and (process_group is not None or partition != "cameras"):
             raise ValueError("native_comm excludes process_group and supports partition='cameras' only")
         self.native_comm = bool(native_comm)
-        # data parallel over cameras: exchange only the gradient rows of splats some rank saw (BhTrainBatch.exchange_mode 1,
+        # exchange only the gradient rows of splats some rank (view or strip) saw (BhTrainBatch.exchange_mode 1,
         # brush_amd/csrc/exchange.hip); False = one dense all-reduce of the whole exchange buffer
         self.sparse_exchange = bool(sparse_exchange)
         self.partition = partition
@@ -980,7 +980,7 @@ class SplatTrainer:
             ns = _f32c(noise_samples, dev).reshape(-1, 3)
             b.noise_samples = ns.data_ptr()
         stats = _ffi.BhTrainStats()
-        b.exchange_mode = 1 if (self.sparse_exchange and not tiles and (self.pg is not None or self.native_comm)) else 0
+        b.exchange_mode = 1 if (self.sparse_exchange and (self.pg is not None or self.native_comm)) else 0
         hook, scale = None, 1.0
         if self.native_comm:
             scale = 1.0 / ctx.comm_world()

@@ -278,12 +278,15 @@ typedef struct BhTrainBatch {
     const float* noise_samples; /* [N,3] N(0,1) device, or NULL = no noise */
     bh_image_hook image_hook;   /* NULL unless the frame is tile-partitioned over ranks */
     void* image_hook_user;
-    /* Data parallel over cameras only.  0: one SUM over visible | gradients (dense).  1: mask-keyed — the hook (or the
+    /* Multi-GPU only.  0: one SUM over visible | gradients (dense).  1: mask-keyed — the hook (or the
      * library's communicator) is called for the visible flags first, then for a compact block holding only the gradient
      * rows of the splats some rank saw (their union is known from the summed flags and identical on every rank); falls
      * back to the dense block when that union exceeds half of the scene.  The result equals mode 0 up to the summation
      * order inside the collective; per view only the splats that reached a pixel carry a gradient, so the message is
-     * typically several times smaller.  Costs one more 4-byte readback per step. */
+     * typically several times smaller.  Costs one more 4-byte readback per step.  Applies to the tile-partitioned frame too
+     * (image_hook set): a strip's rows are non-zero only for the splats that reached one of its pixels, the compact rows
+     * then carry one more column, the refine weight (the strips' partial sums add up), and the dense fall-back is the whole
+     * span behind the visible section. */
     int32_t exchange_mode;
     /* Tile-partitioned frame only (image_hook set).  0: the hook all-gathers the whole image and every rank evaluates the
      * loss on all of it.  1: strip-wise loss — the hook only has to deliver the image rows within 21 px (one tile row + the
@@ -311,7 +314,8 @@ typedef struct BhTrainStats {
  *     RefineRecord keeps running MAXima (refine_weight_norm, max_screen_size), which a caller reduces
  *     over ranks with MAX once, before refine — not every step.  vis_weight counts views.
  *   - one frame partitioned by tile rows (image_hook set): sum_count = the whole buffer — the refine
- *     weight is a per-pixel sum, so the strips' partial sums add; `visible` is clamped to 1 afterwards.
+ *     weight is a per-pixel sum, so the strips' partial sums add; `visible` is clamped to 1 afterwards
+ *     (exchange_mode 1: the visible section, then the compact rows incl. the refine weight, as above).
  * One buffer = one collective per step (BhTrainBatch.exchange_mode 0; mode 1 calls the hook twice: for the leading visible
  * section, then for a compact scratch block — the contract is always "sum `sum_count` floats at `exchange`").  Return 0. */
 typedef int (*bh_grad_hook)(void* user, float* exchange, uint64_t sum_count);

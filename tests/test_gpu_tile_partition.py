@@ -17,9 +17,10 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-def _problem(n=6000, w=200, h=150, deg=1, seed=0xE1):
+def _problem(n=6000, w=200, h=150, deg=1, seed=0xE1, spread=None):
+    kw = {} if spread is None else {"spread": spread}   # spread 1.8: two thirds of the splats lie outside the frustum
     sc = synth.make_scene(n, seed, sh_degree=deg, log_scale_range=(math.log(0.02), math.log(0.25)),
-                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w))
+                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), **kw)
     return sc, synth.default_camera_params(w, h), w, h
 
 
@@ -75,7 +76,7 @@ def test_strip_gradients_sum_to_the_full_gradients(dev):
         assert float((v - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-12, k
 
 
-def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_loss=True):
+def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_loss=True, sparse=True, spread=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -83,10 +84,11 @@ def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_l
     import brush_amd as ba
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
-    sc, cp, w, h = _problem(n=4000, w=160, h=112)
+    sc, cp, w, h = _problem(n=4000, w=160, h=112, spread=spread)
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, partition=partition)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, partition=partition,
+                              sparse_exchange=sparse)
     trainer.rebalance_every = rebalance_every
     trainer.strip_loss = strip_loss
     batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
@@ -94,7 +96,7 @@ def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_l
     for _ in range(steps):
         trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
         st = trainer.stats()
-        shares.append((st.loss, trainer._strip_loss_now))
+        shares.append((st.loss, trainer._strip_loss_now, st.exchange_rows))
         losses.append(trainer.reduce_loss(st))     # strip-wise loss: the ranks' shares sum to the frame's loss
     trainer.sync_refine_stats()  # max_screen_size is strip-local until refine asks for it
     q.put((rank, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(), losses,
@@ -103,17 +105,18 @@ def _worker(rank, world, port, q, partition, rebalance_every=8, steps=2, strip_l
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("strip_loss", [True, False])
-def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev, strip_loss):
+@pytest.mark.parametrize("strip_loss,sparse", [(True, True), (False, False), (True, False)])
+def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev, strip_loss, sparse):
     """strip_loss: each rank evaluates L1 + SSIM on its own strip after fetching 21-px halos from its neighbour (no
-    whole-image all-gather); otherwise every rank gathers the frame and evaluates the whole loss.  Both must follow the
-    single-GPU trajectory."""
+    whole-image all-gather); otherwise every rank gathers the frame and evaluates the whole loss.  sparse: the
+    mask-keyed exchange (visible flags, then the compact rows — gradients AND refine weight — of the splats some strip
+    saw) instead of one dense sum of the whole buffer.  All of them must follow the single-GPU trajectory."""
     import brush_amd as ba
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tiles", 8, 2, strip_loss)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tiles", 8, 2, strip_loss, sparse, 1.8)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
@@ -123,14 +126,20 @@ def test_two_rank_tile_partitioned_step_equals_single_gpu_step(dev, strip_loss):
     r0, r1 = res
     assert r0[8] is None                     # 2 steps < rebalance_every: equal-height strips throughout
     if strip_loss:   # both strips (64 and 48 px) are taller than the halo: the strip-wise path ran, each rank holds a share
-        assert all(on for _, on in r0[9]) and all(on for _, on in r1[9])
+        assert all(x[1] for x in r0[9]) and all(x[1] for x in r1[9])
         assert all(0.0 < a[0] and 0.0 < b[0] and abs(a[0] - b[0]) > 1e-6 for a, b in zip(r0[9], r1[9]))
     else:
-        assert not any(on for _, on in r0[9]) and [a[0] for a in r0[9]] == [b[0] for b in r1[9]]
+        assert not any(x[1] for x in r0[9]) and [a[0] for a in r0[9]] == [b[0] for b in r1[9]]
+    rows = [x[2] for x in r0[9]]
+    assert rows == [x[2] for x in r1[9]]
+    if sparse:   # the union of the two strips' contributing splats: a real subset of the scene, sent as compact rows
+        assert all(0 < r <= 2000 for r in rows), rows
+    else:
+        assert rows == [0, 0]
     for a, b in zip(r0[1:8], r1[1:8]):  # replicas identical
         assert np.array_equal(np.asarray(a), np.asarray(b))
     # single-GPU reference on this process
-    sc, cp, w, h = _problem(n=4000, w=160, h=112)
+    sc, cp, w, h = _problem(n=4000, w=160, h=112, spread=1.8)
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
     cfg = ba.TrainConfig()
