@@ -4,7 +4,7 @@
 // that view (visible[] = 1; ~10 % of the rows at the 1 M / 1080p bench workload), so instead of all-reducing the dense
 // [N, 11 + 3C] gradient block every step, bh_train_step (BhTrainBatch.exchange_mode = 1)
 //   1. sums the visible flags over the ranks (needed anyway: vis_weight counts views)      — 4 B per splat
-//   2. takes U = { i : summed visible > 0 } — identical on every rank — and lists it in ascending order (count / spine / place),
+//   2. takes U = { i : summed visible > 0 } — identical on every rank — and lists it in ascending order (count / place),
 //   3. gathers the rows of U into a compact [|U|, 11 + 3C] block, sums THAT, scatters it back.
 // Rows outside U are zero on every rank, so the dense buffer ends up exactly as a dense all-reduce would leave it
 // (up to the summation order inside the collective).  When U is more than half of the scene the dense block is summed
@@ -68,11 +68,28 @@ __global__ __launch_bounds__(EX_WG) void union_spine_kernel(uint32_t* __restrict
     if (threadIdx.x == 0) total_out[0] = s_carry;
 }
 
-// idx[rank] = splat id: thread t owns the 16 consecutive splats base + 16 t .. (ascending ids -> ascending ranks)
+// idx[rank] = splat id: thread t owns the 16 consecutive splats base + 16 t .. (ascending ids -> ascending ranks).
+// SELF_SPINE (up to 4 * 256 blocks = 4 M splats): `block_offsets` holds the RAW block counts and every block adds up the
+// ones in front of it itself (one coalesced load per thread) — the one-block spine launch is 5 us of pure latency; the
+// last block also delivers the total.
+constexpr uint32_t EX_SELF_SPINE_MAX = 4 * EX_WG;
+template <bool SELF_SPINE>
 __global__ __launch_bounds__(EX_WG) void union_place_kernel(const float* __restrict__ visible_sum, uint32_t n, const uint32_t* __restrict__ block_offsets,
-                                                           uint32_t* __restrict__ idx) {
+                                                           uint32_t* __restrict__ idx, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_w[EX_WG / 64];
+    __shared__ uint32_t s_a[EX_WG / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ahead = 0;
+    if (SELF_SPINE) {
+#pragma unroll
+        for (uint32_t k = 0; k < EX_SELF_SPINE_MAX / EX_WG; ++k) {
+            const uint32_t i = k * EX_WG + threadIdx.x;
+            if (i < blockIdx.x) ahead += block_offsets[i];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ahead += __shfl_down(ahead, off);
+        if (lane == 0) s_a[wave] = ahead;
+    }
     const uint32_t first = blockIdx.x * EX_TILE + threadIdx.x * EX_EPT;
     uint32_t bits = 0, cnt = 0;
 #pragma unroll
@@ -85,7 +102,8 @@ __global__ __launch_bounds__(EX_WG) void union_place_kernel(const float* __restr
     const uint32_t incl = ex_wave_incl_scan(cnt, lane);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    uint32_t ofs = block_offsets[blockIdx.x];
+    uint32_t ofs = SELF_SPINE ? (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]) : block_offsets[blockIdx.x];
+    if (SELF_SPINE && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) total_out[0] = ofs + (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 #pragma unroll
     for (int w = 0; w < EX_WG / 64; ++w) ofs += w < wave ? s_w[w] : 0u;
     uint32_t r = ofs + incl - cnt;
@@ -117,9 +135,13 @@ int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32
     const uint32_t nb = (n + EX_TILE - 1) / EX_TILE;
     hipLaunchKernelGGL(union_count_kernel, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch);
     BH_LAUNCH_CHECK(ctx, "union_count_kernel");
-    hipLaunchKernelGGL(union_spine_kernel, dim3(1), dim3(EX_WG), 0, ctx->stream, block_scratch, nb, count_dev);
-    BH_LAUNCH_CHECK(ctx, "union_spine_kernel");
-    hipLaunchKernelGGL(union_place_kernel, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch, idx);
+    if (nb <= EX_SELF_SPINE_MAX) {
+        hipLaunchKernelGGL(union_place_kernel<true>, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch, idx, count_dev);
+    } else {
+        hipLaunchKernelGGL(union_spine_kernel, dim3(1), dim3(EX_WG), 0, ctx->stream, block_scratch, nb, count_dev);
+        BH_LAUNCH_CHECK(ctx, "union_spine_kernel");
+        hipLaunchKernelGGL(union_place_kernel<false>, dim3(nb), dim3(EX_WG), 0, ctx->stream, visible_sum, n, block_scratch, idx, count_dev);
+    }
     BH_LAUNCH_CHECK(ctx, "union_place_kernel");
     return 0;
 }
