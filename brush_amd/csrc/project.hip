@@ -198,7 +198,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     if (gid < prep.visible_words) prep.visible[gid] = 0u;
     if (gid < prep.tile_words) prep.tile_table[gid] = 0u;
     if (gid < 2u * COUNTER_SLOTS && prep.next_counters) prep.next_counters[gid] = 0ull;
-    for (uint32_t i = gid; i < prep.span_f4; i += gridDim.x * PROJ_WG) prep.span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (size_t i = gid; i < prep.span_f4; i += (size_t)gridDim.x * PROJ_WG) prep.span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t key = 0xFFFFFFFFu;
     float radius = 0.0f;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     __shared__ WalkLds s_walk[PROJ_WAVES];
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
-    for (uint32_t i = cg; i < zero_f4; i += gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (size_t i = cg; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
