@@ -246,11 +246,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             visible = true;
         } while (false);
     }
-#ifdef BH_K1_NO_PROJ  // measurement-only variant
-    if (visible && mx == 123.456f) {
-#else
     if (visible) {  // project_visible.rs:56-87
-#endif
         const Vec3A v = normalize(sub(mean, camera_pos(u)));
         constexpr int C = (DEG + 1) * (DEG + 1);
         const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
@@ -269,13 +265,8 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
-#ifdef BH_K1_NO_WALK  // measurement-only variant
-    const uint32_t tiles_hit = nb;
-    (void)w;
-#else
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); });
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
-#endif
     if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
@@ -297,13 +288,9 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         uint32_t v = 0, h = 0;
 #pragma unroll
         for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; }
-#ifdef BH_K1_NO_ATOMIC  // measurement-only variant
-        if (v == 0xFFFFFFFFu) counters[0] = h;
-#else
         unsigned long long* slot = counters + 2u * (blockIdx.x & (COUNTER_SLOTS - 1u));
         if (v) atomicAdd(&slot[0], (unsigned long long)v);
         if (h) atomicAdd(&slot[1], (unsigned long long)h);
-#endif
     }
 }
 
