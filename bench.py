@@ -2,22 +2,30 @@
 """bench.py — headline benchmark of the hot path on MI355X.
 
 A "step" is one SplatTrainer.step (forward render -> L1+SSIM loss -> backward ->
-statistics -> Adam) on ONE 1920x1080 view of the 1 M-splat synthetic scene
+statistics -> Adam + the visibility-gated mean noise, background jittered: the reference's
+default step, train.rs:176-429) on ONE 1920x1080 view of the 1 M-splat synthetic scene
 (BASELINE.json configs[2]), inputs already resident in HBM.
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank
-renders a different view per step and the gradients are all-reduced over RCCL
-between backward and Adam (data parallel over cameras, weak scaling).
+
+--gpus N: data parallel over cameras, one rank per GPU, gradients all-reduced over RCCL between
+backward and Adam (weak scaling).  Started either by `python -m torch.distributed.run ... bench.py
+--gpus N` (RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`, in which
+case this process re-executes itself through torch.distributed.run with N ranks on 127.0.0.1.  It
+fails loudly when fewer than N devices are visible: it never prints an N=1 line for an N>1 request.
 
 Prints ONE JSON line on rank 0 (contract: see the task statement), including
-  roofline     — dominant kernel (rasterize_backward_kernel), algorithmic bytes per
-                 launch / its average duration measured with HIP events on the ctx stream
-  cpu_baseline — the CPU oracle (a C++ restatement of Brush's kernels; Brush has no CPU
-                 backend) timed on the host cores on one full step of the same workload
+  roofline      — dominant kernel (rasterize_backward_kernel) against HBM: the bytes the launch actually
+                  touches / its average duration measured with HIP events on the ctx stream
+  roofline_valu — the same kernel (and the forward blend) against the VALU issue rate, which is what bounds them
+  cpu_baseline  — the CPU oracle (a C++ restatement of Brush's kernels; Brush has no CPU backend) timed on the
+                  host cores on full steps of the same workload
+  non_saturating — a second, non-headline measurement on a scene whose tiles do not saturate early
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,14 +33,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md:
+# "v_fma_f32 (wave64): 2 cyc"), 2.4 GHz -> 1228.8 G wave-instructions/s (full-rate ops; half-rate ops count double)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+# rasterize_backward_kernel issues this many VALU instructions per blended (splat, tile) — SQ_INSTS_VALU / I_blended,
+# profiles/*_sq_counters.csv when present, else this static count from the ISA dump (profiles/*_isa_histogram.txt)
+VALU_PER_ISECT_STATIC = {"rasterize_backward_kernel": 263.0, "rasterize_kernel": 120.0}
+
+# stages whose working set the previous kernel left in the 256 MB Infinity Cache: their GB/s is not an HBM rate
+CACHE_RESIDENT = {"ProjectBackwards": "reads v_combined / writes into the gradient span K1 zero-filled, both still in the 256 MB Infinity Cache",
+                  "OptimizerStep": "reads the gradient span the backward just wrote (Infinity-Cache resident at SH degree 0)"}
 
 
-def stage_bytes(n, nv, ni, pixels, tiles, coeffs):
-    """Algorithmic HBM bytes per stage (SURVEY.md §8d / DESIGN.md §5)."""
+def stage_bytes(n, nv, ni, ni_blended, pixels, tiles, coeffs):
+    """HBM bytes per stage: algorithmic (SURVEY.md §8d / DESIGN.md §5), except the two blend kernels, which are charged
+    only for the intersections they consume before every pixel of a tile saturates."""
     c = coeffs
     return {
         # K1 also stores the projected record by splat id and clears visible + the train step's gradient span on its way
@@ -44,14 +60,53 @@ def stage_bytes(n, nv, ni, pixels, tiles, coeffs):
         "MapGaussiansToIntersect": 32 * nv + 8 * ni + 76 * nv + 40 * nv,
         "TileSort": 40 * ni,
         "GetTileOffsets": 4 * ni + 8 * tiles,
-        "Rasterize": 44 * ni + 16 * pixels,
+        "Rasterize": 44 * ni_blended + 16 * pixels,
         "ImageLoss": (16 + 4 + 12) * pixels,
         "ImageLossBackward": (16 + 4 + 16) * pixels,
-        "ZeroGradBuffers": (48 + 12 * c) * n + 40 * nv,
-        "RasterizeBackwards": 80 * ni + 32 * pixels,
+        "RasterizeBackwards": 80 * ni_blended + 32 * pixels,
         "ProjectBackwards": (88 + 12 * c) * nv + (48 + 12 * c) * nv,
-        "OptimizerStep": 28 * 11 * n + (20 * 3 * c + 8) * n + 36 * n,  # Adam x3 + refine statistics, one launch
+        "OptimizerStep": 28 * 11 * n + (20 * 3 * c + 8) * n + 36 * n,  # Adam x3 + refine statistics + noise, one launch
     }
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run with N ranks."""
+    dry = os.environ.get("BH_BENCH_DRYRUN") == "1"
+    if not dry:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node — refusing to print a line for fewer ranks than requested"
+                             % (args.gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """BH_BENCH_DRYRUN=1 (tests/test_bench_spawn.py, CPU): every rank joins a gloo group and rank 0 prints the line's
+    skeleton — checks the spawn / rendezvous / one-line contract without a GPU."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"metric": "dry run", "n_gpus": dist.get_world_size(), "ranks_joined": int(t.item()), "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -63,10 +118,12 @@ def main():
     ap.add_argument("--workload", default="1m_1080p")
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
-                    help="N>1 gradient exchange: 'torch' = torch.distributed all_reduce (backend nccl = RCCL) from the exchange hook; "
-                         "'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in bh_train_step); the "
-                         "unique id travels through a torch TCPStore on MASTER_ADDR:MASTER_PORT+1")
+    ap.add_argument("--no-extra", action="store_true", help="skip the second (non-saturating scene) measurement")
+    ap.add_argument("--no-noise", action="store_true", help="leave out the two stochastic terms of the reference's default step (mean noise, background jitter)")
+    ap.add_argument("--comm", choices=["torch", "native"], default="native",
+                    help="N>1 gradient exchange: 'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in "
+                         "bh_train_step, no Python callback per step; the unique id is broadcast over the torch process group); "
+                         "'torch' = torch.distributed all_reduce (backend nccl = RCCL) from the exchange hook")
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse",
                     help="N>1 (cameras and tiles): 'sparse' = mask-keyed exchange (visible flags, then only the gradient rows of splats some rank "
                          "saw; dense fallback above half of the scene), 'dense' = one all-reduce of the whole exchange buffer")
@@ -79,6 +136,19 @@ def main():
                          "'tiles' = ONE view partitioned by strips of tile rows (strong scaling, BASELINE.json configs[4])")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (args.gpus == 1 and os.environ.get("BH_FORCE_PG") == "1"):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if os.environ.get("BH_BENCH_DRYRUN") == "1":
+        return dry_run(args)
+
+    import numpy as np
+    import torch
+
     # the contract is ONE JSON line on stdout: keep the real stdout aside and point fd 1 at stderr, so that banners
     # printed by native libraries (RCCL prints its version to stdout when a communicator is created) cannot join it
     sys.stdout.flush()
@@ -86,13 +156,14 @@ def main():
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no device (only %d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    # BH_FORCE_PG=1: build the RCCL process group even for one rank (developer smoke test of the exchange-hook path on a 1-GPU box)
+    # BH_FORCE_PG=1: build the RCCL process group even for one rank (developer smoke test of the exchange path on a 1-GPU box)
     if world > 1 or os.environ.get("BH_FORCE_PG") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,38 +176,23 @@ def main():
     import brush_amd as ba
     from brush_amd import synth
 
-    scene, w, h = synth.config_scene(args.workload, args.sh_degree, n=args.splats or None)
-    n = scene["transforms"].shape[0]
-    coeffs = scene["sh"].shape[1]
-    cp = synth.default_camera_params(w, h)
-    # one view per rank: rank r looks at the scene with a small extra yaw so the ranks'
-    # gradients differ (data parallel over cameras); rank 0 is the named config's camera
     tile_mode = args.parallel == "tiles" and world > 1
-    yaw = 0.0 if tile_mode else 0.02 * rank
-    rot = (0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0))
-    cam = ba.Camera(position=cp["pos"], rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"])
-    splats = ba.Splats(scene["transforms"], scene["sh"], scene["raw_opac"], device=dev)
-    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
-    batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
     ctx = ba.get_context(dev)
-    native = args.comm == "native" and not tile_mode and (world > 1 or os.environ.get("BH_FORCE_PG") == "1")
+    native = args.comm == "native" and not tile_mode and pg is not None
     if native:
-        from torch.distributed import TCPStore
-        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29517")) + 1, world, rank == 0)
-        if rank == 0:
-            store.set("bh_comm_id", ba.Context.comm_unique_id())
-        ctx.comm_init(rank, world, store.get("bh_comm_id"))
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
-                              native_comm=native, sparse_exchange=args.exchange == "sparse")
-
-    loader = None
-    if args.feed == "loader":
-        rng = np.random.default_rng(1 + rank)
-        host_views = [(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), cam.uniforms((w, h))) for _ in range(6)]
-        loader = ba.SceneLoader(host_views, seed=rank, slots=3, ctx=ctx)
-
-    def next_batch():
-        return loader.next_batch() if loader is not None else batch
+        import torch.distributed as dist
+        # rank 0's RCCL unique id travels over the process group that exists anyway (used for the barriers and the timing MAX)
+        ids = [bytes(ba.Context.comm_unique_id()) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=dev)
+        try:
+            ctx.comm_init(rank, world, ids[0])
+        except Exception as e:  # both paths are RCCL; say which one ran (the line's "exchange.comm")
+            print("bench.py: library communicator unavailable (%s); using the torch.distributed exchange hook" % (e,), file=sys.stderr)
+            native = False
+        ok = torch.tensor([1 if native else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if native and int(ok.item()) == 0:
+            native = False
 
     def barrier():
         if pg is not None:
@@ -144,120 +200,221 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        trainer.step(next_batch(), splats)
-    barrier()
-    # timed region: HIP events only around the dominant kernel (2 per step); bracketing all ~15 stages
-    # costs ~0.1 ms of host time per step, so the per-stage table comes from a separate untimed pass
-    ctx.profile(2)
-    ctx.profile_fetch()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(next_batch(), splats)
-    barrier()
-    dt = time.perf_counter() - t0
-    dominant = ctx.profile_fetch()
-    ctx.profile(1)
-    for _ in range(min(args.steps, 10)):
-        trainer.step(batch, splats)
-    barrier()
-    stages = ctx.profile_fetch()
-    stages.update(dominant)   # the dominant kernel's duration is the one measured inside the timed region
-    ctx.profile(0)
-    st = trainer.stats()
-    # how much of the per-tile lists the blend kernels actually consume before every pixel saturates (outside the
-    # timed region): the forward shrinks each tile's list end to its last useful splat
-    _, aux = ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
-    to = aux.tile_offsets.to(torch.int64)
-    isect_blended = int((to[:, 1] - to[:, 0]).clamp(min=0).sum().item())
+    def measure(workload, steps, warmup, with_stages):
+        """Time `steps` train steps of `workload`; returns a dict of raw measurements (rank-local)."""
+        scene, w, h = synth.config_scene(workload, args.sh_degree, n=args.splats or None)
+        n = scene["transforms"].shape[0]
+        coeffs = scene["sh"].shape[1]
+        cp = synth.default_camera_params(w, h)
+        # one view per rank: rank r looks at the scene with a small extra yaw so the ranks'
+        # gradients differ (data parallel over cameras); rank 0 is the named config's camera
+        yaw = 0.0 if tile_mode else 0.02 * rank
+        rot = (0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0))
+        cam = ba.Camera(position=cp["pos"], rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"])
+        splats = ba.Splats(scene["transforms"], scene["sh"], scene["raw_opac"], device=dev)
+        gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
+        batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
+        # seed: the reference's default step draws the mean noise and jitters the background every step
+        trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
+                                  native_comm=native, sparse_exchange=args.exchange == "sparse", seed=None if args.no_noise else 0xB5EED)
+        loader = None
+        if args.feed == "loader":
+            rng = np.random.default_rng(1 + rank)
+            host_views = [(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), cam.uniforms((w, h))) for _ in range(6)]
+            loader = ba.SceneLoader(host_views, seed=rank, slots=3, ctx=ctx)
 
-    if pg is not None:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        def next_batch():
+            return loader.next_batch() if loader is not None else batch
+
+        for _ in range(warmup):
+            trainer.step(next_batch(), splats)
+        barrier()
+        # timed region: HIP events only around the dominant kernel (2 per step); bracketing all ~15 stages
+        # costs ~0.1 ms of host time per step, so the per-stage table comes from a separate untimed pass
+        ctx.profile(2)
+        ctx.profile_fetch()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(next_batch(), splats)
+        barrier()
+        dt = time.perf_counter() - t0
+        dominant = ctx.profile_fetch()
+        stages = {}
+        if with_stages:
+            ctx.profile(1)
+            for _ in range(min(steps, 10)):
+                trainer.step(batch, splats)
+            barrier()
+            stages = ctx.profile_fetch()
+        stages.update(dominant)   # the dominant kernel's duration is the one measured inside the timed region
+        ctx.profile(0)
+        st = trainer.stats()
+        # how much of the per-tile lists the blend kernels actually consume before every pixel saturates (outside the
+        # timed region): the forward shrinks each tile's list end to its last useful splat
+        _, aux = ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
+        to = aux.tile_offsets.to(torch.int64)
+        isect_blended = int((to[:, 1] - to[:, 0]).clamp(min=0).sum().item())
+        if pg is not None:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        if loader is not None:
+            loader.close()
+        return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, stages=stages, stats=st, isect_blended=isect_blended, loader=loader is not None)
+
+    def blend_rooflines(m, steps):
+        """HBM and VALU rooflines of the two blend kernels from one measurement."""
+        nv, ni, ib = m["stats"].num_visible, m["stats"].num_intersections, m["isect_blended"]
+        pixels = m["w"] * m["h"]
+        dom_ms = m["stages"].get("RasterizeBackwards", (0.0, 0))
+        dom_ms = dom_ms[0] / max(dom_ms[1], 1)
+        touched = 80 * ib + 32 * pixels
+        listed = 80 * ni + 32 * pixels
+        ach = touched / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        hbm = {"bound": "hbm", "kernel": "rasterize_backward_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": touched, "avg_launch_ms": round(dom_ms, 4),
+               "intersections_listed": ni, "intersections_blended": ib,
+               "frac_listed": round(listed / 1e9 / (dom_ms * 1e-3) / HBM_PEAK_GBS, 4) if dom_ms > 0 else 0.0,
+               "note": "achieved = bytes the launch touches (80 B per BLENDED intersection + 32 B per pixel) / measured duration. frac_listed is the "
+                       "SURVEY 8d figure that charges every LISTED intersection (80*I + 32*P): the kernel stops each tile once all its pixels "
+                       "saturate, so that figure counts reads it never makes and can exceed 1. The kernel is VALU-issue bound: see roofline_valu."}
+        valu = {}
+        for stage, kern in (("RasterizeBackwards", "rasterize_backward_kernel"), ("Rasterize", "rasterize_kernel")):
+            ms, calls = m["stages"].get(stage, (0.0, 0))
+            ms = ms / max(calls, 1)
+            if ms <= 0:
+                continue
+            per, src = valu_per_isect(kern)
+            insts = per * ib
+            g = insts / 1e9 / (ms * 1e-3)
+            valu[kern] = {"bound": "valu", "achieved": round(g, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": round(g / VALU_PEAK_GINST, 4),
+                          "valu_insts_per_blended_intersection": per, "source": src, "avg_launch_ms": round(ms, 4),
+                          "ns_per_blended_intersection": round(ms * 1e6 / max(ib, 1), 3),
+                          "G_pixel_splat_evals_per_s": round(256.0 * ib / 1e9 / (ms * 1e-3), 1)}
+        return hbm, valu
+
+    m = measure(args.workload, args.steps, args.warmup, True)
+
+    extra = None
+    if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats:
+        ex_steps = max(10, min(args.steps, 30))
+        me = measure("1m_1080p_lowopac", ex_steps, 3, True)
+        ehbm, evalu = blend_rooflines(me, ex_steps)
+        est = me["stats"]
+        extra = {"workload": "1m_1080p_lowopac: the configs[2] scene with opacities U(0.02, 0.1) instead of U(0.05, 0.95) — tiles do not saturate early, "
+                             "the blend kernels consume %.0f %% of every list (NOT a BASELINE.json config; context for the blend kernels only)"
+                             % (100.0 * me["isect_blended"] / max(est.num_intersections, 1)),
+                 "steps": ex_steps, "ms_per_step": round(me["dt"] / ex_steps * 1e3, 4), "views_per_s": round(ex_steps / me["dt"], 2),
+                 "num_visible": est.num_visible, "num_intersections": est.num_intersections, "intersections_blended": me["isect_blended"],
+                 "roofline": ehbm, "roofline_valu": evalu,
+                 "stages_ms": {k: round(ms / max(c, 1), 4) for k, (ms, c) in me["stages"].items()}}
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
+        steps = args.steps
+        dt, st = m["dt"], m["stats"]
+        n, w, h, coeffs = m["n"], m["w"], m["h"], m["coeffs"]
+        ms_per_step = dt / steps * 1e3
         nv, ni = st.num_visible, st.num_intersections
         pixels, tiles = w * h, ((w + 15) // 16) * ((h + 15) // 16)
-        sb = stage_bytes(n, nv, ni, pixels, tiles, coeffs)
+        sb = stage_bytes(n, nv, ni, m["isect_blended"], pixels, tiles, coeffs)
         stage_out = {}
-        for name, (ms, calls) in stages.items():
+        for name, (ms, calls) in m["stages"].items():
+            if calls == 0 or (name == "ZeroGradBuffers" and ms / max(calls, 1) < 0.004):
+                continue   # an empty scope (the fills ride on K1 / K5): nothing to report
             avg = ms / max(calls, 1)
             e = {"ms": round(avg, 4)}
             if name in sb and avg > 0:
-                e["algo_MB"] = round(sb[name] / 1e6, 2)
+                e["MB"] = round(sb[name] / 1e6, 2)
                 e["GBps"] = round(sb[name] / 1e9 / (avg * 1e-3), 1)
+                if name in CACHE_RESIDENT:
+                    e["cache_resident"] = CACHE_RESIDENT[name]
+                else:
+                    e["hbm_frac"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
             stage_out[name] = e
         fwd_names = ["ProjectSplats", "DepthSort", "PrefixSumGaussHits", "ProjectVisible", "MapGaussiansToIntersect", "TileSort", "GetTileOffsets", "Rasterize"]
         bwd_names = ["ZeroGradBuffers", "RasterizeBackwards", "ProjectBackwards"]
         fwd_ms = sum(stage_out[k]["ms"] for k in fwd_names if k in stage_out)
         bwd_ms = sum(stage_out[k]["ms"] for k in bwd_names if k in stage_out)
-        dom = "RasterizeBackwards"
-        dom_ms = stage_out.get(dom, {}).get("ms", 0.0)
-        dom_bytes = sb[dom]
-        achieved = dom_bytes / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        hbm, valu = blend_rooflines(m, steps)
         # the committed PMC passes were taken on the headline workload: no counter figure for any other
         headline = args.workload == "1m_1080p" and args.sh_degree == 0 and not args.splats and not tile_mode
         traffic, traffic_src = pmc_traffic_bytes("rasterize_backward_kernel") if headline else (None, None)
+        hbm["traffic"] = traffic
+        hbm["traffic_source"] = traffic_src
+        step_bytes = sum(sb[k] for k in stage_out if k in sb)
         out = {
             "metric": "train views/sec @ 1M Gaussians, 1080p (fwd + L1/SSIM loss + bwd + Adam per view)",
-            "value": round((1 if tile_mode else world) * args.steps / dt, 3),
+            "value": round((1 if tile_mode else world) * steps / dt, 3),
             "unit": "views/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong" if tile_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if loader is None else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
+            "data": "synthetic" if not m["loader"] else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
-                       "num_visible": nv, "num_intersections": ni, "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
-                                       "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else "")) if world > 1 else "single GPU"},
-            "exchange": ({"mode": args.exchange, "rows_last_step": st.exchange_rows, "rows_total": n} if pg is not None or native else None),
+                       "num_visible": nv, "num_intersections": ni,
+                       "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
+                       "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
+                                       "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
+            "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "rows_last_step": st.exchange_rows, "rows_total": n} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),
-            "roofline": {"bound": "hbm", "kernel": "rasterize_backward_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "intersections_blended": isect_blended,
-                         "note": "achieved = SURVEY 8d algorithmic bytes (80*I + 32*P, every listed intersection) / measured duration; the kernel "
-                                 "stops each tile when all its pixels saturate and blends only %d of the %d listed intersections (%.1f %%), so it is "
-                                 "VALU-issue bound, not HBM bound (DESIGN.md §5): %.2f ns per blended (splat, tile), %.1f G pixel-splat evaluations/s"
-                                 % (isect_blended, ni, 100.0 * isect_blended / max(ni, 1), (dom_ms * 1e6 / max(isect_blended, 1)),
-                                    256.0 * isect_blended / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0)},
+            "roofline": hbm,
+            "roofline_valu": valu,
+            "step_hbm": {"bytes_per_step": step_bytes, "GBps": round(step_bytes / 1e9 / (ms_per_step * 1e-3), 1),
+                         "frac": round(step_bytes / 1e9 / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4),
+                         "note": "sum of the per-stage bytes (blend kernels: touched bytes) / ms_per_step"},
             "stages": stage_out,
         }
+        if extra is not None:
+            out["non_saturating"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cp, w, h)
+            out["cpu_baseline"] = cpu_baseline(m["scene"], m["cp"], w, h)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if loader is not None:
-        loader.close()
     if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def _newest(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def pmc_traffic_bytes(kernel_substr):
     """HBM bytes per launch of `kernel_substr` from the newest profiles/*_hbm_traffic.csv
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction applied)."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
-    if not files:
+    f = _newest("*_hbm_traffic.csv")
+    if not f:
         return None, None
-    for r in csv.DictReader(open(files[-1])):
-        if kernel_substr in r["kernel"]:
-            return float(r["HBM_MB_per_launch_corrected"]) * 1e6, os.path.basename(files[-1])
+    for r in csv.DictReader(open(f)):
+        if r["kernel"].startswith("void bh::" + kernel_substr) or r["kernel"].startswith(kernel_substr) or ("::" + kernel_substr + "<") in r["kernel"]:
+            return float(r["HBM_MB_per_launch_corrected"]) * 1e6, os.path.basename(f)
     return None, None
 
 
+def valu_per_isect(kernel):
+    """VALU wave-instructions per blended (splat, tile): measured (SQ_INSTS_VALU per launch / intersections blended, the newest
+    profiles/*_sq_counters.csv written by scripts/collect_profiles.py) or the static ISA count."""
+    import csv
+    f = _newest("*_sq_counters.csv")
+    if f:
+        for r in csv.DictReader(open(f)):
+            if r["kernel"] == kernel and float(r.get("valu_per_blended_isect") or 0) > 0:
+                return float(r["valu_per_blended_isect"]), os.path.basename(f)
+    return VALU_PER_ISECT_STATIC[kernel], "static ISA count"
+
+
 def cpu_baseline(scene, cp, w, h):
-    """One full step of the SAME workload on the CPU oracle (OpenMP over splats/tiles)."""
+    """Full steps of the SAME workload on the CPU oracle (OpenMP over splats/tiles): one warm-up, then the median of 5."""
     import brush_amd as ba
     from brush_amd import synth
     from oracle import bo
@@ -265,13 +422,17 @@ def cpu_baseline(scene, cp, w, h):
     sc = {k: v.copy() for k, v in scene.items()}
     otr = OracleTrainer(bo, ba.TrainConfig(), median_scene_scale=5.0)
     gt = synth.synthetic_gt_packed(w, h, seed=7)
-    steps = 3
-    t = time.perf_counter()
-    for _ in range(steps):
+    otr.step(sc, bo.camera(**cp), gt, (0.0, 0.0, 0.0))   # warm-up (page faults, OpenMP pool)
+    times = []
+    t_all = time.perf_counter()
+    for _ in range(5):
+        t = time.perf_counter()
         otr.step(sc, bo.camera(**cp), gt, (0.0, 0.0, 0.0))
-    dt = time.perf_counter() - t
-    return {"value": round(steps / dt, 5), "unit": "views/s", "cores": bo.num_threads(), "kind": "port",
-            "sample": "%d full train steps (1 view each) of the same workload; %.2f s wall" % (steps, dt),
+        times.append(time.perf_counter() - t)
+    wall = time.perf_counter() - t_all
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 5), "unit": "views/s", "cores": bo.num_threads(), "kind": "port",
+            "sample": "median of 5 full train steps (1 view each, no noise term) of the same workload after 1 warm-up step; %.2f s wall" % wall,
             "what": "C++/OpenMP restatement of Brush's CubeCL kernels (oracle/brush_oracle.cpp); Brush itself has no CPU backend"}
 
 

@@ -92,7 +92,7 @@ class BhRefineStats(C.Structure):
 class BhTrainBatch(C.Structure):
     _fields_ = [
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
-        ("background", C.c_float * 3), ("noise_samples", C.c_void_p),
+        ("background", C.c_float * 3), ("noise_samples", C.c_void_p), ("device_noise", C.c_int32), ("noise_seed", C.c_uint64),
         ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p), ("exchange_mode", C.c_int32), ("strip_loss", C.c_int32),
     ]
 
@@ -158,6 +158,9 @@ SYMBOLS = {
     "bh_allreduce_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
+    "bh_sample_background": (None, [C.c_uint64, C.c_uint32, fp, C.c_float, fp]),
+    "bh_normal_samples": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "bh_philox4x32_10": (None, [u32p, u32p, u32p]),
     "bh_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
 }

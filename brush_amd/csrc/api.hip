@@ -9,6 +9,7 @@
 #include <new>
 
 #include "context.h"
+#include "device_rng.h"
 
 namespace bh {
 
@@ -194,6 +195,10 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         return nullptr;
     }
     std::memset(ctx->host_counters, 0, bh::HOST_COUNTERS_BYTES);
+    // developer knobs: read here once, never on the per-step path
+    ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
+    if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
+    if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipHostFree(ctx->host_counters);
@@ -224,10 +229,7 @@ const char* bh_last_error(bh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 int bh_sync(bh_ctx* ctx) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->pending_loss_dst) {  // the last train step's loss, staged through pinned memory
-        *ctx->pending_loss_dst = reinterpret_cast<float*>(ctx->host_counters)[15];
-        ctx->pending_loss_dst = nullptr;
-    }
+    deliver_pending_loss(ctx);  // the last train step's loss, staged through pinned memory
     return 0;
 }
 
@@ -539,7 +541,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
         const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
         const float class_width = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
-        ctx->lpt = (bwd_info && getenv("BH_NO_LPT") == nullptr) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
+        ctx->lpt = (bwd_info && !ctx->knob_no_lpt) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
         BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
                                 bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible, ctx->lpt,
                                 class_width < 8.0f ? 8.0f : class_width));
@@ -705,6 +707,33 @@ int bh_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, f
     return launch_gather_stats(ctx, refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, n);
 }
 
+// ---- the stochastic terms of step() (device_rng.h) ----------------------------------------
+void bh_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const Philox4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// sample_background_color (train.rs:896-908): base + U(-strength, strength)^3, clamped to [0,1]
+void bh_sample_background(uint64_t seed, uint32_t step, const float base[3], float strength, float out[3]) {
+    float u[3] = {0.5f, 0.5f, 0.5f};
+    if (strength > 0.0f) {
+        const Philox4 r = philox4x32_10(0u, step, 0u, RNG_STREAM_BACKGROUND, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[0] = unit_open(r.x); u[1] = unit_open(r.y); u[2] = unit_open(r.z);
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float v = strength > 0.0f ? base[k] + (2.0f * u[k] - 1.0f) * strength : base[k];
+        out[k] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
+int bh_normal_samples(bh_ctx* ctx, uint64_t seed, uint32_t step, uint64_t n, float* out) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (n > 0 && !out) return set_error(ctx, BH_ERR_INVALID_ARG, "normal_samples: null argument");
+    if (n > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_INVALID_ARG, "normal_samples: n must fit 32 bits (the splat index is one counter word)");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_normal_samples(ctx, out, n, seed, step);
+}
+
 // ---- Mip-Splatting 3D filter ---------------------------------------------------------
 int bh_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw_opacities, const float* min_scale, uint32_t n,
                       float* out_transforms, float* out_raw_opacities) {
@@ -748,8 +777,9 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     BH_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = st->n, C = (st->sh_degree + 1) * (st->sh_degree + 1);
     const uint32_t W = batch->camera.img_w, H = batch->camera.img_h;
-    st->step_count += 1;  // train.rs:183
-    const uint32_t step = st->step_count;
+    // train.rs:183 — committed to `st` only once the update is queued: a step that fails half-way (OOM, hook / RCCL error)
+    // applied no update, so Adam's t and the lr_mean schedule must not have advanced for the retry
+    const uint32_t step = st->step_count + 1;
 
     // ---- the exchange buffer: visible[N] | v_transforms[10N] | v_sh[3CN] | v_raw_opac[N] | v_refine[N], every section
     // starting on a 16-byte boundary (padded to a multiple of 4 floats; the padding stays zero) so the update kernel
@@ -841,7 +871,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     auto* loss_dev = (float*)ensure(ctx, SLOT_LOSS_SCALAR, 16);
     if (!v_output || !loss_dev) return BH_ERR_OOM;
     // the loss scalar goes straight into pinned host memory (bh_sync hands it to stats->loss): no copy launch
-    float* loss_host = reinterpret_cast<float*>(ctx->host_counters) + 15;
+    float* loss_host = reinterpret_cast<float*>(ctx->host_counters) + HOST_LOSS_WORD;
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
@@ -899,18 +929,25 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     // ---- refine statistics (train.rs:280-298) + optimizer (train.rs:300-381): one launch
     const double decay = std::pow(cfg->lr_mean_end / cfg->lr_mean, 1.0 / (double)cfg->total_train_iters);
     const double lr_mean = cfg->lr_mean * std::pow(decay, (double)((int)step - 1)) * (double)cfg->median_scene_scale;
+    // visibility-gated noise on the means (train.rs:389-416): injected samples, or drawn on the device (device_rng.h)
+    const bool noise_on = cfg->mean_noise_weight > 0.0f && n > 0 && (batch->noise_samples || batch->device_noise);
+    const float noise_scale = (float)lr_mean * cfg->mean_noise_weight;
+    // device-drawn noise without a 3D-filter floor rides on the update launch (the gate reads the opacity that launch just wrote)
+    const bool noise_fused = noise_on && !batch->noise_samples && !st->min_scale;
     {
         ProfScope ps(ctx, "OptimizerStep");
         float tab[10];
         for (int i = 0; i < 3; ++i) tab[i] = (float)lr_mean;
         for (int i = 3; i < 7; ++i) tab[i] = (float)cfg->lr_rotation;
         for (int i = 7; i < 10; ++i) tab[i] = (float)cfg->lr_scale;
+        const NoiseArgs na{batch->noise_seed, step, noise_scale, cfg->median_scene_scale};
         // sh: DC at full lr, bands >= 1 scaled by 1/lr_coeffs_sh_scale
         BH_TRY(launch_train_update(ctx, st, g_tr, g_sh, g_op, s_refine, s_visible, s_radius, grad_scale, tile_mode, tab,
-                                   (float)cfg->lr_coeffs_dc, 1.0f / cfg->lr_coeffs_sh_scale, (float)cfg->lr_opac, step, 0.9f, 0.999f, 1e-15f));
+                                   (float)cfg->lr_coeffs_dc, 1.0f / cfg->lr_coeffs_sh_scale, (float)cfg->lr_opac, step, 0.9f, 0.999f, 1e-15f,
+                                   noise_fused ? &na : nullptr));
     }
-    // ---- visibility-gated noise on the means (train.rs:389-416)
-    if (batch->noise_samples && cfg->mean_noise_weight > 0.0f) {
+    st->step_count = step;   // the update is queued: the step counts
+    if (noise_on && !noise_fused) {
         ProfScope ps(ctx, "MeanNoise");
         // the gate reads splats.opacities() of the UPDATED parameters (train.rs:389), i.e. through the fold when a floor is set
         const float* gate_opac = st->raw_opacities;
@@ -920,8 +957,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
             BH_TRY(launch_fold_min_scale(ctx, st->transforms, st->raw_opacities, st->min_scale, n, ft, fo));
             gate_opac = fo;
         }
-        BH_TRY(launch_mean_noise(ctx, st->transforms, gate_opac, s_visible, batch->noise_samples, n,
-                                 (float)lr_mean * cfg->mean_noise_weight, cfg->median_scene_scale));
+        BH_TRY(launch_mean_noise(ctx, st->transforms, gate_opac, s_visible, batch->noise_samples, n, noise_scale, cfg->median_scene_scale,
+                                 batch->noise_seed, step));
     }
     stats->num_visible = ro.num_visible;
     stats->num_intersections = ro.num_intersections;

@@ -66,6 +66,13 @@ struct Buffer {
 
 constexpr int MAX_PROF = 32;
 
+// K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
+constexpr uint32_t COUNTER_SLOTS = 128;
+// pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots | the loss word.
+// The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
+constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_SLOTS * 4;
+constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_SLOTS * 16 + 64;
+
 struct Profiler {
     int level = 0;  // 0 off, 1 every stage, 2 only the dominant kernel (2 events per step)
     const char* names[MAX_PROF];
@@ -114,12 +121,24 @@ struct bh_ctx {
     int comm_rank = 0, comm_world = 1;
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
+    bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
+    // developer knobs (A/B measurements), read from the environment ONCE at bh_create
+    bool knob_no_lpt = false;         // BH_NO_LPT: backward tiles in index order
+    uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
+    uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
     bh::Profiler prof;
 };
 
 namespace bh {
 
 int set_error(bh_ctx* ctx, int code, const std::string& msg);
+// after ANY host wait on the ctx stream: hand the last train step's loss (pinned staging word) to its BhTrainStats
+inline void deliver_pending_loss(bh_ctx* ctx) {
+    if (ctx->pending_loss_dst) {
+        *ctx->pending_loss_dst = reinterpret_cast<const volatile float*>(ctx->host_counters)[HOST_LOSS_WORD];
+        ctx->pending_loss_dst = nullptr;
+    }
+}
 int check_hip(bh_ctx* ctx, hipError_t e, const char* what);
 // Grow-only allocation of a scratch slot; returns nullptr (and sets the error) on failure.
 void* ensure(bh_ctx* ctx, Slot s, size_t bytes);
@@ -152,9 +171,6 @@ ViewUniforms make_uniforms(const BhCamera& c);
 
 // ---- launchers (each in its own TU) --------------------------------------------
 // project.hip
-// K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
-constexpr uint32_t COUNTER_SLOTS = 128;
-constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_SLOTS * 16;   // [16] u32 scalars (loss, refine, exchange rows) | the counter slots
 
 // Buffers K1 clears on the way (every splat thread stores a few zeros: three fill launches fewer per forward).
 struct ForwardPrep {
@@ -207,14 +223,18 @@ int launch_sum(bh_ctx* ctx, const float* x, uint64_t n, float scale, float* out_
 int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len,
                 const float* col_scale, float lr, uint32_t t, bool reduce_m2, float beta1, float beta2, float eps);
 // statistics + the three Adam updates of a train step in one launch (tab_t: per-column lr of `transforms`)
+// noise != NULL: the visibility-gated mean noise of train.rs:389-416, drawn on the device (device_rng.h), rides on the same launch
+struct NoiseArgs { uint64_t seed; uint32_t step; float scale, clamp_abs; };
 int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
                         const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
                         bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
-                        float beta1, float beta2, float eps);
+                        float beta1, float beta2, float eps, const NoiseArgs* noise = nullptr);
 int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
                         const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
+// samples == NULL: drawn on the device from (seed, step, splat)
 int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible,
-                      const float* samples, uint64_t n, float noise_scale, float clamp_abs);
+                      const float* samples, uint64_t n, float noise_scale, float clamp_abs, uint64_t seed = 0, uint32_t step = 0);
+int launch_normal_samples(bh_ctx* ctx, float* out, uint64_t n, uint64_t seed, uint32_t step);
 
 // filter3d.hip — Mip-Splatting 3D filter (scale floor): fold, its VJP, the floor itself
 int launch_fold_min_scale(bh_ctx* ctx, const float* transforms, const float* raw_opac, const float* min_scale, uint32_t n,

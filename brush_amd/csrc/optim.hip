@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "context.h"
+#include "device_rng.h"
 
 namespace bh {
 
@@ -122,12 +123,9 @@ int launch_adam(bh_ctx* ctx, float* param, const float* grad, float* m1, float* 
         if (row_len > 255) return set_error(ctx, BH_ERR_UNSUPPORTED, "adam (reduced second moment): row_len must be <= 255");
         const uint64_t nb = (rows + ADAM_ROWS - 1) / ADAM_ROWS;
         const size_t lds = ((size_t)ADAM_ROWS * (row_len + 1) + ADAM_ROWS) * sizeof(float);
-        if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (row_len > 62): opt in once per process
-            static bool raised = false;
-            if (!raised) {
-                BH_HIP(ctx, hipFuncSetAttribute((const void*)adam_rowreduced_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                raised = true;
-            }
+        if (lds > 64 * 1024 && !ctx->adam_lds_raised) {  // above the default dynamic-LDS limit (row_len > 62): opt in once per ctx (the attribute is per device)
+            BH_HIP(ctx, hipFuncSetAttribute((const void*)adam_rowreduced_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ctx->adam_lds_raised = true;
         }
         hipLaunchKernelGGL(adam_rowreduced_kernel, dim3((unsigned)nb), dim3(OPT_WG), lds, ctx->stream, param, grad, m1, m2, rows, row_len, col_scale, a);
         BH_LAUNCH_CHECK(ctx, "adam_rowreduced_kernel");
@@ -157,6 +155,10 @@ struct UpdateArgs {
     uint32_t vis_clamp;    // tile-partitioned frame: visible arrives summed over strips -> min(v, 1)
     float tab_t[10];       // lr_mean x3, lr_rotation x4, lr_scale x3
     float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
+    // visibility-gated noise on the means (train.rs:389-416) drawn on the device and added right behind the Adam update
+    uint32_t noise_on, noise_step;
+    float noise_scale, noise_clamp;
+    uint64_t noise_seed;
 };
 
 // VEC: every tensor base is 16-byte aligned -> 128-bit loads / stores (a block's region starts at a multiple of
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
     float* s_g = s_dyn;                       // [rows][row_len + 1]
     float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
+    float* s_noise = s_v + (uint32_t)ROWS;            // [rows][3], only with noise_on
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
@@ -215,13 +218,28 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         float p = opac[i];
         adam_elem(p, g, mm1, mm2, a, u.lr_opac);
         opac[i] = p;
+        if (u.noise_on) {   // the gate reads the UPDATED opacity (train.rs:389)
+            const float w = mean_noise_gate(p, visible[i]);
+            float nz[3] = {0.0f, 0.0f, 0.0f};
+            if (w != 0.0f) {
+                const float wm = w * u.noise_scale;
+                normal3(u.noise_seed, u.noise_step, (uint32_t)i, nz[0], nz[1], nz[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nz[k] = clampf(nz[k] * wm, -u.noise_clamp, u.noise_clamp);
+            }
+            s_noise[threadIdx.x * 3u] = nz[0];
+            s_noise[threadIdx.x * 3u + 1u] = nz[1];
+            s_noise[threadIdx.x * 3u + 2u] = nz[2];
+        }
     }
+    if (u.noise_on) __syncthreads();   // block-uniform
     // ---- transforms: full second moment, per-column lr
     {
         const uint32_t count = nrows * 10u;
         const uint64_t base = row0 * 10u;
         auto one = [&](float g_raw, float m1v, float m2v, float pv, uint32_t e, float& o_m1, float& o_m2, float& o_p) {
-            const uint32_t c = e - ((e * 52429u) >> 19) * 10u;  // e % 10 (e < 2560)
+            const uint32_t r = (e * 52429u) >> 19;  // e / 10 (e < 2560)
+            const uint32_t c = e - r * 10u;
             const float g = g_raw * u.gscale;
             const float mm1 = a.first ? g * a.f1 : m1v * a.beta1 + g * a.f1;
             const float gsq = g * g;
@@ -231,6 +249,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             float p = pv;
             float m1c = mm1;
             adam_elem(p, g, m1c, mm2, a, u.tab_t[c] * 1.0f);
+            if (u.noise_on && c < 3u) p = p + s_noise[r * 3u + c];
             o_p = p;
         };
         const uint32_t vec_end = VEC ? (count & ~3u) : 0u;
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
 int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
                         const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
                         bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
-                        float beta1, float beta2, float eps) {
+                        float beta1, float beta2, float eps, const NoiseArgs* noise) {
     const uint32_t n = st->n, C = (st->sh_degree + 1) * (st->sh_degree + 1);
     if (n == 0) return 0;
     if (t == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "adam: t is 1-based");
@@ -319,16 +338,18 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     u.a.first = t == 1 ? 1u : 0u;
     u.lr_sh = lr_sh; u.lr_opac = lr_opac; u.gscale = gscale;
     u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
+    u.noise_on = noise ? 1u : 0u;
+    u.noise_step = noise ? noise->step : 0u;
+    u.noise_scale = noise ? noise->scale : 0.0f;
+    u.noise_clamp = noise ? noise->clamp_abs : 0.0f;
+    u.noise_seed = noise ? noise->seed : 0ull;
     for (int i = 0; i < 10; ++i) u.tab_t[i] = tab_t[i];
     for (uint32_t k = 0; k < 75; ++k) u.tab_sh[k] = (k / 3 == 0) ? 1.0f : sh_rest_scale;
     // splats per block: ~13 KB of LDS-staged SH gradients keeps >= 8 blocks resident per CU (measured at 1 M splats:
     // SH degree 3: 0.368 ms @256, 0.300 @128, 0.290 @64, 0.327 @32; degree 0 is best at 256)
     uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
-    if (const char* e = getenv("BH_UPDATE_ROWS")) {  // developer knob (A/B measurements): 64 | 128 | 256
-        const int r = atoi(e);
-        if (r == 64 || r == 128 || r == 256) rows = (uint32_t)r;
-    }
-    const size_t lds = ((size_t)rows * (u.sh_len + 1) + rows) * sizeof(float);
+    if (ctx->knob_update_rows) rows = ctx->knob_update_rows;  // developer knob BH_UPDATE_ROWS (read once at bh_create)
+    const size_t lds = ((size_t)rows * (u.sh_len + 1) + rows + (noise ? 3 * rows : 0)) * sizeof(float);
     const unsigned nb = (unsigned)(((uint64_t)n + rows - 1) / rows);
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
     bool vec = true;
@@ -366,29 +387,49 @@ int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weigh
 }
 
 // train.rs:389-416: means += clamp(sample * (1 - sigmoid(raw_opac))^150 * visible * scale, +-clamp_abs)
+// samples == NULL: the N(0,1) samples are drawn on the spot (device_rng.h, keyed by seed / step / splat).
 __global__ __launch_bounds__(OPT_WG) void mean_noise_kernel(float* __restrict__ transforms, const float* __restrict__ raw_opac,
                                                            const float* __restrict__ visible, const float* __restrict__ samples,
-                                                           uint64_t n, float noise_scale, float clamp_abs) {
+                                                           uint64_t n, float noise_scale, float clamp_abs, uint64_t seed, uint32_t step) {
     const uint64_t i = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
     if (i >= n) return;
-    const float inv_opac = 1.0f - sigmoid(raw_opac[i]);
-    // x^150 = x^128 * x^16 * x^4 * x^2
-    const float x2 = inv_opac * inv_opac, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32, x128 = x64 * x64;
-    // visible is a 0/1 flag; a data-parallel caller hands in the SUM over its views -> gate with min(v, 1)
-    const float w = clampf(x128 * x16 * x4 * x2, 0.0f, 1.0f) * __builtin_fminf(visible[i], 1.0f);
+    const float w = mean_noise_gate(raw_opac[i], visible[i]);
     const float wm = w * noise_scale;
+    float smp[3];
+    if (samples) {
+        smp[0] = samples[i * 3]; smp[1] = samples[i * 3 + 1]; smp[2] = samples[i * 3 + 2];
+    } else {
+        if (w == 0.0f) return;   // sample * 0 = 0 for every finite sample: the means do not move
+        normal3(seed, step, (uint32_t)i, smp[0], smp[1], smp[2]);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float nz = clampf(samples[i * 3 + k] * wm, -clamp_abs, clamp_abs);
+        const float nz = clampf(smp[k] * wm, -clamp_abs, clamp_abs);
         transforms[i * 10 + k] = transforms[i * 10 + k] + nz;
     }
 }
 
 int launch_mean_noise(bh_ctx* ctx, float* transforms, const float* raw_opac, const float* visible, const float* samples,
-                      uint64_t n, float noise_scale, float clamp_abs) {
+                      uint64_t n, float noise_scale, float clamp_abs, uint64_t seed, uint32_t step) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mean_noise_kernel, dim3((unsigned)((n + OPT_WG - 1) / OPT_WG)), dim3(OPT_WG), 0, ctx->stream, transforms, raw_opac, visible, samples, n, noise_scale, clamp_abs);
+    hipLaunchKernelGGL(mean_noise_kernel, dim3((unsigned)((n + OPT_WG - 1) / OPT_WG)), dim3(OPT_WG), 0, ctx->stream, transforms, raw_opac, visible, samples, n, noise_scale, clamp_abs, seed, step);
     BH_LAUNCH_CHECK(ctx, "mean_noise_kernel");
+    return 0;
+}
+
+// the raw N(0,1) samples a step would draw: out [n,3] (tests; callers that want the reference's `samples` tensor)
+__global__ __launch_bounds__(OPT_WG) void normal_samples_kernel(float* __restrict__ out, uint64_t n, uint64_t seed, uint32_t step) {
+    const uint64_t i = (uint64_t)blockIdx.x * OPT_WG + threadIdx.x;
+    if (i >= n) return;
+    float a, b, c;
+    normal3(seed, step, (uint32_t)i, a, b, c);
+    out[i * 3] = a; out[i * 3 + 1] = b; out[i * 3 + 2] = c;
+}
+
+int launch_normal_samples(bh_ctx* ctx, float* out, uint64_t n, uint64_t seed, uint32_t step) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(normal_samples_kernel, dim3((unsigned)((n + OPT_WG - 1) / OPT_WG)), dim3(OPT_WG), 0, ctx->stream, out, n, seed, step);
+    BH_LAUNCH_CHECK(ctx, "normal_samples_kernel");
     return 0;
 }
 

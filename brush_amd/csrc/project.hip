@@ -122,7 +122,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
 // replaces the per-splat LDS cursor (an atomic with return per hit) and compacts the stores: lanes with a hit write
 // consecutive addresses.  Relies on K1 having counted with the same inlined test (it has: will_primitive_contribute).
 BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
-                                    uint32_t wave_base, uint32_t tile_bw, uint32_t cg0, uint32_t* __restrict__ tile_ids,
+                                    uint32_t wave_base, uint32_t wave_total, uint32_t tile_bw, uint32_t cg0, uint32_t* __restrict__ tile_ids,
                                     uint32_t* __restrict__ isect_gids) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
@@ -168,12 +168,22 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
         }
         const unsigned long long hits = __ballot(hit);
         if (hit) {
-            const uint32_t idx = wave_base + emitted + (uint32_t)__popcll(hits & below);
-            tile_ids[idx] = tile;
-            isect_gids[idx] = owner;
+            // never outside the wave's own slot range [wave_base, wave_base + wave_total), whatever K1 counted
+            const uint32_t local = emitted + (uint32_t)__popcll(hits & below);
+            if (local < wave_total) {
+                tile_ids[wave_base + local] = tile;
+                isect_gids[wave_base + local] = owner;
+            }
         }
         emitted += (uint32_t)__popcll(hits);
         before += (uint32_t)__popcll(marks);
+    }
+    // map_gaussians.rs:73-79: leftover budget becomes sentinel rows (tile id 0xFFFFFFFF sorts behind every tile and is
+    // skipped by tile_offsets_kernel).  Dead code as long as K1's count and this walk agree — which they do: both inline the
+    // same will_primitive_contribute on the same stored values — but a drift would otherwise leave uninitialised rows.
+    for (uint32_t k = emitted + (uint32_t)lane; k < wave_total; k += 64u) {
+        tile_ids[wave_base + k] = 0xFFFFFFFFu;
+        isect_gids[wave_base + k] = 0u;
     }
     return emitted;
 }
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
-    uint32_t base = 0, pf_count = 0, nb = 0;
+    uint32_t base = 0, end = 0, nb = 0;
     if (cg < nv) {
         const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
         float p[9];
@@ -397,19 +407,19 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
         compute_bbox_extent(conic, pt, ex, ey);
         bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_y0, tile_y1);
         base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
-        pf_count = cum_tiles_hit[cg] - base;
+        end = cum_tiles_hit[cg];
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
     }
     WalkLds& w = s_walk[wave];
     // first output slot of the wave = the slot range start of its first splat (lanes past nv hold nb = 0 and emit nothing)
     const uint32_t cg0 = cg - (uint32_t)lane;
     const uint32_t wave_base = __shfl(base, 0);
+    // ... and its budget ends where the wave's last splat's range ends (K1's counts, through the scan)
+    const uint32_t last_lane = cg0 < nv ? (nv - 1u - cg0 < 63u ? nv - 1u - cg0 : 63u) : 0u;
+    const uint32_t wave_total = __shfl(end, (int)last_lane) - wave_base;
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
-    (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
-    // map_gaussians.rs:73-79 pads leftover budget with sentinel rows; it cannot happen here (K1's count and this walk
-    // are the same inlined test on the same values), and the compacted emit above relies on exactly that.
-    (void)pf_count;
+    (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
     (void)tile_bh;
 }
 

@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
                     if (prev < num_tiles) tile_offsets[prev * 2 + 1] = i;
                     tile_offsets[tid * 2] = i;
                 }
+            } else if (i > 0u && prev < num_tiles) {
+                // valid -> sentinel transition: close the last valid tile (the reference leaves its end at 0 here,
+                // get_tile_offset.rs:28-57 / SURVEY App. B.2)
+                tile_offsets[prev * 2 + 1] = i;
             }
             prev = tid;
         }

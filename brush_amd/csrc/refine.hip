@@ -48,7 +48,7 @@ BH_DEV float hash_unit(uint64_t seed, uint64_t stream, uint64_t i) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z = z ^ (z >> 31);
-    return ((float)(uint32_t)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    return ((float)(uint32_t)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);  // 23 bits: k + 0.5 is exact, u in (0,1) with uniform spacing
 }
 
 // exponential clock of weight w: smaller = sampled earlier; +inf when the weight is not a
@@ -376,6 +376,7 @@ static int refine_plan_impl(bh_ctx* ctx, const BhRefineConfig* cfg, const BhTrai
     uint32_t* hc = ctx->host_counters;
     BH_HIP(ctx, hipMemcpyAsync(hc, ctl, C_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    deliver_pending_loss(ctx);   // a train step queued before this plan has finished now: its loss word is final
     if (hc[C_NKEEP] == 0 && !no_prune) {  // prune_points: "Trying to create empty splat!" -> nothing is pruned (train.rs:866-869)
         return refine_plan_impl(ctx, cfg, st, out, 1);
     }
@@ -462,6 +463,7 @@ int bh_splat_bounds(bh_ctx* ctx, const float* transforms, uint32_t n, float perc
         float* hp = reinterpret_cast<float*>(ctx->host_counters);
         BH_HIP(ctx, hipMemcpyAsync(hp, picks, 24, hipMemcpyDeviceToHost, ctx->stream));
         BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        deliver_pending_loss(ctx);
         bool ok = true;
         for (int k = 0; k < 6; ++k) ok = ok && std::isfinite(hp[k]);
         if (ok) {

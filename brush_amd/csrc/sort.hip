@@ -219,9 +219,8 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
     const uint32_t base_w = bits / passes, wide = bits % passes;   // the first `wide` passes take one extra bit
     const bool small = n <= SMALL_SORT_MAX;
     uint32_t kpt = small ? 8u : 16u;
-    if (const char* e = getenv("BH_SORT_KPT")) {   // developer knob (A/B measurements): 4 | 8 | 16
-        const int k = atoi(e);
-        if ((k == 4 && n <= (1u << 22)) || k == 8 || k == 16) kpt = (uint32_t)k;
+    if (const uint32_t k = ctx->knob_sort_kpt) {   // developer knob BH_SORT_KPT (read once at bh_create): 4 | 8 | 16
+        if ((k == 4 && n <= (1u << 22)) || k == 8 || k == 16) kpt = k;
     }
     const uint32_t tile = SORT_WG * kpt;
     const uint32_t nblocks = (n + tile - 1) / tile;

@@ -818,8 +818,14 @@ class SplatTrainer:
     rank-local until `sync_refine_stats()` (called by `refine`) MAX-reduces them."""
 
     def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
-                 partition: str = "cameras", native_comm: bool = False, sparse_exchange: bool = True):
-        """partition (only with a process_group): "cameras" = data parallel, every rank its own view,
+                 partition: str = "cameras", native_comm: bool = False, sparse_exchange: bool = True, seed: Optional[int] = None):
+        """seed: an int turns on the two stochastic terms of the reference's step — the visibility-gated noise on the
+        means (train.rs:389-416) and the background jitter (train.rs:896-908) — drawn by the library's counter-based
+        generator as pure functions of (seed, step[, splat]); data-parallel ranks must pass the same seed.  None (the
+        default of this mirror, which the parity tests rely on): the terms appear only when injected through
+        step(background=..., noise_samples=...).
+
+        partition (only with a process_group): "cameras" = data parallel, every rank its own view,
         mean gradient; "tiles" = every rank renders a strip of tile rows of the SAME view, strips are
         all-gathered before the loss and the partial gradients summed."""
         if partition not in ("cameras", "tiles"):
@@ -829,6 +835,7 @@ class SplatTrainer:
         if native_comm and (process_group is not None or partition != "cameras"):
             raise ValueError("native_comm excludes process_group and supports partition='cameras' only")
         self.native_comm = bool(native_comm)
+        self.seed = None if seed is None else (int(seed) & 0xFFFFFFFFFFFFFFFF)
         # exchange only the gradient rows of splats some rank (view or strip) saw (BhTrainBatch.exchange_mode 1,
         # brush_amd/csrc/exchange.hip); False = one dense all-reduce of the whole exchange buffer
         self.sparse_exchange = bool(sparse_exchange)
@@ -883,13 +890,25 @@ class SplatTrainer:
         self.state = dict(m1_t=z(n, 10), m2_t=z(n, 10), m1_sh=z(*splats.sh_coeffs.shape), m2_sh=z(n), m1_o=z(n), m2_o=z(n),
                           refine_weight_norm=z(n), vis_weight=z(n), max_screen_size=z(n))
 
-    def sample_background(self, rng=None):
-        # train.rs:896-908: base + U(-s, s)^3, clamped to [0,1]
+    def sample_background(self, rng=None, step=None):
+        """train.rs:896-908: base + U(-s, s)^3, clamped to [0,1].  With the trainer's seed: the library's generator at
+        (seed, step); else from `rng` (a random.Random) if given; else the base colour."""
         s = self.config.background_noise_strength
         base = self.config.background_color
+        if self.seed is not None and rng is None:
+            out = (C.c_float * 3)()
+            _ffi.load().bh_sample_background(self.seed, int(self.step_count + 1 if step is None else step), (C.c_float * 3)(*[float(b) for b in base]), float(s), out)
+            return tuple(out)
         if s <= 0.0 or rng is None:
             return tuple(base)
         return tuple(min(1.0, max(0.0, b + (rng.random() * 2.0 - 1.0) * s)) for b in base)
+
+    def normal_samples(self, n, step, device, ctx=None):
+        """The [n,3] N(0,1) samples the seeded step number `step` draws (bh_normal_samples)."""
+        ctx = ctx or self.ctx or get_context(device)
+        out = torch.empty((int(n), 3), dtype=torch.float32, device=device)
+        ctx.check(ctx.lib.bh_normal_samples(ctx._h, int(self.seed or 0), int(step), int(n), _ptr(out)))
+        return out
 
     def _make_hook(self, dev):
         import torch.distributed as dist
@@ -973,12 +992,14 @@ class SplatTrainer:
         gt = _as_u32(batch.img_packed, dev)
         b.gt_packed = gt.data_ptr()
         b.has_alpha, b.alpha_is_mask = int(batch.has_alpha), int(batch.alpha_is_mask)
-        bg = background if background is not None else c.background_color
+        bg = background if background is not None else (self.sample_background() if self.seed is not None else c.background_color)
         b.background[0], b.background[1], b.background[2] = [float(v) for v in bg]
         ns = None
         if noise_samples is not None:
             ns = _f32c(noise_samples, dev).reshape(-1, 3)
             b.noise_samples = ns.data_ptr()
+        elif self.seed is not None:
+            b.device_noise, b.noise_seed = 1, self.seed
         stats = _ffi.BhTrainStats()
         b.exchange_mode = 1 if (self.sparse_exchange and (self.pg is not None or self.native_comm)) else 0
         hook, scale = None, 1.0

@@ -275,7 +275,13 @@ typedef struct BhTrainBatch {
     /* Stochastic terms are injected so a step is reproducible (the reference draws
      * them from burn's GPU PRNG / rand::rng(), train.rs:395-399,896-908): */
     float background[3];       /* background actually used this step */
-    const float* noise_samples; /* [N,3] N(0,1) device, or NULL = no noise */
+    const float* noise_samples; /* [N,3] N(0,1) device: injected samples (parity tests), or NULL */
+    /* device_noise != 0 and noise_samples == NULL: the samples are drawn inside the step by a counter-based generator
+     * (Philox-4x32-10 + Box-Muller, brush_amd/csrc/device_rng.h) as a pure function of (noise_seed, step number, splat
+     * index) — what `Tensor::random(.., Normal(0,1))` is in the reference (train.rs:395-399).  Data-parallel ranks passing
+     * the same seed on identical replicas draw identical noise.  Both unset = no noise term. */
+    int32_t device_noise;
+    uint64_t noise_seed;
     bh_image_hook image_hook;   /* NULL unless the frame is tile-partitioned over ranks */
     void* image_hook_user;
     /* Multi-GPU only.  0: one SUM over visible | gradients (dense).  1: mask-keyed — the hook (or the
@@ -335,6 +341,15 @@ int bh_allreduce_sum_f32(bh_ctx* ctx, float* buf, uint64_t count);
 int bh_allreduce_max_f32(bh_ctx* ctx, float* buf, uint64_t count); /* e.g. RefineRecord maxima before refine */
 int bh_allgather_bytes(bh_ctx* ctx, const void* send, void* recv /*world * bytes_per_rank*/, uint64_t bytes_per_rank); /* e.g. image strips */
 
+/* The stochastic terms of step().  bh_sample_background: sample_background_color (train.rs:896-908) from the same
+ * counter-based generator — base + U(-strength, strength)^3 clamped to [0,1], a pure function of (seed, step); host only.
+ * bh_normal_samples: the [n,3] N(0,1) samples a device_noise step with this (seed, step) draws (tests; callers that
+ * want the tensor).  bh_philox4x32_10: the raw generator (known-answer tests against the published vectors); host only. */
+void bh_sample_background(uint64_t seed, uint32_t step, const float base[3] /*host*/, float strength, float out[3] /*host*/);
+int bh_normal_samples(bh_ctx* ctx, uint64_t seed, uint32_t step, uint64_t n, float* out /*[n,3] device*/);
+void bh_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* state->step_count is advanced only when the call succeeds (a failed step applied no update and may be retried). */
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);

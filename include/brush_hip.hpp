@@ -317,6 +317,7 @@ struct TrainConfig {  // config.rs:7-132 subset, same defaults
     double lr_mean = 2e-5, lr_mean_end = 2e-7, lr_coeffs_dc = 2e-3, lr_opac = 0.012, lr_scale = 5e-3, lr_rotation = 2e-3;
     float lr_coeffs_sh_scale = 10.0f, ssim_weight = 0.2f, match_alpha_weight = 0.1f, mean_noise_weight = 50.0f;
     float background_color[3] = {0.0f, 0.0f, 0.0f};
+    float background_noise_strength = 0.1f;
     bool render_mip = false;
     uint32_t max_splats = 10000000, refine_every = 200, growth_stop_iter = 15000;
     float growth_grad_threshold = 0.0025f, growth_select_fraction = 0.25f, split_at_screen_size = 0.5f, opac_decay = 0.004f;
@@ -339,7 +340,11 @@ class SplatTrainer {
     uint32_t step_count() const { return step_count_; }
 
     // SplatTrainer::step (train.rs:176-429): forward, L1+SSIM (+alpha) loss, backward, statistics, Adam, optional noise.
-    // `noise_samples`: device [N,3] N(0,1) or null; `background`: the colour actually used this step.
+    // The two stochastic terms (mean noise train.rs:389-416, background jitter :896-908): with a seed (set_seed) they are
+    // drawn by the library's counter-based generator as functions of (seed, step) — the reference's default behaviour;
+    // without one they only appear when injected: `noise_samples` device [N,3] N(0,1) or null, `background` the colour
+    // actually used this step (parity tests).
+    void set_seed(uint64_t seed) { seed_ = seed; have_seed_ = true; }
     TrainStepStats step(const SceneBatch& batch, Splats& splats, const float* noise_samples = nullptr, const float* background = nullptr) {
         ensure_state(splats);
         BhTrainConfig c = c_config(splats);
@@ -350,7 +355,10 @@ class SplatTrainer {
         b.has_alpha = batch.has_alpha;
         b.alpha_is_mask = batch.alpha_is_mask;
         for (int k = 0; k < 3; ++k) b.background[k] = background ? background[k] : cfg_.background_color[k];
+        if (!background && have_seed_) bh_sample_background(seed_, step_count_ + 1, cfg_.background_color, cfg_.background_noise_strength, b.background);
         b.noise_samples = noise_samples;
+        b.device_noise = (!noise_samples && have_seed_) ? 1 : 0;
+        b.noise_seed = seed_;
         BhTrainStats stats{};
         ctx_.check(bh_train_step(ctx_.get(), &c, &st, &b, nullptr, nullptr, 1.0f, &stats));
         step_count_ = st.step_count;
@@ -460,6 +468,8 @@ class SplatTrainer {
     bool have_state_ = false, have_bounds_ = false;
     float center_[3] = {0, 0, 0}, extent_[3] = {1, 1, 1};
     uint32_t step_count_ = 0;
+    uint64_t seed_ = 0;
+    bool have_seed_ = false;
     std::vector<float> view_cams_;
 };
 

@@ -114,3 +114,44 @@ def test_product_code_never_touches_the_oracle():
                         if re.search(r"import\s+oracle|from\s+oracle|brush_oracle|\bbo_[a-z_]+\(", s):
                             bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_philox_known_answers():
+    """Philox-4x32-10 (brush_amd/csrc/device_rng.h) against the published Random123 known-answer vectors
+    (kat_vectors: zero, all-ones and pi-digits inputs)."""
+    import ctypes as C
+    from brush_amd import _ffi
+    lib = _ffi.load()
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        out = (C.c_uint32 * 4)()
+        lib.bh_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+
+
+def test_sample_background_is_the_reference_law():
+    """sample_background_color (train.rs:896-908): base + U(-s, s)^3 clamped to [0,1]; here a pure function of (seed, step)."""
+    import ctypes as C
+    import numpy as np
+    from brush_amd import _ffi
+    lib = _ffi.load()
+
+    def bg(seed, step, base, s):
+        out = (C.c_float * 3)()
+        lib.bh_sample_background(seed, step, (C.c_float * 3)(*base), s, out)
+        return np.array(out, np.float32)
+    assert np.array_equal(bg(1, 5, (0.2, 0.5, 0.9), 0.0), np.array((0.2, 0.5, 0.9), np.float32))      # strength 0: the base colour
+    assert np.array_equal(bg(1, 5, (-0.5, 0.5, 1.5), 0.0), np.array((0.0, 0.5, 1.0), np.float32))     # ... clamped
+    assert np.array_equal(bg(7, 3, (0.5,) * 3, 0.1), bg(7, 3, (0.5,) * 3, 0.1))
+    assert not np.array_equal(bg(7, 3, (0.5,) * 3, 0.1), bg(7, 4, (0.5,) * 3, 0.1))
+    assert not np.array_equal(bg(7, 3, (0.5,) * 3, 0.1), bg(8, 3, (0.5,) * 3, 0.1))
+    smp = np.stack([bg(11, k, (0.5,) * 3, 0.1) for k in range(1, 4001)])
+    assert smp.min() >= 0.4 and smp.max() <= 0.6
+    assert abs(float(smp.mean()) - 0.5) < 2e-3 and abs(float(smp.std()) - 0.1 / np.sqrt(3.0)) < 2e-3   # U(-s, s): sd = s / sqrt(3)
+    assert abs(float(np.corrcoef(smp[:, 0], smp[:, 1])[0, 1])) < 0.06
+    edge = np.stack([bg(11, k, (0.0, 1.0, 0.5), 0.1) for k in range(1, 201)])
+    assert edge.min() >= 0.0 and edge.max() <= 1.0 and (edge[:, 0] == 0.0).any() and (edge[:, 1] == 1.0).any()

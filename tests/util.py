@@ -164,3 +164,12 @@ def assert_adam_close(a, b, lr, steps=1, what="", extra_abs=0.0):
     frac = float(np.mean(d > tol))
     assert frac <= 1e-3, (what, "fraction beyond 2%% of lr: %.2e" % frac, float(d.max()))
     assert float(d.max()) <= 2.1 * lr * steps + extra_abs, (what, float(d.max()))
+
+
+def random_camera(seed):
+    """crates/brush-bench-test/tests/finite_diff.rs:592-606 (pinhole, identity rotation, same SplitMix64 stream)."""
+    rng = Sm64(((seed * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF) ^ 0xCAFE)
+    dist = rng.uniform(2.5, 5.0)
+    pos = (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), -dist)
+    fov = rng.uniform(0.4, 0.9)
+    return dict(pos=pos, rot_xyzw=(0.0, 0.0, 0.0, 1.0), fov_x=fov, fov_y=fov, center_uv=(0.5, 0.5))
