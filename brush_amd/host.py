@@ -33,6 +33,9 @@ class Context:
         # submit on torch's current stream (handle 0 = the default stream) so tensor ops
         # and brush_hip kernels are ordered without extra synchronisation
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        # own stream (hipStreamNonBlocking): NOT ordered against torch's streams — the caller synchronises hand-overs
+        # (what a viewer / trainer pair on separate threads wants, brush-async/src/lib.rs:4-17)
+        self.uses_torch_stream = bool(use_torch_stream)
         self._h = self.lib.bh_create(self.device.index, C.c_void_p(stream), 0 if use_torch_stream else 1)
         if not self._h:
             raise BrushHipError("bh_create failed on %s" % self.device)
@@ -889,6 +892,8 @@ class SplatTrainer:
         z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
         self.state = dict(m1_t=z(n, 10), m2_t=z(n, 10), m1_sh=z(*splats.sh_coeffs.shape), m2_sh=z(n), m1_o=z(n), m2_o=z(n),
                           refine_weight_norm=z(n), vis_weight=z(n), max_screen_size=z(n))
+        if self.ctx is not None and not self.ctx.uses_torch_stream:
+            torch.cuda.current_stream(dev).synchronize()   # the zero-fills ran on torch's stream, the step runs on the ctx's own
 
     def sample_background(self, rng=None, step=None):
         """train.rs:896-908: base + U(-s, s)^3, clamped to [0,1].  With the trainer's seed: the library's generator at

@@ -93,8 +93,17 @@ def _problem(dev, ba, n=6000, w=160, h=96, deg=1, seed=0xD0):
     return sc, batch
 
 
+def _rows_agree(x, y, tol):
+    return np.abs(x.astype(np.float64) - y.astype(np.float64)).max(axis=1) <= tol
+
+
 @pytest.mark.parametrize("floor", [False, True])
 def test_seeded_step_equals_injected_samples(dev, floor):
+    """A seeded step (noise drawn inside the update launch; with a 3D-filter floor: by the stand-alone noise kernel) against
+    the same step with bh_normal_samples' tensor and bh_sample_background's colour injected.  Two runs of a step are not
+    bit-identical (the backward sums with float atomics, and Adam turns a last-bit change of a gradient into a last-bit change
+    of the update, a sign flip of a ~0 gradient into 2 lr), so: >= 99.5 % of the rows agree to 1e-3 lr_mean — the noise itself is
+    of the order of lr_mean, a wrong sample, gate or scale would move every noised row by that much."""
     import brush_amd as ba
     sc, batch = _problem(dev, ba)
     n = sc["transforms"].shape[0]
@@ -105,14 +114,18 @@ def test_seeded_step_equals_injected_samples(dev, floor):
         if floor:
             spl.with_min_scale(torch.full((n,), 0.01, device=dev))
         tr = _trainer(ba, seed)
-        for step in range(1, 4):
-            if injected:
-                bg = tr.sample_background()
-                tr.step(batch, spl, background=bg, noise_samples=tr.normal_samples(n, step, dev))
-            else:
-                tr.step(batch, spl)
-        runs.append((spl.transforms.cpu().numpy(), spl.raw_opacities.cpu().numpy(), tr.stats().loss))
-    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+        if injected:
+            tr.step(batch, spl, background=tr.sample_background(), noise_samples=tr.normal_samples(n, 1, dev))
+        else:
+            tr.step(batch, spl)
+        st = tr.stats()
+        runs.append((spl.transforms.cpu().numpy(), spl.raw_opacities.cpu().numpy(), st.loss, st.lr_mean))
+    lr = runs[0][3]
+    noised = np.abs(runs[0][0][:, :3] - sc["transforms"][:, :3]).max(axis=1) > 1.5 * lr   # moved by more than the Adam step: noise
+    assert noised.sum() > 200
+    ok = _rows_agree(runs[0][0][:, :3], runs[1][0][:, :3], 1e-3 * lr)
+    assert ok.mean() >= 0.995 and ok[noised].mean() >= 0.99, (ok.mean(), ok[noised].mean())
+    assert abs(runs[0][2] - runs[1][2]) <= 1e-6 * abs(runs[1][2])
 
 
 def test_same_seed_same_trajectory_and_the_gate(dev):
@@ -125,19 +138,23 @@ def test_same_seed_same_trajectory_and_the_gate(dev):
         tr.step(batch, spl)
         st = tr.stats()
         outs[name] = (spl.transforms.cpu().numpy(), tr, st)
-    assert np.array_equal(outs["a"][0], outs["b"][0]), "same seed -> identical replicas"
-    assert not np.array_equal(outs["a"][0], outs["c"][0])
-    # the noise is what separates a seeded step from an unseeded one (background jitter is off here): rows that moved
-    moved = np.any(outs["a"][0][:, :3] != outs["none"][0][:, :3], axis=1)
-    assert np.array_equal(outs["a"][0][:, 3:], outs["none"][0][:, 3:]), "only the means are noised"
+    lr = outs["a"][2].lr_mean
+    same = _rows_agree(outs["a"][0], outs["b"][0], 1e-3 * lr)
+    assert same.mean() >= 0.995, "same seed -> same noise (what data-parallel replicas rely on)"
+    diff_seed = _rows_agree(outs["a"][0][:, :3], outs["c"][0][:, :3], 1e-3 * lr)
+    # the noise is what separates a seeded step from an unseeded one (background jitter is off here)
+    moved = ~_rows_agree(outs["a"][0][:, :3], outs["none"][0][:, :3], 1e-3 * lr)
+    assert moved.sum() > 200 and diff_seed[moved].mean() < 0.05, "a different seed moves the noised rows elsewhere"
+    assert _rows_agree(outs["a"][0][:, 3:], outs["none"][0][:, 3:], 1e-3 * 2e-3).mean() >= 0.995, "only the means are noised"
     vis = outs["none"][1].state["vis_weight"].cpu().numpy() > 0
-    assert moved.any() and not moved[~vis].any(), "invisible splats never move"
-    # opaque splats (sigmoid(raw) > 0.05 -> (1 - o)^150 < 5e-4) get noise far below the learning-rate step
-    d = np.abs(outs["a"][0][:, :3] - outs["none"][0][:, :3]).max(axis=1)
-    opaque = 1.0 / (1.0 + np.exp(-sc["raw_opac"])) > 0.3
-    assert d[opaque].max() < 1e-9 + 1e-6 * d[moved].max()
-    # magnitude: |noise| <= median_scene_scale, typical size lr_mean * 50 * w
-    assert d.max() <= 3.0 and d[moved].mean() < outs["a"][2].lr_mean * 50 * 4
+    assert np.array_equal(outs["a"][0][~vis], sc["transforms"][~vis]), "invisible splats never move (no gradient, no noise)"
+    # opaque splats: (1 - sigmoid(raw))^150 ~ 0 -> no visible noise; transparent visible ones: noise ~ lr_mean * 50 * w * N(0,1)
+    opaque = (1.0 / (1.0 + np.exp(-sc["raw_opac"].astype(np.float64))) > 0.3) & vis
+    assert (~moved[opaque]).mean() >= 0.99
+    thin = (sc["raw_opac"] == np.float32(-4.0)) & vis
+    assert moved[thin].mean() > 0.9
+    d = np.abs(outs["a"][0][:, :3].astype(np.float64) - outs["none"][0][:, :3]).max(axis=1)
+    assert d.max() <= 3.0 and d[moved].mean() < lr * 50 * 4
 
 
 def test_loss_survives_refine_and_bounds_readbacks(dev):
