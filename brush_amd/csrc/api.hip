@@ -197,6 +197,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     std::memset(ctx->host_counters, 0, bh::HOST_COUNTERS_BYTES);
     // developer knobs: read here once, never on the per-step path
     ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
+    ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
@@ -424,7 +425,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const size_t npad = n ? n : 1;
 
     // two counter pairs: K1 accumulates into one and clears the other for the next forward (no fill launch)
-    constexpr size_t counter_set_bytes = COUNTER_SLOTS * 16, counter_set_words = COUNTER_SLOTS * 4;
+    constexpr size_t counter_set_bytes = COUNTER_SET_BYTES, counter_set_words = COUNTER_SET_BYTES / 4, counter_read_bytes = COUNTER_SLOTS * 16;
     auto* counter_pairs = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 2 * counter_set_bytes);
     uint32_t* counters = counter_pairs ? counter_pairs + counter_set_words * (ctx->counter_phase & 1u) : nullptr;
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
@@ -444,6 +445,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const size_t visible_words = bwd_info ? ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) : 0;
 
     uint32_t nv = 0, ni = 0;
+    bool fused_scan = false;
+    uint32_t* cum_early = nullptr;
     if (n > 0) {
         {
             ProfScope ps(ctx, "ProjectSplats");
@@ -471,13 +474,22 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         // and needs neither count, so it is queued behind the copy BEFORE the host waits: the GPU
         // sorts while the host reads the counts, sizes the buffers and queues the rest.
         auto* hslots = reinterpret_cast<unsigned long long*>(ctx->host_counters + 16);
-        BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_set_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_read_bytes, hipMemcpyDeviceToHost, ctx->stream));
         BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
         {
             ProfScope ps(ctx, "DepthSort");
             // culled splats carry key 0xFFFFFFFF and sort behind every visible one:
             // the stable sort is also the (deterministic) compaction.
-            BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
+            fused_scan = depth_sort_supported(n) && !ctx->knob_generic_depth_sort;
+            if (fused_scan) {
+                // ... and the scan of the tile counts in depth order rides on its last kernel (depth_sort.hip); the arena's
+                // cum slot is sized for n here because the visible count is not known yet
+                cum_early = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, npad * 4);
+                if (!cum_early) return BH_ERR_OOM;
+                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_SLOTS * 4, isect_counts, n, depths_sorted, gfc, cum_early));
+            } else {
+                BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
+            }
         }
         BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
         unsigned long long hc[2] = {0ull, 0ull};
@@ -491,7 +503,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     }
 
     const size_t nvpad = nv ? nv : 1, nipad = ni ? ni : 1;
-    auto* cum = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, nvpad * 4);
+    auto* cum = fused_scan ? cum_early : (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, nvpad * 4);
     auto* projected = (float*)ensure(ctx, SLOT_PROJECTED, nvpad * 9 * 4);
     auto* tile_ids = (uint32_t*)ensure(ctx, SLOT_TILE_IDS, nipad * 4);
     auto* isect_gids = (uint32_t*)ensure(ctx, SLOT_ISECT_GIDS, nipad * 4);
@@ -503,7 +515,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         return BH_ERR_OOM;
 
     if (nv > 0) {
-        {
+        if (!fused_scan) {
             ProfScope ps(ctx, "PrefixSumGaussHits");
             BH_TRY(prefix_sum(ctx, isect_counts, gfc, nv, cum, false));
         }

@@ -68,6 +68,10 @@ constexpr int MAX_PROF = 32;
 
 // K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
 constexpr uint32_t COUNTER_SLOTS = 128;
+// one counter set on the device: [COUNTER_SLOTS][2] u64 (visible, intersections) | [COUNTER_SLOTS][2] u32 (max depth key, max ~key
+// over the visible splats: the key range the depth sort splits on).  Only the first part is read back.
+constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8;
+constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots | the loss word.
 // The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_SLOTS * 4;
@@ -121,9 +125,11 @@ struct bh_ctx {
     int comm_rank = 0, comm_world = 1;
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
+    bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
     // developer knobs (A/B measurements), read from the environment ONCE at bh_create
     bool knob_no_lpt = false;         // BH_NO_LPT: backward tiles in index order
+    bool knob_generic_depth_sort = false;   // BH_GENERIC_DEPTH_SORT: the forward's depth order by the generic 32-bit radix sort + scan
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
     bh::Profiler prof;
@@ -196,6 +202,11 @@ int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, boo
 // sort.hip
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);
+// depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
+// order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.
+bool depth_sort_supported(uint32_t n);
+int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
+                    uint32_t* out_vals, uint32_t* cum);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive);
 // rasterize.hip

@@ -203,11 +203,13 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
+    __shared__ uint32_t s_kmax[PROJ_WAVES];
+    __shared__ uint32_t s_nmax[PROJ_WAVES];
     const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the kernels behind this one (coalesced stores; nobody reads these buffers before K1 retires)
     if (gid < prep.visible_words) prep.visible[gid] = 0u;
     if (gid < prep.tile_words) prep.tile_table[gid] = 0u;
-    if (gid < 2u * COUNTER_SLOTS && prep.next_counters) prep.next_counters[gid] = 0ull;
+    if (gid < COUNTER_SET_U64 && prep.next_counters) prep.next_counters[gid] = 0ull;
     for (size_t i = gid; i < prep.span_f4; i += (size_t)gridDim.x * PROJ_WG) prep.span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t key = 0xFFFFFFFFu;
@@ -289,18 +291,33 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     uint32_t wave_hits = tiles_hit;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
+    // range of the visible depth keys, for the depth sort's split (depth_sort.hip): maxima of key and of ~key
+    uint32_t kmax = visible ? key : 0u, nmax = visible ? ~key : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+    }
     if (lane == 0) {
         s_vis[wave] = (uint32_t)__popcll(ball);
         s_hit[wave] = wave_hits;
+        s_kmax[wave] = kmax;
+        s_nmax[wave] = nmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t v = 0, h = 0;
+        uint32_t v = 0, h = 0, km = 0, nm = 0;
 #pragma unroll
-        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; }
-        unsigned long long* slot = counters + 2u * (blockIdx.x & (COUNTER_SLOTS - 1u));
+        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; km = max(km, s_kmax[k]); nm = max(nm, s_nmax[k]); }
+        const uint32_t sl = blockIdx.x & (COUNTER_SLOTS - 1u);
+        unsigned long long* slot = counters + 2u * sl;
         if (v) atomicAdd(&slot[0], (unsigned long long)v);
         if (h) atomicAdd(&slot[1], (unsigned long long)h);
+        if (v) {
+            uint32_t* mm = reinterpret_cast<uint32_t*>(counters + 2u * COUNTER_SLOTS) + 2u * sl;
+            atomicMax(&mm[0], km);
+            atomicMax(&mm[1], nm);
+        }
     }
 }
 
@@ -330,12 +347,16 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
         BH_HIP(ctx, hipMemsetAsync(prep.visible, 0, (size_t)prep.visible_words * 4, ctx->stream));
         prep.visible_words = 0;
     }
+    if (prep.next_counters && COUNTER_SET_U64 > covered) {
+        BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SET_BYTES, ctx->stream));
+        prep.next_counters = nullptr;
+    }
     if (prep.tile_table && prep.tile_words > covered) {
         BH_HIP(ctx, hipMemsetAsync(prep.tile_table, 0, (size_t)prep.tile_words * 4, ctx->stream));
         prep.tile_words = 0;
     }
     if (n == 0) {
-        if (prep.next_counters) BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SLOTS * 16, ctx->stream));
+        if (prep.next_counters) BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SET_BYTES, ctx->stream));
         if (prep.span && prep.span_f4) BH_HIP(ctx, hipMemsetAsync(prep.span, 0, (size_t)prep.span_f4 * 16, ctx->stream));
         return 0;
     }

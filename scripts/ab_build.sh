@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/brush_amd/variants; mkdir -p $OUT/obj_$NAME
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function $EXTRA"
 cd $ROOT/brush_amd/csrc
-for f in api project sort scan rasterize loss loss_fused optim refine filter3d ply upload comm exchange; do
+for f in api project sort depth_sort scan rasterize loss loss_fused optim refine filter3d ply upload comm exchange; do
   /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
