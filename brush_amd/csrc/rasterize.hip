@@ -342,10 +342,15 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
 //     d(alpha0) needs no accumulator of its own: it is -(sum of v_sigma) / alpha0 (gradient block: 42 -> 32 instructions);
 //   * splats whose alpha0 cannot reach the 0.999 clamp (all of a batch: decided by one ballot at staging time) run a
 //     variant without the v_min / v_cmp / v_cndmask of the clamp;
-constexpr int RED_SLOTS = 3;    // contributing splats parked in LDS per flush: 30 (slot, component) rows for 32 lane pairs
-constexpr int RED_PITCH = 68;   // floats per row: 64 lanes + 4, so the 16 lanes of a b128 read group start in 16 different bank quads
+//   * the ten per-splat sums over the tile's 256 pixels leave the wave through a register butterfly (below) and ONE 10-lane
+//     global_atomic_add_f32.  It is the single most expensive piece left: a build without any reduction (wrong results) runs
+//     232 us instead of 325 — 28 % of the kernel for ~45 instructions, because v_permlane*_swap and DPP adds are slow AND
+//     form a dependent chain.  Three replacements were built, verified against the CPU checker, measured and dropped
+//     (DESIGN.md §8): partials parked in LDS and summed by lane pairs behind a barrier (384 us), the same with the reads issued
+//     one splat later so nobody waits (446 us: the LDS pipe is not idle enough for 6.5 KB more per splat and wave), and the
+//     matrix core (v_mfma_f32_16x16x4_f32 with column selectors: exact, 542 us — the f32 MFMAs do not hide beside the VALU work).
 
-// Register butterfly (BH_BWD_REDUCE == 0): wave-wide sum of ten per-lane values in 28 VALU ops — v_permlane32_swap /
+// Register butterfly: wave-wide sum of ten per-lane values in 28 VALU ops — v_permlane32_swap /
 // v_permlane16_swap fold two registers into one per step ("transpose-reduce"), then a DPP rotate-add finishes inside each
 // 16-lane row.  Afterwards every lane of row r of k[i] holds component comp(i, r): k0 -> g0 g2 g1 g3, k1 -> g4 g6 g5 g7,
 // k2 -> g8 - g9 -.
@@ -368,19 +373,6 @@ BH_DEV float row_allreduce(float x) {
     x = dpp_rot_add<0x121>(x);  // row_ror:1
     return x;
 }
-// How the ten per-splat sums over the tile's pixels leave the wave.  0 (shipped): register butterfly.  The others were built
-// and measured this round and are kept as measurement variants (scripts/ab_build_one.sh): 1 = park in LDS, flush three splats at a
-// time behind a barrier (slower: 384 vs 338 us — the flush parks the wave and 11 KB of LDS cost a wave of occupancy);
-// 2 = matrix core, v_mfma_f32_16x16x4_f32 with column selectors (correct, 542 us: the f32 MFMAs do not hide beside the VALU
-// work); 3 = park in LDS, reads issued one splat later (470 us as built: 16 more live VGPRs spill at 128); 9 = no reduction at
-// all (wrong results; 232 us: the ceiling — the butterfly is 28 % of this kernel).
-#ifndef BH_BWD_REDUCE
-#define BH_BWD_REDUCE 0
-#endif
-typedef float v4f __attribute__((ext_vector_type(4)));
-#ifndef BH_BWD_BODY
-#define BH_BWD_BODY 1     // 1 (shipped): wave-uniform skip + ONE exec-masked region for the gradient block; 0: nested exec-masked regions (+20 M SALU instructions per launch, same time)
-#endif
 
 // exp() of the backward's replay is the forward's exp_blend, bit for bit: the replay has to take the forward's decisions
 // (alpha >= 1/255, T' <= 1e-4) — with v_exp_f32 instead (BH_BWD_HW_EXP, measurement variant: 13 us faster) a pixel sitting
@@ -405,13 +397,6 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                const float* __restrict__ v_output,
                                                                float* __restrict__ v_combined, const uint32_t* __restrict__ lpt) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-#if BH_BWD_REDUCE == 1
-    __shared__ __attribute__((aligned(16))) float s_red[RED_SLOTS * 10 * RED_PITCH];
-#elif BH_BWD_REDUCE == 3
-    __shared__ __attribute__((aligned(16))) float s_red[10 * RED_PITCH];
-#else
-    float* const s_red = nullptr;
-#endif
     uint32_t local_tile;
     if (lpt) {
         // block j of XCD x takes the j-th tile of band x in descending work-class order (wave-uniform scalar code)
@@ -444,10 +429,6 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
     const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
     const float img_w_f = (float)u.img_w, img_h_f = (float)u.img_h;
-    // role of this lane in a flush: lanes 2p and 2p+1 add up the two halves of row p = slot * 10 + component
-    const int f_pair = lane >> 1, f_half = lane & 1;
-    const int f_slot = f_pair / 10, f_comp = f_pair - f_slot * 10;
-    const float* f_row = s_red + f_pair * RED_PITCH + f_half * 32;
     // pixel replay state (rasterize_backwards.rs:186-228).  The reference carries the remaining colour (rgb_final - T_final * bg
     // minus what has been replayed) and only ever uses it inside a dot product with the pixel's v_rgb, so the state kept here
     // is that dot product: S = remaining . v_rgb (one register and one fma per update instead of three).  T = 0: finished.
@@ -474,163 +455,10 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     }
     const float w2 = img_w_f * img_w_f, h2 = img_h_f * img_h_f;   // in VGPRs: an SGPR operand halves a VALU op's issue rate
 
-#if BH_BWD_REDUCE == 3
-    // Wave-wide sums through LDS, with nobody waiting for it.  A contributing splat PARKS its ten per-lane partials in a
-    // [component][lane] block (ten conflict-free ds_write_b32, fire and forget).  At the top of the NEXT splat iteration four
-    // lanes per component issue the reads of their quarter row (one ds_read_b128 x 4 per lane), the iteration's own pixel
-    // work covers their latency, and at its end the 16 values are added up, two quad-DPP adds join the four quarters and
-    // one 10-lane global_atomic_add_f32 sends the splat's gradients off — before the block is parked into again (a wave's
-    // LDS operations retire in order: no barrier anywhere).  The register butterfly this replaces (v_permlane32_swap /
-    // v_permlane16_swap folds + 12 dependent DPP adds) measured 28 % of the whole kernel (a build without any reduction:
-    // 325 -> 232 us): the cross-lane ops are slow AND serialise the wave.
-    const int p_row = lane >> 2, p_part = lane & 3;                     // lanes 0..39: component row, quarter of the row
-    const float* p_src = s_red + (p_row < 10 ? p_row : 9) * RED_PITCH + p_part * 16;
-    bool has_pend = false;      // wave-uniform
-    uint32_t pend_t = 0;
-    float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0, pr2 = pr0, pr3 = pr0;
-    auto pend_issue = [&]() {   // the four reads; consumed by pend_retire()
-        __asm__ volatile("" ::: "memory");   // compiler-only ordering point (the hardware keeps a wave's LDS operations in order)
-        pr0 = *reinterpret_cast<const float4*>(p_src);
-        pr1 = *reinterpret_cast<const float4*>(p_src + 4);
-        pr2 = *reinterpret_cast<const float4*>(p_src + 8);
-        pr3 = *reinterpret_cast<const float4*>(p_src + 12);
-        __asm__ volatile("" ::: "memory");
-    };
-    auto pend_retire = [&]() {
-        float acc = ((pr0.x + pr0.y) + (pr0.z + pr0.w)) + ((pr1.x + pr1.y) + (pr1.z + pr1.w));
-        acc += ((pr2.x + pr2.y) + (pr2.z + pr2.w)) + ((pr3.x + pr3.y) + (pr3.z + pr3.w));
-        acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-        acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]: the row total, in all four lanes
-        // rows 0 (P) and 1 (Q) sit in quads 0 and 1: mirrored inside the 8-lane half, each sees the other's total
-        const float oth = u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0x141, 0xF, 0xF, false));  // row_half_mirror
-        const float* sp = s_splat + pend_t * SPLAT_STRIDE;
-        const float c00 = sp[2], c01 = sp[3], c11 = sp[4];
-        const uint32_t gate = f2u(sp[10]), cg = f2u(sp[11]);
-        bool send = p_part == 0 && p_row < 10;
-        switch (p_row) {
-            // v_xy = v_sigma * conic * (mean - pixel) = -(conic * (P, Q))                          (…:300-307)
-            case 0: acc = -__builtin_fmaf(c00, acc, c01 * oth); break;
-            case 1: acc = -__builtin_fmaf(c11, acc, c01 * oth); break;
-            // v_conic = (1/2 v_sigma dx^2, v_sigma dx dy, 1/2 v_sigma dy^2)                         (…:308-312)
-            case 2: case 4: acc *= 0.5f; break;
-            // colour gradients only where the raw colour was >= 0                                  (…:321-323)
-            case 5: case 6: case 7: send = send && ((gate >> (p_row - 5)) & 1u) != 0u; break;
-            // v_alpha0 = sum v_alpha * G, and v_sigma = -alpha0 G v_alpha  =>  -(sum v_sigma) / alpha0
-            case 8: acc = -acc / sp[5]; break;
-            default: break;
-        }
-        if (send) {
-#ifdef BH_NO_ATOMIC  // measurement-only variant
-            if (acc == 123.456f) v_combined[(size_t)cg * 10 + p_row] = acc;
-#else
-            unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + p_row], acc);
-#endif
-        }
-        has_pend = false;
-    };
-#endif
-#if BH_BWD_REDUCE == 2
-    // Wave-wide sums on the matrix core.  v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] B[k][j] with lane
-    // (i + 16 k) holding A[i][k], lane (j + 16 k) holding B[k][j] and element r of lane (j + 16 b) holding D[4 b + r][j].
-    // Level 1, once per component c: A = the per-lane partials, B = a column selector (1 in lanes with lane % 16 == c):
-    // column c of D collects the 16 four-lane sums of component c; ten components share one accumulator.  Level 2: the
-    // four elements of D are added up (3 VALU adds) and one more MFMA with A = 1 sums the four lane groups: afterwards every
-    // lane l holds the wave total of component l % 16.  The matrix pipe is otherwise idle in this kernel and runs beside
-    // the other waves' VALU work; exact f32 (the 16x16x4 f32 MFMA is an fma chain).  The level-2 step of a splat is
-    // issued when the NEXT contributing splat arrives (or at the end of the batch), so nobody waits for the level-1 chain.
-    float sel[10];
-#pragma unroll
-    for (int c = 0; c < 10; ++c) sel[c] = (lane & 15) == c ? 1.0f : 0.0f;
-    v4f pd0 = {0.0f, 0.0f, 0.0f, 0.0f}, pd1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t pend_t = 0;
-    bool has_pend = false;
-    auto retire = [&]() {
-        const v4f d = pd0 + pd1;
-        const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const v4f r = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, (d.x + d.y) + (d.z + d.w), zero4, 0, 0, 0);
-        float acc = r.x;                 // the wave total of component (lane % 16)
-        const int c = lane & 15;
-        const float oth = u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]: component c ^ 1
-        const float* sp = s_splat + pend_t * SPLAT_STRIDE;
-        const float c00 = sp[2], c01 = sp[3], c11 = sp[4];
-        const uint32_t gate = f2u(sp[10]), cg = f2u(sp[11]);
-        bool send = lane < 10;
-        switch (c) {
-            // v_xy = v_sigma * conic * (mean - pixel) = -(conic * (P, Q))                          (…:300-307)
-            case 0: acc = -__builtin_fmaf(c00, acc, c01 * oth); break;
-            case 1: acc = -__builtin_fmaf(c11, acc, c01 * oth); break;
-            // v_conic = (1/2 v_sigma dx^2, v_sigma dx dy, 1/2 v_sigma dy^2)                         (…:308-312)
-            case 2: case 4: acc *= 0.5f; break;
-            // colour gradients only where the raw colour was >= 0                                  (…:321-323)
-            case 5: case 6: case 7: send = send && ((gate >> (c - 5)) & 1u) != 0u; break;
-            // v_alpha0 = sum v_alpha * G, and v_sigma = -alpha0 G v_alpha  =>  -(sum v_sigma) / alpha0
-            case 8: acc = -acc / sp[5]; break;
-            default: break;
-        }
-        if (send) {
-#ifdef BH_NO_ATOMIC  // measurement-only variant
-            if (acc == 123.456f) v_combined[(size_t)cg * 10 + c] = acc;
-#else
-            unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + c], acc);
-#endif
-        }
-        has_pend = false;
-    };
-#endif
-#if BH_BWD_REDUCE == 1
-    uint32_t nslots = 0;          // parked splats (wave-uniform)
-    uint32_t slot_t[RED_SLOTS];   // their index in the staged batch
-#pragma unroll
-    for (int k = 0; k < RED_SLOTS; ++k) slot_t[k] = 0;
-    // Add up the parked partials and send them off.  Called wave-uniformly; __syncthreads() is the (single-wave) ordering
-    // point between the ds_writes of the park step and the reads here, and between these reads and the next park.
-    // What is parked per lane are the RAW sums (see the splat loop): rows 0 1 = P Q, 2 3 4 = R2 R3 R4, 5 6 7 = rgb,
-    // 8 = sum of v_sigma, 9 = refine; the per-splat linear maps that turn them into the reference's ten gradients are
-    // applied here, once per splat, by the lane that sends the component off.
-    auto flush = [&]() {
-        __syncthreads();
-        if ((uint32_t)f_pair < nslots * 10u) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float4 v = *reinterpret_cast<const float4*>(f_row + 4 * k);
-                acc += (v.x + v.y) + (v.z + v.w);
-            }
-            acc += u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: the row's other half
-            // rows 0 and 1 of a slot sit in the two lane pairs of one quad (10 * slot is even): each sees the other's sum
-            const float oth = u2f(__builtin_amdgcn_update_dpp(0u, f2u(acc), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-            const uint32_t t = f_slot == 0 ? slot_t[0] : (f_slot == 1 ? slot_t[1] : slot_t[2]);
-            const float* sp = s_splat + t * SPLAT_STRIDE;
-            const float c00 = sp[2], c01 = sp[3], c11 = sp[4];
-            const uint32_t gate = f2u(sp[10]), cg = f2u(sp[11]);
-            bool send = f_half == 0;
-            switch (f_comp) {
-                // v_xy = v_sigma * conic * (mean - pixel) = -(conic * (P, Q))                          (…:300-307)
-                case 0: acc = -__builtin_fmaf(c00, acc, c01 * oth); break;
-                case 1: acc = -__builtin_fmaf(c11, acc, c01 * oth); break;
-                // v_conic = (1/2 v_sigma dx^2, v_sigma dx dy, 1/2 v_sigma dy^2)                         (…:308-312)
-                case 2: case 4: acc *= 0.5f; break;
-                // colour gradients only where the raw colour was >= 0                                  (…:321-323)
-                case 5: case 6: case 7: send = send && ((gate >> (f_comp - 5)) & 1u) != 0u; break;
-                // v_alpha0 = sum v_alpha * G, and v_sigma = -alpha0 G v_alpha  =>  -(sum v_sigma) / alpha0
-                case 8: acc = -acc / sp[5]; break;
-                default: break;
-            }
-            if (send) {
-#ifdef BH_NO_ATOMIC  // measurement-only variant
-                if (acc == 123.456f) v_combined[(size_t)cg * 10 + f_comp] = acc;
-#else
-                unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + f_comp], acc);
-#endif
-            }
-        }
-        __syncthreads();
-        nslots = 0;
-    };
-#endif
-
-    // The ten per-lane partial sums of the splat in flight (raw sums, see flush).  They live ACROSS the splat loop and are
-    // cleared only after a park: a splat that touches no pixel leaves them at zero, so the common "no contribution" path
+    // The ten per-lane partial sums of the splat in flight, RAW: aP aQ = sums of v_sigma (pixel - mean), aR2 aR3 aR4 = its second
+    // moments, aCr aCg aCb = rgb, aVs = sum of v_sigma, aRf = refine; the per-splat linear maps that turn them into the
+    // reference's ten gradients are applied once per splat, just before the wave reduction.  They live ACROSS the splat loop
+    // and are cleared only after a reduction: a splat that touches no pixel leaves them at zero, so the common "no contribution" path
     // carries no re-initialisation at all.
     float aP = 0.f, aQ = 0.f, aR2 = 0.f, aR3 = 0.f, aR4 = 0.f, aCr = 0.f, aCg = 0.f, aCb = 0.f, aVs = 0.f, aRf = 0.f;
     // One staged batch.  CLAMP = false: every alpha0 of the batch is <= 0.999, so min(0.999, alpha0 * G) is the identity and
@@ -658,11 +486,6 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 c_y[k] = c11 * dyp[k];
                 e_y[k] = c01 * dyp[k];
             }
-#if BH_BWD_REDUCE == 3
-            // behind the splat's own LDS reads and their first uses: the wait for THOSE must not cover these four
-            const bool retire_now = has_pend;
-            if (retire_now) pend_issue();
-#endif
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -670,7 +493,6 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 // --- replay: identical arithmetic to the forward kernel -------------
                 const float qv = __builtin_fmaf(c_y[m], dyp[m], a_xx[k]);
                 const float sigma = __builtin_fmaf(b_x[k], dyp[m], 0.5f * qv);
-#if BH_BWD_BODY == 1
                 const bool pre = sw[q] > 0.0f && f2u(sigma) <= cut_bits;   // live pixel and 0 <= sigma <= sigma_cut
                 if (__ballot(pre) != 0ull) {   // wave-uniform: one scalar branch steps over a quadrant that cannot reach the cutoff
                     const float gaussian = blend_exp_bwd(-sigma);
@@ -699,7 +521,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                         const float v_alpha = SMOOTH ? v_alpha_eff * (w_cut + alpha * alpha_cutoff_weight_deriv(alpha)) : v_alpha_eff;
                         // geometry / opacity / refine grads only below the alpha clamp (…:332)
                         const float v_sigma = (!CLAMP || alpha_raw <= 0.999f) ? -alpha * v_alpha : 0.0f;
-                        // sums of v_sigma * (pixel - mean) and of its second moments; flush() maps them to v_xy / v_conic
+                        // sums of v_sigma * (pixel - mean) and of its second moments; mapped to v_xy / v_conic once per splat (below)
                         const float ux = v_sigma * dxp[k], uy = v_sigma * dyp[m];
                         aP += ux;
                         aQ += uy;
@@ -717,95 +539,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                         any = true;
                     }
                 }
-#else
-                // live pixel and 0 <= sigma <= sigma_cut (unsigned compare of the bit patterns).  From here on exec-masked
-                // regions, no selects; an empty mask skips the region with ONE scalar branch (s_and_saveexec +
-                // s_cbranch_execz): the whole wave steps over a quadrant none of whose live pixels can reach the cutoff.
-                if (sw[q] > 0.0f && f2u(sigma) <= cut_bits) {
-                    const float gaussian = blend_exp_bwd(-sigma);
-                    const float alpha_raw = color_a * gaussian;
-                    const float alpha = CLAMP ? __builtin_fminf(0.999f, alpha_raw) : alpha_raw;
-                    const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : 1.0f;
-                    if (SMOOTH ? (w_cut > 0.0f) : (alpha >= ALPHA_CUTOFF_MID)) {
-                        const float alpha_eff = SMOOTH ? alpha * w_cut : alpha;
-                        const float one_m = 1.0f - alpha_eff;
-                        const float T = sw[q];
-                        const float next_t = T * one_m;
-                        if (next_t <= 1.0e-4f) {
-                            sw[q] = 0.0f;      // the pixel is done WITHOUT this splat (rasterize.rs:155-160)
-                        } else {
-                            __asm__ volatile("" ::: "memory");   // keep this block a branch target: if-conversion would bring the selects back
-                            // --- gradients (rasterize_backwards.rs:286-381); tolerance-checked, so explicit fma / v_rcp /
-                            //     v_sqrt and algebraically regrouped sums are used freely here -----------------------------
-                            const float vis = alpha_eff * T;
-                            aCr = __builtin_fmaf(vis, vox[q], aCr);
-                            aCg = __builtin_fmaf(vis, voy[q], aCg);
-                            aCb = __builtin_fmaf(vis, voz[q], aCb);
-                            const float ra = __builtin_amdgcn_rcpf(one_m);
-                            // (T c - remaining) . v_rgb = T (c . v_rgb) - S
-                            const float cv = __builtin_fmaf(cb, voz[q], __builtin_fmaf(cgc, voy[q], cr * vox[q]));
-                            const float v_alpha_eff = (__builtin_fmaf(T, cv, -sS[q]) + v_o_w[q]) * ra;
-                            const float v_alpha = SMOOTH ? v_alpha_eff * (w_cut + alpha * alpha_cutoff_weight_deriv(alpha)) : v_alpha_eff;
-                            // geometry / opacity / refine grads only below the alpha clamp (…:332)
-                            const float v_sigma = (!CLAMP || alpha_raw <= 0.999f) ? -alpha * v_alpha : 0.0f;
-                            // sums of v_sigma * (pixel - mean) and of its second moments; flush() maps them to v_xy / v_conic
-                            const float ux = v_sigma * dxp[k], uy = v_sigma * dyp[m];
-                            aP += ux;
-                            aQ += uy;
-                            aR2 = __builtin_fmaf(ux, dxp[k], aR2);
-                            aR3 = __builtin_fmaf(ux, dyp[m], aR3);
-                            aR4 = __builtin_fmaf(uy, dyp[m], aR4);
-                            aVs += v_sigma;
-                            // refine weight: |(v_xy.x W, v_xy.y H)| / max(A, 1e-5), v_xy = -v_sigma conic (pixel - mean)   (…:340-349)
-                            const float ex = e_x[k] + e_y[m], ey = b_x[k] + c_y[m];
-                            const float n2 = __builtin_fmaf(h2 * ey, ey, w2 * (ex * ex));
-                            aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2) * inv_fa[q], aRf);
-                            // --- state update ---------------------------------------------------------
-                            sS[q] = __builtin_fmaf(-vis, cv, sS[q]);
-                            sw[q] = next_t;
-                            any = true;
-                        }
-                    }
-                }
-#endif
             }
-#if BH_BWD_REDUCE == 3
-            if (retire_now) pend_retire();
-            if (__ballot(any) != 0ull) {
-                __asm__ volatile("" ::: "memory");
-                float* row = s_red + lane;
-                row[0 * RED_PITCH] = aP; row[1 * RED_PITCH] = aQ; row[2 * RED_PITCH] = aR2; row[3 * RED_PITCH] = aR3;
-                row[4 * RED_PITCH] = aR4; row[5 * RED_PITCH] = aCr; row[6 * RED_PITCH] = aCg; row[7 * RED_PITCH] = aCb;
-                row[8 * RED_PITCH] = aVs; row[9 * RED_PITCH] = aRf;
-                __asm__ volatile("" ::: "memory");
-                pend_t = t;
-                has_pend = true;
-                aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
-            }
-#elif BH_BWD_REDUCE == 9   // measurement-only: no reduction at all (wrong results) — the ceiling of what a free reduction would buy
-            if (__ballot(any) != 0ull) {
-                if (aP == 123.456f) v_combined[lane] = aP + aQ + aR2 + aR3 + aR4 + aCr + aCg + aCb + aVs + aRf;
-                aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
-            }
-#elif BH_BWD_REDUCE == 2
-            if (__ballot(any) != 0ull) {
-                if (has_pend) retire();
-                const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                pd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aP, sel[0], zero4, 0, 0, 0);
-                pd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aQ, sel[1], zero4, 0, 0, 0);
-                pd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aR2, sel[2], pd0, 0, 0, 0);
-                pd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aR3, sel[3], pd1, 0, 0, 0);
-                pd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aR4, sel[4], pd0, 0, 0, 0);
-                pd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aCr, sel[5], pd1, 0, 0, 0);
-                pd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aCg, sel[6], pd0, 0, 0, 0);
-                pd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aCb, sel[7], pd1, 0, 0, 0);
-                pd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aVs, sel[8], pd0, 0, 0, 0);
-                pd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aRf, sel[9], pd1, 0, 0, 0);
-                pend_t = t;
-                has_pend = true;
-                aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
-            }
-#elif BH_BWD_REDUCE == 0
             if (__ballot(any) != 0ull) {
                 const float g0 = -__builtin_fmaf(c00, aP, c01 * aQ), g1 = -__builtin_fmaf(c11, aQ, c01 * aP);
                 const float g2 = 0.5f * aR2, g4 = 0.5f * aR4;
@@ -828,29 +562,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
 #endif
                 aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
             }
-#else
-            if (__ballot(any) != 0ull) {
-                // park the ten per-lane partials: row (slot, component), column lane
-                float* row = s_red + nslots * (10 * RED_PITCH) + lane;
-                row[0 * RED_PITCH] = aP; row[1 * RED_PITCH] = aQ; row[2 * RED_PITCH] = aR2; row[3 * RED_PITCH] = aR3;
-                row[4 * RED_PITCH] = aR4; row[5 * RED_PITCH] = aCr; row[6 * RED_PITCH] = aCg; row[7 * RED_PITCH] = aCb;
-                row[8 * RED_PITCH] = aVs; row[9 * RED_PITCH] = aRf;
-                if (nslots == 0u) slot_t[0] = t;
-                else if (nslots == 1u) slot_t[1] = t;
-                else slot_t[2] = t;
-                nslots += 1u;
-                if (nslots == (uint32_t)RED_SLOTS) flush();
-                aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
-            }
-#endif
         }
-#if BH_BWD_REDUCE == 1
-        if (nslots != 0u) flush();   // before the staged batch (the slots' splat records) is overwritten
-#elif BH_BWD_REDUCE == 2
-        if (has_pend) retire();      // likewise
-#elif BH_BWD_REDUCE == 3
-        if (has_pend) { pend_issue(); pend_retire(); }   // likewise (the one place that waits for the reads)
-#endif
     };
 
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
