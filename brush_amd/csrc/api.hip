@@ -198,6 +198,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     // developer knobs: read here once, never on the per-step path
     ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
     ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
+    ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
@@ -846,7 +847,9 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     // they are summed, the union of contributing splats is listed and its size starts travelling to the host NOW —
     // the loss and the backward hide the collective's latency and the readback, and the host finds the count ready
     const bool tile_mode = batch->image_hook != nullptr;
-    const bool exchanging = hook || (ctx->comm && ctx->comm_world > 1);
+    // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
+    // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
+    const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
     // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
     auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
         if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");

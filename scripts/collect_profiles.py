@@ -40,3 +40,30 @@ with open(os.path.join(dst, tag + "_hbm_traffic.csv"), "w") as f:
         wr, c2 = write.get(k, (0.0, 0))
         w.writerow([k, max(c, c2), round(fr, 1), round(fr * 2, 1), round(wr, 1), round((fr * 2 + wr) / 1024.0, 2)])
 print(open(os.path.join(dst, tag + "_hbm_traffic.csv")).read()[:3000])
+
+
+# SQ instruction counters of the blend kernels -> VALU wave-instructions per blended intersection (bench.py's roofline_valu)
+sq = os.path.join(src, "pmc_sq", "sq_counter_collection.csv")
+bj = os.path.join(src, "bench_sq.json")
+if os.path.exists(sq) and os.path.exists(bj):
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(sq)):
+        k = r["Kernel_Name"].split("(")[0].strip()
+        e = acc[k][r["Counter_Name"]]
+        e[0] += float(r["Counter_Value"]); e[1] += 1
+    try:
+        blended = json.load(open(bj))["roofline"]["intersections_blended"]
+    except Exception:
+        blended = 0
+    names = {"rasterize_backward_kernel": "rasterize_backward_kernel", "rasterize_kernel": "rasterize_kernel"}
+    with open(os.path.join(dst, tag + "_sq_counters.csv"), "w") as f:
+        w = csv.writer(f)
+        cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]
+        w.writerow(["kernel", "full_name", "launches"] + [c + "_per_launch" for c in cols] + ["intersections_blended", "valu_per_blended_isect"])
+        for k, d in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", [0, 1])[0]):
+            short = next((v for n, v in names.items() if ("::" + n + "<") in k or k.endswith("::" + n)), k.split("::")[-1].split("<")[0])
+            per = {c: (d[c][0] / d[c][1] if c in d and d[c][1] else 0.0) for c in cols}
+            is_blend = short in names.values()
+            w.writerow([short, k, max((d[c][1] for c in d), default=0)] + [round(per[c], 1) for c in cols] +
+                       [blended if is_blend else "", round(per["SQ_INSTS_VALU"] / blended, 2) if is_blend and blended else ""])
+    print(open(os.path.join(dst, tag + "_sq_counters.csv")).read()[:1500])

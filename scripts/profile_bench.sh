@@ -5,16 +5,19 @@ TAG=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
 # the kernel trace over a run long enough for the clocks to settle: with 13 steps the profiled process reads ~10 % slower
 # than an unprofiled one, with 200 the trace's averages and the bench's own events agree to 0.3 %
-LONG="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+LONG="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $LONG > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace exit $?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo "fetch exit $?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- $CMD > $OUT/bench_write.json 2> $OUT/write.err
 echo "write exit $?"
+# instruction counters of the blend kernels (for the VALU roofline: wave-instructions per blended intersection)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o sq -- $CMD > $OUT/bench_sq.json 2> $OUT/sq.err
+echo "sq exit $?"
 find $OUT -name "*.csv" | head -20
 # keep only the small summaries (the raw kernel trace can be large)
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
