@@ -863,8 +863,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         const uint32_t nblk = (n + 4095u) / 4096u;
         auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
         union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
-        compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, ((size_t)n / 2 + 1) * (12 + 3 * C) * 4);
-        if (!blocks || !union_idx || !compact) return BH_ERR_OOM;
+        if (!blocks || !union_idx) return BH_ERR_OOM;   // (the compact block is sized once the union's size is known, below)
         BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
         BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
         BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -928,6 +927,9 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
             if (rows == 0) {
                 // no rank saw any splat: every gradient row is zero everywhere, nothing to send (same decision on all ranks)
             } else if ((uint64_t)rows * 2 <= n) {
+                // sized by what this step sends (grow-only arena): megabytes for a view's worth of rows, not n / 2 rows up front
+                compact = (float*)ensure(ctx, SLOT_EXCH_COMPACT, (size_t)rows * k * 4);
+                if (!compact) return BH_ERR_OOM;
                 BH_TRY(launch_exchange_rows(ctx, true, union_idx, rows, c3, g_tr, g_sh, g_op, g_ref, compact));
                 BH_TRY(sum_over_ranks(compact, (uint64_t)rows * k));
                 BH_TRY(launch_exchange_rows(ctx, false, union_idx, rows, c3, g_tr, g_sh, g_op, g_ref, compact));

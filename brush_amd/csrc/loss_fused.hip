@@ -5,10 +5,13 @@
 // autodiff node :1041-1104.  The reference's backward kernel recomputes the blurred
 // moments on a 28x28 apron per 8x8 block because its forward only keeps the loss map.
 // In a train step both passes always run back to back on the same image, so here
-//   pass A  (one block per 16x16 tile, all colour planes): moments -> SSIM -> per-block
-//           loss partial sum AND the three per-pixel SSIM partials (dmu1, dsigma1,
-//           dsigma12) x chain, written once as 9 planes;
-//   pass B  blurs those planes (26x26 halo) and writes v_output [H,W,4] directly.
+//   pass A  (one block per 16x32 tile, one colour plane at a time through the blur buffers): moments -> SSIM -> loss partial
+//           sums per 16-row tile row AND the three per-pixel SSIM partials (dmu1, dsigma1, dsigma12) x chain, written
+//           once as nine planes [c][j][H][W];
+//   pass B  blurs those planes (26x42 halo per tile) and writes v_output [H,W,4] directly.
+// Every thread owns two vertically adjacent outputs: their 11-tap column windows share 10 of 12 rows, which takes 45 % off
+// the column pass's LDS reads and brings the halo overhead of everything a pass loads from 2.64x to 2.13x (round 2:
+// 155 -> 136 us for the pair; the 16x16 one-output version is in the history).
 // The apron recompute, the CHW loss map, its grid-wide sum, the v_output memset and the
 // HWC<->CHW permutes (lib.rs:1076,1103) all disappear.  Per-output arithmetic keeps the
 // tap-pair accumulation order of loss.hip, but this file is compiled with FMA contraction
@@ -16,7 +19,7 @@
 // outputs to keep reproducible, and the results stay within the 2e-6 the parity tests
 // allow against the oracle (tests/test_gpu_loss_optim.py::test_fused_loss_matches_oracle_and_standalone).
 // (An XCD-banded tile order was measured neutral here — the 256 MB Infinity Cache already
-// absorbs the 60 % halo overlap — and is not used.)
+// absorbs the halo overlap — and is not used.)
 #include <cmath>
 
 #include "context.h"
@@ -55,7 +58,8 @@ struct FusedArgs {
     float bg[3];
     int composite, mask, alpha_match;
     float dl_rgb, dl_alpha;
-    uint32_t ty_base;  // first tile row this launch covers (blockIdx.y is relative to it): strip-wise loss
+    uint32_t ty_base;  // first 16-row tile row this launch covers (blocks are 32 rows tall, counted from it): strip-wise loss
+    uint32_t row_end;  // pass B: first pixel row behind the window (its last block may reach past it)
     // pass B's first block also adds up pass A's per-block loss partials (a separate one-block launch costs 9 us of
     // latency; here the sum rides beside 2000 other blocks)
     const float* sum_src;
@@ -70,20 +74,36 @@ BH_DEV float gt_ch(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) 
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// Tile shape of both passes: 16 columns x 32 rows per 256-thread block, thread (lx, ly) owns the two vertically adjacent
+// outputs (2 ly, 2 ly + 1) of column lx.  The two 11-tap column windows overlap in 10 of 12 rows, so the vertical blur reads
+// 12 rows from LDS for two outputs instead of 22 (-45 %), the horizontal blur runs on 42 rows for 32 outputs instead of
+// 2 x 26 (-19 %), and so does the halo re-read of whatever the pass loads (2.13x instead of 2.64x).  One colour plane at a
+// time goes through the blur buffers, which keeps the block at 40 KB (pass A) / 24 KB (pass B) of LDS.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int TW = 16, TH = 32;
+constexpr int SW = TW + 2 * HALO;   // 26
+constexpr int SR = TH + 2 * HALO;   // 42
+}  // namespace
+
+// ---------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float* __restrict__ img /*[H,W,4]*/,
-                                                                    const uint32_t* __restrict__ gt,
-                                                                    float* __restrict__ partials /*[H,W,3,3]*/,
-                                                                    float* __restrict__ block_sums, FusedArgs a) {
-    __shared__ float2 s_tile[3][SH * SH];          // (pred, gt_eff) per colour plane
-    __shared__ float s_h[3][SH * LB * 5];          // horizontally blurred moments
-    __shared__ float s_red[LB * LB / 64];
-    const int tx0 = blockIdx.x * LB, ty0 = (blockIdx.y + a.ty_base) * LB;
+// partials: nine planes [c][j][H][W] (c = colour, j = dmu1 / dsigma1 / dsigma12, each times the chain factor): planar, so
+// that pass A's stores and pass B's loads are coalesced 4-byte runs along a row
+__global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __restrict__ img /*[H,W,4]*/,
+                                                                const uint32_t* __restrict__ gt,
+                                                                float* __restrict__ partials /*[3][3][H][W]*/,
+                                                                float* __restrict__ block_sums /*per 16-row tile row*/, uint32_t gy, FusedArgs a) {
+    __shared__ float2 s_tile[3][SR * SW];          // (pred, gt_eff) per colour plane
+    __shared__ float s_h[SR * TW * 5];             // horizontally blurred moments of ONE plane
+    __shared__ float s_red[4];
+    const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
-    const int rank = ly * LB + lx;
-    for (int i = rank; i < SH * SH; i += LB * LB) {
-        const int r = i / SH, q = i - r * SH;
+    const int rank = ly * TW + lx;
+    const size_t plane = (size_t)a.h * a.w;
+    for (int i = rank; i < SR * SW; i += 256) {
+        const int r = i / SW, q = i - r * SW;
         const int y = ty0 + r - HALO, x = tx0 + q - HALO;
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -103,71 +123,82 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
         s_tile[1][i] = make_float2(pv.y, g1);
         s_tile[2][i] = make_float2(pv.z, g2);
     }
-    __syncthreads();
-    // horizontal blur of (x, x^2, y, y^2, xy): 3 planes x 26 rows x 8 column PAIRS — an item loads
-    // the 12 pixels its two adjacent outputs share once and squares each of them once
-    for (int i = rank; i < 3 * SH * (LB / 2); i += LB * LB) {
-        const int c = i / (SH * (LB / 2)), rem = i - c * (SH * (LB / 2));
-        const int r = rem / (LB / 2), pair = rem - r * (LB / 2);
-        const float2* row = &s_tile[c][r * SH + 2 * pair];   // row[k] = pixel at tile column 2*pair - HALO + k
-        float x[12], y[12], xx[12], yy[12], xy[12];
+    // this thread's two pixels
+    const int pxx = tx0 + lx;
+    const int py[2] = {ty0 + 2 * ly, ty0 + 2 * ly + 1};
+    const bool inside[2] = {pxx < (int)a.w && py[0] < (int)a.h, pxx < (int)a.w && py[1] < (int)a.h};
+    float ga[2] = {0.f, 0.f}, chain[2] = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const float2 v = row[k];
-            x[k] = v.x; y[k] = v.y;
-            xx[k] = v.x * v.x; yy[k] = v.y * v.y; xy[k] = v.x * v.y;
+    for (int o = 0; o < 2; ++o) {
+        if (inside[o]) {
+            ga[o] = gt_ch(gt[(size_t)py[o] * a.w + (size_t)pxx], 3);
+            chain[o] = a.mask ? a.dl_rgb * ga[o] : a.dl_rgb;
+        }
+    }
+    float acc_rgb = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();   // the tile is loaded (c == 0) / the previous plane's column pass is done with s_h
+        // horizontal blur of (x, x^2, y, y^2, xy): 42 rows x 8 column PAIRS — an item loads the 12 pixels its two adjacent
+        // outputs share once and squares each of them once
+        for (int i = rank; i < SR * (TW / 2); i += 256) {
+            const int r = i / (TW / 2), pair = i - r * (TW / 2);
+            const float2* row = &s_tile[c][r * SW + 2 * pair];   // row[k] = pixel at tile column 2*pair - HALO + k
+            float x[12], y[12], xx[12], yy[12], xy[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const float2 v = row[k];
+                x[k] = v.x; y[k] = v.y;
+                xx[k] = v.x * v.x; yy[k] = v.y * v.y; xy[k] = v.x * v.y;
+            }
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int cc = HALO + o;
+                float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+#pragma unroll
+                for (int d = 1; d < 6; ++d) {
+                    const float wd = a.taps.w[5 - d];
+                    sx += (x[cc - d] + x[cc + d]) * wd;
+                    sx2 += (xx[cc - d] + xx[cc + d]) * wd;
+                    sy += (y[cc - d] + y[cc + d]) * wd;
+                    sy2 += (yy[cc - d] + yy[cc + d]) * wd;
+                    sxy += (xy[cc - d] + xy[cc + d]) * wd;
+                }
+                const float wc = a.taps.w[5];
+                sx += x[cc] * wc;
+                sx2 += xx[cc] * wc;
+                sy += y[cc] * wc;
+                sy2 += yy[cc] * wc;
+                sxy += xy[cc] * wc;
+                float* op = &s_h[(r * TW + 2 * pair + o) * 5];
+                op[0] = sx; op[1] = sx2; op[2] = sy; op[3] = sy2; op[4] = sxy;
+            }
+        }
+        __syncthreads();
+        // vertical blur: rows 2 ly .. 2 ly + 11 of s_h serve both outputs (output o: rows o .. o + 10, centre o + 5)
+        float v[12][5];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float* t = &s_h[((2 * ly + r) * TW + lx) * 5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[r][k] = t[k];
         }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            const int cc = HALO + o;
-            float sx = 0, sx2 = 0, sy = 0, sy2 = 0, sxy = 0;
+            float m[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int d = 1; d < 6; ++d) {
                 const float wd = a.taps.w[5 - d];
-                sx += (x[cc - d] + x[cc + d]) * wd;
-                sx2 += (xx[cc - d] + xx[cc + d]) * wd;
-                sy += (y[cc - d] + y[cc + d]) * wd;
-                sy2 += (yy[cc - d] + yy[cc + d]) * wd;
-                sxy += (xy[cc - d] + xy[cc + d]) * wd;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) m[k] += (v[o + 5 - d][k] + v[o + 5 + d][k]) * wd;
             }
-            const float wc = a.taps.w[5];
-            sx += x[cc] * wc;
-            sx2 += xx[cc] * wc;
-            sy += y[cc] * wc;
-            sy2 += yy[cc] * wc;
-            sxy += xy[cc] * wc;
-            float* op = &s_h[c][(r * LB + 2 * pair + o) * 5];
-            op[0] = sx; op[1] = sx2; op[2] = sy; op[3] = sy2; op[4] = sxy;
-        }
-    }
-    __syncthreads();
-    const int py = ty0 + ly, pxx = tx0 + lx;
-    const bool inside = pxx < (int)a.w && py < (int)a.h;
-    float acc_rgb = 0.0f, acc_alpha = 0.0f;
-    if (inside) {
-        const size_t p = (size_t)py * a.w + (size_t)pxx;
-        const uint32_t val = gt[p];
-        const float ga = gt_ch(val, 3);
-        float chain = a.dl_rgb;
-        if (a.mask) chain = chain * ga;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int d = 1; d < 6; ++d) {
-                const float wd = a.taps.w[5 - d];
-                const float* t = &s_h[c][((ly + HALO - d) * LB + lx) * 5];
-                const float* b = &s_h[c][((ly + HALO + d) * LB + lx) * 5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) o[k] += (t[k] + b[k]) * wd;
-            }
-            const float* cc = &s_h[c][((ly + HALO) * LB + lx) * 5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) o[k] += cc[k] * a.taps.w[5];
-            const float mu1 = o[0], mu2 = o[2];
+            for (int k = 0; k < 5; ++k) m[k] += v[o + 5][k] * a.taps.w[5];
+            if (!inside[o]) continue;
+            const float mu1 = m[0], mu2 = m[2];
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2;
-            const float s1 = __builtin_fmaxf(0.0f, o[1] - mu1_sq), s2 = __builtin_fmaxf(0.0f, o[3] - mu2_sq);
-            const float s12 = o[4] - mu1 * mu2;
+            const float s1 = __builtin_fmaxf(0.0f, m[1] - mu1_sq), s2 = __builtin_fmaxf(0.0f, m[3] - mu2_sq);
+            const float s12 = m[4] - mu1 * mu2;
             const float A = mu1_sq + mu2_sq + SSIM_C1;
             const float B = s1 + s2 + SSIM_C2;
             const float c_top = 2.0f * mu1 * mu2 + SSIM_C1;
@@ -177,53 +208,64 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_forward_kernel(const float
             const float inv_ab = inv_a * inv_b;
             const float cd = c_top * d_top * inv_ab;
             const float ssim = clampf(cd, -1.0f, 1.0f);
-            const float2 pg = s_tile[c][(ly + HALO) * SH + lx + HALO];
+            const float2 pg = s_tile[c][(2 * ly + o + HALO) * SW + lx + HALO];
             float lv = a.l1_w * __builtin_fabsf(pg.x - pg.y) + a.ssim_w * ssim;
-            if (a.mask) lv = lv * ga;
+            if (a.mask) lv = lv * ga[o];
             acc_rgb += lv;
             // SSIM partials for the backward (lib.rs:455-520)
             const bool clamped = cd < -1.0f || cd > 1.0f;
             const float dmu1 = clamped ? 0.0f : 2.0f * mu2 * inv_ab * (d_top - c_top) - 2.0f * mu1 * cd * (inv_a - inv_b);
             const float ds1 = clamped ? 0.0f : -cd * inv_b;
             const float ds12 = clamped ? 0.0f : 2.0f * c_top * inv_ab;
-            // [H,W,3,3]: 36 bytes per pixel (a float4 per colour plane would move a third more bytes, and pass B reads every
-            // pixel 2.6 times through its halo)
-            float* o3 = &partials[(p * 3 + c) * 3];
-            o3[0] = dmu1 * chain;
-            o3[1] = ds1 * chain;
-            o3[2] = ds12 * chain;
-        }
-        if (a.alpha_match) {  // lib.rs:203-214
-            const float pa = img[p * 4 + 3];
-            float v = __builtin_fabsf(pa - ga);
-            if (a.mask) v = v * ga;
-            acc_alpha = v;
+            const size_t p = (size_t)py[o] * a.w + (size_t)pxx;
+            float* o3 = partials + (size_t)(c * 3) * plane + p;
+            o3[0] = dmu1 * chain[o];
+            o3[plane] = ds1 * chain[o];
+            o3[2 * plane] = ds12 * chain[o];
         }
     }
-    // block partial of the scalar loss: dl_rgb * sum(rgb planes) + dl_alpha * sum(alpha plane)
+    float acc_alpha = 0.0f;
+    if (a.alpha_match) {  // lib.rs:203-214
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            if (inside[o]) {
+                const float pa = img[((size_t)py[o] * a.w + (size_t)pxx) * 4 + 3];
+                float vv = __builtin_fabsf(pa - ga[o]);
+                if (a.mask) vv = vv * ga[o];
+                acc_alpha += vv;
+            }
+        }
+    }
+    // partial of the scalar loss per 16-row tile row (the strip-wise loss sums whole tile rows): waves 0-1 hold the block's
+    // upper 16 rows (ly < 8), waves 2-3 the lower ones.   dl_rgb * sum(rgb planes) + dl_alpha * sum(alpha plane)
     float acc = acc_rgb * a.dl_rgb + acc_alpha * a.dl_alpha;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((rank & 63) == 0) s_red[rank >> 6] = acc;
     __syncthreads();
-    if (rank == 0) block_sums[(blockIdx.y + a.ty_base) * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (rank < 2) {
+        const uint32_t tile_row = a.ty_base + 2u * blockIdx.y + (uint32_t)rank;
+        if (tile_row < gy) block_sums[(size_t)tile_row * gridDim.x + blockIdx.x] = s_red[2 * rank] + s_red[2 * rank + 1];
+    }
 }
 
 // ---------------------------------------------------------------------------
 // pass B
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
-                                                                     const float* __restrict__ partials /*[H,W,3,3]*/,
-                                                                     float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
-    __shared__ float4 s_part[3][SH * SH];      // chain * (dmu1, dsigma1, dsigma12, -)
-    __shared__ float4 s_h2[3][SH * LB];
-    const int tx0 = blockIdx.x * LB, ty0 = (blockIdx.y + a.ty_base) * LB;
+__global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
+                                                                 const float* __restrict__ partials /*[3][3][H][W]*/,
+                                                                 float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
+    __shared__ float s_part[3][SR * SW];       // chain * (dmu1, dsigma1, dsigma12) of ONE colour plane
+    __shared__ float s_h2[3][SR * TW];
+    // strip-wise loss: the launch covers pixel rows [row0, row1) (whole 16-row tile rows); blocks are 32 rows tall
+    const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
-    const int rank = ly * LB + lx;
+    const int rank = ly * TW + lx;
+    const size_t plane = (size_t)a.h * a.w;
     if (blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {   // block-uniform
         __shared__ float s_w[4];
         float acc = 0.0f;
-        for (int i = rank; i < a.sum_n; i += LB * LB) acc += a.sum_src[i];
+        for (int i = rank; i < a.sum_n; i += 256) acc += a.sum_src[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if ((rank & 63) == 0) s_w[rank >> 6] = acc;
@@ -234,81 +276,88 @@ __global__ __launch_bounds__(LB * LB) void loss_fused_backward_kernel(const floa
             if (a.loss_host) a.loss_host[0] = total;
         }
     }
-    for (int i = rank; i < SH * SH; i += LB * LB) {
-        const int r = i / SH, q = i - r * SH;
-        const int y = ty0 + r - HALO, x = tx0 + q - HALO;
-        const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
-        const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pxx = tx0 + lx;
+    const int py[2] = {ty0 + 2 * ly, ty0 + 2 * ly + 1};
+    // rows at or behind row_end belong to the next strip (the window ends on a 16-row boundary, blocks are 32 tall)
+    const bool inside[2] = {pxx < (int)a.w && py[0] < (int)a.h && py[0] < (int)a.row_end, pxx < (int)a.w && py[1] < (int)a.h && py[1] < (int)a.row_end};
+    float4 pv[2];
+    uint32_t val[2] = {0u, 0u};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* q = &partials[(p * 3 + c) * 3];
-            s_part[c][i] = in ? make_float4(q[0], q[1], q[2], 0.0f) : z;
+    for (int o = 0; o < 2; ++o) {
+        pv[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside[o]) {
+            const size_t p = (size_t)py[o] * a.w + (size_t)pxx;
+            pv[o] = *reinterpret_cast<const float4*>(&img[p * 4]);
+            val[o] = gt[p];
         }
     }
-    __syncthreads();
-    for (int i = rank; i < 3 * SH * LB; i += LB * LB) {
-        const int c = i / (SH * LB), rem = i - c * (SH * LB);
-        const int r = rem / LB, col = (rem - r * LB) + HALO;
-        const float4* row = &s_part[c][r * SH];
-        float a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-        for (int d = 1; d < 6; ++d) {
-            const float wd = a.taps.w[5 - d];
-            const float4 l = row[col - d], rr = row[col + d];
-            a0 += (l.x + rr.x) * wd;
-            a1 += (l.y + rr.y) * wd;
-            a2 += (l.z + rr.z) * wd;
-        }
-        const float4 cc = row[col];
-        a0 += cc.x * a.taps.w[5];
-        a1 += cc.y * a.taps.w[5];
-        a2 += cc.z * a.taps.w[5];
-        s_h2[c][rem] = make_float4(a0, a1, a2, 0.0f);
-    }
-    __syncthreads();
-    const int py = ty0 + ly, pxx = tx0 + lx;
-    if (!(pxx < (int)a.w && py < (int)a.h)) return;
-    const size_t p = (size_t)py * a.w + (size_t)pxx;
-    const float4 pv = *reinterpret_cast<const float4*>(&img[p * 4]);
-    const uint32_t val = gt[p];
-    const float ga = gt_ch(val, 3);
-    float chain_c = a.dl_rgb;
-    if (a.mask) chain_c = chain_c * ga;
-    const float pred_c[3] = {pv.x, pv.y, pv.z};
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    float out[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-        float s[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int d = 1; d < 6; ++d) {
-            const float wd = a.taps.w[5 - d];
-            const float4 t = s_h2[c][(ly + HALO - d) * LB + lx];
-            const float4 b = s_h2[c][(ly + HALO + d) * LB + lx];
-            s[0] += (t.x + b.x) * wd;
-            s[1] += (t.y + b.y) * wd;
-            s[2] += (t.z + b.z) * wd;
+        __syncthreads();   // the previous plane's column pass is done with the buffers
+        const float* pc = partials + (size_t)(c * 3) * plane;
+        for (int i = rank; i < SR * SW; i += 256) {
+            const int r = i / SW, q = i - r * SW;
+            const int y = ty0 + r - HALO, x = tx0 + q - HALO;
+            const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
+            const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
+            s_part[0][i] = in ? pc[p] : 0.0f;
+            s_part[1][i] = in ? pc[plane + p] : 0.0f;
+            s_part[2][i] = in ? pc[2 * plane + p] : 0.0f;
         }
-        const float4 cc = s_h2[c][(ly + HALO) * LB + lx];
-        s[0] += cc.x * a.taps.w[5];
-        s[1] += cc.y * a.taps.w[5];
-        s[2] += cc.z * a.taps.w[5];
-        float ge = gt_ch(val, c);
-        if (a.composite) ge = ge + (1.0f - ga) * a.bg[c];
-        const float p1 = pred_c[c];
-        const float ssim_grad = s[0] + (2.0f * p1) * s[1] + ge * s[2];
-        const float diff = p1 - ge;
-        const float l1_sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
-        out[c] = a.ssim_w * ssim_grad + a.l1_w * l1_sign * chain_c;
+        __syncthreads();
+        for (int i = rank; i < 3 * SR * TW; i += 256) {
+            const int j = i / (SR * TW), rem = i - j * (SR * TW);
+            const int r = rem / TW, col = (rem - r * TW) + HALO;
+            const float* row = &s_part[j][r * SW];
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 1; d < 6; ++d) acc += (row[col - d] + row[col + d]) * a.taps.w[5 - d];
+            acc += row[col] * a.taps.w[5];
+            s_h2[j][rem] = acc;
+        }
+        __syncthreads();
+        float v[3][12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 12; ++r) v[j][r] = s_h2[j][(2 * ly + r) * TW + lx];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float sres[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int d = 1; d < 6; ++d) acc += (v[j][o + 5 - d] + v[j][o + 5 + d]) * a.taps.w[5 - d];
+                acc += v[j][o + 5] * a.taps.w[5];
+                sres[j] = acc;
+            }
+            const float ga = gt_ch(val[o], 3);
+            float chain_c = a.dl_rgb;
+            if (a.mask) chain_c = chain_c * ga;
+            float ge = gt_ch(val[o], c);
+            if (a.composite) ge = ge + (1.0f - ga) * a.bg[c];
+            const float p1 = c == 0 ? pv[o].x : (c == 1 ? pv[o].y : pv[o].z);
+            const float ssim_grad = sres[0] + (2.0f * p1) * sres[1] + ge * sres[2];
+            const float diff = p1 - ge;
+            const float l1_sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+            out[o][c] = a.ssim_w * ssim_grad + a.l1_w * l1_sign * chain_c;
+        }
     }
-    if (a.alpha_match) {  // lib.rs:392-412
-        const float diff = pv.w - ga;
-        const float sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
-        float chain = a.dl_alpha;
-        if (a.mask) chain = chain * ga;
-        out[3] = sign * chain;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        if (!inside[o]) continue;
+        if (a.alpha_match) {  // lib.rs:392-412
+            const float ga = gt_ch(val[o], 3);
+            const float diff = pv[o].w - ga;
+            const float sign = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
+            float chain = a.dl_alpha;
+            if (a.mask) chain = chain * ga;
+            out[o][3] = sign * chain;
+        }
+        *reinterpret_cast<float4*>(&v_output[((size_t)py[o] * a.w + (size_t)pxx) * 4]) = make_float4(out[o][0], out[o][1], out[o][2], out[o][3]);
     }
-    *reinterpret_cast<float4*>(&v_output[p * 4]) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 // loss scalar -> loss_out[0];  dloss/d(out_img) -> v_output [H,W,4].
@@ -325,7 +374,7 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
     if (tile_y1 > gy) tile_y1 = gy;
     if (tile_y0 >= tile_y1) return set_error(ctx, BH_ERR_INVALID_ARG, "image loss: empty tile-row window");
     const uint32_t a0 = tile_y0 > 0 ? tile_y0 - 1 : 0, a1 = tile_y1 < gy ? tile_y1 + 1 : gy;  // pass A window
-    const dim3 block(LB, LB);
+    const dim3 block(TW, 16);
     const size_t hw = (size_t)h * w;
     auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));   // 9 floats per pixel used (the slot is shared with loss.hip's map)
     auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)gx * gy * sizeof(float));
@@ -340,19 +389,21 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
     {
         ProfScope ps(ctx, "ImageLoss");
         a.ty_base = a0;
+        a.row_end = h;
         a.sum_src = nullptr; a.sum_n = 0; a.loss_out = nullptr; a.loss_host = nullptr;
-        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, a1 - a0), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a);
+        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, (a1 - a0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, gy, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
     }
     {
         ProfScope ps(ctx, "ImageLossBackward");
         a.ty_base = tile_y0;
+        a.row_end = tile_y1 * LB < h ? tile_y1 * LB : h;
         // the loss = the strip's own tiles only (block_sums is indexed by absolute tile row)
         a.sum_src = block_sums + (size_t)tile_y0 * gx;
         a.sum_n = (int)((tile_y1 - tile_y0) * gx);
         a.loss_out = loss_out;
         a.loss_host = loss_host;
-        hipLaunchKernelGGL(loss_fused_backward_kernel, dim3(gx, tile_y1 - tile_y0), block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
+        hipLaunchKernelGGL(loss_fused_backward_kernel, dim3(gx, (tile_y1 - tile_y0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_backward_kernel");
     }
     return 0;
