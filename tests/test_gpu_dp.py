@@ -31,7 +31,7 @@ def _scene():
                             tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * H / W), spread=1.8)
 
 
-def _worker(rank, world, port, q, sparse):
+def _worker(rank, world, port, q, sparse, seed=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,11 +42,14 @@ def _worker(rank, world, port, q, sparse):
     sc = _scene()
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(W, H, seed=3 + rank).view(np.int32)).to(dev)
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, sparse_exchange=sparse)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, sparse_exchange=sparse, seed=seed)
     batch = ba.SceneBatch(gt, util.hip_camera(ba, _cam_params(rank)))
     out, rows = [], []
     for _ in range(2):
-        trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        if seed is None:
+            trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        else:
+            trainer.step(batch, spl)   # background jitter + mean noise from the library's generator, keyed by (seed, step)
         rows.append(trainer.stats().exchange_rows)
         out.append((spl.transforms.cpu().numpy().copy(), spl.sh_coeffs.cpu().numpy().copy(), spl.raw_opacities.cpu().numpy().copy()))
     trainer.sync_refine_stats()  # the running maxima are rank-local until refine asks for them
@@ -145,3 +148,30 @@ def test_sparse_exchange_on_one_rank_is_the_identity(dev):
         assert st.exchange_rows == 0 and st.num_visible > 200
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_with_device_noise_stay_identical():
+    """The seeded step (noise drawn on the device, background jittered): both ranks pass the same seed, the gate uses the SUMMED
+    visible flags and the identically updated opacity, so the replicas must stay bit-identical without exchanging a sample — and
+    the noise must actually have been applied (the trajectory differs from the unseeded one)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for seed in (0x5EED, None):
+        q = ctx.Queue()
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, True, seed)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        (_, o0, vis0, *_), (_, o1, vis1, *_) = res
+        for step in range(2):
+            for a, b in zip(o0[step], o1[step]):
+                assert np.array_equal(a, b), "replicas diverged (seed %r, step %d)" % (seed, step)
+        runs[seed] = (o0[1][0], vis0)
+    moved = np.any(runs[0x5EED][0][:, :3] != runs[None][0][:, :3], axis=1)
+    assert moved.sum() > 20, "the seeded run shows no noise"
+    assert not moved[runs[None][1] == 0].any(), "a splat no rank saw was moved"
