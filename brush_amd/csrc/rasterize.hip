@@ -242,9 +242,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                     const bool sat = next_t <= 1.0e-4f;
                     const bool contrib = ok && !sat;
                     const float vis = contrib ? alpha_eff * tr[q] : 0.0f;
-                    pr[q] += s1.z * vis;
-                    pg[q] += s1.w * vis;
-                    pb[q] += s2.x * vis;
+                    pr[q] = __builtin_fmaf(s1.z, vis, pr[q]);   // (explicit fma: part of the numerical specification, as in the CPU checker)
+                    pg[q] = __builtin_fmaf(s1.w, vis, pg[q]);
+                    pb[q] = __builtin_fmaf(s2.x, vis, pb[q]);
                     tr[q] = ok ? (sat ? -tr[q] : next_t) : tr[q];
                     any = any || contrib;
                 }

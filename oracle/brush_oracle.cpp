@@ -1601,9 +1601,10 @@ int render_forward(Render& R, const BoCamera& cam, uint32_t n, uint32_t sh_degre
                         if (next_t <= 1.0e-4f) break;  // done (rasterize.rs:139-140)
                         if (bwd_info) vis_mark[cg] = 1;  // benign race: all writers store 1
                         const float vis = alpha_eff * t_acc;
-                        pr += std::fmax(s[6], 0.0f) * vis;
-                        pg += std::fmax(s[7], 0.0f) * vis;
-                        pb += std::fmax(s[8], 0.0f) * vis;
+                        // three explicit fma (numerical specification): rgb += max(c, 0) * vis
+                        pr = std::fmaf(std::fmax(s[6], 0.0f), vis, pr);
+                        pg = std::fmaf(std::fmax(s[7], 0.0f), vis, pg);
+                        pb = std::fmaf(std::fmax(s[8], 0.0f), vis, pb);
                         t_acc = next_t;
                         last_useful = is + 1;
                     }
