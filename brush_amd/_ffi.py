@@ -104,7 +104,7 @@ class BhTrainStats(C.Structure):
 
 class BhPlyInfo(C.Structure):
     _fields_ = [("num_splats", C.c_uint64), ("sh_degree", C.c_uint32), ("row_floats", C.c_uint32), ("body_offset", C.c_uint64),
-                ("render_mode", C.c_int32), ("has_up_axis", C.c_int32), ("up_axis", C.c_float * 3)]
+                ("render_mode", C.c_int32), ("has_up_axis", C.c_int32), ("up_axis", C.c_float * 3), ("compressed", C.c_int32)]
 
 
 GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -142,6 +142,7 @@ SYMBOLS = {
     "bh_splat_to_ply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, fp, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bh_ply_parse_header": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(BhPlyInfo)]),
     "bh_splats_from_ply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bh_splats_from_ply_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bh_uploader_create": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "bh_uploader_destroy": (None, [C.c_void_p]),
     "bh_uploader_last_error": (C.c_char_p, [C.c_void_p]),

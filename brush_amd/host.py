@@ -433,6 +433,7 @@ class ParseMetadata:
     render_mode: Optional[str]
     total_splats: int
     sh_degree: int
+    compressed: bool = False   # a SuperSplat-compressed file (import.rs:244-250, 407-600)
 
 
 def ply_parse_header(data: bytes) -> ParseMetadata:
@@ -440,23 +441,36 @@ def ply_parse_header(data: bytes) -> ParseMetadata:
     info = _ffi.BhPlyInfo()
     rc = _ffi.load().bh_ply_parse_header(data, len(data), C.byref(info))
     if rc != 0:
-        raise BrushHipError("unsupported PLY (%d): only binary_little_endian float vertex rows are read" % rc if rc == -5 else "malformed PLY (%d)" % rc)
+        raise BrushHipError("unsupported PLY (%d): only binary_little_endian float vertex rows (or SuperSplat-compressed chunks) are read" % rc
+                            if rc == -5 else "malformed PLY (%d)" % rc)
     return ParseMetadata(tuple(info.up_axis) if info.has_up_axis else None, {0: "default", 1: "mip"}.get(info.render_mode), int(info.num_splats),
-                         int(info.sh_degree))
+                         int(info.sh_degree), bool(info.compressed))
 
 
-def load_splat_from_ply(data: bytes, device=None, render_mip=None, ctx: Optional[Context] = None):
-    """load_splat_from_ply + SplatData::into_splats (import.rs:166-170, 57-75) -> (Splats, ParseMetadata).
-    render_mip None = take the file's SplatRenderMode comment (default mode when absent)."""
+def load_splat_from_ply(data: bytes, device=None, render_mip=None, ctx: Optional[Context] = None, subsample_points: Optional[int] = None,
+                        max_splats: Optional[int] = None):
+    """load_splat_from_ply + SplatData::into_splats (import.rs:166-181, 77-97) -> (Splats, ParseMetadata).
+    render_mip None = take the file's SplatRenderMode comment (default mode when absent).
+    subsample_points = s keeps every s-th row (rows s-1, 2s-1, ...: import.rs:346-349); max_splats then applies
+    SplatData::subsample (import.rs:49-74: rows 0, step, 2 step, ... with step = ceil(n / max_splats); 0 / None = no cap), as
+    the training stream does (brush-process/src/train_stream.rs:111).  meta.total_splats is the number of rows kept."""
     meta = ply_parse_header(data)
     device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ctx = ctx or get_context(device)
-    n, c = meta.total_splats, (meta.sh_degree + 1) ** 2
+    s = int(subsample_points or 1)
+    if s < 1:
+        raise BrushHipError("subsample_points must be >= 1")
+    first, step, n = s - 1, s, meta.total_splats // s
+    if max_splats and n > max_splats:
+        step2 = -(-n // int(max_splats))
+        n, step = -(-n // step2), step * step2
+    c = (meta.sh_degree + 1) ** 2
     tr = torch.empty((n, 10), dtype=torch.float32, device=device)
     sh = torch.empty((n, c, 3), dtype=torch.float32, device=device)
     op = torch.empty((n,), dtype=torch.float32, device=device)
-    ctx.check(ctx.lib.bh_splats_from_ply(ctx._h, data, len(data), _ptr(tr), _ptr(sh), _ptr(op)))
+    ctx.check(ctx.lib.bh_splats_from_ply_strided(ctx._h, data, len(data), first, step, n, _ptr(tr), _ptr(sh), _ptr(op)))
     mip = (meta.render_mode == "mip") if render_mip is None else bool(render_mip)
+    meta.total_splats = n
     return Splats(tr, sh, op, mip, device), meta
 
 

@@ -21,7 +21,7 @@
  *   bh_compute_min_scale <- compute_min_scale                brush-train/src/train.rs:102-125
  *   bh_uploader_*       <- view_to_packed_data + the SceneLoader hand-off   brush-dataset/src/scene.rs:97-136, scene_loader.rs:59-174
  *   bh_splat_to_ply     <- splat_to_ply                       brush-serde/src/export.rs:86-204
- *   bh_ply_parse_header / bh_splats_from_ply <- load_splat_from_ply (plain PLY)  brush-serde/src/import.rs:166-330
+ *   bh_ply_parse_header / bh_splats_from_ply[_strided] <- load_splat_from_ply (plain + SuperSplat-compressed PLY, subsample)  brush-serde/src/import.rs:49-74,166-600
  *   bh_camera_setup[_model] <- Camera::{build_pinhole_params, world_to_local}, fov_to_focal,
  *                          calculate_jacobian_clamp_limits    brush-render/src/camera.rs:63-254
  *                          (+ kernels/camera_model/{pinhole,kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs: pinhole, Kannala-Brandt 4, radial-tangential 8,
@@ -405,20 +405,28 @@ int bh_splat_to_ply(bh_ctx* ctx, const float* transforms, const float* sh_coeffs
 typedef struct BhPlyInfo {
     uint64_t num_splats;
     uint32_t sh_degree;   /* from the number of f_dc_/f_rest_ properties */
-    uint32_t row_floats;  /* properties per vertex row */
+    uint32_t row_floats;  /* properties per vertex row when all are float; 0 for rows of mixed scalar types /
+                             a red-green-blue colour override (ply_gaussian.rs:36-99) and for compressed files */
     uint64_t body_offset; /* first byte after end_header */
     int32_t render_mode;  /* -1 unknown, 0 default, 1 mip ("SplatRenderMode:" comment) */
     int32_t has_up_axis;
     float up_axis[3];     /* "Vertical axis:" comment: x -> +X, y -> -Y, z -> -Z, or three numbers */
+    int32_t compressed;   /* 1: a SuperSplat / PlayCanvas compressed file (chunk + packed vertex [+ sh] elements,
+                             import.rs:407-600, quant.rs); row_floats is 0 then */
 } BhPlyInfo;
-/* Host only.  BH_ERR_UNSUPPORTED for files this build does not read (ascii / big-endian, non-float
- * vertex properties, SuperSplat-compressed chunks); BH_ERR_INVALID_ARG for malformed ones. */
+/* Host only.  BH_ERR_UNSUPPORTED for files this build does not read (ascii / big-endian, vertex properties of
+ * types the format does not use); BH_ERR_INVALID_ARG for malformed ones. */
 int bh_ply_parse_header(const void* bytes /*host*/, uint64_t len, BhPlyInfo* info /*host*/);
 /* load_splat_from_ply + SplatData::into_splats (import.rs:166-170, 57-75): one H2D copy of the body, columns
- * scattered on the device; absent properties take the reference's defaults (rotation 1,0,0,0; log-scale -4;
+ * scattered on the device (compressed files: the packed words are decoded on the device, one thread per splat); absent properties take the reference's defaults (rotation 1,0,0,0; log-scale -4;
  * SH DC 0.5; raw opacity 0).  Outputs sized from bh_ply_parse_header: transforms [N,10], sh_coeffs
  * [N,(d+1)^2,3], raw_opacities [N].  Blocking. */
 int bh_splats_from_ply(bh_ctx* ctx, const void* bytes /*host*/, uint64_t len, float* transforms, float* sh_coeffs, float* raw_opacities);
+/* The same, keeping only file rows first, first + step, ... (`count` of them; UINT64_MAX = all that exist): the
+ * `subsample_points` argument of load_splat_from_ply (import.rs:170-181: first = s - 1, step = s, count = rows / s) and
+ * SplatData::subsample (import.rs:49-74: first = 0, step = ceil(rows / max_splats)).  The output tensors hold `count` rows. */
+int bh_splats_from_ply_strided(bh_ctx* ctx, const void* bytes, uint64_t len, uint64_t first, uint64_t step, uint64_t count,
+                                      float* transforms, float* sh_coeffs, float* raw_opacities);
 
 /* ---- host image -> packed device batch (brush-dataset) ---------------------------- */
 /* SceneBatch::img_packed producer: view_to_packed_data (brush-dataset/src/scene.rs:97-136) moved to the

@@ -297,17 +297,29 @@ inline std::vector<uint8_t> splat_to_ply(const Context& ctx, const Splats& s, co
                               s.render_mip ? 1 : 0, up_axis, out.data(), need, &need));
     return out;
 }
-inline std::pair<Splats, BhPlyInfo> load_splat_from_ply(const Context& ctx, const std::vector<uint8_t>& bytes) {
+// subsample_points = s keeps every s-th file row (s-1, 2s-1, ...: import.rs:346-349), max_splats then caps the count the way
+// SplatData::subsample does (rows 0, step, 2 step, ...; import.rs:49-74).  info.num_splats is the number of rows kept.
+inline std::pair<Splats, BhPlyInfo> load_splat_from_ply(const Context& ctx, const std::vector<uint8_t>& bytes, uint32_t subsample_points = 1,
+                                                        size_t max_splats = 0) {
     BhPlyInfo info{};
     const int rc = bh_ply_parse_header(bytes.data(), bytes.size(), &info);
     if (rc != 0) throw Error(rc, rc == BH_ERR_UNSUPPORTED ? "unsupported PLY variant" : "malformed PLY");
+    if (subsample_points < 1) throw Error(BH_ERR_INVALID_ARG, "subsample_points must be >= 1");
+    uint64_t first = subsample_points - 1, step = subsample_points, n = info.num_splats / subsample_points;
+    if (max_splats != 0 && n > max_splats) {
+        const uint64_t step2 = (n + max_splats - 1) / max_splats;
+        n = (n + step2 - 1) / step2;
+        step *= step2;
+    }
     Splats s;
-    const size_t n = info.num_splats, c = (size_t)(info.sh_degree + 1) * (info.sh_degree + 1);
+    const size_t c = (size_t)(info.sh_degree + 1) * (info.sh_degree + 1);
     s.transforms.resize(n * 10);
     s.sh_coeffs.resize(n * c * 3);
     s.raw_opacities.resize(n);
     s.render_mip = info.render_mode == 1;
-    ctx.check(bh_splats_from_ply(ctx.get(), bytes.data(), bytes.size(), s.transforms.data(), s.sh_coeffs.data(), s.raw_opacities.data()));
+    ctx.check(bh_splats_from_ply_strided(ctx.get(), bytes.data(), bytes.size(), first, step, n, s.transforms.data(), s.sh_coeffs.data(),
+                                         s.raw_opacities.data()));
+    info.num_splats = n;
     return {std::move(s), info};
 }
 

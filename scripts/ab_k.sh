@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 for v in "$@"; do
   if [ "$v" = default ]; then lib=""; else lib="brush_amd/variants/libbrush_hip_$v.so"; fi
   for wl in 1m_1080p 1m_1080p_lowopac; do
-    BRUSH_HIP_LIB=$lib WORKLOAD=$wl STEPS=${STEPS:-30} python scripts/stage_times.py 2>/dev/null | sed "s/^/$v $wl /" | python -c "
+    BRUSH_HIP_LIB=$lib WORKLOAD=$wl STEPS=${STEPS:-30} timeout 120 python scripts/stage_times.py 2>/dev/null | sed "s/^/$v $wl /" | python -c "
 import sys,re
 for l in sys.stdin:
     head, _, rest = l.partition('|')

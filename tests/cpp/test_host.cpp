@@ -208,6 +208,18 @@ static void test_training_refine_ply(const bh::Context& ctx) {
     for (size_t i = 0; i < a.size() / 10; ++i)
         for (int k = 7; k < 10; ++k) scales_same = scales_same && a[i * 10 + k] == b[i * 10 + k];
     CHECK(scales_same && back.raw_opacities.download() == baked.raw_opacities.download(), "exported scales / opacities carry the baked floor");
+    {   // import.rs:651-670 (subsample_points) and :49-74 (SplatData::subsample)
+        auto [half, hinfo] = bh::load_splat_from_ply(ctx, ply, 2);
+        const auto full_sh = back.sh_coeffs.download(), half_sh = half.sh_coeffs.download();
+        bool same = hinfo.num_splats == info.num_splats / 2 && half_sh.size() == (size_t)hinfo.num_splats * 3;
+        for (size_t i = 0; same && i < hinfo.num_splats; ++i)
+            for (int k = 0; k < 3; ++k) same = same && half_sh[i * 3 + k] == full_sh[(2 * i + 1) * 3 + k];
+        CHECK(same, "subsample_points = 2 keeps rows 1, 3, 5, ...");
+        auto [capped, cinfo] = bh::load_splat_from_ply(ctx, ply, 1, 100);
+        const uint64_t step = (info.num_splats + 99) / 100;
+        CHECK(cinfo.num_splats <= 100 && cinfo.num_splats == (info.num_splats + step - 1) / step, "max_splats caps the count with a ceil step");
+        CHECK(capped.sh_coeffs.download()[3] == full_sh[step * 3], "max_splats keeps rows 0, step, 2 step, ...");
+    }
     std::printf("ok training_refine_ply  loss %.4f -> %.4f, %u splats after refine, ply %zu bytes\n", first, last, rs.total_splats, ply.size());
 }
 
