@@ -109,20 +109,19 @@ constexpr int BATCH = 64;
 constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend (~1e-7)
 
 // exp(x) for the blend loops, x = -sigma <= 0 wherever the result is used (lanes that fail the
-// sigma pre-test compute a value nobody reads).  Base-2 form chosen for gfx950 issue rates: ten
-// full-rate VALU ops (mul, add, sub, sub, 5 fma, lshl_add) where the Cephes sequence of bh_expf
+// sigma pre-test compute a value nobody reads).  Base-2 form chosen for gfx950 issue rates: nine
+// full-rate VALU ops (fma, sub, fma, 5 fma, lshl_add) where the Cephes sequence of bh_expf
 // takes 14 with three half-rate ones (rndne, cvt, ldexp): k = rint(x*log2e) through the 1.5*2^23
-// magic add, 2^f from a degree-5 minimax polynomial on [-0.5, 0.5] (1.6e-7 max rel. error), and the
+// magic add (fused into the product), 2^f from a degree-5 minimax polynomial on [-0.5, 0.5] (1.6e-7 max rel. error), and the
 // exponent spliced in by adding k << 23 to the bit pattern.  The CPU checker used by the tests
 // restates the same sequence, so images stay bit-identical to it.
 BH_DEV float exp_blend(float x) {
 #ifdef BH_HW_EXP  // measurement-only variant (not the shipped numerical spec)
     return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
 #endif
-    const float t = x * 1.44269504088896341f;
-    const float s = t + 12582912.0f;
-    const float kf = s - 12582912.0f;
-    const float f = t - kf;
+    const float s = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float nkf = 12582912.0f - s;                               // -rint(x log2e), exact (as a subtraction: both fmas keep
+    const float f = __builtin_fmaf(x, 1.44269504088896341f, nkf);    //  their constant as a literal, no SGPR operand)
     float p = 1.3274633092805743e-3f;
     p = __builtin_fmaf(p, f, 9.671961888670921e-3f);
     p = __builtin_fmaf(p, f, 5.5506784468889236e-2f);
@@ -142,7 +141,9 @@ BH_DEV uint32_t tile_of_block(uint32_t b, uint32_t num_tiles) {
 // Everything that is per-splat rather than per-pixel is done here once by the
 // staging lane: colour clamp (rasterize.rs:147-149), the gate bits of the backward
 // and the conservative sigma bound used for the wave-uniform quadrant skip.
-template <bool SMOOTH>
+// HALF_CONIC (the forward): c00 and c11 are staged halved — sigma = 1/2 (c00 dx^2 + c11 dy^2) + c01 dx dy then needs no
+// multiply by 1/2 per pixel, and scaling by a power of two commutes with every rounding on the way: bit-identical.
+template <bool SMOOTH, bool HALF_CONIC>
 BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float* __restrict__ projected,
                             uint32_t batch_start, uint32_t cnt, int lane, float* s_splat) {
     uint32_t cg = 0;
@@ -156,8 +157,9 @@ BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float
         const float cut = __builtin_fmaxf(bh_logf(v[5] / thr) + SIGMA_CUT_MARGIN, 0.0f);
         const uint32_t gate = (v[6] >= 0.0f ? 1u : 0u) | (v[7] >= 0.0f ? 2u : 0u) | (v[8] >= 0.0f ? 4u : 0u);
         float4* d = reinterpret_cast<float4*>(s_splat + lane * SPLAT_STRIDE);
-        d[0] = make_float4(v[0], v[1], v[2], v[3]);
-        d[1] = make_float4(v[4], v[5], __builtin_fmaxf(v[6], 0.0f), __builtin_fmaxf(v[7], 0.0f));
+        const float diag = HALF_CONIC ? 0.5f : 1.0f;
+        d[0] = make_float4(v[0], v[1], diag * v[2], v[3]);
+        d[1] = make_float4(diag * v[4], v[5], __builtin_fmaxf(v[6], 0.0f), __builtin_fmaxf(v[7], 0.0f));
         d[2] = make_float4(__builtin_fmaxf(v[8], 0.0f), cut, u2f(gate), u2f(cg));
     }
     return cg;
@@ -202,18 +204,22 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     const uint32_t range_lo = tile_offsets[tile * 2];
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
     uint32_t last_useful = range_lo;
+    uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
+    asm volatile("" : "+v"(sign_mask));
 
+    // (A per-batch variant without the v_min of the 0.999 clamp — the backward's trick — was measured here: the second copy of
+    //  the loop costs 16 VGPRs, 8 -> 7 waves per SIMD, 160 -> 170 us.)
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
         const bool live = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
         if (__ballot(live) == 0ull) break;
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
         __syncthreads();  // previous batch fully consumed (single wave: cheap)
-        const uint32_t cg = stage_batch<SMOOTH>(isect_gids, projected, batch_start, cnt, lane, s_splat);
+        const uint32_t cg = stage_batch<SMOOTH, true>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
         for (uint32_t t = 0; t < cnt; ++t) {
-            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00 c01
-            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11 a r g
+            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
+            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut
             const uint32_t cut_bits = f2u(s2.y);
             float a_xx[2], b_x[2], c_y[2], dy[2];
@@ -229,10 +235,12 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = q & 1, m = q >> 1;
-                const float qv = __builtin_fmaf(c_y[m], dy[m], a_xx[k]);
-                const float sigma = __builtin_fmaf(b_x[k], dy[m], 0.5f * qv);
-                // live pixel and 0 <= sigma <= sigma_cut (unsigned compare of the bit patterns)
-                const bool pre = tr[q] > 0.0f && f2u(sigma) <= cut_bits;
+                const float half_qv = __builtin_fmaf(c_y[m], dy[m], a_xx[k]);   // (the staged diagonal is halved)
+                const float sigma = __builtin_fmaf(b_x[k], dy[m], half_qv);
+                // live pixel and 0 <= sigma <= sigma_cut: ONE unsigned compare — a finished pixel carries a negative T, and
+                // its sign bit ORed into sigma's bit pattern puts the key above every cut (one full-rate v_and_or_b32 instead
+                // of a second half-rate v_cmp and a scalar and)
+                const bool pre = ((f2u(tr[q]) & sign_mask) | f2u(sigma)) <= cut_bits;
                 if (__ballot(pre) != 0ull) {
                     const float alpha = __builtin_fminf(0.999f, s1.y * exp_blend(-sigma));
                     const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
@@ -493,7 +501,9 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 // --- replay: identical arithmetic to the forward kernel -------------
                 const float qv = __builtin_fmaf(c_y[m], dyp[m], a_xx[k]);
                 const float sigma = __builtin_fmaf(b_x[k], dyp[m], 0.5f * qv);
-                const bool pre = sw[q] > 0.0f && f2u(sigma) <= cut_bits;   // live pixel and 0 <= sigma <= sigma_cut
+                // live pixel and 0 <= sigma <= sigma_cut  (the forward's single-compare form of this test — sign bit of a negative
+                // "finished" T ORed into the key — was measured here too: +1 %, four more VGPRs push the kernel over 96)
+                const bool pre = sw[q] > 0.0f && f2u(sigma) <= cut_bits;
                 if (__ballot(pre) != 0ull) {   // wave-uniform: one scalar branch steps over a quadrant that cannot reach the cutoff
                     const float gaussian = blend_exp_bwd(-sigma);
                     const float alpha_raw = color_a * gaussian;
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
         __syncthreads();
-        stage_batch<SMOOTH>(isect_gids, projected, batch_start, cnt, lane, s_splat);
+        stage_batch<SMOOTH, false>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
         const bool mine_clamps = (uint32_t)lane < cnt && s_splat[lane * SPLAT_STRIDE + 5] > 0.999f;
         if (__ballot(mine_clamps) != 0ull) run_batch(std::true_type{}, cnt);

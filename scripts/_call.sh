@@ -1,4 +1,5 @@
 cd /root/repo
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_ply.py tests/test_gpu_cpp_host.py -x -q 2>&1 | tail -15 > gpurun_out/c2_ply.txt
-cat gpurun_out/c2_ply.txt
+timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_backward.py tests/test_gpu_full_size.py tests/test_gpu_train_step.py -x -q 2>&1 | tail -5 > gpurun_out/c5_tests.txt
+STEPS=30 timeout 600 bash scripts/ab_k.sh old ac default old ac default > gpurun_out/c5_ab.txt 2>&1
+cat gpurun_out/c5_tests.txt gpurun_out/c5_ab.txt
