@@ -85,10 +85,12 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
     }
     // The lanes of one wave talk to each other through LDS below.  In hardware a wave's LDS operations retire in
     // order, so no s_barrier is needed — but the COMPILER reasons per lane and would forward a lane's own store to
-    // its later load: a wavefront-scope fence (no instructions, only an ordering point) and volatile accesses to the
-    // mark strip keep every cross-lane read a real load.
+    // its later load: compiler-only memory barriers (no instructions) keep every cross-lane read a real ds_read.
+    // (NOT `volatile`: a volatile pointer into the struct loses the LDS address space — the strip was being accessed
+    // with flat_store_byte / flat_load_ubyte sc0 sc1, each followed by s_waitcnt vmcnt(0), i.e. every step of the walk
+    // also waited for its own global stores to land.)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    volatile uint8_t* flags = w.flags;
+    uint8_t* flags = w.flags;
     const uint32_t tot = __shfl(incl, 63);
     const unsigned long long le = below | (1ull << lane);
     uint32_t before = 0;  // ranks that start before `base` (wave-uniform)
@@ -97,7 +99,9 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
         flags[lane] = 0;
         const uint32_t rel = start - base;   // wraps for starts before base -> fails the range test
         if (nz && rel < 64u) flags[rel] = 1;
+        asm volatile("" ::: "memory");
         const unsigned long long marks = __ballot(flags[lane] != 0);
+        asm volatile("" ::: "memory");
         const uint32_t c = base + (uint32_t)lane;
         if (c < tot) {
             const uint32_t r = before + (uint32_t)__popcll(marks & le) - 1u;
@@ -141,7 +145,7 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
         w.lane_of[rank] = (uint32_t)lane;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // see flat_tile_walk
-    volatile uint8_t* flags = w.flags;
+    uint8_t* flags = w.flags;
     const uint32_t tot = __shfl(incl, 63);
     const unsigned long long le = below | (1ull << lane);
     uint32_t before = 0;   // ranks that start before `base` (wave-uniform)
@@ -150,7 +154,9 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
         flags[lane] = 0;
         const uint32_t rel = start - base;
         if (nz && rel < 64u) flags[rel] = 1;
+        asm volatile("" ::: "memory");
         const unsigned long long marks = __ballot(flags[lane] != 0);
+        asm volatile("" ::: "memory");
         const uint32_t c = base + (uint32_t)lane;
         bool hit = false;
         uint32_t tile = 0, owner = 0;
