@@ -53,10 +53,25 @@ __global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __r
     __syncthreads();
     constexpr int SORT_TILE = SORT_WG * SORT_KPT;
     const uint32_t base = blockIdx.x * SORT_TILE;
+    if (base + (uint32_t)SORT_TILE <= n && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0) {
+        // every block but the last: 16-byte loads (which thread counts which key is irrelevant to a histogram)
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);   // base is a multiple of 1024 keys
+        uint4 v[SORT_KPT / 4];
 #pragma unroll
-    for (int k = 0; k < SORT_KPT; ++k) {
-        const uint32_t idx = base + k * SORT_WG + tid;
-        if (idx < n) atomicAdd(&s_hist[wave][digit_of(keys[idx], shift, mask)], 1u);
+        for (int k = 0; k < SORT_KPT / 4; ++k) v[k] = k4[k * SORT_WG + tid];
+#pragma unroll
+        for (int k = 0; k < SORT_KPT / 4; ++k) {
+            atomicAdd(&s_hist[wave][digit_of(v[k].x, shift, mask)], 1u);
+            atomicAdd(&s_hist[wave][digit_of(v[k].y, shift, mask)], 1u);
+            atomicAdd(&s_hist[wave][digit_of(v[k].z, shift, mask)], 1u);
+            atomicAdd(&s_hist[wave][digit_of(v[k].w, shift, mask)], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SORT_KPT; ++k) {
+            const uint32_t idx = base + k * SORT_WG + tid;
+            if (idx < n) atomicAdd(&s_hist[wave][digit_of(keys[idx], shift, mask)], 1u);
+        }
     }
     __syncthreads();
     uint32_t total = 0;
@@ -132,12 +147,25 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
     const uint32_t wave_base = block_base + wave * (64 * SORT_KPT);
     uint32_t key[SORT_KPT], val[SORT_KPT], rank[SORT_KPT];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // this thread's two table entries are needed only after the ranking: issue their loads first so the (strided, L2)
+    // round trip runs under it
+    const uint32_t my_offset = offsets[(size_t)tid * nblocks + blockIdx.x];
+    const uint32_t my_gtotal = digit_totals ? digit_totals[tid] : 0u;
+    if (block_base + (uint32_t)SORT_TILE <= n) {   // every block but the last: no bounds tests around the loads
 #pragma unroll
-    for (int k = 0; k < SORT_KPT; ++k) {
-        const uint32_t idx = wave_base + k * 64 + lane;
-        const bool valid = idx < n;
-        key[k] = valid ? keys[idx] : 0xFFFFFFFFu;
-        val[k] = valid ? (HAS_VALS ? vals[idx] : idx) : 0u;
+        for (int k = 0; k < SORT_KPT; ++k) {
+            const uint32_t idx = wave_base + k * 64 + lane;
+            key[k] = keys[idx];
+            val[k] = HAS_VALS ? vals[idx] : idx;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SORT_KPT; ++k) {
+            const uint32_t idx = wave_base + k * 64 + lane;
+            const bool valid = idx < n;
+            key[k] = valid ? keys[idx] : 0xFFFFFFFFu;
+            val[k] = valid ? (HAS_VALS ? vals[idx] : idx) : 0u;
+        }
     }
 #pragma unroll
     for (int k = 0; k < SORT_KPT; ++k) {
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
     }
     // exclusive scan of the 256 digit totals across the block
     {
-        const uint32_t gt = digit_totals ? digit_totals[tid] : 0u;
+        const uint32_t gt = my_gtotal;
         uint32_t incl = total, gincl = gt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -183,7 +211,7 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
         const uint32_t excl = incl - total + wofs;
         const uint32_t below = gincl - gt + gofs;  // keys with a smaller digit (0 when offsets already hold the full scan)
         s_dbase[tid] = excl;
-        s_gofs[tid] = below + offsets[(size_t)tid * nblocks + blockIdx.x] - excl;
+        s_gofs[tid] = below + my_offset - excl;
     }
     __syncthreads();
     // local reorder: position inside the block's digit-sorted tile

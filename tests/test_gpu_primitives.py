@@ -56,6 +56,22 @@ def test_sorting_sizes_bits_and_stability(dev, oracle_lib, n, bits):
     assert np.array_equal(ov, rv) and np.array_equal(ok, rk)
 
 
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_sorting_keys_at_unaligned_addresses(dev, off):
+    """The histogram's 16-byte loads are only taken for 16-byte aligned key pointers: an offset view (4-byte aligned) sorts the same."""
+    import brush_amd as ba
+    n = 3 * 4096 + 77
+    rng = np.random.default_rng(off)
+    keys = rng.integers(0, 2 ** 13, n + off, dtype=np.uint64).astype(np.uint32)
+    vals = np.arange(n + off, dtype=np.uint32)
+    kd = torch.from_numpy(keys.view(np.int32)).to(dev)[off:]
+    vd = torch.from_numpy(vals.view(np.int32)).to(dev)[off:]
+    assert kd.data_ptr() % 16 != 0
+    ok, ov = ba.radix_argsort(kd, vd, 13)
+    idx = np.argsort(keys[off:], kind="stable")
+    assert np.array_equal(ok.cpu().numpy().view(np.uint32), keys[off:][idx]) and np.array_equal(ov.cpu().numpy().view(np.uint32), vals[off:][idx])
+
+
 def test_sorting_implicit_values_and_inplace(dev):
     import brush_amd as ba
     rng = np.random.default_rng(5)
