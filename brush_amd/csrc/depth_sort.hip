@@ -104,13 +104,30 @@ __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __res
     for (int i = tid; i < DS_WAVES * DS_RADIX; i += DS_WG) { (&s_hist[0][0])[i] = 0; (&s_csum[0][0])[i] = 0; }
     const DepthSplit sp = depth_split(minmax, s_red);   // (contains the barrier behind the clears)
     const uint32_t base = blockIdx.x * DS_TILE;
+    auto count_one = [&](uint32_t key, uint32_t cnt) {
+        const uint32_t d = depth_digit(key, sp);
+        atomicAdd(&s_hist[wave][d], 1u);
+        if (d != 255u) atomicAdd(&s_csum[wave][d], cnt);
+    };
+    if (base + (uint32_t)DS_TILE <= n && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(counts)) & 15u) == 0) {
+        // every chunk but the last: 16-byte loads (which thread counts which key is irrelevant to a histogram)
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
+        const uint4* c4 = reinterpret_cast<const uint4*>(counts + base);
+        uint4 kv[DS_KPT / 4], cv[DS_KPT / 4];
 #pragma unroll
-    for (int k = 0; k < DS_KPT; ++k) {
-        const uint32_t idx = base + k * DS_WG + tid;
-        if (idx < n) {
-            const uint32_t d = depth_digit(keys[idx], sp);
-            atomicAdd(&s_hist[wave][d], 1u);
-            if (d != 255u) atomicAdd(&s_csum[wave][d], counts[idx]);
+        for (int k = 0; k < DS_KPT / 4; ++k) { kv[k] = k4[k * DS_WG + tid]; cv[k] = c4[k * DS_WG + tid]; }
+#pragma unroll
+        for (int k = 0; k < DS_KPT / 4; ++k) {
+            count_one(kv[k].x, cv[k].x);
+            count_one(kv[k].y, cv[k].y);
+            count_one(kv[k].z, cv[k].z);
+            count_one(kv[k].w, cv[k].w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DS_KPT; ++k) {
+            const uint32_t idx = base + k * DS_WG + tid;
+            if (idx < n) count_one(keys[idx], counts[idx]);
         }
     }
     __syncthreads();
@@ -199,14 +216,25 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
     const uint32_t wave_first = wave * (64 * KPT);
     uint32_t key[KPT], val[KPT], rank[KPT], dig[KPT];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (count == (uint32_t)DS_TILE) {   // a full chunk: no bounds tests around the loads
 #pragma unroll
-    for (int k = 0; k < KPT; ++k) {
-        const uint32_t e = wave_first + k * 64 + lane;
-        const bool valid = e < count;
-        key[k] = valid ? src_k[first + e] : 0u;
-        val[k] = valid ? (src_v ? src_v[first + e] : first + e) : 0u;
-        // invalid tail elements take digit 255 and sit at the highest in-chunk positions: they never disturb a valid rank
-        dig[k] = valid ? digit(key[k]) : 255u;
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t e = wave_first + k * 64 + lane;
+            key[k] = src_k[first + e];
+            val[k] = src_v ? src_v[first + e] : first + e;
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) dig[k] = digit(key[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const uint32_t e = wave_first + k * 64 + lane;
+            const bool valid = e < count;
+            key[k] = valid ? src_k[first + e] : 0u;
+            val[k] = valid ? (src_v ? src_v[first + e] : first + e) : 0u;
+            // invalid tail elements take digit 255 and sit at the highest in-chunk positions: they never disturb a valid rank
+            dig[k] = valid ? digit(key[k]) : 255u;
+        }
     }
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {

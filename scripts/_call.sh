@@ -1,7 +1,7 @@
 cd /root/repo
 mkdir -p gpurun_out
 rm -f gpurun_out/c9.txt
-timeout 600 python -m pytest tests/test_gpu_primitives.py -x -q 2>&1 | tail -3 >> gpurun_out/c9.txt
+timeout 600 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_depth_sort.py -x -q 2>&1 | tail -3 >> gpurun_out/c9.txt
 for v in presort default presort default; do
   if [ "$v" = default ]; then lib=""; else lib="brush_amd/variants/libbrush_hip_$v.so"; fi
   echo "== $v" >> gpurun_out/c9.txt
