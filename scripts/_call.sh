@@ -1,10 +1,4 @@
 cd /root/repo
 mkdir -p gpurun_out
-rm -f gpurun_out/c9.txt
-timeout 600 python -m pytest tests/test_gpu_primitives.py tests/test_gpu_depth_sort.py -x -q 2>&1 | tail -3 >> gpurun_out/c9.txt
-for v in presort default presort default; do
-  if [ "$v" = default ]; then lib=""; else lib="brush_amd/variants/libbrush_hip_$v.so"; fi
-  echo "== $v" >> gpurun_out/c9.txt
-  BRUSH_HIP_LIB=$lib WORKLOAD=1m_1080p STEPS=30 timeout 120 python scripts/stage_times.py 2>/dev/null >> gpurun_out/c9.txt
-done
-cat gpurun_out/c9.txt
+STEPS=30 timeout 600 bash scripts/ab_k.sh default bw6 al64 al256 default bw6 al64 al256 > gpurun_out/c10.txt 2>&1
+cat gpurun_out/c10.txt
