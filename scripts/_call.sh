@@ -1,5 +1,9 @@
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_backward.py tests/test_gpu_camera_models.py -x -q 2>&1 | tail -5 > gpurun_out/c12_tests.txt
-STEPS=30 timeout 600 bash scripts/ab_k.sh presort default presort default > gpurun_out/c12_ab.txt 2>&1
-cat gpurun_out/c12_tests.txt gpurun_out/c12_ab.txt
+rm -f gpurun_out/c14.txt
+for v in default lv1 lv2 lv3 default; do
+  if [ "$v" = default ]; then lib=""; else lib="brush_amd/variants/libbrush_hip_$v.so"; fi
+  echo "== $v" >> gpurun_out/c14.txt
+  BRUSH_HIP_LIB=$lib WORKLOAD=1m_1080p STEPS=20 timeout 120 python scripts/stage_times.py 2>/dev/null | sed 's/.*Rasterize /Rasterize /' >> gpurun_out/c14.txt
+done
+cat gpurun_out/c14.txt
