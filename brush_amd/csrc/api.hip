@@ -412,7 +412,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (cam->img_w == 0 || cam->img_h == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "Can't render images with 0 size.");  // render.rs:50-53
     if (sh_degree > 4) return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     if (cam->model > BH_CAMERA_THIN_PRISM_FISHEYE) return set_error(ctx, BH_ERR_INVALID_ARG, "unknown camera model");
-    if (cam->img_w > 16368 || cam->img_h > 16368) return set_error(ctx, BH_ERR_UNSUPPORTED, "images larger than 16368 px per side are not supported (tile grid <= 1023 x 1023)");
+    // (a splat's candidate box is walked with a 24-bit index: tile grids up to 4095 x 4095)
+    if (cam->img_w > 65520 || cam->img_h > 65520) return set_error(ctx, BH_ERR_UNSUPPORTED, "images larger than 65520 px per side are not supported (tile grid <= 4095 x 4095)");
     if (n > 0 && (!transforms || !sh_coeffs || !raw_opacities)) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null splat tensor");
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
     BH_HIP(ctx, hipSetDevice(ctx->device));

@@ -45,11 +45,22 @@ constexpr int PROJ_WAVES = PROJ_WG / 64;
 struct WalkLds {
     uint32_t count[64];   // by rank: hits per splat (K1) / emit cursor (K5)
     float mx[64], my[64], c00[64], c01[64], c11[64], pt[64], rcp_w[64];   // by rank
-    uint32_t box[64];     // by rank: min_x | min_y << 10 | width << 20   (tile grids up to 1023 x 1023)
+    uint32_t box[64];     // by rank: min_x | min_y << 16   (tile grids up to 4095 x 4095: api.hip's image-size limit)
+    uint32_t boxw[64];    // by rank: box width in tiles
     uint32_t start[64];   // by rank: first candidate of the splat
     uint32_t lane_of[64]; // by rank: the lane (splat slot) it came from
     uint8_t flags[64];    // scratch strip for the per-step start marks
 };
+
+// i / bw for a candidate index inside a box: the float quotient is exact for boxes of up to ~1000 rows (error <= rows * 2^-22
+// against the 0.5 / bw margin) and at most one off for anything a 4095 x 4095 tile grid can hold (i < 2^24); one correction each
+// way makes it exact everywhere.
+BH_DEV uint32_t walk_row(uint32_t i, uint32_t bw, float rcp_w) {
+    uint32_t row = (uint32_t)(((float)i + 0.5f) * rcp_w);
+    if (row * bw > i) --row;
+    else if ((row + 1u) * bw <= i) ++row;
+    return row;
+}
 
 BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -79,7 +90,8 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
         w.rcp_w[rank] = 1.0f / (float)bb_w;
-        w.box[rank] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
+        w.box[rank] = bb.min_x | (bb.min_y << 16);
+        w.boxw[rank] = bb_w;
         w.start[rank] = start;
         w.lane_of[rank] = (uint32_t)lane;
     }
@@ -107,11 +119,10 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t r = before + (uint32_t)__popcll(marks & le) - 1u;
             const uint32_t i = c - w.start[r];
             const uint32_t box = w.box[r];
-            const uint32_t bw = box >> 20;
-            // i / bw via float: exact for boxes up to 1023 tiles high (error <= rows * 2^-23 << 0.5 / bw)
-            const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[r]);
-            const uint32_t tx = (box & 1023u) + (i - row * bw);
-            const uint32_t ty = ((box >> 10) & 1023u) + row;
+            const uint32_t bw = w.boxw[r];
+            const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
+            const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
+            const uint32_t ty = (box >> 16) + row;
             if (will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
         }
         before += (uint32_t)__popcll(marks);
@@ -140,7 +151,8 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
         w.rcp_w[rank] = 1.0f / (float)bb_w;
-        w.box[rank] = bb.min_x | (bb.min_y << 10) | (bb_w << 20);
+        w.box[rank] = bb.min_x | (bb.min_y << 16);
+        w.boxw[rank] = bb_w;
         w.start[rank] = start;
         w.lane_of[rank] = (uint32_t)lane;
     }
@@ -164,10 +176,10 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
             const uint32_t r = before + (uint32_t)__popcll(marks & le) - 1u;
             const uint32_t i = c - w.start[r];
             const uint32_t box = w.box[r];
-            const uint32_t bw = box >> 20;
-            const uint32_t row = (uint32_t)(((float)i + 0.5f) * w.rcp_w[r]);
-            const uint32_t tx = (box & 1023u) + (i - row * bw);
-            const uint32_t ty = ((box >> 10) & 1023u) + row;
+            const uint32_t bw = w.boxw[r];
+            const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
+            const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
+            const uint32_t ty = (box >> 16) + row;
             hit = will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
             tile = tx + ty * tile_bw;
             owner = cg0 + w.lane_of[r];

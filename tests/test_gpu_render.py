@@ -97,6 +97,24 @@ def test_odd_image_sizes_rotated_offcentre_camera(dev, oracle_lib, w, h):
     assert np.abs(img.cpu().numpy() - ref.image()).max() <= IMG_TOL
 
 
+@pytest.mark.parametrize("w,h", [(20000, 48), (48, 18000)])
+def test_panoramic_image_wider_than_1023_tiles(dev, oracle_lib, w, h):
+    """No reference limit on the image size: the walk's box records hold 16-bit tile coordinates and its candidate index ->
+    (row, column) split is corrected to exact integer division, so tile grids beyond 1023 tiles per side (round 1's limit)
+    and splats whose boxes span more than a thousand tiles are walked like any other."""
+    import brush_amd as ba
+    scene = synth.make_scene(300, 0x5A, sh_degree=0, log_scale_range=(math.log(0.02), math.log(0.2)))
+    scene["transforms"][:12, 7:10] = math.log(30.0)   # a dozen giants: boxes over the whole strip
+    scene["raw_opac"][:12] = -3.0
+    fov_long, fov_short = 2.4, 2.4 * min(w, h) / max(w, h)
+    cp = dict(pos=(0.0, 0.0, -1.5), rot_xyzw=(0.0, 0.0, 0.0, 1.0), fov_x=fov_long if w > h else fov_short, fov_y=fov_short if w > h else fov_long,
+              center_uv=(0.5, 0.5))
+    img, aux, ref = render_both(ba, oracle_lib, dev, scene, cp, w, h, bg=(0.2, 0.1, 0.0))
+    assert aux.num_intersections > 5000 and max(w, h) // 16 > 1023
+    assert_stagewise_exact(aux, ref)
+    assert np.abs(img.cpu().numpy() - ref.image()).max() <= IMG_TOL
+
+
 def test_few_splats_under_a_large_tile_table(dev, oracle_lib):
     """K1 clears the tile table and the visible flags on its way, one word per splat thread; with 40 splats under a
     1920x1080 frame (16 448 table words) its grid cannot cover them and the launcher has to fall back to plain fills.
