@@ -32,7 +32,6 @@ namespace {
 
 constexpr int LB = 16;
 constexpr int HALO = 5;
-constexpr int SH = LB + 2 * HALO;  // 26
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 constexpr float INV_255 = 1.0f / 255.0f;
