@@ -22,7 +22,15 @@ The forward follows, in the reference's order of operations:
   kernels/camera_model/pinhole.rs:25-57 (pinhole projection + clamped Jacobian),
   kernels/sh.rs:47-136 (real SH up to degree 3, Sloan 2013 constants),
   kernels/rasterize.rs:129-166 (front-to-back blend, alpha clamp 0.999, cutoff 1/255, T <= 1e-4 stop).
-Only the pinhole model, default (non-mip) mode, hard alpha cutoff.  Small scenes only (O(pixels x splats)).
+Default (non-mip) mode, hard alpha cutoff.  Small scenes only (O(pixels x splats)).
+
+Lens models (kernels/camera_model/{kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs): only the PROJECTION
+FUNCTIONS are written down here (project_kb4 :19-58, project_rt8 :23-62, project_tpf :64-82); the 2x3 Jacobian that carries the
+covariance to the image is obtained by autograd from them (create_graph=True), so the reference's analytic Jacobians AND its
+hand-written second-order terms (calculate_projection_vjp_*) are both checked against something that contains neither.
+The radial-tangential model evaluates its Jacobian at the clamped normalised point like the pinhole one (…_rt8 :64-96); the two
+fisheye models do not clamp (kannala_brandt_4.rs:60-62).  Intrinsics and the visibility cone (fx, fy, cx, cy, clamp limits,
+half_max_render_fov) are taken from the oracle's camera set-up, which the ABI tests pin separately.
 """
 import math
 
@@ -65,6 +73,36 @@ def _sh_color(coeffs, d):
     return c
 
 
+def _project(model, dist, p, fx, fy, cx, cy):
+    """p [N,3] camera-space points -> (u, v) [N] pixel coordinates, float64 torch ops only."""
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    if model == "pinhole":
+        return fx * x / z + cx, fy * y / z + cy
+    if model == "rt8":
+        k1, k2, k3, k4, k5, k6, p1, p2 = [float(v) for v in dist]
+        xn, yn = x / z, y / z
+        r2 = xn * xn + yn * yn
+        r4, r6 = r2 * r2, r2 * r2 * r2
+        d = (1.0 + k1 * r2 + k2 * r4 + k3 * r6) / (1.0 + k4 * r2 + k5 * r4 + k6 * r6)
+        xd = xn * d + 2.0 * p1 * xn * yn + p2 * (r2 + 2.0 * xn * xn)
+        yd = yn * d + 2.0 * p2 * xn * yn + p1 * (r2 + 2.0 * yn * yn)
+        return fx * xd + cx, fy * yd + cy
+    k1, k2, k3, k4 = [float(v) for v in dist[:4]]
+    r = torch.sqrt(x * x + y * y)
+    th = torch.atan2(r, z)
+    t2 = th * th
+    d = th * (1.0 + k1 * t2 + k2 * t2 * t2 + k3 * t2 * t2 * t2 + k4 * t2 * t2 * t2 * t2)
+    u, v = fx * d * x / r + cx, fy * d * y / r + cy
+    if model == "kb4":
+        return u, v
+    assert model == "tpf"
+    p1, p2, sx1, sy1 = [float(v) for v in dist[4:8]]
+    r2 = x * x + y * y
+    nu = 2.0 * p1 * x * y + p2 * (3.0 * x * x + y * y) + sx1 * r2
+    nv = 2.0 * p2 * x * y + p1 * (x * x + 3.0 * y * y) + sy1 * r2
+    return u + fx * nu / (z * z), v + fy * nv / (z * z)
+
+
 def camera_matrices(pos, rot_xyzw, fov_x, fov_y, center_uv, w, h):
     """camera.rs:63-101,200-254 in float64: world->camera rotation [3,3] and translation [3], intrinsics, clamp limits."""
     x, y, z, ww = [float(v) for v in rot_xyzw]
@@ -82,30 +120,46 @@ def camera_matrices(pos, rot_xyzw, fov_x, fov_y, center_uv, w, h):
     return r, t, (fx, fy, cx, cy), lim
 
 
-def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0)):
+def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=None):
     """transforms [N,10] (mean, quat wxyz un-normalised, log-scale), sh [N,C,3], raw_opac [N]: float64 torch tensors
-    (requires_grad as wanted); cam: dict(pos, rot_xyzw, fov_x, fov_y, center_uv).  Returns the [h,w,4] image."""
+    (requires_grad as wanted); cam: dict(pos, rot_xyzw, fov_x, fov_y, center_uv[, model, dist]).  Returns the [h,w,4] image.
+    intrinsics (lens models): dict(fx, fy, cx, cy, lim=(pos_x, pos_y, neg_x, neg_y), half_max_render_fov) from the camera set-up."""
     dt = torch.float64
     r_np, t_np, (fx, fy, cx, cy), lim = camera_matrices(cam["pos"], cam["rot_xyzw"], cam["fov_x"], cam["fov_y"], cam["center_uv"], w, h)
+    model = cam.get("model", "pinhole")
+    if model != "pinhole":
+        fx, fy, cx, cy = intrinsics["fx"], intrinsics["fy"], intrinsics["cx"], intrinsics["cy"]
+        lim = intrinsics["lim"]
     rc, tc = torch.tensor(r_np, dtype=dt), torch.tensor(t_np, dtype=dt)
     mean, quat, log_s = transforms[:, 0:3], transforms[:, 3:7], transforms[:, 7:10]
     n = transforms.shape[0]
     mean_c = mean @ rc.T + tc
     zc = mean_c[:, 2]
-    keep = (zc >= 0.01) & (zc <= 1e10)   # project_forward.rs:47-51 (the scenes used here keep every splat in front)
+    if model == "pinhole":
+        keep = (zc >= 0.01) & (zc <= 1e10)   # project_forward.rs:47-51 (the scenes used here keep every splat in front)
+    else:                                    # :52-61: inside the render cone
+        theta = torch.atan2(torch.sqrt(mean_c[:, 0] ** 2 + mean_c[:, 1] ** 2), zc)
+        keep = (theta <= intrinsics["half_max_render_fov"]) & (zc <= 1e10)
     q = quat / quat.norm(dim=1, keepdim=True)
     m = _quat_to_mat(q) * torch.exp(log_s)[:, None, :]             # R(q) diag(s)
     cov_c = rc @ (m @ m.transpose(1, 2)) @ rc.T
     xz = torch.clamp(mean_c[:, 0] / zc, lim[2], lim[0])             # pinhole.rs:33-57: the Jacobian uses clamped x/z, y/z
     yz = torch.clamp(mean_c[:, 1] / zc, lim[3], lim[1])
     zero = torch.zeros_like(zc)
-    jac = torch.stack([torch.stack([fx / zc, zero, -fx / zc * xz], -1), torch.stack([zero, fy / zc, -fy / zc * yz], -1)], -2)
+    if model == "pinhole":
+        jac = torch.stack([torch.stack([fx / zc, zero, -fx / zc * xz], -1), torch.stack([zero, fy / zc, -fy / zc * yz], -1)], -2)
+    else:
+        # Jacobian of the projection by autograd, at the (rt8: clamped) camera-space point; create_graph keeps it differentiable
+        q = torch.stack([xz * zc, yz * zc, zc], -1) if model == "rt8" else mean_c
+        ju, jv = _project(model, cam["dist"], q, fx, fy, cx, cy)
+        ru = torch.autograd.grad(ju.sum(), q, create_graph=True)[0]
+        rv = torch.autograd.grad(jv.sum(), q, create_graph=True)[0]
+        jac = torch.stack([ru, rv], -2)
     cov2 = jac @ cov_c @ jac.transpose(1, 2)
     a, b, c = cov2[:, 0, 0] + 0.3, cov2[:, 0, 1], cov2[:, 1, 1] + 0.3   # helpers.rs:180-195 default mode: + 0.3 I, comp = 1
     det = a * c - b * b
     c00, c01, c11 = c / det, -b / det, a / det                          # conic = inverse
-    mx = fx * mean_c[:, 0] / zc + cx
-    my = fy * mean_c[:, 1] / zc + cy
+    mx, my = _project(model, cam.get("dist", ()), mean_c, fx, fy, cx, cy)
     alpha0 = torch.sigmoid(raw_opac)
     cam_pos = torch.tensor(np.asarray(cam["pos"], np.float64), dtype=dt)
     vd = mean - cam_pos
@@ -137,12 +191,12 @@ def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0)):
     return torch.cat([rgb + T[..., None] * bgt, (1.0 - T)[..., None]], dim=-1)
 
 
-def gradients(scene, cam, w, h, weights, bg=(0.0, 0.0, 0.0)):
+def gradients(scene, cam, w, h, weights, bg=(0.0, 0.0, 0.0), intrinsics=None):
     """d( sum(weights * image) ) / d(transforms, sh, raw_opac) by autograd; numpy float64 in and out."""
     tr = torch.tensor(np.asarray(scene["transforms"], np.float64), requires_grad=True)
     sh = torch.tensor(np.asarray(scene["sh"], np.float64), requires_grad=True)
     op = torch.tensor(np.asarray(scene["raw_opac"], np.float64), requires_grad=True)
-    img = render(tr, sh, op, cam, w, h, bg)
+    img = render(tr, sh, op, cam, w, h, bg, intrinsics)
     loss = (img * torch.tensor(np.asarray(weights, np.float64))).sum()
     loss.backward()
     return img.detach().numpy(), tr.grad.numpy(), sh.grad.numpy(), op.grad.numpy()

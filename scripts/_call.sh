@@ -1,5 +1,10 @@
 cd /root/repo
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/c18_full.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/c18_full.txt 2>&1
-cat gpurun_out/c18_full.txt
+rm -f gpurun_out/c19.txt
+timeout 600 python -m pytest tests/test_gpu_depth_sort.py tests/test_gpu_render.py -x -q 2>&1 | tail -3 >> gpurun_out/c19.txt
+for v in presort default presort default; do
+  if [ "$v" = default ]; then lib=""; else lib="brush_amd/variants/libbrush_hip_$v.so"; fi
+  echo "== $v" >> gpurun_out/c19.txt
+  BRUSH_HIP_LIB=$lib WORKLOAD=1m_1080p STEPS=30 timeout 120 python scripts/stage_times.py 2>/dev/null | cut -c1-150 >> gpurun_out/c19.txt
+done
+cat gpurun_out/c19.txt

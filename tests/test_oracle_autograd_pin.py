@@ -19,10 +19,12 @@ def _compare(scene, camp, w, h, bg, seed, rel=2e-5):
     rng = np.random.default_rng(seed)
     wts = (rng.uniform(-1.0, 1.0, (h, w, 4)) / (h * w)).astype(np.float32)
     cam = bo.camera(img_w=w, img_h=h, **camp)
+    intr = dict(fx=float(cam.fx), fy=float(cam.fy), cx=float(cam.cx), cy=float(cam.cy), half_max_render_fov=float(cam.half_max_render_fov),
+                lim=(float(cam.lim_pos_x), float(cam.lim_pos_y), float(cam.lim_neg_x), float(cam.lim_neg_y)))
     r = bo.Render().forward(cam, scene["transforms"], scene["sh"], scene["raw_opac"], bg=bg, flags=bo.FLAG_BWD_INFO)
     r.backward(wts)
     n = scene["transforms"].shape[0]
-    img, g_tr, g_sh, g_op = autograd_ref.gradients(scene, camp, w, h, wts, bg)
+    img, g_tr, g_sh, g_op = autograd_ref.gradients(scene, camp, w, h, wts, bg, intr)
     assert r.num_visible > 0
     assert np.abs(r.image().astype(np.float64) - img).max() <= 1e-5, "forward images differ"
     out = {}
@@ -87,3 +89,20 @@ def test_rotated_offcentre_nonsquare_camera_and_jacobian_clamp():
     sc["transforms"][0, 0:3] = (1.9, 0.1, -1.0)      # x/z ~ 0.95 > lim_pos_x = 1.15 * tan(0.3) ~ 0.36: clamped, still reaches the image
     sc["transforms"][0, 7:10] = (-0.3, -0.5, -0.4)   # large enough to cover pixels from out there
     _compare(sc, util.STD_CAM, 32, 32, (0.0, 0.0, 0.0), 10)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_lens_models_match_autograd(seed):
+    """finite_diff.rs:730-776, 1180-1225: the reference checks its lens VJPs by finite differences; here every model's backward
+    — analytic Jacobian AND the second-order terms of calculate_projection_vjp_{kb4,rt8,tpf} — is compared with autograd
+    through the bare projection function (oracle/autograd_ref.py::_project).  random_camera_with_model cycles the four
+    models; the heavy-distortion cameras follow."""
+    n = 2 + seed % 7
+    camp = util.random_camera_with_model(seed)
+    _compare(util.random_scene(seed, n), camp, 40, 40, (0.1, 0.2, 0.3), 300 + seed, rel=5e-5)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_heavy_distortion_lenses_match_autograd(seed):
+    camp = util.heavy_distortion_camera(seed)
+    _compare(util.random_scene(40 + seed, 5), camp, 40, 40, (0.0, 0.0, 0.0), 400 + seed, rel=1e-4)
