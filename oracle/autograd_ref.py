@@ -22,7 +22,8 @@ The forward follows, in the reference's order of operations:
   kernels/camera_model/pinhole.rs:25-57 (pinhole projection + clamped Jacobian),
   kernels/sh.rs:47-136 (real SH up to degree 3, Sloan 2013 constants),
   kernels/rasterize.rs:129-166 (front-to-back blend, alpha clamp 0.999, cutoff 1/255, T <= 1e-4 stop).
-Default (non-mip) mode, hard alpha cutoff.  Small scenes only (O(pixels x splats)).
+Default and Mip-Splatting mode (helpers.rs:180-195), hard and smooth alpha cutoff (helpers.rs:23-34).  Small scenes only
+(O(pixels x splats)).
 
 Lens models (kernels/camera_model/{kannala_brandt_4,radial_tangential_8,thin_prism_fisheye}.rs): only the PROJECTION
 FUNCTIONS are written down here (project_kb4 :19-58, project_rt8 :23-62, project_tpf :64-82); the 2x3 Jacobian that carries the
@@ -120,7 +121,7 @@ def camera_matrices(pos, rot_xyzw, fov_x, fov_y, center_uv, w, h):
     return r, t, (fx, fy, cx, cy), lim
 
 
-def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=None):
+def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=None, mip=False, smooth=False, comp_is_constant=True):
     """transforms [N,10] (mean, quat wxyz un-normalised, log-scale), sh [N,C,3], raw_opac [N]: float64 torch tensors
     (requires_grad as wanted); cam: dict(pos, rot_xyzw, fov_x, fov_y, center_uv[, model, dist]).  Returns the [h,w,4] image.
     intrinsics (lens models): dict(fx, fy, cx, cy, lim=(pos_x, pos_y, neg_x, neg_y), half_max_render_fov) from the camera set-up."""
@@ -156,11 +157,21 @@ def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=N
         rv = torch.autograd.grad(jv.sum(), q, create_graph=True)[0]
         jac = torch.stack([ru, rv], -2)
     cov2 = jac @ cov_c @ jac.transpose(1, 2)
-    a, b, c = cov2[:, 0, 0] + 0.3, cov2[:, 0, 1], cov2[:, 1, 1] + 0.3   # helpers.rs:180-195 default mode: + 0.3 I, comp = 1
+    # helpers.rs:180-195: + 0.3 I (comp = 1), or Mip-Splatting: + 0.1 I and opacity * sqrt(det raw / det blurred)
+    blur = 0.1 if mip else 0.3
+    det_raw = torch.clamp(cov2[:, 0, 0] * cov2[:, 1, 1] - cov2[:, 0, 1] * cov2[:, 0, 1], min=0.0)
+    a, b, c = cov2[:, 0, 0] + blur, cov2[:, 0, 1], cov2[:, 1, 1] + blur
     det = a * c - b * b
     c00, c01, c11 = c / det, -b / det, a / det                          # conic = inverse
     mx, my = _project(model, cam.get("dist", ()), mean_c, fx, fy, cx, cy)
     alpha0 = torch.sigmoid(raw_opac)
+    if mip:
+        # The reference's backward treats the compensation factor as a CONSTANT of the geometry: project_backwards.rs:181-183
+        # multiplies v_raw_opac by filter_comp, and :190-196 builds v_cov2d from the conic alone — there is no
+        # d(filter_comp)/d(cov2d) term.  comp_is_constant=True reproduces that (a stop-gradient); False is the true derivative
+        # of the forward, which the reference's gradients therefore are NOT in Mip mode (tests/test_oracle_autograd_pin.py).
+        comp = torch.sqrt(det_raw / det)
+        alpha0 = alpha0 * (comp.detach() if comp_is_constant else comp)
     cam_pos = torch.tensor(np.asarray(cam["pos"], np.float64), dtype=dt)
     vd = mean - cam_pos
     vd = vd / vd.norm(dim=1, keepdim=True)
@@ -179,7 +190,13 @@ def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=N
         dx, dy = px - mx[i], py - my[i]
         sigma = 0.5 * (c00[i] * dx * dx + c11[i] * dy * dy) + c01[i] * dx * dy
         alpha = torch.clamp(alpha0[i] * torch.exp(-sigma), max=0.999)
-        ok = (sigma >= 0) & (alpha >= 1.0 / 255.0) & ~done
+        if smooth:   # helpers.rs:23-34: smoothstep over [1/255 - 5e-4, 1/255 + 5e-4] instead of the step at 1/255
+            tt = torch.clamp((alpha - (1.0 / 255.0 - 0.5e-3)) / 1.0e-3, 0.0, 1.0)
+            w_cut = tt * tt * (3.0 - 2.0 * tt)
+            ok = (sigma >= 0) & (w_cut > 0) & ~done
+            alpha = alpha * w_cut
+        else:
+            ok = (sigma >= 0) & (alpha >= 1.0 / 255.0) & ~done
         next_t = T * (1.0 - alpha)
         sat = ok & (next_t <= 1e-4)                 # rasterize.rs:155-160: the pixel is done WITHOUT adding this splat
         contrib = ok & ~sat
@@ -191,12 +208,12 @@ def render(transforms, sh, raw_opac, cam, w, h, bg=(0.0, 0.0, 0.0), intrinsics=N
     return torch.cat([rgb + T[..., None] * bgt, (1.0 - T)[..., None]], dim=-1)
 
 
-def gradients(scene, cam, w, h, weights, bg=(0.0, 0.0, 0.0), intrinsics=None):
+def gradients(scene, cam, w, h, weights, bg=(0.0, 0.0, 0.0), intrinsics=None, mip=False, smooth=False, comp_is_constant=True):
     """d( sum(weights * image) ) / d(transforms, sh, raw_opac) by autograd; numpy float64 in and out."""
     tr = torch.tensor(np.asarray(scene["transforms"], np.float64), requires_grad=True)
     sh = torch.tensor(np.asarray(scene["sh"], np.float64), requires_grad=True)
     op = torch.tensor(np.asarray(scene["raw_opac"], np.float64), requires_grad=True)
-    img = render(tr, sh, op, cam, w, h, bg, intrinsics)
+    img = render(tr, sh, op, cam, w, h, bg, intrinsics, mip, smooth, comp_is_constant)
     loss = (img * torch.tensor(np.asarray(weights, np.float64))).sum()
     loss.backward()
     return img.detach().numpy(), tr.grad.numpy(), sh.grad.numpy(), op.grad.numpy()

@@ -15,16 +15,20 @@ from oracle import autograd_ref, bo
 import util
 
 
-def _compare(scene, camp, w, h, bg, seed, rel=2e-5):
+def _compare(scene, camp, w, h, bg, seed, rel=2e-5, mip=False, smooth=False, comp_is_constant=True, expect_mismatch=False):
     rng = np.random.default_rng(seed)
     wts = (rng.uniform(-1.0, 1.0, (h, w, 4)) / (h * w)).astype(np.float32)
     cam = bo.camera(img_w=w, img_h=h, **camp)
     intr = dict(fx=float(cam.fx), fy=float(cam.fy), cx=float(cam.cx), cy=float(cam.cy), half_max_render_fov=float(cam.half_max_render_fov),
                 lim=(float(cam.lim_pos_x), float(cam.lim_pos_y), float(cam.lim_neg_x), float(cam.lim_neg_y)))
-    r = bo.Render().forward(cam, scene["transforms"], scene["sh"], scene["raw_opac"], bg=bg, flags=bo.FLAG_BWD_INFO)
+    flags = bo.FLAG_BWD_INFO | (bo.FLAG_MIP if mip else 0) | (bo.FLAG_SMOOTH_CUTOFF if smooth else 0)
+    r = bo.Render().forward(cam, scene["transforms"], scene["sh"], scene["raw_opac"], bg=bg, flags=flags)
     r.backward(wts)
     n = scene["transforms"].shape[0]
-    img, g_tr, g_sh, g_op = autograd_ref.gradients(scene, camp, w, h, wts, bg, intr)
+    img, g_tr, g_sh, g_op = autograd_ref.gradients(scene, camp, w, h, wts, bg, intr, mip, smooth, comp_is_constant)
+    if expect_mismatch:   # -> worst relative disagreement of the geometry gradients
+        a = r.get("v_transforms").reshape(n, 10).astype(np.float64)
+        return max(np.abs(a[:, sl] - g_tr[:, sl]).max() / np.abs(g_tr[:, sl]).max() for sl in (slice(0, 3), slice(3, 7), slice(7, 10)))
     assert r.num_visible > 0
     assert np.abs(r.image().astype(np.float64) - img).max() <= 1e-5, "forward images differ"
     out = {}
@@ -106,3 +110,28 @@ def test_lens_models_match_autograd(seed):
 def test_heavy_distortion_lenses_match_autograd(seed):
     camp = util.heavy_distortion_camera(seed)
     _compare(util.random_scene(40 + seed, 5), camp, 40, 40, (0.0, 0.0, 0.0), 400 + seed, rel=1e-4)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("mip,smooth", [(True, False), (False, True), (True, True)])
+def test_mip_and_smooth_cutoff_match_autograd(seed, mip, smooth):
+    """Mip-Splatting (helpers.rs:180-195: blur 0.1 and the sqrt(det raw / det blurred) opacity compensation — a constant of the
+    geometry in the reference's backward, see below) and the smooth alpha cutoff of the training passes (helpers.rs:23-47: a
+    smoothstep weight and its hand-written derivative)."""
+    n = 2 + seed % 7
+    camp = util.random_camera(seed) if seed % 2 else util.random_camera_with_model(seed)
+    _compare(util.random_scene(seed, n), camp, 40, 40, (0.2, 0.1, 0.3), 500 + seed, rel=5e-5, mip=mip, smooth=smooth)
+
+
+def test_mip_compensation_is_a_constant_in_the_reference_backward():
+    """A finding of this pin, recorded as a test: in Mip mode the reference's backward is NOT the derivative of its forward.
+    project_backwards.rs:181-196 scales v_raw_opac by filter_comp but never differentiates filter_comp = sqrt(det raw / det
+    blurred) with respect to the 2D covariance, so the geometry gradients miss that path.  The oracle (and the HIP kernels)
+    restate the reference, so they agree with autograd when the factor is detached (the test above, 1e-6) and disagree with
+    the true derivative by 0.1 - 6 % of max|g| — parity means following the reference here, not the calculus."""
+    worst = 0.0
+    for seed in (1, 2, 3, 4):
+        camp = util.random_camera(seed) if seed % 2 else util.random_camera_with_model(seed)
+        worst = max(worst, _compare(util.random_scene(seed, 2 + seed % 7), camp, 40, 40, (0.2, 0.1, 0.3), 500 + seed, mip=True,
+                                    comp_is_constant=False, expect_mismatch=True))
+    assert worst > 1e-3
