@@ -96,3 +96,35 @@ def test_compute_min_scale_matches_numpy():
     near = d.argmin(1)
     px = got * cams[near, 3] / np.linalg.norm(tr[:, :3] - cams[near, :3], axis=1)
     assert np.allclose(px[near != 2], np.sqrt(0.1), rtol=1e-4)
+
+
+def test_fold_min_scale_backward_matches_torch_autograd():
+    """The reference gets this backward from burn's autodiff over the tensor expression (gaussian_splats.rs:86-111); the oracle's
+    (and the library's) hand-derived chain rule is pinned against torch.autograd over the same expression in float64."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 500
+    tr = rng.normal(size=(n, 10)).astype(np.float32)
+    tr[:, 7:] = rng.uniform(-6.0, -1.0, (n, 3)).astype(np.float32)
+    op = rng.normal(0.0, 2.5, n).astype(np.float32)
+    op[:5] = 14.0    # sigmoid * coef lands on the upper clamp only if coef ~ 1: keep a few splats near it
+    f = rng.uniform(0.0, 0.08, n).astype(np.float32)
+    f[:3] = 0.0
+    v_t = rng.normal(size=(n, 10)).astype(np.float32)
+    v_o = rng.normal(size=n).astype(np.float32)
+    t64 = torch.tensor(tr.astype(np.float64), requires_grad=True)
+    o64 = torch.tensor(op.astype(np.float64), requires_grad=True)
+    f64 = torch.tensor(f.astype(np.float64))
+    s2 = torch.exp(2.0 * t64[:, 7:10])
+    s2f = s2 + (f64 * f64)[:, None]
+    new_t = torch.cat([t64[:, :7], 0.5 * torch.log(s2f)], 1)
+    coef = torch.sqrt(s2.prod(1) / s2f.prod(1))
+    o = torch.clamp(torch.sigmoid(o64) * coef, 1e-6, 1.0 - 1e-6)
+    new_o = torch.log(o / (1.0 - o))
+    ((new_t * torch.tensor(v_t.astype(np.float64))).sum() + (new_o * torch.tensor(v_o.astype(np.float64))).sum()).backward()
+    ft, fo = bo.fold_min_scale(tr, op, f)
+    # (opacities compared as probabilities: at the 1 - 1e-6 clamp the logit amplifies one f32 ulp of the clamp bound to 1e-2)
+    assert np.allclose(ft, new_t.detach().numpy(), rtol=2e-6, atol=2e-6) and np.allclose(1.0 / (1.0 + np.exp(-fo.astype(np.float64))), o.detach().numpy(), rtol=0, atol=2e-7)
+    gt, go = bo.fold_min_scale_backward(tr, op, f, v_t, v_o)
+    wt, wo = t64.grad.numpy(), o64.grad.numpy()
+    assert np.abs(gt - wt).max() <= 2e-5 * np.abs(wt).max() and np.abs(go - wo).max() <= 2e-5 * np.abs(wo).max()
