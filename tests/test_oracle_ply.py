@@ -235,3 +235,35 @@ def test_header_parser_accepts_mixed_rows():
         with pytest.raises(ba.BrushHipError):
             ba.ply_parse_header(bad)
     assert ba.ply_parse_header(_mixed_ply(10, colour=None, extra=False)[0]).total_splats == 10   # a bare x y z cloud
+
+
+def test_header_parser_survives_mutated_headers():
+    """Host-side robustness: random byte flips, deletions, insertions and truncations of three kinds of header either parse
+    (and then the declared body fits the buffer: the parser checks it) or are rejected — never a crash."""
+    import brush_amd as ba
+    rng = np.random.default_rng(0)
+    bases = [ply.make_compressed_ply(600, 2, seed=3), ply.splat_to_ply(*_splats(50, 3)), _mixed_ply(80, colour="uchar")[0]]
+    parsed = rejected = 0
+    for it in range(1500):
+        b = bytearray(bases[it % 3])
+        hdr_end = b.index(b"end_header") + 11
+        for _ in range(int(rng.integers(1, 6))):
+            mode, pos = int(rng.integers(0, 4)), int(rng.integers(0, max(hdr_end, 1)))
+            if mode == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif mode == 1:
+                del b[pos:pos + int(rng.integers(1, 12))]
+            elif mode == 2:
+                b[pos:pos] = bytes(rng.integers(32, 127, int(rng.integers(1, 10)), dtype=np.uint8))
+            else:
+                b = b[:int(rng.integers(0, len(b) + 1))]
+            hdr_end = min(hdr_end, len(b))
+            if hdr_end <= 1:
+                break
+        try:
+            meta = ba.ply_parse_header(bytes(b))
+            parsed += 1
+            assert meta.total_splats >= 0 and 0 <= meta.sh_degree <= 4
+        except ba.BrushHipError:
+            rejected += 1
+    assert parsed > 0 and rejected > 1000
