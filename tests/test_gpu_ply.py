@@ -191,3 +191,39 @@ def test_splat_data_subsample_reference_case(dev):
         ctx = ba.get_context(dev)
         t = torch.empty((10, 10), device=dev)
         ctx.check(ctx.lib.bh_splats_from_ply_strided(ctx._h, data, len(data), 5, 2, 4, t.data_ptr(), t.data_ptr(), t.data_ptr()))   # rows 5 7 9 11: past the end
+
+
+def test_mutated_headers_that_parse_also_load(dev):
+    """Whatever the host parser accepts, the device decode must take without faulting (its row / column offsets come from the
+    header): mutated files that still parse are loaded, and the context stays usable."""
+    import brush_amd as ba
+    from test_oracle_ply import _mixed_ply
+    rng = np.random.default_rng(1)
+    bases = [ply.make_compressed_ply(600, 2, seed=3), ply.splat_to_ply(*_splats(50, 3)), _mixed_ply(80, colour="uchar")[0]]
+    loaded = 0
+    for it in range(900):
+        b = bytearray(bases[it % 3])
+        hdr_end = b.index(b"end_header") + 11
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, hdr_end))
+            if rng.integers(0, 2):
+                b[pos] = int(rng.integers(32, 127))
+            else:
+                b[pos:pos] = bytes(rng.integers(48, 58, 1, dtype=np.uint8))   # a stray digit: counts and indices change
+        try:
+            meta = ba.ply_parse_header(bytes(b))
+        except ba.BrushHipError:
+            continue
+        if meta.total_splats > 2_000_000:
+            continue
+        try:
+            spl, _ = ba.load_splat_from_ply(bytes(b), device=dev)
+            loaded += 1
+            assert spl.transforms.shape[0] == meta.total_splats
+        except ba.BrushHipError:
+            pass
+    assert loaded > 10
+    torch.cuda.synchronize()
+    want = ply.load_compressed_ply(bases[0])
+    spl, _ = ba.load_splat_from_ply(bases[0], device=dev)
+    assert np.array_equal(spl.transforms.cpu().numpy()[:, :3], want["transforms"][:, :3])
