@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 mea
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 # rasterize_backward_kernel issues this many VALU instructions per blended (splat, tile) — SQ_INSTS_VALU / I_blended,
 # profiles/*_sq_counters.csv when present, else this static count from the ISA dump (profiles/*_isa_histogram.txt)
-VALU_PER_ISECT_STATIC = {"rasterize_backward_kernel": 249.4, "rasterize_kernel": 103.8}   # profiles/r2d_sq_counters.csv
+VALU_PER_ISECT_STATIC = {"rasterize_backward_kernel": 249.4, "rasterize_kernel": 103.8}   # profiles/r2f_sq_counters.csv
 
 # stages whose working set the previous kernel left in the 256 MB Infinity Cache: their GB/s is not an HBM rate
 CACHE_RESIDENT = {"ProjectBackwards": "reads v_combined / writes into the gradient span K1 zero-filled, both still in the 256 MB Infinity Cache",
