@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("BRUSH_HIP_LIB") or os.path.join(_DIR, "libbrush_hip.s
 FLAG_MIP = 1
 FLAG_BWD_INFO = 2
 FLAG_SMOOTH_CUTOFF = 4
+FLAG_SLICED_LISTS = 8
 
 fp = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -44,6 +45,7 @@ class BhRenderOut(C.Structure):
         ("compact_gid_from_isect", C.c_void_p), ("tile_id_from_isect", C.c_void_p),
         ("global_from_compact_gid", C.c_void_p), ("cum_tiles_hit", C.c_void_p),
         ("intersect_counts", C.c_void_p), ("depths_sorted", C.c_void_p),
+        ("tile_offsets_far", C.c_void_p), ("list_budget", C.c_uint32),
     ]
 
 
@@ -58,7 +60,7 @@ class BhTrainConfig(C.Structure):
         ("lr_coeffs_dc", C.c_double), ("lr_coeffs_sh_scale", C.c_float), ("lr_opac", C.c_double),
         ("lr_scale", C.c_double), ("lr_rotation", C.c_double), ("ssim_weight", C.c_float),
         ("match_alpha_weight", C.c_float), ("mean_noise_weight", C.c_float), ("background", C.c_float * 3),
-        ("median_scene_scale", C.c_float), ("render_mip", C.c_int32),
+        ("median_scene_scale", C.c_float), ("render_mip", C.c_int32), ("exact_lists", C.c_int32),
     ]
 
 
@@ -122,6 +124,8 @@ SYMBOLS = {
     "bh_fov_to_focal": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
     "bh_focal_to_fov": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
     "bh_render_forward": (C.c_int, [C.c_void_p, C.POINTER(BhCamera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, fp, C.c_uint32, C.POINTER(BhRenderOut)]),
+    "bh_set_list_slicing": (C.c_int, [C.c_void_p, C.c_float]),
+    "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
     "bh_last_render_out": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),

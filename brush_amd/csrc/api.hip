@@ -427,7 +427,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const size_t npad = n ? n : 1;
 
     // two counter pairs: K1 accumulates into one and clears the other for the next forward (no fill launch)
-    constexpr size_t counter_set_bytes = COUNTER_SET_BYTES, counter_set_words = COUNTER_SET_BYTES / 4, counter_read_bytes = COUNTER_SLOTS * 16;
+    constexpr size_t counter_set_bytes = COUNTER_SET_BYTES, counter_set_words = COUNTER_SET_BYTES / 4, counter_read_bytes = COUNTER_READ_BYTES;
     auto* counter_pairs = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 2 * counter_set_bytes);
     uint32_t* counters = counter_pairs ? counter_pairs + counter_set_words * (ctx->counter_phase & 1u) : nullptr;
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
@@ -445,8 +445,22 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
     const size_t visible_words = bwd_info ? ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) : 0;
+    // depth-sliced lists: [0] near-slice splats  [1] near-slice pairs  [2] tiles the near slice left unsaturated  [3] spare |
+    // done bits | far tile offsets [T,2].  Cleared by K1 with the tile table, whether or not this frame ends up slicing.
+    const bool want_sliced = (flags & BH_FLAG_SLICED_LISTS) != 0;
+    const size_t slice_bit_words = ((size_t)num_tiles + 31) / 32;
+    const size_t slice_words = want_sliced ? 4 + slice_bit_words + (size_t)num_tiles * 2 : 0;
+    uint32_t* slice_tab = nullptr;
+    if (want_sliced) {
+        slice_tab = (uint32_t*)ensure(ctx, SLOT_SLICE, slice_words * 4);
+        if (!slice_tab) return BH_ERR_OOM;
+    }
+    // where THIS forward's blend kernel leaves its slicing hint: the feedback words of the counter set the NEXT forward reads back
+    uint32_t* feedback_next = counter_pairs ? counter_pairs + counter_set_words * ((ctx->counter_phase & 1u) ^ 1u) + COUNTER_FB_WORD : nullptr;
 
     uint32_t nv = 0, ni = 0;
+    uint32_t fb_need = 0;                  // previous forward: most exact-list slots any saturated tile needed
+    unsigned long long fb_unsat_pairs = 0; // ... and pairs it listed for tiles that never saturated
     bool fused_scan = false;
     uint32_t* cum_early = nullptr;
     if (n > 0) {
@@ -460,6 +474,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.visible_words = (uint32_t)visible_words;
             prep.tile_table = tile_offsets;
             prep.tile_words = num_tiles * 2 + 8 * 16;
+            prep.slice_table = slice_tab;
+            prep.slice_words = (uint32_t)slice_words;
             ctx->grads_prezeroed = false;
             if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
@@ -488,7 +504,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 // cum slot is sized for n here because the visible count is not known yet
                 cum_early = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, npad * 4);
                 if (!cum_early) return BH_ERR_OOM;
-                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_SLOTS * 4, isect_counts, n, depths_sorted, gfc, cum_early));
+                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, isect_counts, n, depths_sorted, gfc, cum_early));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
@@ -499,9 +515,15 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
         nv = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
+        // the previous forward's slicing hint came along in the same copy
+        const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
+        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[2 * k] > fb_need) fb_need = hfb[2 * k]; fb_unsat_pairs += hfb[2 * k + 1]; }
     } else {   // no K1 to clear them on the way
         BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
         if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
+        if (counter_pairs) {   // counter_phase does not flip without K1: clear what this frame's blend kernel will add to
+            BH_HIP(ctx, hipMemsetAsync(feedback_next, 0, COUNTER_SLOTS * 8, ctx->stream));
+        }
     }
 
     const size_t nvpad = nv ? nv : 1, nipad = ni ? ni : 1;
@@ -515,6 +537,53 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
     if (!cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted || !out_img)
         return BH_ERR_OOM;
+
+    // ---- depth-sliced lists (BH_FLAG_SLICED_LISTS) --------------------------------------------------------------------------
+    // The reference lists EVERY (tile, splat) pair and sorts them all (map_gaussians.rs:15-80, render.rs:228-230), although a tile
+    // stops blending once its 256 pixels are saturated (rasterize.rs:116-189): at 1 M splats / 1080p the blend reads 9 % of the
+    // sorted list, at 6 M / 4K 1.7 %.  The splats are in depth order and cum_tiles_hit is their slot ranges, so "slot end <= budget"
+    // is a NEAR slice of the depth order whose pairs are the first I0 slots of the exact list.  List + sort + blend that slice;
+    // tiles whose pixels all saturated are final (one bit each); the FAR rest is listed only into tiles that are not
+    // (count -> scan -> emit against the bit table), sorted behind the near list and blended from the parked pixel state.
+    // Everything the far slice launches is a no-op when no tile is left (a device-side gate: no host round trip).  Per pixel the
+    // same splats are folded in the same order: out_img, visible[], the blended part of every list and the gradients are those
+    // of the exact path.  The near slice's size comes from the PREVIOUS forward on this ctx (how many slots its slowest
+    // saturating tile needed, + 25 %), or from bh_set_list_slicing; scenes that do not saturate keep the single exact list.
+    uint32_t budget = ni;   // == ni: one slice, the exact lists
+    if (want_sliced && ni > 0) {
+        float share = ctx->slice_fraction;
+        if (!(share > 0.0f)) {
+            const double prev = (double)ctx->prev_intersections;
+            if (!ctx->had_forward || prev == 0.0) share = 0.25f;
+            else if ((double)fb_unsat_pairs > 0.5 * prev) share = 1.0f;        // most of the list belongs to tiles that never saturate
+            else if (fb_need == 0u) share = 0.25f;
+            else share = (float)(1.25 * (double)fb_need / prev);
+            if (share > 0.7f) share = 1.0f;
+        }
+        if (share < 1.0f) {
+            const double b = (double)share * (double)ni;
+            const uint32_t floor_b = ni < (1u << 16) ? ni : (1u << 16);
+            budget = b < (double)floor_b ? floor_b : (uint32_t)b;
+            if (budget > ni) budget = ni;
+        }
+        ctx->last_slice_share = (float)((double)budget / (double)ni);
+    }
+    const bool sliced = budget < ni;
+    uint32_t* slice_info = slice_tab;
+    uint32_t* done_bits = slice_tab ? slice_tab + 4 : nullptr;
+    uint32_t* tile_offsets_far = slice_tab ? slice_tab + 4 + slice_bit_words : nullptr;
+    uint32_t tile_bits = 0;
+    while (tile_bits < 32 && (num_tiles >> tile_bits) != 0) tile_bits++;  // render.rs:228
+    RasterSlice rs;
+    rs.cum = cum;
+    rs.feedback = feedback_next;
+    // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
+    const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
+    const float class_width_raw = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
+    const float class_width = class_width_raw < 8.0f ? 8.0f : class_width_raw;
+    ctx->lpt = (bwd_info && !ctx->knob_no_lpt) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
+    float* out_f32 = bwd_info ? (float*)out_img : nullptr;
+    uint32_t* out_u8 = bwd_info ? nullptr : (uint32_t*)out_img;
 
     if (nv > 0) {
         if (!fused_scan) {
@@ -536,29 +605,59 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                     if (!vc) return BH_ERR_OOM;
                     ctx->vcombined_prezeroed = true;
                 }
-                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u));
+                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u,
+                                            sliced ? budget : 0xFFFFFFFFu, sliced ? slice_info : nullptr));
             }
             {
                 ProfScope ps(ctx, "TileSort");
-                uint32_t bits = 0;
-                while (bits < 32 && (num_tiles >> bits) != 0) bits++;  // render.rs:228
-                BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, bits, tile_ids_sorted, isect_gids_sorted));
+                if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted));
+                else BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, tile_bits, tile_ids_sorted, isect_gids_sorted));
             }
         }
     }
     {
-        ProfScope ps(ctx, "GetTileOffsets");
-        BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets, /*pre_zeroed=*/true));   // K1 cleared the table (or a fill did, for n == 0)
+        ProfScope ps(ctx, "GetTileOffsets");   // K1 cleared the table (or a fill did, for n == 0)
+        if (sliced) BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, budget, slice_info + 1, nullptr, nullptr, num_tiles, tile_offsets));
+        else BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets, /*pre_zeroed=*/true));
     }
-    {
+    if (!sliced) {
         ProfScope ps(ctx, "Rasterize");   // `visible` was cleared by K1 as well
-        // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
-        const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
-        const float class_width = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
-        ctx->lpt = (bwd_info && !ctx->knob_no_lpt) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
-        BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc,
-                                bwd_info ? (float*)out_img : nullptr, bwd_info ? nullptr : (uint32_t*)out_img, visible, ctx->lpt,
-                                class_width < 8.0f ? 8.0f : class_width));
+        BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
+                                class_width, /*phase=*/0, &rs));
+    } else {
+        auto* state = (float*)ensure(ctx, SLOT_SLICE_STATE, pixels * 16);
+        auto* far_counts = (uint32_t*)ensure(ctx, SLOT_SLICE_COUNTS, nvpad * 4);
+        auto* far_cum = (uint32_t*)ensure(ctx, SLOT_SLICE_CUM, nvpad * 4);
+        if (!state || !far_counts || !far_cum) return BH_ERR_OOM;
+        rs.done_bits = done_bits;
+        rs.unsat_count = slice_info + 2;
+        rs.state = state;
+        rs.offsets_near = tile_offsets;
+        const uint32_t* gate = slice_info + 2;
+        {
+            ProfScope ps(ctx, "Rasterize");
+            BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
+                                    class_width, /*phase=*/1, &rs));
+        }
+        // the far slice: at most ni - (near pairs) more, listed only into unsaturated tiles; all of it gated on the device
+        const uint32_t far_max = ni;
+        {
+            ProfScope ps(ctx, "MapGaussiansToIntersect");
+            BH_TRY(launch_map_gaussians_far(ctx, nv, u, proj_by_gid, gfc, projected, cum, budget, done_bits, gate, far_counts, far_cum, tile_ids, isect_gids));
+        }
+        {
+            ProfScope ps(ctx, "TileSort");   // lands behind the near list: absolute offsets, one array for the backward
+            BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, far_max, far_cum + (nv - 1), gate, slice_info + 1, tile_bits, tile_ids_sorted, isect_gids_sorted));
+        }
+        {
+            ProfScope ps(ctx, "GetTileOffsets");
+            BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, far_max, far_cum + (nv - 1), gate, slice_info + 1, num_tiles, tile_offsets_far));
+        }
+        {
+            ProfScope ps(ctx, "Rasterize");
+            BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets_far, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
+                                    class_width, /*phase=*/2, &rs));
+        }
     }
 
     BhRenderOut r{};
@@ -580,6 +679,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     r.cum_tiles_hit = cum;
     r.intersect_counts = isect_counts;
     r.depths_sorted = (float*)depths_sorted;
+    r.tile_offsets_far = sliced ? tile_offsets_far : nullptr;
+    r.list_budget = budget;
     *out = r;
     ctx->last = r;
     ctx->cam = *cam;
@@ -589,8 +690,19 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     ctx->flags = flags;
     ctx->bg[0] = background[0]; ctx->bg[1] = background[1]; ctx->bg[2] = background[2];
     ctx->have_forward = true;
+    ctx->had_forward = true;
+    ctx->prev_intersections = ni;
     return 0;
 }
+
+int bh_set_list_slicing(bh_ctx* ctx, float near_share) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (near_share != near_share || near_share > 1.0f) return set_error(ctx, BH_ERR_INVALID_ARG, "set_list_slicing: the near slice's share must be <= 1 (<= 0: automatic)");
+    ctx->slice_fraction = near_share > 0.0f ? near_share : 0.0f;
+    return 0;
+}
+
+float bh_last_list_share(bh_ctx* ctx) { return ctx ? ctx->last_slice_share : 0.0f; }
 
 // ---- backward ------------------------------------------------------------------
 int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
@@ -642,7 +754,8 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "RasterizeBackwards", /*dominant=*/true);
         if (r.num_intersections > 0)
             BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
-                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, ctx->lpt));
+                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, ctx->lpt,
+                                             r.tile_offsets_far));
     }
     {
         ProfScope ps(ctx, "ProjectBackwards");
@@ -822,7 +935,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
 
     // ---- forward (train.rs:211-215); `visible` lands directly in the exchange buffer
     BhRenderOut ro;
-    const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0);
+    const uint32_t flags = BH_FLAG_BWD_INFO | (cfg->render_mip ? BH_FLAG_MIP : 0) | (cfg->exact_lists ? 0 : BH_FLAG_SLICED_LISTS);
     ctx->ext_visible = s_visible;
     ctx->ext_visible_floats = o_tr;  // the forward clears the section incl. its padding
     ctx->ext_max_radius = s_radius;

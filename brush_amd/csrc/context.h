@@ -56,6 +56,10 @@ enum Slot : int {
     SLOT_EXCH_IDX,
     SLOT_EXCH_COMPACT,
     SLOT_PROJECTED_BY_GID,   // [N,9] projected records at their splat id (visible splats only)
+    SLOT_SLICE,              // depth-sliced forward: 4 control words | done bits [ceil(T/32)] | far tile offsets [T,2]
+    SLOT_SLICE_STATE,        // [H,W,4] raw blend state of the tiles the near slice left unsaturated
+    SLOT_SLICE_COUNTS,       // [Nv] live-tile hits per far splat / their inclusive scan
+    SLOT_SLICE_CUM,
     SLOT_COUNT
 };
 
@@ -68,14 +72,22 @@ constexpr int MAX_PROF = 32;
 
 // K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
 constexpr uint32_t COUNTER_SLOTS = 128;
-// one counter set on the device: [COUNTER_SLOTS][2] u64 (visible, intersections) | [COUNTER_SLOTS][2] u32 (max depth key, max ~key
-// over the visible splats: the key range the depth sort splits on).  Only the first part is read back.
-constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8;
+// one counter set on the device:
+//   [COUNTER_SLOTS][2] u64  visible, intersections (K1's block totals)
+//   [COUNTER_SLOTS][2] u32  slicing feedback, written by the blend kernel of the forward BEFORE the one that accumulates into this
+//                           set (rasterize.hip SliceArgs::feedback): max exact-list slots a saturated tile needed | pairs listed
+//                           for tiles that never saturated
+//   [COUNTER_SLOTS][2] u32  max depth key, max ~key over the visible splats: the key range the depth sort splits on.
+// The first two parts are read back together (one copy), the third stays on the device.
+constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8 + COUNTER_SLOTS * 8;
 constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
-// pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots | the loss word.
-// The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
-constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_SLOTS * 4;
-constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_SLOTS * 16 + 64;
+constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 4;       // u32 index of the feedback part inside a set
+constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_SLOTS * 6;   // ... of the key-range part
+constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8;
+// pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
+// loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
+constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
+constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_READ_BYTES + 64;
 
 struct Profiler {
     int level = 0;  // 0 off, 1 every stage, 2 only the dominant kernel (2 events per step)
@@ -124,6 +136,12 @@ struct bh_ctx {
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
     int comm_rank = 0, comm_world = 1;
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
+    // depth-sliced lists (BH_FLAG_SLICED_LISTS): share of the pair list the near slice takes.  <= 0: chosen per frame from the
+    // previous frame's feedback (bh_set_list_slicing)
+    float slice_fraction = 0.0f;
+    bool had_forward = false;         // a forward ran on this ctx before (its feedback words are meaningful)
+    uint32_t prev_intersections = 0;  // ... and listed this many pairs
+    float last_slice_share = 1.0f;    // what the last sliced forward used (1 = one slice = the exact lists); diagnostics
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
@@ -188,14 +206,21 @@ struct ForwardPrep {
     uint32_t tile_words = 0;
     float4* span = nullptr;                       // train step: the gradient span of the exchange buffer (grid-stride float4 clear)
     uint32_t span_f4 = 0;
+    uint32_t* slice_table = nullptr;              // depth-sliced forward: control words + done bits + far tile offsets
+    uint32_t slice_words = 0;
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
                            float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
+// budget: only splats whose slot range ends at or below it are emitted (the near slice of a depth-sliced forward; 0xFFFFFFFF =
+// all); slice_info (device, 2 words) then receives the slice's splat count and pair count.
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
-                         float4* zero_span = nullptr, uint32_t zero_f4 = 0);
+                         float4* zero_span = nullptr, uint32_t zero_f4 = 0, uint32_t budget = 0xFFFFFFFFu, uint32_t* slice_info = nullptr);
+int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
+                             float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
+                             uint32_t* counts, uint32_t* far_cum, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
@@ -203,24 +228,43 @@ int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, boo
 // sort.hip
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);
+// the same with the number of pairs in device memory (host: only the bound n_max): n = min(*n_dev, n_max), 0 if *gate == 0
+// (gate may be NULL); the result is written *out_base elements into out_keys / out_vals (out_base may be NULL).  bits > 8.
+int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
+                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals);
 // depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
 // order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
                     uint32_t* out_vals, uint32_t* cum);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
-int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive);
+// gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
+int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);
 // rasterize.hip
 int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t num_isect, uint32_t num_tiles,
                         uint32_t* tile_offsets, bool pre_zeroed = false);
+// the list's length in device memory (min(*n_dev, n_max), 0 if *gate == 0); it starts *base entries into tile_ids_sorted and the
+// offsets written are absolute (gate / base may be NULL).  The table must already be zero.
+int launch_tile_offsets_dev(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
+                            const uint32_t* base, uint32_t num_tiles, uint32_t* tile_offsets);
+// scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
+struct RasterSlice {
+    uint32_t* done_bits = nullptr;
+    uint32_t* unsat_count = nullptr;
+    float* state = nullptr;
+    const uint32_t* offsets_near = nullptr;
+    const uint32_t* cum = nullptr;
+    uint32_t* feedback = nullptr;
+};
 // lpt: the longest-first tile order scratch (8*16 counters directly behind tile_offsets, then the class lists); NULL = index order
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,
                      const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
-                     uint32_t* lpt, float class_width);
+                     uint32_t* lpt, float class_width, int phase = 0, const RasterSlice* slice = nullptr);
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
-                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt);
+                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
+                              const uint32_t* tile_offsets_far = nullptr);
 // loss.hip
 int launch_image_loss_forward(bh_ctx* ctx, const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h,
                               uint32_t w, const BhLossConfig& cfg, float* loss_map);

@@ -74,9 +74,21 @@ BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 // Visits every (splat, tile) candidate of the wave; calls on_hit(rank, tile_x, tile_y) for the
 // contributing ones.  `nb` = box area of this lane's splat (0 = none).  Returns this lane's rank
 // (valid when nb > 0): per-splat results are read back from w.count[rank].
-template <class OnHit>
+// keep(tx, ty) is evaluated BEFORE the contribution test: the depth-sliced forward's second slice walks only the tiles that are
+// still unsaturated (a bit test against a 1 KB table instead of the ellipse-rectangle test); K1 / the exact path keep everything.
+struct KeepAllTiles { BH_DEV bool operator()(uint32_t, uint32_t) const { return true; } };
+struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are final
+    const uint32_t* done_bits;
+    uint32_t tile_bw;
+    BH_DEV bool operator()(uint32_t tx, uint32_t ty) const {
+        const uint32_t t = tx + ty * tile_bw;
+        return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u;
+    }
+};
+
+template <class OnHit, class Keep = KeepAllTiles>
 BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
-                               OnHit on_hit) {
+                               OnHit on_hit, Keep keep = Keep{}) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
     const bool nz = nb > 0u;
@@ -123,7 +135,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
             const uint32_t ty = (box >> 16) + row;
-            if (will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
+            if (keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
         }
         before += (uint32_t)__popcll(marks);
     }
@@ -136,9 +148,10 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
 // candidates in (splat, tile) order — so the n-th hit of the wave simply goes to slot wave_base + n.  A ballot prefix
 // replaces the per-splat LDS cursor (an atomic with return per hit) and compacts the stores: lanes with a hit write
 // consecutive addresses.  Relies on K1 having counted with the same inlined test (it has: will_primitive_contribute).
+template <class Keep = KeepAllTiles>
 BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
                                     uint32_t wave_base, uint32_t wave_total, uint32_t tile_bw, uint32_t cg0, uint32_t* __restrict__ tile_ids,
-                                    uint32_t* __restrict__ isect_gids) {
+                                    uint32_t* __restrict__ isect_gids, Keep keep = Keep{}) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
     const bool nz = nb > 0u;
@@ -180,7 +193,7 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
             const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
             const uint32_t ty = (box >> 16) + row;
-            hit = will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
+            hit = keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
             tile = tx + ty * tile_bw;
             owner = cg0 + w.lane_of[r];
         }
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // housekeeping for the kernels behind this one (coalesced stores; nobody reads these buffers before K1 retires)
     if (gid < prep.visible_words) prep.visible[gid] = 0u;
     if (gid < prep.tile_words) prep.tile_table[gid] = 0u;
+    if (gid < prep.slice_words) prep.slice_table[gid] = 0u;
     if (gid < COUNTER_SET_U64 && prep.next_counters) prep.next_counters[gid] = 0ull;
     for (size_t i = gid; i < prep.span_f4; i += (size_t)gridDim.x * PROJ_WG) prep.span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         if (v) atomicAdd(&slot[0], (unsigned long long)v);
         if (h) atomicAdd(&slot[1], (unsigned long long)h);
         if (v) {
-            uint32_t* mm = reinterpret_cast<uint32_t*>(counters + 2u * COUNTER_SLOTS) + 2u * sl;
+            uint32_t* mm = reinterpret_cast<uint32_t*>(counters) + COUNTER_MINMAX_WORD + 2u * sl;
             atomicMax(&mm[0], km);
             atomicMax(&mm[1], nm);
         }
@@ -372,6 +386,10 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
     if (prep.tile_table && prep.tile_words > covered) {
         BH_HIP(ctx, hipMemsetAsync(prep.tile_table, 0, (size_t)prep.tile_words * 4, ctx->stream));
         prep.tile_words = 0;
+    }
+    if (prep.slice_table && prep.slice_words > covered) {
+        BH_HIP(ctx, hipMemsetAsync(prep.slice_table, 0, (size_t)prep.slice_words * 4, ctx->stream));
+        prep.slice_words = 0;
     }
     if (n == 0) {
         if (prep.next_counters) BH_HIP(ctx, hipMemsetAsync(prep.next_counters, 0, COUNTER_SET_BYTES, ctx->stream));
@@ -417,12 +435,21 @@ int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_g
 // gather through the depth permutation), uses it for the walk and stores it at row cg of `projected` — the compact,
 // depth-ordered table the blend kernels and the backward read (coalesced 36-byte rows).  A separate gather launch
 // (project_visible_kernel, still used when a frame has no intersections at all) cost 27 us.
+// Depth-sliced lists (BH_FLAG_SLICED_LISTS, api.hip): the splats are in depth order and `cum_tiles_hit` is monotone, so
+// "cum_tiles_hit[cg] <= budget" cuts the depth order into a NEAR slice — whose pairs are exactly the first I0 <= budget slots of
+// the exact list — and a FAR rest.  FAR = false emits the near slice (budget = 0xFFFFFFFF: everything, the exact path) and
+// reports where it ended (slice_info[0] = n0 splats, [1] = I0 pairs); FAR = true emits the rest, only into tiles whose pixels
+// are not final yet (done_bits), at slots given by the scan of slice_count_kernel's counts.
+template <bool FAR>
 __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected_by_gid,
     const uint32_t* __restrict__ global_from_compact_gid, float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
-    uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4) {
+    uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4, uint32_t budget,
+    uint32_t* __restrict__ slice_info, const uint32_t* __restrict__ far_cum, const uint32_t* __restrict__ done_bits,
+    const uint32_t* __restrict__ gate) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
+    if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
     for (size_t i = cg; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -431,45 +458,120 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
     uint32_t base = 0, end = 0, nb = 0;
+    bool mine = false;   // this lane's splat belongs to the slice being emitted (and, FAR, still reaches a live tile)
     if (cg < nv) {
+        const uint32_t cum_end = cum_tiles_hit[cg];
+        if (FAR) {
+            base = cg == 0 ? 0u : far_cum[cg - 1];
+            end = far_cum[cg];
+            mine = cum_end > budget && end > base;
+        } else {
+            base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+            end = cum_end;
+            mine = cum_end <= budget;
+            if (slice_info) {   // where the near slice ends (the next splat's range does not fit, or there is none)
+                const uint32_t next_end = cg + 1u < nv ? cum_tiles_hit[cg + 1u] : 0xFFFFFFFFu;
+                if (mine && (cg + 1u == nv || next_end > budget)) { slice_info[0] = cg + 1u; slice_info[1] = cum_end; }
+                if (!mine && cg == 0u) { slice_info[0] = 0u; slice_info[1] = 0u; }
+            }
+        }
+        if (mine) {
+            const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
+            float p[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p[k] = src[k];
+            float* dst = projected + (size_t)cg * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = p[k];
+            xy_x = p[0]; xy_y = p[1];
+            conic = Sym2{p[2], p[3], p[4]};
+            pt = bh_logf(p[5] * 255.0f);
+            float ex, ey;
+            compute_bbox_extent(conic, pt, ex, ey);
+            bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_y0, tile_y1);
+            nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
+        }
+    }
+    const unsigned long long mine_mask = __ballot(mine);
+    if (mine_mask == 0ull) return;   // (wave-uniform; the kernel has no block barrier)
+    WalkLds& w = s_walk[wave];
+    const uint32_t cg0 = cg - (uint32_t)lane;
+    // The wave's splats own ONE contiguous slot range: from the range start of its first emitting splat to the range end of
+    // its last one (lanes in between that emit nothing have empty ranges: base == end, or — near slice — do not exist, the
+    // slice being a prefix of the depth order).
+    const int first_lane = __builtin_ctzll(mine_mask), last_lane = 63 - __builtin_clzll(mine_mask);
+    const uint32_t wave_base = __shfl(base, first_lane);
+    const uint32_t wave_total = __shfl(end, last_lane) - wave_base;
+    // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
+    // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
+    if (FAR) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
+    else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
+    (void)tile_bh;
+}
+
+// Second slice, pass 1: how many LIVE tiles (done bit clear) does each far splat reach?  counts[cg] = 0 for the near slice.
+// Same walk, same test as K1 / K5 (only the tile filter in front of it), so the emit pass cannot disagree with the count.
+__global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint32_t tile_bw, uint32_t tile_y0, uint32_t tile_y1,
+                                                             const float* __restrict__ projected_by_gid,
+                                                             const uint32_t* __restrict__ global_from_compact_gid,
+                                                             const uint32_t* __restrict__ cum_tiles_hit, uint32_t budget,
+                                                             const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
+                                                             uint32_t* __restrict__ counts) {
+    __shared__ WalkLds s_walk[PROJ_WAVES];
+    if (*gate == 0u) return;
+    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
+    Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
+    TileBbox bb = TileBbox{0, 0, 0, 0};
+    uint32_t nb = 0;
+    if (cg < nv && cum_tiles_hit[cg] > budget) {
         const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
-        float p[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) p[k] = src[k];
-        float* dst = projected + (size_t)cg * 9;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dst[k] = p[k];
-        xy_x = p[0]; xy_y = p[1];
-        conic = Sym2{p[2], p[3], p[4]};
-        pt = bh_logf(p[5] * 255.0f);
+        xy_x = src[0]; xy_y = src[1];
+        conic = Sym2{src[2], src[3], src[4]};
+        pt = bh_logf(src[5] * 255.0f);
         float ex, ey;
         compute_bbox_extent(conic, pt, ex, ey);
         bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_y0, tile_y1);
-        base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
-        end = cum_tiles_hit[cg];
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
     }
     WalkLds& w = s_walk[wave];
-    // first output slot of the wave = the slot range start of its first splat (lanes past nv hold nb = 0 and emit nothing)
-    const uint32_t cg0 = cg - (uint32_t)lane;
-    const uint32_t wave_base = __shfl(base, 0);
-    // ... and its budget ends where the wave's last splat's range ends (K1's counts, through the scan)
-    const uint32_t last_lane = cg0 < nv ? (nv - 1u - cg0 < 63u ? nv - 1u - cg0 : 63u) : 0u;
-    const uint32_t wave_total = __shfl(end, (int)last_lane) - wave_base;
-    // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
-    // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
-    (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
-    (void)tile_bh;
+    uint32_t hits = 0;
+    if (__ballot(nb > 0u) != 0ull) {
+        const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); },
+                                              KeepLiveTiles{done_bits, tile_bw});
+        hits = nb ? w.count[wrank] : 0u;
+    }
+    if (cg < nv) counts[cg] = hits;
 }
 
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
-                         float4* zero_span, uint32_t zero_f4) {
+                         float4* zero_span, uint32_t zero_f4, uint32_t budget, uint32_t* slice_info) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    hipLaunchKernelGGL(map_gaussians_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                       projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4);
+    hipLaunchKernelGGL(map_gaussians_kernel<false>, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                       projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
+    return 0;
+}
+
+// The far slice of a depth-sliced forward: count -> scan -> emit, all three no-ops when *gate (the number of tiles the near
+// slice left unsaturated) is zero.  counts / far_cum: [nv] scratch.
+int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
+                             float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
+                             uint32_t* counts, uint32_t* far_cum, uint32_t* tile_ids, uint32_t* isect_gids) {
+    if (nv == 0) return 0;
+    const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    hipLaunchKernelGGL(slice_count_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_y0, u.tile_y1, projected_by_gid, gid, cum_tiles_hit,
+                       budget, done_bits, gate, counts);
+    BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
+    BH_TRY(prefix_sum(ctx, counts, nullptr, nv, far_cum, false, gate));
+    hipLaunchKernelGGL(map_gaussians_kernel<true>, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                       projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, (uint32_t*)nullptr, (const uint32_t*)far_cum,
+                       done_bits, gate);
+    BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");
     return 0;
 }
 

@@ -31,12 +31,23 @@ namespace bh {
 // K15: get_tile_offsets (get_tile_offset.rs:11-58)
 // ---------------------------------------------------------------------------
 // Four consecutive intersections per thread (one 16-byte load + the element in front of them).
+// dyn (depth-sliced forward): the list's length lives in device memory (n_dev, 0 when *gate == 0) and the list starts *base
+// entries into tile_ids; the offsets written are absolute.  All NULL: the plain kernel.
+struct OffsetsDyn {
+    const uint32_t* n_dev = nullptr;
+    const uint32_t* gate = nullptr;
+    const uint32_t* base = nullptr;
+};
 __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ tile_ids, uint32_t num_isect,
-                                                          uint32_t num_tiles, uint32_t* __restrict__ tile_offsets) {
+                                                          uint32_t num_tiles, uint32_t* __restrict__ tile_offsets, OffsetsDyn dyn) {
+    uint32_t ofs = 0;
+    if (dyn.gate && *dyn.gate == 0u) return;
+    if (dyn.n_dev) { const uint32_t v = *dyn.n_dev; num_isect = v < num_isect ? v : num_isect; }
+    if (dyn.base) { ofs = *dyn.base; tile_ids += ofs; }
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4u;
     if (i0 >= num_isect) return;
     uint32_t t[4];
-    if (i0 + 4u <= num_isect) {
+    if (i0 + 4u <= num_isect && (ofs & 3u) == 0u) {
         const uint4 v = *reinterpret_cast<const uint4*>(&tile_ids[i0]);
         t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     } else {
@@ -50,17 +61,17 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
         if (i < num_isect) {
             const uint32_t tid = t[k];
             if (tid < num_tiles) {  // (sentinel rows are skipped)
-                if (i == num_isect - 1u) tile_offsets[tid * 2 + 1] = i + 1u;
+                if (i == num_isect - 1u) tile_offsets[tid * 2 + 1] = ofs + i + 1u;
                 if (i == 0u) {
-                    tile_offsets[tid * 2] = 0u;
+                    tile_offsets[tid * 2] = ofs;
                 } else if (tid != prev) {
-                    if (prev < num_tiles) tile_offsets[prev * 2 + 1] = i;
-                    tile_offsets[tid * 2] = i;
+                    if (prev < num_tiles) tile_offsets[prev * 2 + 1] = ofs + i;
+                    tile_offsets[tid * 2] = ofs + i;
                 }
             } else if (i > 0u && prev < num_tiles) {
                 // valid -> sentinel transition: close the last valid tile (the reference leaves its end at 0 here,
                 // get_tile_offset.rs:28-57 / SURVEY App. B.2)
-                tile_offsets[prev * 2 + 1] = i;
+                tile_offsets[prev * 2 + 1] = ofs + i;
             }
             prev = tid;
         }
@@ -73,7 +84,20 @@ int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n
     // (pre_zeroed: the forward's K1 already did, project.hip ForwardPrep)
     if (!pre_zeroed) BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
     if (num_isect == 0) return 0;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 1023) / 1024), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 1023) / 1024), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets, OffsetsDyn{});
+    BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");
+    return 0;
+}
+
+// the table must be zero already; n_max bounds *n_dev
+int launch_tile_offsets_dev(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
+                            const uint32_t* base, uint32_t num_tiles, uint32_t* tile_offsets) {
+    if (n_max == 0) return 0;
+    OffsetsDyn dyn;
+    dyn.n_dev = n_dev;
+    dyn.gate = gate;
+    dyn.base = base;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((n_max + 1023) / 1024), dim3(256), 0, ctx->stream, tile_ids_sorted, n_max, num_tiles, tile_offsets, dyn);
     BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");
     return 0;
 }
@@ -178,16 +202,35 @@ BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float
 #else
 #define BH_FWD_ATTR
 #endif
-template <bool BWD_INFO, bool SMOOTH>
+// Depth-sliced lists (BH_FLAG_SLICED_LISTS; api.hip has the whole story).  The per-tile lists are built for a NEAR slice of the
+// depth order first; PHASE 1 blends it and a tile whose 256 pixels all saturated is final (bit set in done_bits) — at the
+// bench workload that is every tile after a fifth of the pairs.  A tile with live pixels left parks its raw (rgb, T) state and
+// is counted in *unsat_count; the FAR slice is then listed for those tiles only and PHASE 2 resumes them.  The per-pixel
+// arithmetic is the same sequential fold over the same splats in the same order, so the image is bit-identical to PHASE 0 (the
+// exact path: one list per tile).  Every phase also leaves a two-word hint for the next frame's slicing in `feedback`.
+struct SliceArgs {
+    uint32_t* done_bits = nullptr;          // [ceil(T/32)] bit per tile: its pixels are final
+    uint32_t* unsat_count = nullptr;        // tiles PHASE 1 left unsaturated (the gate of everything the far slice launches)
+    float* state = nullptr;                 // [H,W,4] raw rgb + signed T of those tiles
+    const uint32_t* offsets_near = nullptr; // PHASE 2: the near slice's [T,2] table (shrunk ends: the tile's backward work so far)
+    const uint32_t* cum = nullptr;          // cum_tiles_hit [Nv]: the exact list's slot ranges (feedback)
+    uint32_t* feedback = nullptr;           // [COUNTER_SLOTS][2]: max slots a saturated tile needed | listed pairs of unsaturated tiles
+};
+
+template <bool BWD_INFO, bool SMOOTH, int PHASE>
 __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
                                                       const uint32_t* __restrict__ global_from_compact,
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
-                                                      float* __restrict__ visible, uint32_t* __restrict__ lpt) {
+                                                      float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
     const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
     if (local_tile >= u.num_tiles) return;
     const uint32_t tile = u.tile_begin + local_tile;
+    if (PHASE == 2) {
+        if (*sl.unsat_count == 0u) return;                                     // the near slice finished the frame
+        if ((sl.done_bits[tile >> 5] >> (tile & 31u)) & 1u) return;            // ... or this tile
+    }
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
@@ -197,13 +240,19 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     float tr[4], pr[4], pg[4], pb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const bool inside = (px0 + 8 * (q & 1)) < u.img_w && (py0 + 8 * (q >> 1)) < u.img_h;
+        const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
+        const bool inside = px < u.img_w && py < u.img_h;
         tr[q] = inside ? 1.0f : -1.0f;
         pr[q] = pg[q] = pb[q] = 0.0f;
+        if (PHASE == 2 && inside) {   // resume where PHASE 1 stopped
+            const float4 st = *reinterpret_cast<const float4*>(&sl.state[((size_t)px + (size_t)py * u.img_w) * 4]);
+            pr[q] = st.x; pg[q] = st.y; pb[q] = st.z; tr[q] = st.w;
+        }
     }
     const uint32_t range_lo = tile_offsets[tile * 2];
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
     uint32_t last_useful = range_lo;
+    uint32_t reached = range_lo;        // one past the last splat the loop looked at (forward-only passes keep no last_useful)
     uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
     asm volatile("" : "+v"(sign_mask));
 
@@ -217,6 +266,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         const uint32_t cg = stage_batch<SMOOTH, true>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
+        reached = batch_start + cnt;
         for (uint32_t t = 0; t < cnt; ++t) {
             const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
@@ -267,13 +317,30 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             // to fail the quadrant tests) cannot contribute.  Checked every 8th splat; the batch loop's own test ends the tile.
             if ((t & 7u) == 7u) {
                 const bool still = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
-                if (__ballot(still) == 0ull) break;
+                if (__ballot(still) == 0ull) { reached = batch_start + t + 1; break; }
             }
         }
         if (BWD_INFO) {
             // rasterize.rs:143-145: mark splats that touched at least one pixel
             if ((contrib_mask >> lane) & 1ull) visible[global_from_compact[cg]] = 1.0f;
         }
+    }
+    const bool live_end = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+    const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
+
+    if (PHASE == 1 && !saturated) {
+        // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
+            if (px < u.img_w && py < u.img_h)
+                *reinterpret_cast<float4*>(&sl.state[((size_t)px + (size_t)py * u.img_w) * 4]) = make_float4(pr[q], pg[q], pb[q], tr[q]);
+        }
+        if (lane == 0) {
+            if (BWD_INFO) tile_offsets[tile * 2 + 1] = last_useful;
+            atomicAdd(sl.unsat_count, 1u);
+        }
+        return;
     }
 
 #pragma unroll
@@ -297,23 +364,57 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
         }
     }
-    // rasterize.rs:183-189: shrink the tile's end to one past the last useful splat
-    if (BWD_INFO && lane == 0) {
-        tile_offsets[tile * 2 + 1] = last_useful;
-        if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
-            const uint32_t work = last_useful - range_lo;
-            const uint32_t cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
-            const uint32_t list = (blockIdx.x & 7u) * LPT_CLASSES + cls;
-            const uint32_t pos = atomicAdd(&lpt[list], 1u);
-            lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
+    if (lane == 0) {
+        if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
+        uint32_t work = last_useful - range_lo;
+        uint32_t listed = range_hi - range_lo;
+        if (PHASE == 2) {   // the tile's backward work / list = what both slices contributed
+            const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
+            work += n_hi - n_lo;
+            listed += n_hi - n_lo;
+        }
+        // rasterize.rs:183-189: shrink the tile's end to one past the last useful splat
+        if (BWD_INFO) {
+            tile_offsets[tile * 2 + 1] = last_useful;
+            if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
+                const uint32_t cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
+                const uint32_t list = (blockIdx.x & 7u) * LPT_CLASSES + cls;
+                const uint32_t pos = atomicAdd(&lpt[list], 1u);
+                lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
+            }
+        }
+        // hint for the next frame's slicing (read back with its counters): how many slots of the exact list a tile needed before
+        // it saturated (max over tiles), and how many pairs are listed for tiles that never saturate
+        if (sl.feedback) {
+            uint32_t* fb = sl.feedback + 2u * (blockIdx.x & (COUNTER_SLOTS - 1u));
+            const uint32_t stop = BWD_INFO ? last_useful : reached;
+            if (saturated) {
+                if (stop > range_lo) atomicMax(&fb[0], sl.cum[isect_gids[stop - 1u]]);
+                else if (PHASE == 2) {   // (saturated by the near slice's last splats, nothing blended here)
+                    const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
+                    if (n_hi > n_lo) atomicMax(&fb[0], sl.cum[isect_gids[n_hi - 1u]]);
+                }
+            } else if (listed) {
+                atomicAdd(&fb[1], listed);
+            }
         }
     }
+}
+
+template <bool BWD_INFO, bool SMOOTH>
+static void launch_rasterize_phase(int phase, dim3 grid, hipStream_t stream, const RasterUniforms& u, const uint32_t* isect_gids, uint32_t* tile_offsets,
+                                   const float* projected, const uint32_t* gfc, float* out_img, uint32_t* out_packed, float* visible, uint32_t* lpt,
+                                   const SliceArgs& sl) {
+    const dim3 block(64);
+    if (phase == 1) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 1>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
+    else if (phase == 2) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 2>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
+    else hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 0>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
 }
 
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,
                      const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
-                     uint32_t* lpt, float class_width) {
+                     uint32_t* lpt, float class_width, int phase, const RasterSlice* slice) {
     RasterUniforms u;
     u.rcp_class_width = 1.0f / (class_width > 1.0f ? class_width : 1.0f);
     u.tile_bw = vu.tile_bw;
@@ -322,14 +423,23 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     u.img_w = vu.img_w;
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
+    SliceArgs sl;
+    if (slice) {
+        sl.done_bits = slice->done_bits;
+        sl.unsat_count = slice->unsat_count;
+        sl.state = slice->state;
+        sl.offsets_near = slice->offsets_near;
+        sl.cum = slice->cum;
+        sl.feedback = slice->feedback;
+    }
+    if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
+        return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
+    if (sl.feedback && !sl.cum) sl.feedback = nullptr;
     const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
-    const dim3 grid(nblocks), block(64);
-    if (bwd_info && smooth)
-        hipLaunchKernelGGL((rasterize_kernel<true, true>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
-    else if (bwd_info)
-        hipLaunchKernelGGL((rasterize_kernel<true, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
-    else
-        hipLaunchKernelGGL((rasterize_kernel<false, false>), grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt);
+    const dim3 grid(nblocks);
+    if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
+    else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
+    else launch_rasterize_phase<false, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     BH_LAUNCH_CHECK(ctx, "rasterize_kernel");
     return 0;
 }
@@ -403,7 +513,8 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
                                                                const float* __restrict__ v_output,
-                                                               float* __restrict__ v_combined, const uint32_t* __restrict__ lpt) {
+                                                               float* __restrict__ v_combined, const uint32_t* __restrict__ lpt,
+                                                               const uint32_t* __restrict__ tile_offsets_far) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
     uint32_t local_tile;
     if (lpt) {
@@ -428,9 +539,12 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
         if (local_tile >= u.num_tiles) return;
     }
     const uint32_t tile = u.tile_begin + local_tile;
-    const uint32_t range_lo = tile_offsets[tile * 2];
-    const uint32_t range_hi = tile_offsets[tile * 2 + 1];
-    if (range_hi <= range_lo) return;
+    // the tile's blended splats, front to back: one list (the exact path), or the near slice's followed by the far slice's
+    // (depth-sliced forward; the far table is all zero for a tile the near slice finished)
+    const uint32_t seg_lo0 = tile_offsets[tile * 2], seg_hi0 = tile_offsets[tile * 2 + 1];
+    uint32_t seg_lo1 = 0, seg_hi1 = 0;
+    if (tile_offsets_far) { seg_lo1 = tile_offsets_far[tile * 2]; seg_hi1 = tile_offsets_far[tile * 2 + 1]; }
+    if (seg_hi0 <= seg_lo0 && seg_hi1 <= seg_lo1) return;
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
@@ -575,20 +689,25 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
         }
     };
 
-    for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
-        const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
-        __syncthreads();
-        stage_batch<SMOOTH, false>(isect_gids, projected, batch_start, cnt, lane, s_splat);
-        __syncthreads();
-        const bool mine_clamps = (uint32_t)lane < cnt && s_splat[lane * SPLAT_STRIDE + 5] > 0.999f;
-        if (__ballot(mine_clamps) != 0ull) run_batch(std::true_type{}, cnt);
-        else run_batch(std::false_type{}, cnt);
+#pragma nounroll
+    for (int seg = 0; seg < 2; ++seg) {   // ONE copy of the batch loop for both segments (its body is ~1.6 k instructions)
+        const uint32_t range_lo = seg ? seg_lo1 : seg_lo0, range_hi = seg ? seg_hi1 : seg_hi0;
+        for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
+            const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
+            __syncthreads();
+            stage_batch<SMOOTH, false>(isect_gids, projected, batch_start, cnt, lane, s_splat);
+            __syncthreads();
+            const bool mine_clamps = (uint32_t)lane < cnt && s_splat[lane * SPLAT_STRIDE + 5] > 0.999f;
+            if (__ballot(mine_clamps) != 0ull) run_batch(std::true_type{}, cnt);
+            else run_batch(std::false_type{}, cnt);
+        }
     }
 }
 
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
-                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt) {
+                              const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
+                              const uint32_t* tile_offsets_far) {
     RasterUniforms u;
     u.rcp_class_width = 1.0f;
     u.tile_bw = vu.tile_bw;
@@ -603,13 +722,13 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     hipEvent_t ea = ctx->prof.ext_a, eb = ctx->prof.ext_b;
     ctx->prof.ext_a = ctx->prof.ext_b = nullptr;
     if (ea && smooth)
-        hipExtLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+        hipExtLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
     else if (ea)
-        hipExtLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+        hipExtLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
     else if (smooth)
-        hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+        hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
     else
-        hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt);
+        hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
     BH_LAUNCH_CHECK(ctx, "rasterize_backward_kernel");
     return 0;
 }

@@ -51,8 +51,9 @@ BH_DEV uint32_t load_elem(const uint32_t* __restrict__ in, const uint32_t* __res
 
 template <bool GATHER>
 __global__ __launch_bounds__(SCAN_WG) void scan_reduce_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather,
-                                                             uint32_t n, uint32_t* __restrict__ sums) {
+                                                             uint32_t n, uint32_t* __restrict__ sums, const uint32_t* __restrict__ gate) {
     __shared__ uint32_t s_wave[SCAN_WG / 64];
+    if (gate && *gate == 0u) return;   // (depth-sliced forward: nothing left to list, the result is never read)
     const uint32_t base = blockIdx.x * SCAN_TILE;
     uint32_t acc = 0;
 #pragma unroll
@@ -73,8 +74,9 @@ __global__ __launch_bounds__(SCAN_WG) void scan_reduce_kernel(const uint32_t* __
 }
 
 // single block: sums[i] <- exclusive prefix of sums
-__global__ __launch_bounds__(SCAN_WG) void scan_spine_kernel(uint32_t* __restrict__ sums, uint32_t nb) {
+__global__ __launch_bounds__(SCAN_WG) void scan_spine_kernel(uint32_t* __restrict__ sums, uint32_t nb, const uint32_t* __restrict__ gate) {
     __shared__ uint32_t s_wave[SCAN_WG / 64];
+    if (gate && *gate == 0u) return;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nb; base += SCAN_TILE) {
         uint32_t v[SCAN_EPT];
@@ -107,9 +109,10 @@ constexpr uint32_t SELF_SPINE_MAX = 4 * SCAN_WG;
 template <bool GATHER, bool EXCLUSIVE, bool SELF_SPINE>
 __global__ __launch_bounds__(SCAN_WG) void scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather,
                                                             uint32_t n, const uint32_t* __restrict__ sums,
-                                                            uint32_t* __restrict__ out) {
+                                                            uint32_t* __restrict__ out, const uint32_t* __restrict__ gate) {
     __shared__ uint32_t s_wave[SCAN_WG / 64];
     __shared__ uint32_t s_tile[SCAN_TILE + SCAN_TILE / 16];
+    if (gate && *gate == 0u) return;
     const uint32_t base = blockIdx.x * SCAN_TILE;
     uint32_t ahead = 0;   // this thread's share of the totals of the blocks in front
     if (SELF_SPINE) {
@@ -158,35 +161,35 @@ __global__ __launch_bounds__(SCAN_WG) void scan_apply_kernel(const uint32_t* __r
 }
 
 template <bool GATHER>
-static int scan_impl(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive) {
+static int scan_impl(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate) {
     const uint32_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t* sums = nullptr;
     if (nb > 1) {
         sums = (uint32_t*)ensure(ctx, SLOT_SCAN_SUMS, (size_t)nb * 4);
         if (!sums) return BH_ERR_OOM;
-        hipLaunchKernelGGL(scan_reduce_kernel<GATHER>, dim3(nb), dim3(SCAN_WG), 0, ctx->stream, in, gather, n, sums);
+        hipLaunchKernelGGL(scan_reduce_kernel<GATHER>, dim3(nb), dim3(SCAN_WG), 0, ctx->stream, in, gather, n, sums, gate);
         BH_LAUNCH_CHECK(ctx, "scan_reduce_kernel");
         if (nb > SELF_SPINE_MAX) {
-            hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_WG), 0, ctx->stream, sums, nb);
+            hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(SCAN_WG), 0, ctx->stream, sums, nb, gate);
             BH_LAUNCH_CHECK(ctx, "scan_spine_kernel");
         }
     }
     const bool self_spine = nb > 1 && nb <= SELF_SPINE_MAX;
     const dim3 grid(nb), block(SCAN_WG);
     if (self_spine) {
-        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
-        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out, gate);
+        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, true>), grid, block, 0, ctx->stream, in, gather, n, sums, out, gate);
     } else {
-        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
-        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out);
+        if (exclusive) hipLaunchKernelGGL((scan_apply_kernel<GATHER, true, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out, gate);
+        else hipLaunchKernelGGL((scan_apply_kernel<GATHER, false, false>), grid, block, 0, ctx->stream, in, gather, n, sums, out, gate);
     }
     BH_LAUNCH_CHECK(ctx, "scan_apply_kernel");
     return 0;
 }
 
-int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive) {
+int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate) {
     if (n == 0) return 0;
-    return gather ? scan_impl<true>(ctx, in, gather, n, out, exclusive) : scan_impl<false>(ctx, in, gather, n, out, exclusive);
+    return gather ? scan_impl<true>(ctx, in, gather, n, out, exclusive, gate) : scan_impl<false>(ctx, in, gather, n, out, exclusive, gate);
 }
 
 }  // namespace bh

@@ -42,12 +42,32 @@ BH_DEV unsigned long long match_digit(uint32_t d) {
     return m;
 }
 
+// Device-side length (the depth-sliced forward, api.hip): the host knows only an upper bound `n` of the number of pairs; the
+// exact count sits in device memory (`n_dev`), `gate` == 0 switches the whole sort off (every block leaves at once), and the
+// last pass writes its output `*out_base` elements into the destination.  The grid and the [digit][block] table are sized for
+// the bound; blocks past the live count return before touching anything.  All three NULL: the plain sort.
+struct SortDyn {
+    const uint32_t* n_dev = nullptr;
+    const uint32_t* gate = nullptr;
+    const uint32_t* out_base = nullptr;
+};
+BH_DEV uint32_t sort_live_n(uint32_t n, const SortDyn& dyn) {
+    if (dyn.gate && *dyn.gate == 0u) return 0u;
+    if (dyn.n_dev) {
+        const uint32_t v = *dyn.n_dev;
+        return v < n ? v : n;
+    }
+    return n;
+}
+
 // hist[digit * nblocks + block]
 // (electing one leader per digit group with 8 ballots instead of the LDS atomic was measured: tile sort 132 -> 155 us)
 template <int SORT_KPT>
 __global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                            uint32_t mask, uint32_t nblocks, uint32_t* __restrict__ hist) {
+                                                            uint32_t mask, uint32_t nblocks, uint32_t* __restrict__ hist, SortDyn dyn) {
     __shared__ uint32_t s_hist[SORT_WAVES][RADIX];
+    n = sort_live_n(n, dyn);
+    if (blockIdx.x * (uint32_t)(SORT_WG * SORT_KPT) >= n) return;   // (only with a device-side length)
     const int tid = threadIdx.x, wave = tid >> 6;
     for (int i = tid; i < SORT_WAVES * RADIX; i += SORT_WG) (&s_hist[0][0])[i] = 0;
     __syncthreads();
@@ -84,45 +104,51 @@ __global__ __launch_bounds__(SORT_WG) void radix_hist_kernel(const uint32_t* __r
 // row d and also emits the row total); the scatter kernel adds the 256-entry prefix over
 // the digit totals itself.  3 launches per pass instead of the 5 of a generic
 // reduce/spine/apply scan over the whole table.
-constexpr int ROWSCAN_MAX_EPT = 16;  // rows of up to 4096 blocks (16.7 M keys); longer tables use the generic scan
-__global__ __launch_bounds__(SORT_WG) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
-                                                               uint32_t* __restrict__ digit_totals) {
+constexpr int ROWSCAN_MAX_EPT = 16;  // rows of up to 4096 blocks (16.7 M keys) in one trip; longer rows loop with a carry
+__global__ __launch_bounds__(SORT_WG) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t n, uint32_t tile,
+                                                               uint32_t* __restrict__ digit_totals, SortDyn dyn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t d = blockIdx.x;
+    const uint32_t live_n = sort_live_n(n, dyn);
+    if (live_n == 0u) return;
+    const uint32_t live = (live_n + tile - 1u) / tile;   // blocks that wrote their column (== nblocks for the plain sort)
     uint32_t* row = hist + (size_t)d * nblocks;
-    // the row stays in registers: entry k*256 + tid (coalesced), up to ROWSCAN_MAX_EPT chunks
-    uint32_t v[ROWSCAN_MAX_EPT], incl[ROWSCAN_MAX_EPT];
     __shared__ uint32_t s_chunk[ROWSCAN_MAX_EPT][SORT_WAVES];
-#pragma unroll
-    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
-        const uint32_t i = (uint32_t)k * SORT_WG + tid;
-        v[k] = i < nblocks ? row[i] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
-        uint32_t x = v[k];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(x, off);
-            if (lane >= off) x += t;
-        }
-        incl[k] = x;
-        if (lane == 63) s_chunk[k][wave] = x;
-    }
-    __syncthreads();
     uint32_t run = 0;
+    for (uint32_t c0 = 0; c0 < live; c0 += (uint32_t)ROWSCAN_MAX_EPT * SORT_WG) {
+        // the row segment stays in registers: entry c0 + k*256 + tid (coalesced), ROWSCAN_MAX_EPT chunks
+        uint32_t v[ROWSCAN_MAX_EPT], incl[ROWSCAN_MAX_EPT];
 #pragma unroll
-    for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) {
-            const uint32_t c = s_chunk[k][w];
-            before += w < wave ? c : 0u;
-            total += c;
+        for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+            const uint32_t i = c0 + (uint32_t)k * SORT_WG + tid;
+            v[k] = i < live ? row[i] : 0u;
         }
-        const uint32_t i = (uint32_t)k * SORT_WG + tid;
-        if (i < nblocks) row[i] = run + before + incl[k] - v[k];
-        run += total;
+#pragma unroll
+        for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+            uint32_t x = v[k];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(x, off);
+                if (lane >= off) x += t;
+            }
+            incl[k] = x;
+            if (lane == 63) s_chunk[k][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ROWSCAN_MAX_EPT; ++k) {
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const uint32_t c = s_chunk[k][w];
+                before += w < wave ? c : 0u;
+                total += c;
+            }
+            const uint32_t i = c0 + (uint32_t)k * SORT_WG + tid;
+            if (i < live) row[i] = run + before + incl[k] - v[k];
+            run += total;
+        }
+        __syncthreads();   // s_chunk is rewritten by the next trip
     }
     if (tid == 0) digit_totals[d] = run;
 }
@@ -132,8 +158,15 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
                                                                uint32_t n, uint32_t shift, uint32_t mask, uint32_t nblocks,
                                                                const uint32_t* __restrict__ offsets,  // exclusive scan of hist
                                                                const uint32_t* __restrict__ digit_totals,  // row-scan mode: offsets are per-row, add the digit prefix
-                                                               uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals) {
+                                                               uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals, SortDyn dyn) {
     constexpr int SORT_TILE = SORT_WG * SORT_KPT;
+    n = sort_live_n(n, dyn);
+    if (blockIdx.x * (uint32_t)SORT_TILE >= n) return;   // (only with a device-side length)
+    if (dyn.out_base) {   // the last pass of a sort that appends to an existing list
+        const uint32_t ob = *dyn.out_base;
+        out_keys += ob;
+        out_vals += ob;
+    }
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX];   // per-wave running digit counts -> wave bases
     __shared__ uint32_t s_dbase[RADIX];             // exclusive scan of block digit totals
     __shared__ uint32_t s_gofs[RADIX];              // global offset of (digit, block) minus s_dbase
@@ -237,10 +270,11 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
     }
 }
 
-int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
-                  uint32_t* out_keys, uint32_t* out_vals) {
+static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                              uint32_t* out_keys, uint32_t* out_vals, const SortDyn& dyn) {
     if (bits > 32) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: bits must be <= 32");
     if (n == 0) return 0;
+    const bool dynamic = dyn.n_dev || dyn.gate || dyn.out_base;
     // digits of equal width: 13-bit tile ids sort as 7 + 6 bits, not 8 + 5 — the wider a pass, the shorter the digit runs
     // a block writes (4096 keys over 256 digits = 64-byte bursts; over 128 digits = 128-byte bursts)
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
@@ -257,13 +291,15 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
     uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * nblocks + RADIX) * 4);
     if (!totals) return BH_ERR_OOM;
     uint32_t* hist = totals + RADIX;
-    const bool rowscan = nblocks <= (uint32_t)ROWSCAN_MAX_EPT * SORT_WG;
+    // (a device-side length always takes the row scan: it walks only the live part of each row, however long the table)
+    const bool rowscan = dynamic || nblocks <= (uint32_t)ROWSCAN_MAX_EPT * SORT_WG;
     // Ping-pong through two scratch pairs; pass 0 reads the caller's input (never
     // written), the last pass lands in out_* unless that would alias its source
     // (single-pass in-place call), in which case it is staged and copied.
     uint32_t* sk[2] = {nullptr, nullptr};
     uint32_t* sv[2] = {nullptr, nullptr};
     const bool in_place = keys == out_keys || (vals && vals == out_vals);
+    if (dynamic && (in_place || passes == 1) && dyn.out_base) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: an appending sort needs two passes and distinct buffers");
     if (passes > 1 || in_place) {
         sk[0] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, bytes);
         sv[0] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, bytes);
@@ -284,15 +320,17 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
             dst_k = out_keys;
             dst_v = out_vals;
         }
+        SortDyn pd = dyn;
+        if (!last) pd.out_base = nullptr;
         const uint32_t width = base_w + (p < wide ? 1u : 0u);
         const uint32_t shift = p * base_w + (p < wide ? p : wide);
         const uint32_t mask = (1u << width) - 1u;
-        if (kpt == 4u) hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
-        else if (kpt == 8u) hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
-        else hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist);
+        if (kpt == 4u) hipLaunchKernelGGL(radix_hist_kernel<4>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist, pd);
+        else if (kpt == 8u) hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist, pd);
+        else hipLaunchKernelGGL(radix_hist_kernel<16>, dim3(nblocks), dim3(SORT_WG), 0, ctx->stream, src_k, n, shift, mask, nblocks, hist, pd);
         BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
         if (rowscan) {
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(SORT_WG), 0, ctx->stream, hist, nblocks, totals);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(SORT_WG), 0, ctx->stream, hist, nblocks, n, tile, totals, pd);
             BH_LAUNCH_CHECK(ctx, "radix_rowscan_kernel");
         } else {
             BH_TRY(prefix_sum(ctx, hist, nullptr, RADIX * nblocks, hist, /*exclusive=*/true));
@@ -300,14 +338,14 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
         const uint32_t* tot = rowscan ? totals : nullptr;
         const dim3 grid(nblocks), block(SORT_WG);
         if (kpt == 4u) {
-            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
-            else hipLaunchKernelGGL((radix_scatter_kernel<false, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 4>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
         } else if (kpt == 8u) {
-            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
-            else hipLaunchKernelGGL((radix_scatter_kernel<false, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 8>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
         } else {
-            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
-            else hipLaunchKernelGGL((radix_scatter_kernel<false, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v);
+            if (src_v) hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
+            else hipLaunchKernelGGL((radix_scatter_kernel<false, 16>), grid, block, 0, ctx->stream, src_k, src_v, n, shift, mask, nblocks, hist, tot, dst_k, dst_v, pd);
         }
         BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
         src_k = dst_k;
@@ -316,6 +354,20 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
     if (src_k != out_keys) BH_HIP(ctx, hipMemcpyAsync(out_keys, src_k, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (src_v != out_vals) BH_HIP(ctx, hipMemcpyAsync(out_vals, src_v, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
+}
+
+int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
+                  uint32_t* out_keys, uint32_t* out_vals) {
+    return radix_argsort_impl(ctx, keys, vals, n, bits, out_keys, out_vals, SortDyn{});
+}
+
+int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
+                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals) {
+    SortDyn dyn;
+    dyn.n_dev = n_dev;
+    dyn.gate = gate;
+    dyn.out_base = out_base;
+    return radix_argsort_impl(ctx, keys, vals, n_max, bits, out_keys, out_vals, dyn);
 }
 
 }  // namespace bh

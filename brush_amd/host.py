@@ -309,6 +309,10 @@ class RenderAux:
     cum_tiles_hit: torch.Tensor
     intersect_counts: torch.Tensor
     depths_sorted: torch.Tensor
+    # depth-sliced lists (render_splats(..., sliced=True), the train step's default): the far slice's [T,2] segment table, or
+    # None when the lists are the exact ones; list_budget = exact-list slots the near slice covered
+    tile_offsets_far: Optional[torch.Tensor] = None
+    list_budget: int = 0
 
     def validate(self, num_splats):
         # render_aux.rs:30-45
@@ -317,7 +321,13 @@ class RenderAux:
         assert self.num_intersections <= max(self.num_visible, 1) * max(tiles, 1)
 
 
-def _forward(ctx, splats, camera, img_size, background, pass_):
+def set_list_slicing(near_share: float, ctx: Optional["Context"] = None, device=None):
+    """Near slice's share of the pair list for sliced forwards on `ctx` (bh_set_list_slicing): (0, 1] fixed, <= 0 automatic."""
+    ctx = ctx or get_context(device)
+    ctx.check(ctx.lib.bh_set_list_slicing(ctx._h, float(near_share)))
+
+
+def _forward(ctx, splats, camera, img_size, background, pass_, sliced=False):
     if img_size[0] <= 0 or img_size[1] <= 0:
         raise BrushHipError("Can't render images with 0 size.")  # render.rs:50-53
     cam = camera if isinstance(camera, _ffi.BhCamera) else camera.uniforms(img_size)
@@ -326,6 +336,8 @@ def _forward(ctx, splats, camera, img_size, background, pass_):
         flags |= _ffi.FLAG_BWD_INFO
     if pass_.smooth_cutoff():
         flags |= _ffi.FLAG_SMOOTH_CUTOFF
+    if sliced:
+        flags |= _ffi.FLAG_SLICED_LISTS
     out = _ffi.BhRenderOut()
     bg = (C.c_float * 3)(*[float(b) for b in background])
     n = splats.num_splats()
@@ -354,20 +366,23 @@ def _aux_from(out, n, w, h, device, copy):
         cum_tiles_hit=mk(out.cum_tiles_hit, (nv,), i32),
         intersect_counts=mk(out.intersect_counts, (n,), i32),
         depths_sorted=mk(out.depths_sorted, (nv,), f32),
+        tile_offsets_far=mk(out.tile_offsets_far, (T, 2), i32) if out.tile_offsets_far else None,
+        list_budget=int(out.list_budget),
     )
 
 
 def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), pass_: RasterPass = RasterPass.Forward,
-                  ctx: Optional[Context] = None, copy=True, tile_rows=None):
+                  ctx: Optional[Context] = None, copy=True, tile_rows=None, sliced=False):
     """Forward render. RasterPass.Forward returns a packed rgba8 image [H,W] (int32
     bit pattern, r in bits 0-7); the Backward variants return f32 [H,W,4].
     Returns (image, RenderAux). With copy=False the tensors alias ctx scratch
-    memory and are only valid until the next render on `ctx`."""
+    memory and are only valid until the next render on `ctx`.
+    sliced=True: BH_FLAG_SLICED_LISTS (same image / visible / counts; the list outputs are truncated, see the header)."""
     ctx = ctx or get_context(splats.device)
     w, h = int(img_size[0]), int(img_size[1])
     if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
         camera = camera.uniforms((w, h), tile_rows)
-    _, out, _ = _forward(ctx, splats, camera, (w, h), background, pass_)
+    _, out, _ = _forward(ctx, splats, camera, (w, h), background, pass_, sliced)
     if pass_.bwd_info():
         img = _view(out.out_img, (h, w, 4), torch.float32, splats.device)
     else:
@@ -378,7 +393,7 @@ def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), 
 
 
 def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pass_: RasterPass = RasterPass.Backward,
-                      ctx: Optional[Context] = None, tile_rows=None):
+                      ctx: Optional[Context] = None, tile_rows=None, sliced=False):
     """Differentiable render: forward (Backward pass flags) + backward for a given
     dL/d(out_img) `v_output` [H,W,4] (a tensor, or a callable img -> v_output).
     Returns dict(img, aux, v_transforms, v_sh_coeffs, v_raw_opacities, v_refine_weight, v_combined)."""
@@ -388,7 +403,7 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     dev = splats.device
     if tile_rows is not None and not isinstance(camera, _ffi.BhCamera):
         camera = camera.uniforms((w, h), tile_rows)
-    _, out, (r_t, r_o) = _forward(ctx, splats, camera, (w, h), background, pass_)
+    _, out, (r_t, r_o) = _forward(ctx, splats, camera, (w, h), background, pass_, sliced)
     img = _view(out.out_img, (h, w, 4), torch.float32, dev).clone()
     aux = _aux_from(out, splats.num_splats(), w, h, dev, True)
     if callable(v_output):
@@ -600,6 +615,9 @@ class TrainConfig:
     background_color: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     background_noise_strength: float = 0.1
     render_mip: bool = False
+    # not in the reference: False = the step's forward builds depth-sliced per-tile lists (BH_FLAG_SLICED_LISTS, same results);
+    # True = the reference's full lists
+    exact_lists: bool = False
     # refine options (config.rs:47-86)
     max_splats: int = 10_000_000
     refine_every: int = 200
@@ -982,6 +1000,7 @@ class SplatTrainer:
         cfg.background[0], cfg.background[1], cfg.background[2] = c.background_color
         cfg.median_scene_scale = self.median_scene_scale
         cfg.render_mip = 1 if (c.render_mip or splats.render_mip) else 0
+        cfg.exact_lists = 1 if getattr(c, "exact_lists", False) else 0
         s = self.state
         st = _ffi.BhTrainState()
         st.n, st.sh_degree = splats.num_splats(), splats.sh_degree()
@@ -1047,6 +1066,8 @@ class SplatTrainer:
         out = _ffi.BhRenderOut()
         ctx.check(ctx.lib.bh_last_render_out(ctx._h, C.byref(out)))
         per_row = self._rows_blended(_view(out.tile_offsets, (tile_bh * tile_bw, 2), torch.int32, dev), tile_bh, tile_bw)
+        if out.tile_offsets_far:   # depth-sliced lists: a tile's blended splats = its near segment + its far segment
+            per_row = per_row + self._rows_blended(_view(out.tile_offsets_far, (tile_bh * tile_bw, 2), torch.int32, dev), tile_bh, tile_bw)
         dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
         self._row_weights = [float(x) + 1.0 for x in per_row.tolist()]  # +1: empty rows still cost a launch slot
 

@@ -67,7 +67,19 @@ enum {
 enum {
     BH_FLAG_MIP = 1,           /* SplatRenderMode::Mip */
     BH_FLAG_BWD_INFO = 2,      /* RasterPass::Backward: f32 RGBA out + visible[] + tile-end shrink */
-    BH_FLAG_SMOOTH_CUTOFF = 4  /* RasterPass::BackwardSmoothCutoff (test-only C^1 alpha cutoff) */
+    BH_FLAG_SMOOTH_CUTOFF = 4, /* RasterPass::BackwardSmoothCutoff (test-only C^1 alpha cutoff) */
+    /* Not in the reference: build the per-tile lists in two depth slices instead of listing and sorting every (tile, splat)
+     * pair (map_gaussians.rs:15-80 + render.rs:228-230).  A tile stops blending once its pixels are saturated
+     * (rasterize.rs:116-189), so on scenes that saturate most of the sorted list is never read: the near slice of the depth
+     * order is listed, sorted and blended first, and the rest is listed only into tiles that still have live pixels.
+     * IDENTICAL to the exact path: out_img / out_img_packed bit for bit, visible[], max_radius, num_visible,
+     * num_intersections (K1's count of the exact list), projected rows of every listed splat, and — through
+     * bh_render_backward — all gradients and the refine weights (same replay; float-atomic order aside).
+     * TRUNCATED under this flag: compact_gid_from_isect / tile_id_from_isect hold the near slice's pairs sorted by tile, then
+     * the far slice's; tile_offsets indexes the near part, tile_offsets_far the far part (a tile's blended splats are
+     * tile_offsets[t] followed by tile_offsets_far[t]); projected rows of splats that were never listed are undefined.
+     * bh_train_step uses it by default (its reference counterpart returns only num_visible and the loss, train.rs:418-427). */
+    BH_FLAG_SLICED_LISTS = 8
 };
 
 /* Camera models = CameraModel (brush-render/src/kernels/camera_model/mod.rs:31-38).  The reference
@@ -122,6 +134,11 @@ typedef struct BhRenderOut {
     uint32_t* cum_tiles_hit;           /* [Nv] inclusive scan of per-splat tile counts */
     uint32_t* intersect_counts;        /* [N] tiles hit per splat (0 when culled) */
     float* depths_sorted;              /* [Nv] */
+    /* BH_FLAG_SLICED_LISTS and the frame was actually sliced: [T,2] start,end of each tile's far-slice segment (absolute
+     * indices into compact_gid_from_isect; 0,0 for tiles the near slice finished); NULL otherwise */
+    uint32_t* tile_offsets_far;
+    /* slots of the exact list the near slice covers (== num_intersections: one slice, the lists are the exact ones) */
+    uint32_t list_budget;
 } BhRenderOut;
 
 /* ---- context ------------------------------------------------------------- */
@@ -153,6 +170,14 @@ double bh_focal_to_fov(double focal, uint32_t pixels, uint32_t model, const floa
 int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uint32_t sh_degree,
                       const float* transforms, const float* sh_coeffs, const float* raw_opacities,
                       const float* background /*host [3]*/, uint32_t flags, BhRenderOut* out /*host*/);
+
+/* BH_FLAG_SLICED_LISTS: the near slice's share of the pair list.  near_share in (0, 1]: fixed (1 = never slice);
+ * <= 0 (the default): chosen per frame from the previous forward on this ctx — 1.25 x the slots its slowest saturating
+ * tile needed, a quarter of the list when there is no history, one slice when most pairs belong to tiles that never
+ * saturate.  Results do not depend on the choice, only the time does. */
+int bh_set_list_slicing(bh_ctx* ctx, float near_share);
+/* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
+float bh_last_list_share(bh_ctx* ctx);
 
 /* Backward of the last BH_FLAG_BWD_INFO forward on this ctx.  v_output [H,W,4].
  * All four outputs are dense and fully overwritten (zero where the splat got no
@@ -240,6 +265,7 @@ typedef struct BhTrainConfig {
     float background[3];          /* base background colour */
     float median_scene_scale;     /* bounds.median_size() */
     int32_t render_mip;
+    int32_t exact_lists;          /* 0 (default): the step's forward runs with BH_FLAG_SLICED_LISTS; 1: the reference's full lists */
 } BhTrainConfig;
 
 /* Parameters + optimizer state of one model replica, all device memory owned

@@ -331,6 +331,7 @@ struct TrainConfig {  // config.rs:7-132 subset, same defaults
     float background_color[3] = {0.0f, 0.0f, 0.0f};
     float background_noise_strength = 0.1f;
     bool render_mip = false;
+    bool exact_lists = false;  // not in the reference: false = depth-sliced per-tile lists in step() (BH_FLAG_SLICED_LISTS, same results)
     uint32_t max_splats = 10000000, refine_every = 200, growth_stop_iter = 15000;
     float growth_grad_threshold = 0.0025f, growth_select_fraction = 0.25f, split_at_screen_size = 0.5f, opac_decay = 0.004f;
 };
@@ -462,6 +463,7 @@ class SplatTrainer {
         for (int k = 0; k < 3; ++k) c.background[k] = cfg_.background_color[k];
         c.median_scene_scale = median_;
         c.render_mip = (cfg_.render_mip || s.render_mip) ? 1 : 0;
+        c.exact_lists = cfg_.exact_lists ? 1 : 0;
         return c;
     }
     BhTrainState c_state(Splats& s) {

@@ -236,3 +236,89 @@ def test_6m_4k_sh3_forward_stagewise_exact_vs_oracle(dev, oracle_lib):
     assert np.array_equal(aux.visible.cpu().numpy(), ref.get("visible"))
     d = np.abs(img.cpu().numpy() - ref.image())
     assert d.max() <= 1e-6, "L-inf %g" % d.max()
+
+
+@pytest.mark.parametrize("share", [0.0, 0.04])
+def test_1m_1080p_sliced_lists_vs_oracle(dev, oracle_lib, scene_1m, share):
+    """BH_FLAG_SLICED_LISTS at configs[2]'s size against the oracle's exact pipeline: image, visible flags and counts exact,
+    every tile's blended list (near segment + far segment) == the oracle's shrunk list, gradients within the stated 1e-4.
+    share 0 = the automatic choice (no history: a quarter of the list, every tile done in the near slice); 0.04 leaves about
+    half of the tiles to the far slice."""
+    import brush_amd as ba
+    from test_gpu_backward import assert_grads_match
+    sc, w, h = scene_1m
+    cp = synth.default_camera_params(w, h)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    rng = np.random.default_rng(3)
+    v = (rng.uniform(-1, 1, (h, w, 4)) / (h * w)).astype(np.float32)
+    bg = (0.1, 0.2, 0.3)
+    ctx = ba.Context(dev)   # fresh: no slicing history
+    try:
+        ba.set_list_slicing(share, ctx)
+        res = ba.render_splats_bwd(spl, util.hip_camera(ba, cp), (w, h), bg, torch.from_numpy(v).to(dev), ctx=ctx, sliced=True)
+        aux = res["aux"]
+        assert aux.tile_offsets_far is not None and aux.list_budget < aux.num_intersections
+        ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=bg)
+        ref.backward(v)
+        assert aux.num_visible == ref.num_visible and aux.num_intersections == ref.num_intersections
+        assert np.abs(res["img"].cpu().numpy() - ref.image()).max() <= 1e-6
+        assert np.array_equal(aux.visible.cpu().numpy(), ref.get("visible"))
+        assert np.array_equal(aux.max_radius.cpu().numpy(), ref.get("max_radius"))
+        gids = util.u32(aux.compact_gid_from_isect)
+        near, far = util.u32(aux.tile_offsets).reshape(-1, 2), util.u32(aux.tile_offsets_far).reshape(-1, 2)
+        og, oo = ref.get("compact_gid_from_isect"), ref.get("tile_offsets").reshape(-1, 2)
+        two_segments = 0
+        for t in range(near.shape[0]):
+            mine = gids[near[t, 0]:max(near[t, 0], near[t, 1])]
+            if far[t, 1] > far[t, 0]:
+                mine = np.concatenate([mine, gids[far[t, 0]:far[t, 1]]])
+                two_segments += 1
+            assert np.array_equal(mine, og[oo[t, 0]:max(oo[t, 0], oo[t, 1])]), "tile %d" % t
+        if share > 0:
+            assert 100 < two_segments < near.shape[0]
+        assert_grads_match(res, ref)
+    finally:
+        ctx.close()
+
+
+def test_6m_4k_sh3_sliced_equals_exact(dev):
+    """configs[4] on one GPU with sliced lists: the far slice's sort is sized for all 168 M pairs (41 k-block tables, the
+    device-length row scan looping over its rows) while holding a few hundred thousand: image / flags / blended lists as
+    the exact path's"""
+    import brush_amd as ba
+    sc, w, h = synth.config_scene("6m_4k", 3)
+    cp = synth.default_camera_params(w, h)
+    cam = util.hip_camera(ba, cp)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    ctx = ba.get_context(dev)
+    img_e, aux_e = ba.render_splats(spl, cam, (w, h), (0.1, 0.2, 0.3), ba.RasterPass.Backward)
+    ends_e = (aux_e.tile_offsets[:, 1] - aux_e.tile_offsets[:, 0]).clamp(min=0).long()
+    vis_e, nv, ni = aux_e.visible, aux_e.num_visible, aux_e.num_intersections
+    # the blended entries of the exact lists, flattened tile by tile
+    def flat(aux, table):
+        lo, hi = table[:, 0].long(), table[:, 1].long()
+        ln = (hi - lo).clamp(min=0)
+        idx = torch.repeat_interleave(lo - (torch.cumsum(ln, 0) - ln), ln) + torch.arange(int(ln.sum()), device=lo.device)
+        return aux.compact_gid_from_isect.long()[idx], ln
+    ge, le = flat(aux_e, aux_e.tile_offsets)
+    del aux_e
+    for share in (0.004, 0.03):
+        ba.set_list_slicing(share, ctx)
+        try:
+            img_s, aux_s = ba.render_splats(spl, cam, (w, h), (0.1, 0.2, 0.3), ba.RasterPass.Backward, sliced=True)
+        finally:
+            ba.set_list_slicing(0.0, ctx)
+        assert torch.equal(img_e, img_s) and torch.equal(vis_e, aux_s.visible)
+        assert (aux_s.num_visible, aux_s.num_intersections) == (nv, ni) and aux_s.tile_offsets_far is not None
+        gn, ln = flat(aux_s, aux_s.tile_offsets)
+        gf, lf = flat(aux_s, aux_s.tile_offsets_far)
+        assert torch.equal(ln + lf, le) and torch.equal(ln + lf, ends_e)
+        # per tile: near entries then far entries == the exact entries (compare as sorted (tile, position) streams)
+        T = ln.shape[0]
+        tile_n = torch.repeat_interleave(torch.arange(T, device=dev), ln)
+        tile_f = torch.repeat_interleave(torch.arange(T, device=dev), lf)
+        tile_all = torch.cat([tile_n, tile_f])
+        g_all = torch.cat([gn, gf])
+        order = torch.sort(tile_all, stable=True).indices    # stable: near before far inside a tile
+        assert torch.equal(g_all[order], ge)
+        del img_s, aux_s

@@ -1,0 +1,226 @@
+"""Depth-sliced per-tile lists (BH_FLAG_SLICED_LISTS, the train step's default) against the exact path and the oracle.
+
+Contract (include/brush_hip.h): out_img / out_img_packed bit for bit, visible[], max_radius, num_visible,
+num_intersections, gradients and refine weights are those of the exact path; the list outputs are truncated but a
+tile's blended splats — its near segment followed by its far segment — are exactly the exact path's shrunk list.
+Reference semantics: kernels/rasterize.rs:116-189 (a tile stops once its pixels saturate), map_gaussians.rs:15-80."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from brush_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n, w, h, seed, opacity=(0.05, 0.95), scales=(0.02, 0.2), sh_degree=0):
+    sc = synth.make_scene(n, seed, sh_degree=sh_degree, log_scale_range=(math.log(scales[0]), math.log(scales[1])),
+                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), opacity_range=opacity)
+    return sc, synth.default_camera_params(w, h)
+
+
+def _blended_lists(aux):
+    """per tile: the compact gids the blend kernels consumed, front to back"""
+    gids = util.u32(aux.compact_gid_from_isect)
+    near = util.u32(aux.tile_offsets).reshape(-1, 2)
+    far = util.u32(aux.tile_offsets_far).reshape(-1, 2) if aux.tile_offsets_far is not None else None
+    out = []
+    for t in range(near.shape[0]):
+        seg = gids[near[t, 0]:max(near[t, 1], near[t, 0])]
+        if far is not None and far[t, 1] > far[t, 0]:
+            seg = np.concatenate([seg, gids[far[t, 0]:far[t, 1]]])
+        out.append(seg)
+    return out
+
+
+def _assert_same_render(ba, spl, cam, size, bg, share, pass_=None, tile_rows=None):
+    pass_ = pass_ or ba.RasterPass.Backward
+    ctx = ba.get_context(spl.device)
+    img_e, aux_e = ba.render_splats(spl, cam, size, bg, pass_, tile_rows=tile_rows)
+    ba.host.set_list_slicing(share, ctx)
+    try:
+        img_s, aux_s = ba.render_splats(spl, cam, size, bg, pass_, tile_rows=tile_rows, sliced=True)
+    finally:
+        ba.host.set_list_slicing(0.0, ctx)
+    if tile_rows is not None:   # a strip render writes only its own pixel rows
+        r0, r1 = tile_rows[0] * 16, min(tile_rows[1] * 16, size[1])
+        img_e, img_s = img_e[r0:r1], img_s[r0:r1]
+    assert torch.equal(img_e, img_s), "image differs (share %g): max %g" % (share, float((img_e.float() - img_s.float()).abs().max()))
+    assert aux_e.num_visible == aux_s.num_visible and aux_e.num_intersections == aux_s.num_intersections
+    assert torch.equal(aux_e.max_radius, aux_s.max_radius)
+    assert torch.equal(aux_e.global_from_compact_gid, aux_s.global_from_compact_gid)
+    if pass_.bwd_info():
+        assert torch.equal(aux_e.visible, aux_s.visible)
+        le, ls = _blended_lists(aux_e), _blended_lists(aux_s)
+        for t, (a, b) in enumerate(zip(le, ls)):
+            assert np.array_equal(a, b), "tile %d: blended list differs (share %g)" % (t, share)
+        # projected rows of every blended splat are the exact path's
+        used = np.unique(np.concatenate(le)) if le else np.zeros(0, np.int64)
+        pe, ps = aux_e.projected_splats.cpu().numpy(), aux_s.projected_splats.cpu().numpy()
+        assert np.array_equal(pe[used], ps[used])
+    return aux_e, aux_s
+
+
+@pytest.mark.parametrize("share", [0.0, 0.02, 0.1, 0.35, 0.8, 1.0])
+@pytest.mark.parametrize("opacity", [(0.05, 0.95), (0.02, 0.1)])
+def test_sliced_forward_equals_exact(dev, share, opacity):
+    """saturating and non-saturating scenes, from a near slice that finishes nothing to one that holds everything"""
+    import brush_amd as ba
+    n, w, h = 30000, 320, 208
+    sc, cp = _scene(n, w, h, 0x51, opacity)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    aux_e, aux_s = _assert_same_render(ba, spl, cam, (w, h), (0.1, 0.3, 0.2), share)
+    if 0.0 < share < 1.0:
+        assert aux_s.list_budget < aux_s.num_intersections and aux_s.tile_offsets_far is not None
+    if share == 1.0:
+        assert aux_s.tile_offsets_far is None and aux_s.list_budget == aux_s.num_intersections
+        assert torch.equal(aux_e.compact_gid_from_isect, aux_s.compact_gid_from_isect)
+
+
+@pytest.mark.parametrize("share", [0.03, 0.3])
+def test_sliced_forward_only_and_smooth_passes(dev, share):
+    import brush_amd as ba
+    n, w, h = 20000, 250, 170   # ragged edge tiles
+    sc, cp = _scene(n, w, h, 0x52, sh_degree=1)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    _assert_same_render(ba, spl, cam, (w, h), (0.0, 0.0, 0.0), share, ba.RasterPass.Forward)
+    _assert_same_render(ba, spl, cam, (w, h), (0.3, 0.1, 0.5), share, ba.RasterPass.BackwardSmoothCutoff)
+
+
+def test_sliced_strip_render(dev):
+    """tile-row window (one frame over several ranks): the strip's tiles slice like a whole frame's"""
+    import brush_amd as ba
+    n, w, h = 20000, 256, 256
+    sc, cp = _scene(n, w, h, 0x53)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    for rows in ((0, 5), (5, 11), (11, 16)):
+        _assert_same_render(ba, spl, cam, (w, h), (0.2, 0.2, 0.2), 0.1, tile_rows=rows)
+
+
+@pytest.mark.parametrize("share,opacity", [(0.05, (0.05, 0.95)), (0.3, (0.05, 0.95)), (0.2, (0.02, 0.1))])
+def test_sliced_backward_equals_exact_and_oracle(dev, oracle_lib, share, opacity):
+    import brush_amd as ba
+    n, w, h = 20000, 256, 160
+    sc, cp = _scene(n, w, h, 0x54, opacity, sh_degree=2)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    bg = (0.1, 0.2, 0.3)
+    rng = np.random.default_rng(5)
+    v_out = torch.from_numpy(rng.normal(size=(h, w, 4)).astype(np.float32)).to(dev)
+    ctx = ba.get_context(dev)
+    ex = ba.render_splats_bwd(spl, cam, (w, h), bg, v_out)
+    ba.host.set_list_slicing(share, ctx)
+    try:
+        sl = ba.render_splats_bwd(spl, cam, (w, h), bg, v_out, sliced=True)
+    finally:
+        ba.host.set_list_slicing(0.0, ctx)
+    assert sl["aux"].tile_offsets_far is not None
+    assert torch.equal(ex["img"], sl["img"])
+    ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=bg, flags=oracle_lib.FLAG_BWD_INFO)
+    ref.backward(v_out.cpu().numpy())
+    for key, okey in (("v_transforms", "v_transforms"), ("v_sh_coeffs", "v_coeffs"), ("v_raw_opacities", "v_raw_opac"), ("v_refine_weight", "v_refine")):
+        a, b = ex[key].cpu().numpy().reshape(-1), sl[key].cpu().numpy().reshape(-1)
+        o = ref.get(okey).reshape(-1)
+        scale = max(float(np.abs(o).max()), 1e-12)
+        # the two HIP paths run the same replay; only the float-atomic order differs
+        assert float(np.abs(a - b).max()) <= 2e-6 * scale, key
+        assert float(np.abs(b - o).max()) <= 1e-4 * scale, key   # the gradients' stated tolerance vs the oracle
+
+
+def test_sliced_lists_hold_the_exact_lists_prefix(dev):
+    """the near slice's pairs are the first `budget` slots of the exact list: sorted by tile they are, per tile, a prefix
+    of the exact tile list (in order)"""
+    import brush_amd as ba
+    n, w, h = 30000, 320, 208
+    sc, cp = _scene(n, w, h, 0x55)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    ctx = ba.get_context(dev)
+    _, aux_e = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward)   # forward-only: ends are not shrunk
+    ba.host.set_list_slicing(0.25, ctx)
+    try:
+        _, aux_s = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward, sliced=True)
+    finally:
+        ba.host.set_list_slicing(0.0, ctx)
+    ge, gs = util.u32(aux_e.compact_gid_from_isect), util.u32(aux_s.compact_gid_from_isect)
+    oe, os_ = util.u32(aux_e.tile_offsets).reshape(-1, 2), util.u32(aux_s.tile_offsets).reshape(-1, 2)
+    cum = util.u32(aux_e.cum_tiles_hit)
+    n0 = int(np.searchsorted(cum, aux_s.list_budget, side="right"))   # splats whose slot range ends within the budget
+    total = 0
+    for t in range(oe.shape[0]):
+        a, b = ge[oe[t, 0]:oe[t, 1]], gs[os_[t, 0]:os_[t, 1]]
+        assert np.array_equal(a[:len(b)], b)
+        assert np.all(b < n0) and (len(b) == len(a) or a[len(b)] >= n0)
+        total += len(b)
+    assert total == (int(cum[n0 - 1]) if n0 else 0) <= aux_s.list_budget
+
+
+def test_automatic_share_follows_the_previous_frame(dev):
+    """no history: a quarter of the list; a saturating scene: 1.25 x what its slowest tile needed; a scene whose tiles never
+    saturate: one slice (the exact lists)"""
+    import brush_amd as ba
+    n, w, h = 60000, 320, 208
+    ctx = ba.Context(dev)
+    try:
+        cam = util.hip_camera(ba, synth.default_camera_params(w, h))
+        sc, _ = _scene(n, w, h, 0x56, scales=(0.03, 0.3))
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        lib = ctx.lib
+        img0, aux0 = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        assert abs(lib.bh_last_list_share(ctx._h) - 0.25) < 1e-3 or aux0.num_intersections < (1 << 18)
+        img1, aux1 = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        share1 = lib.bh_last_list_share(ctx._h)
+        assert torch.equal(img0, img1)
+        # what the frame needed: the exact-list slot end of the deepest blended splat over the saturated tiles
+        lists = _blended_lists(aux1)
+        cum = util.u32(aux1.cum_tiles_hit)
+        alpha = img1[..., 3].cpu().numpy()
+        need = max(int(cum[l[-1]]) for l in lists if len(l))
+        if float(alpha.min()) > 0.999:   # every tile saturated: the hint is exactly 1.25 x need
+            assert abs(share1 * aux1.num_intersections - min(1.25 * need, aux1.num_intersections)) <= 0.02 * aux1.num_intersections + (1 << 16)
+        assert share1 < 1.0
+        # a scene that does not saturate: after one frame of feedback the lists are the exact ones
+        sc2, _ = _scene(n, w, h, 0x56, opacity=(0.01, 0.03), scales=(0.005, 0.02))
+        spl2 = ba.Splats(sc2["transforms"], sc2["sh"], sc2["raw_opac"], device=dev)
+        ba.render_splats(spl2, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        _, aux3 = ba.render_splats(spl2, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        assert lib.bh_last_list_share(ctx._h) == 1.0 and aux3.tile_offsets_far is None
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("sh_degree", [0, 3])
+def test_train_step_sliced_equals_exact(dev, sh_degree):
+    """the default (sliced) step and the exact_lists step from the same state: same loss, counts and update"""
+    import brush_amd as ba
+    n, w, h = 20000, 256, 160
+    sc, cp = _scene(n, w, h, 0x57, sh_degree=sh_degree)
+    gt = synth.synthetic_gt_packed(w, h)
+    cam = util.hip_camera(ba, cp)
+    res = {}
+    for exact in (True, False):
+        cfg = ba.TrainConfig(exact_lists=exact)
+        tr = ba.SplatTrainer(cfg, median_scene_scale=3.0)
+        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+        batch = ba.SceneBatch(torch.from_numpy(gt.view(np.int32)).to(dev), cam)
+        losses = []
+        for _ in range(3):
+            tr.step(batch, spl, background=(0.1, 0.1, 0.1))
+            losses.append(tr.stats().loss)
+        res[exact] = (losses, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(),
+                      tr.state["refine_weight_norm"].cpu().numpy(), tr.state["vis_weight"].cpu().numpy(), tr.stats())
+    le, ls = res[True][0], res[False][0]
+    assert res[True][6].num_visible == res[False][6].num_visible and res[True][6].num_intersections == res[False][6].num_intersections
+    assert all(abs(a - b) <= 1e-6 * max(1.0, abs(a)) for a, b in zip(le, ls))
+    cfg = ba.TrainConfig()
+    util.assert_adam_close(res[True][1][:, 3:7], res[False][1][:, 3:7], cfg.lr_rotation, 3, "rotation")
+    util.assert_adam_close(res[True][1][:, 7:10], res[False][1][:, 7:10], cfg.lr_scale, 3, "scale")
+    util.assert_adam_close(res[True][3], res[False][3], cfg.lr_opac, 3, "opacity")
+    util.assert_adam_close(res[True][2], res[False][2], cfg.lr_coeffs_dc, 3, "sh")
+    assert np.mean(res[True][5] != res[False][5]) <= 2e-3
