@@ -131,6 +131,10 @@ def main():
                     help="'resident' (the headline): the GT batch is already in HBM when the timed region starts; 'loader': every step "
                          "takes a fresh 1080p RGB8 host image through SceneLoader/BatchUploader (pinned ring + copy stream + device "
                          "packing) - the PCIe-inclusive rate quoted in DESIGN.md, never `value` of the headline line")
+    ap.add_argument("--lists", choices=["sliced", "exact"], default="sliced",
+                    help="'sliced' (bh_train_step's default): per-tile lists built in two depth slices, the far one only into tiles the near one "
+                         "left unsaturated (same image / gradients); 'exact': every (tile, splat) pair listed and sorted, as the reference does")
+    ap.add_argument("--near-share", type=float, default=0.0, help="--lists sliced: fix the near slice's share of the pair list (developer A/B; 0 = automatic)")
     ap.add_argument("--parallel", choices=["cameras", "tiles"], default="cameras",
                     help="N>1: 'cameras' = data parallel, one view per rank (weak scaling, the headline); "
                          "'tiles' = ONE view partitioned by strips of tile rows (strong scaling, BASELINE.json configs[4])")
@@ -178,6 +182,8 @@ def main():
 
     tile_mode = args.parallel == "tiles" and world > 1
     ctx = ba.get_context(dev)
+    if args.near_share > 0:
+        ba.set_list_slicing(args.near_share, ctx)
     native = args.comm == "native" and not tile_mode and pg is not None
     if native:
         import torch.distributed as dist
@@ -215,7 +221,7 @@ def main():
         gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
         batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
         # seed: the reference's default step draws the mean noise and jitters the background every step
-        trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
+        trainer = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
                                   native_comm=native, sparse_exchange=args.exchange == "sparse", seed=None if args.no_noise else 0xB5EED)
         loader = None
         if args.feed == "loader":
@@ -249,6 +255,7 @@ def main():
         stages.update(dominant)   # the dominant kernel's duration is the one measured inside the timed region
         ctx.profile(0)
         st = trainer.stats()
+        list_share = float(ctx.lib.bh_last_list_share(ctx._h)) if args.lists == "sliced" else 1.0
         # how much of the per-tile lists the blend kernels actually consume before every pixel saturates (outside the
         # timed region): the forward shrinks each tile's list end to its last useful splat
         _, aux = ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
@@ -261,7 +268,7 @@ def main():
             dt = float(tmax.item())
         if loader is not None:
             loader.close()
-        return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, stages=stages, stats=st, isect_blended=isect_blended, loader=loader is not None)
+        return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, stages=stages, stats=st, isect_blended=isect_blended, loader=loader is not None, list_share=list_share)
 
     def blend_rooflines(m, steps):
         """HBM and VALU rooflines of the two blend kernels from one measurement."""
@@ -307,6 +314,7 @@ def main():
                              % (100.0 * me["isect_blended"] / max(est.num_intersections, 1)),
                  "steps": ex_steps, "ms_per_step": round(me["dt"] / ex_steps * 1e3, 4), "views_per_s": round(ex_steps / me["dt"], 2),
                  "num_visible": est.num_visible, "num_intersections": est.num_intersections, "intersections_blended": me["isect_blended"],
+                 "list_share": me["list_share"],
                  "roofline": ehbm, "roofline_valu": evalu,
                  "stages_ms": {k: round(ms / max(c, 1), 4) for k, (ms, c) in me["stages"].items()}}
 
@@ -358,6 +366,8 @@ def main():
             "data": "synthetic" if not m["loader"] else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
                        "num_visible": nv, "num_intersections": ni,
+                       "lists": ("depth-sliced: near slice = %.3f of the pair list (chosen from the previous step's feedback), the far slice only into tiles "
+                                 "it left unsaturated; image / gradients identical to the exact lists" % m["list_share"]) if args.lists == "sliced" else "exact (every pair listed and sorted)",
                        "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
                        "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},

@@ -160,6 +160,51 @@ ProfScope::~ProfScope() {
     ctx->prof.pending.push_back({idx, a, b});
 }
 
+
+// ---- the far slice of a depth-sliced forward (see bh_render_forward) -------------------------------------------------------------
+// count -> scan -> emit the remaining splats into the tiles that still have live pixels, sort them behind the near list (absolute
+// offsets: one array for the backward), blend from the parked state.  Every kernel is gated on the device by the number of
+// unsaturated tiles, so queueing it for a frame that does not need it is correct, just ~50 us of empty launches.
+int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
+    const uint32_t* gate = j.slice_info + 2;
+    const uint32_t far_max = j.ni;   // the host's bound; the live count is far_cum[nv - 1] on the device
+    {
+        ProfScope ps(ctx, "MapGaussiansToIntersect");
+        BH_TRY(launch_map_gaussians_far(ctx, j.nv, j.u, j.proj_by_gid, j.gfc, j.projected, j.cum, j.budget, j.done_bits, gate, j.far_counts, j.far_cum,
+                                        j.tile_ids, j.isect_gids));
+    }
+    {
+        ProfScope ps(ctx, "TileSort");
+        BH_TRY(radix_argsort_dev(ctx, j.tile_ids, j.isect_gids, far_max, j.far_cum + (j.nv - 1), gate, j.slice_info + 1, j.tile_bits, j.tile_ids_sorted,
+                                 j.isect_gids_sorted));
+    }
+    {
+        ProfScope ps(ctx, "GetTileOffsets");
+        BH_TRY(launch_tile_offsets_dev(ctx, j.tile_ids_sorted, far_max, j.far_cum + (j.nv - 1), gate, j.slice_info + 1, j.num_tiles, j.tile_offsets_far));
+    }
+    {
+        ProfScope ps(ctx, "Rasterize");
+        BH_TRY(launch_rasterize(ctx, j.u, j.bg, j.bwd_info, j.smooth, j.isect_gids_sorted, j.tile_offsets_far, j.projected, j.gfc, j.out_f32, j.out_u8, j.visible,
+                                j.lpt, j.class_width, /*phase=*/2, &j.rs));
+    }
+    ctx->far_launches++;
+    return 0;
+}
+
+// A sliced forward that left the decision to the host: wait for the near slice's gate word and queue the far slice only if some
+// tile is still unsaturated.  *launched (optional) tells the caller whether out_img changed after the near slice.
+int finish_far_slice(bh_ctx* ctx, bool* launched) {
+    if (launched) *launched = false;
+    if (!ctx->far_job.pending) return 0;
+    ctx->far_job.pending = false;
+    BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
+    const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
+    ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
+    if (unsat == 0u) return 0;
+    if (launched) *launched = true;
+    return enqueue_far_slice(ctx, ctx->far_job);
+}
+
 }  // namespace bh
 
 using namespace bh;
@@ -201,7 +246,9 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
-    if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
         (void)hipGetLastError();
         (void)hipHostFree(ctx->host_counters);
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -221,6 +268,7 @@ void bh_destroy(bh_ctx* ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
+    if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
     if (ctx->comm) (void)bh_comm_destroy(ctx);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -230,6 +278,7 @@ const char* bh_last_error(bh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int bh_sync(bh_ctx* ctx) {
     if (!ctx) return BH_ERR_INVALID_ARG;
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     deliver_pending_loss(ctx);  // the last train step's loss, staged through pinned memory
     return 0;
@@ -417,6 +466,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (n > 0 && (!transforms || !sh_coeffs || !raw_opacities)) return set_error(ctx, BH_ERR_INVALID_ARG, "render_forward: null splat tensor");
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
     BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));   // (a deferred decision nobody collected)
     ctx->have_forward = false;
     ctx->vcombined_prezeroed = false;   // set below only by the kernels of THIS forward
     ctx->grads_prezeroed = false;
@@ -510,6 +560,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             }
         }
         BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+        if (ctx->gate_learn) {   // the previous sliced frame queued its far slice unasked: did it need it?
+            ctx->gate_learn = false;
+            ctx->far_direct = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD] != 0u;
+        }
         unsigned long long hc[2] = {0ull, 0ull};
         for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { hc[0] += hslots[2 * k]; hc[1] += hslots[2 * k + 1]; }
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
@@ -562,7 +616,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         }
         if (share < 1.0f) {
             const double b = (double)share * (double)ni;
-            const uint32_t floor_b = ni < (1u << 16) ? ni : (1u << 16);
+            const uint32_t floor_b = ni < 1024u ? ni : 1024u;
             budget = b < (double)floor_b ? floor_b : (uint32_t)b;
             if (budget > ni) budget = ni;
         }
@@ -633,30 +687,30 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         rs.unsat_count = slice_info + 2;
         rs.state = state;
         rs.offsets_near = tile_offsets;
-        const uint32_t* gate = slice_info + 2;
         {
             ProfScope ps(ctx, "Rasterize");
             BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
                                     class_width, /*phase=*/1, &rs));
         }
-        // the far slice: at most ni - (near pairs) more, listed only into unsaturated tiles; all of it gated on the device
-        const uint32_t far_max = ni;
-        {
-            ProfScope ps(ctx, "MapGaussiansToIntersect");
-            BH_TRY(launch_map_gaussians_far(ctx, nv, u, proj_by_gid, gfc, projected, cum, budget, done_bits, gate, far_counts, far_cum, tile_ids, isect_gids));
-        }
-        {
-            ProfScope ps(ctx, "TileSort");   // lands behind the near list: absolute offsets, one array for the backward
-            BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, far_max, far_cum + (nv - 1), gate, slice_info + 1, tile_bits, tile_ids_sorted, isect_gids_sorted));
-        }
-        {
-            ProfScope ps(ctx, "GetTileOffsets");
-            BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, far_max, far_cum + (nv - 1), gate, slice_info + 1, num_tiles, tile_offsets_far));
-        }
-        {
-            ProfScope ps(ctx, "Rasterize");
-            BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets_far, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
-                                    class_width, /*phase=*/2, &rs));
+        FarJob& j = ctx->far_job;
+        j.u = u;
+        j.bg[0] = background[0]; j.bg[1] = background[1]; j.bg[2] = background[2];
+        j.bwd_info = bwd_info; j.smooth = smooth;
+        j.nv = nv; j.ni = ni; j.budget = budget; j.num_tiles = num_tiles; j.tile_bits = tile_bits;
+        j.proj_by_gid = proj_by_gid; j.gfc = gfc; j.projected = projected; j.cum = cum;
+        j.slice_info = slice_info; j.done_bits = done_bits; j.tile_offsets_far = tile_offsets_far;
+        j.far_counts = far_counts; j.far_cum = far_cum;
+        j.tile_ids = tile_ids; j.isect_gids = isect_gids; j.tile_ids_sorted = tile_ids_sorted; j.isect_gids_sorted = isect_gids_sorted;
+        j.out_f32 = out_f32; j.out_u8 = out_u8; j.visible = visible; j.lpt = ctx->lpt; j.class_width = class_width; j.rs = rs;
+        // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)
+        BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->far_direct) {
+            BH_TRY(enqueue_far_slice(ctx, j));
+            ctx->gate_learn = true;
+        } else {
+            BH_HIP(ctx, hipEventRecord(ctx->gate_ev, ctx->stream));
+            j.pending = true;
+            if (!ctx->defer_far) BH_TRY(finish_far_slice(ctx, nullptr));
         }
     }
 
@@ -714,6 +768,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     if (!v_output || !v_transforms || !v_sh_coeffs || !v_raw_opacities || !v_refine_weight)
         return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward: null argument");
     BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     const BhRenderOut& r = ctx->last;
     const uint32_t n = ctx->n, nv = r.num_visible, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
     const size_t nvpad = nv ? nv : 1;
@@ -769,6 +824,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
 int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out) {
     if (!ctx || !out) return BH_ERR_INVALID_ARG;
     if (!ctx->have_forward) return set_error(ctx, BH_ERR_STATE, "no forward render on this context yet");
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     *out = ctx->last;
     return 0;
 }
@@ -941,8 +997,13 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_max_radius = s_radius;
     ctx->ext_grad_begin = exch + o_tr;       // ... and the whole gradient span (padding included): K1 does both on its way
     ctx->ext_grad_floats = exch_count - o_tr;
+    // depth-sliced lists: whether the far slice has to run is known once the near slice's blend has; a single-GPU step does not
+    // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
+    const bool exchanging_any = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
+    ctx->defer_far = !batch->image_hook && !exchanging_any;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
+    ctx->defer_far = false;
     ctx->ext_visible = nullptr;
     ctx->ext_max_radius = nullptr;
     ctx->ext_grad_begin = nullptr;
@@ -1003,14 +1064,24 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const float dl_rgb = 1.0f / (float)(hw * 3);
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
-    if (batch->image_hook && batch->strip_loss) {
-        // one frame over several ranks: the hook delivered only the 21-px halos; loss and dL/dimg for this rank's strip
-        // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
-        const ViewUniforms wu = make_uniforms(batch->camera);
-        BH_TRY(launch_image_loss_fused_window(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, wu.tile_y0, wu.tile_y1,
-                                              loss_dev, v_output, loss_host));
-    } else {
-        BH_TRY(launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host));
+    auto queue_loss = [&]() -> int {
+        if (batch->image_hook && batch->strip_loss) {
+            // one frame over several ranks: the hook delivered only the 21-px halos; loss and dL/dimg for this rank's strip
+            // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
+            const ViewUniforms wu = make_uniforms(batch->camera);
+            return launch_image_loss_fused_window(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, wu.tile_y0, wu.tile_y1,
+                                                  loss_dev, v_output, loss_host);
+        }
+        return launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host);
+    };
+    BH_TRY(queue_loss());
+    if (ctx->far_job.pending) {
+        // The loss above ran on the near slice's image, which is the frame's image unless some tile was left unsaturated — the
+        // host finds out while it runs.  Then (rare on scenes that saturate: the near slice is sized with a margin from the last
+        // frame) the far slice is queued and the loss is evaluated again on the finished image.
+        bool far_ran = false;
+        BH_TRY(finish_far_slice(ctx, &far_ran));
+        if (far_ran) BH_TRY(queue_loss());
     }
 
     // ---- backward (train.rs:278)

@@ -87,7 +87,8 @@ constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8;
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
-constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_READ_BYTES + 64;
+constexpr size_t HOST_GATE_WORD = HOST_LOSS_WORD + 16;   // depth-sliced forward: tiles the near slice left unsaturated
+constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_READ_BYTES + 64 + 64;
 
 struct Profiler {
     int level = 0;  // 0 off, 1 every stage, 2 only the dominant kernel (2 events per step)
@@ -105,6 +106,44 @@ struct Profiler {
     hipEvent_t ext_a = nullptr, ext_b = nullptr;
 };
 
+// scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
+struct RasterSlice {
+    uint32_t* done_bits = nullptr;
+    uint32_t* unsat_count = nullptr;
+    float* state = nullptr;
+    const uint32_t* offsets_near = nullptr;
+    const uint32_t* cum = nullptr;
+    uint32_t* feedback = nullptr;
+};
+
+// The far slice of a depth-sliced forward, ready to be queued: everything launch_* needs (api.hip enqueue_far_slice).
+struct FarJob {
+    bool pending = false;   // the near slice is queued and its gate word is on its way to the host; the far slice is undecided
+    ViewUniforms u{};
+    float bg[3] = {0, 0, 0};
+    bool bwd_info = false, smooth = false;
+    uint32_t nv = 0, ni = 0, budget = 0, num_tiles = 0, tile_bits = 0;
+    const float* proj_by_gid = nullptr;
+    const uint32_t* gfc = nullptr;
+    float* projected = nullptr;
+    const uint32_t* cum = nullptr;
+    uint32_t* slice_info = nullptr;
+    uint32_t* done_bits = nullptr;
+    uint32_t* tile_offsets_far = nullptr;
+    uint32_t* far_counts = nullptr;
+    uint32_t* far_cum = nullptr;
+    uint32_t* tile_ids = nullptr;
+    uint32_t* isect_gids = nullptr;
+    uint32_t* tile_ids_sorted = nullptr;
+    uint32_t* isect_gids_sorted = nullptr;
+    float* out_f32 = nullptr;
+    uint32_t* out_u8 = nullptr;
+    float* visible = nullptr;
+    uint32_t* lpt = nullptr;
+    float class_width = 8.0f;
+    RasterSlice rs{};
+};
+
 }  // namespace bh
 
 struct bh_ctx {
@@ -115,6 +154,7 @@ struct bh_ctx {
     bh::Buffer slots[bh::SLOT_COUNT];
     uint32_t* host_counters = nullptr;  // pinned, HOST_COUNTERS_BYTES
     hipEvent_t readback_ev = nullptr;   // marks the count readback of the forward (the depth sort is queued behind it)
+    hipEvent_t gate_ev = nullptr;       // depth-sliced forward: the near slice's blend + the copy of its gate word have run
     bool counters_ready = false;        // the counter pair the next forward accumulates into is known to be zero
     uint32_t counter_phase = 0;         // which half of SLOT_COUNTERS that is
     // state of the last forward (what RenderBackwards saves, bwd/burn_glue.rs:336-371)
@@ -142,6 +182,15 @@ struct bh_ctx {
     bool had_forward = false;         // a forward ran on this ctx before (its feedback words are meaningful)
     uint32_t prev_intersections = 0;  // ... and listed this many pairs
     float last_slice_share = 1.0f;    // what the last sliced forward used (1 = one slice = the exact lists); diagnostics
+    // The far slice costs ~12 launches even when every one of them is a no-op (~4.5 us each on this chip), so whether to queue
+    // it is decided on the HOST where possible: far_direct = the previous sliced frame needed it -> queue it right away
+    // (device-gated, no host wait; the gate word is copied out to keep learning); otherwise the host reads the gate word —
+    // bh_render_forward waits for it, bh_train_step queues the loss kernels first and waits behind them (far_job.pending).
+    bool far_direct = false;
+    bool defer_far = false;           // set by bh_train_step around its forward: return with far_job.pending instead of waiting
+    bool gate_learn = false;          // a gate word copied out by a far_direct frame has not been looked at yet
+    uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice
+    bh::FarJob far_job;
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
@@ -157,6 +206,8 @@ struct bh_ctx {
 namespace bh {
 
 int set_error(bh_ctx* ctx, int code, const std::string& msg);
+int enqueue_far_slice(bh_ctx* ctx, const FarJob& j);
+int finish_far_slice(bh_ctx* ctx, bool* launched);
 // after ANY host wait on the ctx stream: hand the last train step's loss (pinned staging word) to its BhTrainStats
 inline void deliver_pending_loss(bh_ctx* ctx) {
     if (ctx->pending_loss_dst) {
@@ -229,7 +280,7 @@ int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, boo
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);
 // the same with the number of pairs in device memory (host: only the bound n_max): n = min(*n_dev, n_max), 0 if *gate == 0
-// (gate may be NULL); the result is written *out_base elements into out_keys / out_vals (out_base may be NULL).  bits > 8.
+// (gate may be NULL); the result is written *out_base elements into out_keys / out_vals (out_base may be NULL).  Not in place.
 int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
                       const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals);
 // depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
@@ -247,15 +298,7 @@ int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n
 // offsets written are absolute (gate / base may be NULL).  The table must already be zero.
 int launch_tile_offsets_dev(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
                             const uint32_t* base, uint32_t num_tiles, uint32_t* tile_offsets);
-// scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
-struct RasterSlice {
-    uint32_t* done_bits = nullptr;
-    uint32_t* unsat_count = nullptr;
-    float* state = nullptr;
-    const uint32_t* offsets_near = nullptr;
-    const uint32_t* cum = nullptr;
-    uint32_t* feedback = nullptr;
-};
+
 // lpt: the longest-first tile order scratch (8*16 counters directly behind tile_offsets, then the class lists); NULL = index order
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool bwd_info, bool smooth,
                      const uint32_t* isect_gids, uint32_t* tile_offsets, const float* projected,

@@ -440,7 +440,11 @@ int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_g
 // the exact list — and a FAR rest.  FAR = false emits the near slice (budget = 0xFFFFFFFF: everything, the exact path) and
 // reports where it ended (slice_info[0] = n0 splats, [1] = I0 pairs); FAR = true emits the rest, only into tiles whose pixels
 // are not final yet (done_bits), at slots given by the scan of slice_count_kernel's counts.
-template <bool FAR>
+// SPW = splats per wave (lanes SPW.. hold no splat but walk candidates like every lane).  The walk is a serial chain of LDS round
+// trips per 64 candidates, and the near slice of a sliced frame is the few nearest = LARGEST splats: 64 of them in one wave are
+// ~16 k candidates = 250 trips (38 us for the slowest wave, the kernel's whole duration, with most of the chip idle).  16 per
+// wave: four times the waves, a quarter of the chain.  The exact path (every splat, the chip is full anyway) keeps 64.
+template <bool FAR, int SPW>
 __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1, const float* __restrict__ projected_by_gid,
     const uint32_t* __restrict__ global_from_compact_gid, float* __restrict__ projected,
@@ -450,10 +454,12 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t* __restrict__ gate) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
-    const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
+    const uint32_t tid_lin = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
-    for (size_t i = cg; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (size_t i = tid_lin; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cg0 = (blockIdx.x * PROJ_WAVES + (uint32_t)wave) * (uint32_t)SPW;   // the wave's first splat
+    const uint32_t cg = lane < SPW ? cg0 + (uint32_t)lane : 0xFFFFFFFFu;
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
@@ -495,7 +501,6 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const unsigned long long mine_mask = __ballot(mine);
     if (mine_mask == 0ull) return;   // (wave-uniform; the kernel has no block barrier)
     WalkLds& w = s_walk[wave];
-    const uint32_t cg0 = cg - (uint32_t)lane;
     // The wave's splats own ONE contiguous slot range: from the range start of its first emitting splat to the range end of
     // its last one (lanes in between that emit nothing have empty ranges: base == end, or — near slice — do not exist, the
     // slice being a prefix of the depth order).
@@ -550,9 +555,17 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
                          float4* zero_span, uint32_t zero_f4, uint32_t budget, uint32_t* slice_info) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    hipLaunchKernelGGL(map_gaussians_kernel<false>, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                       projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    if (slice_info) {   // the near slice of a sliced frame: few, large splats (see SPW)
+        constexpr int SPW = 16;
+        const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
+        hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL((map_gaussians_kernel<false, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    }
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
 }
@@ -568,7 +581,7 @@ int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, co
                        budget, done_bits, gate, counts);
     BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
     BH_TRY(prefix_sum(ctx, counts, nullptr, nv, far_cum, false, gate));
-    hipLaunchKernelGGL(map_gaussians_kernel<true>, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+    hipLaunchKernelGGL((map_gaussians_kernel<true, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                        projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, (uint32_t*)nullptr, (const uint32_t*)far_cum,
                        done_bits, gate);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");

@@ -299,7 +299,7 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
     uint32_t* sk[2] = {nullptr, nullptr};
     uint32_t* sv[2] = {nullptr, nullptr};
     const bool in_place = keys == out_keys || (vals && vals == out_vals);
-    if (dynamic && (in_place || passes == 1) && dyn.out_base) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: an appending sort needs two passes and distinct buffers");
+    if (dynamic && in_place) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: a device-length sort needs distinct input and output buffers");
     if (passes > 1 || in_place) {
         sk[0] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, bytes);
         sv[0] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, bytes);
