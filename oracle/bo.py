@@ -50,15 +50,18 @@ def build(force=False):
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
+# "spec": the numerical specification (what the HIP kernels are compared with).  "literal1" / "literal2": the #[cube] sources
+# as written (BO_LITERAL in brush_oracle.cpp) — only for measuring the specification's drift against them.
+VARIANTS = {"spec": "libbrush_oracle.so", "literal1": "libbrush_oracle_literal1.so", "literal2": "libbrush_oracle_literal2.so"}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        L = C.CDLL(_LIB_PATH)
+def lib(variant="spec"):
+    if variant not in _libs:
+        path = os.path.join(_DIR, VARIANTS[variant])
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_DIR, "brush_oracle.cpp")):
+            subprocess.check_call(["make", "-C", _DIR, "-s", VARIANTS[variant]])
+        L = C.CDLL(path)
         fp, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
         L.bo_expf.restype = C.c_float; L.bo_expf.argtypes = [C.c_float]
         L.bo_logf.restype = C.c_float; L.bo_logf.argtypes = [C.c_float]
@@ -102,8 +105,8 @@ def lib():
         L.bo_fold_min_scale_backward.argtypes = [fp, fp, fp, C.c_uint64, fp, fp]
         L.bo_compute_min_scale.restype = None
         L.bo_compute_min_scale.argtypes = [fp, C.c_uint64, fp, C.c_uint32, C.c_float, fp]
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
 def _fp(a):
@@ -156,12 +159,13 @@ class Render:
     """One forward (+ optional backward) of the oracle. Mirrors RenderOutput /
     RenderAuxInner (brush-render/src/render_aux.rs:17-68)."""
 
-    def __init__(self):
-        self._h = C.c_void_p(lib().bo_render_create())
+    def __init__(self, variant="spec"):
+        self._lib = lib(variant)
+        self._h = C.c_void_p(self._lib.bo_render_create())
 
     def __del__(self):
         try:
-            lib().bo_render_free(self._h)
+            self._lib.bo_render_free(self._h)
         except Exception:
             pass
 
@@ -176,24 +180,24 @@ class Render:
         self.cam = cam
         self.flags = flags
         bgv = f32(bg)
-        rc = lib().bo_render_forward(self._h, C.byref(cam), n, self.sh_degree, _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac), _fp(bgv), flags)
+        rc = self._lib.bo_render_forward(self._h, C.byref(cam), n, self.sh_degree, _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac), _fp(bgv), flags)
         if rc != 0:
             raise RuntimeError("bo_render_forward failed (rc=%d)" % rc)
-        self.num_visible = lib().bo_num_visible(self._h)
-        self.num_intersections = lib().bo_num_intersections(self._h)
-        self.num_tiles = lib().bo_num_tiles(self._h)
+        self.num_visible = self._lib.bo_num_visible(self._h)
+        self.num_intersections = self._lib.bo_num_intersections(self._h)
+        self.num_tiles = self._lib.bo_num_tiles(self._h)
         return self
 
     def backward(self, v_output):
         v = f32(v_output).reshape(self.cam.img_h, self.cam.img_w, 4)
-        rc = lib().bo_render_backward(self._h, _fp(v), _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac))
+        rc = self._lib.bo_render_backward(self._h, _fp(v), _fp(self.transforms), _fp(self.sh), _fp(self.raw_opac))
         if rc != 0:
             raise RuntimeError("bo_render_backward failed (rc=%d)" % rc)
         return self
 
     def get(self, name):
         cnt = C.c_uint64(0)
-        fn = getattr(lib(), "bo_get_" + name)
+        fn = getattr(self._lib, "bo_get_" + name)
         ct = C.c_float if _GETTERS[name] == np.float32 else C.c_uint32
         fn.restype = C.POINTER(ct)
         fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -207,7 +211,7 @@ class Render:
 
     def stage_seconds(self):
         names = ["project_forward", "depth_sort", "scan", "project_visible", "map_isect", "tile_sort", "tile_offsets", "rasterize", "rasterize_bwd", "project_bwd"]
-        return {k: lib().bo_stage_seconds(self._h, i) for i, k in enumerate(names)}
+        return {k: self._lib.bo_stage_seconds(self._h, i) for i, k in enumerate(names)}
 
 
 def radix_argsort(keys, vals, bits=32):

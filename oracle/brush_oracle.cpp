@@ -27,6 +27,17 @@
 //     reference uses an atomic slot counter; equal-depth order is therefore
 //     "by splat id", a strict refinement of the reference.
 //
+//
+// BO_LITERAL (compile-time; oracle/Makefile builds all three): the choices above are legal executions of the under-specified
+// WGSL arithmetic, but they are CHOICES — two of them (the blend's colour accumulation as fma, exp_blend) were made in round 2
+// together with the HIP kernels.  The literal builds freeze the #[cube] sources as written so that the drift of the shipped
+// specification against them can be measured and bounded (tests/test_oracle_literal_drift.py):
+//   BO_LITERAL = 1: exp / ln / atan2 are the C library's expf / logf / atan2f (what a shader compiler's builtin is closest to),
+//                   no fma anywhere except calc_sigma's two (the round-1 specification);
+//   BO_LITERAL = 2: calc_sigma as well: `0.5*(c00*dx*dx + c11*dy*dy) + c01*dx*dy` evaluated left to right, every product and
+//                   sum rounded (brush-cube/src/lib.rs:573-578 verbatim) — no fma in the whole render path.
+// Only the render path (forward + backward kernels) is affected; sort / scan / loss / Adam have no such choices.
+//
 // Every function cites the reference file:line it follows (paths relative to
 // /root/reference/crates/).
 
@@ -39,6 +50,10 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+
+#ifndef BO_LITERAL
+#define BO_LITERAL 0
 #endif
 
 namespace {
@@ -55,6 +70,9 @@ inline bool is_finite_f32(float x) { return ((f2u(x) >> 23) & 0xFFu) != 0xFFu; }
 // Fixed-polynomial expf (Cephes-style, Cody-Waite reduction, explicit fma).
 // Stands in for WGSL `exp` (brush-cube/src/lib.rs:562, kernels/helpers.rs:331).
 inline float bo_expf_impl(float x) {
+#if BO_LITERAL >= 1
+    return ::expf(x);
+#endif
     if (x != x) return x;
     if (x > 88.72283f) return INFINITY;
     if (x < -103.9f) return 0.0f;
@@ -79,6 +97,9 @@ inline float bo_expf_impl(float x) {
 // polynomial on [-0.5, 0.5] (max rel. error 1.6e-7 in f32), exponent spliced in with an integer
 // add.  Used only where 0 <= sigma: x <= 0.  Below -87 the result is defined as 0.
 inline float bo_exp_blend(float x) {
+#if BO_LITERAL >= 1
+    return ::expf(x);   // kernels/rasterize.rs:131: f32::exp(-sigma)
+#endif
     if (!(x >= -87.0f)) return 0.0f;
     if (x > 0.0f) return 1.0f;  // sigma < 0: the caller discards the value
     const float s = fmaf(x, 1.44269504088896341f, 12582912.0f);   // 1.5 * 2^23 + rint(x log2e): one rounding of the exact product
@@ -96,6 +117,9 @@ inline float bo_exp_blend(float x) {
 // Fixed-polynomial logf (Cephes-style). Stands in for WGSL `log`
 // (kernels/project_forward.rs:96, kernels/map_gaussians.rs:30).
 inline float bo_logf_impl(float x) {
+#if BO_LITERAL >= 1
+    return ::logf(x);
+#endif
     if (x != x) return x;
     if (x < 0.0f) return NAN;
     if (x == 0.0f) return -INFINITY;
@@ -267,6 +291,9 @@ inline Sym3 transpose_congruence(Sym3 s, const Mat3& m) {
 inline float calc_sigma(float px, float py, Sym2 conic, float xy_x, float xy_y) {
     const float dx = px - xy_x;
     const float dy = py - xy_y;
+#if BO_LITERAL >= 2
+    return 0.5f * (conic.c00 * dx * dx + conic.c11 * dy * dy) + conic.c01 * dx * dy;   // lib.rs:577 as written
+#endif
     const float q = fmaf(conic.c11 * dy, dy, (conic.c00 * dx) * dx);
     return fmaf(conic.c01 * dx, dy, 0.5f * q);
 }
@@ -542,6 +569,9 @@ inline float bo_atanf_pos(float x) {  // x >= 0 (or NaN)
     return y0 + fmaf(p * z, x, x);
 }
 inline float bo_atan2f_impl(float y, float x) {
+#if BO_LITERAL >= 1
+    return ::atan2f(y, x);
+#endif
     if (x != x || y != y) return x + y;
     if (y == 0.0f) return (x < 0.0f || (x == 0.0f && std::signbit(x))) ? (std::signbit(y) ? -3.14159265358979323846f : 3.14159265358979323846f) : y;
     const float ay = fabsf(y), ax = fabsf(x);
@@ -1601,9 +1631,15 @@ int render_forward(Render& R, const BoCamera& cam, uint32_t n, uint32_t sh_degre
                         if (bwd_info) vis_mark[cg] = 1;  // benign race: all writers store 1
                         const float vis = alpha_eff * t_acc;
                         // three explicit fma (numerical specification): rgb += max(c, 0) * vis
+#if BO_LITERAL >= 1
+                        pr += std::fmax(s[6], 0.0f) * vis;   // kernels/rasterize.rs:147-149 as written
+                        pg += std::fmax(s[7], 0.0f) * vis;
+                        pb += std::fmax(s[8], 0.0f) * vis;
+#else
                         pr = std::fmaf(std::fmax(s[6], 0.0f), vis, pr);
                         pg = std::fmaf(std::fmax(s[7], 0.0f), vis, pg);
                         pb = std::fmaf(std::fmax(s[8], 0.0f), vis, pb);
+#endif
                         t_acc = next_t;
                         last_useful = is + 1;
                     }
