@@ -1,0 +1,127 @@
+"""The reference's only dataset fixture — apps/brush-c/tests/data/test_dataset (a 100-point trimesh cloud `init.ply` with
+uchar red / green / blue / alpha, one 50x50 RGBA view `train/r_0.png`, a nerfstudio `transforms.json`) — driven the way
+apps/brush-c/tests/integration.rs:40-183 drives it (10 steps, refine every 5, export), through the C ABI:
+    init.ply -> bh_splats_from_ply (vs oracle/ply.py) | transforms.json -> Camera (formats/nerfstudio.rs) |
+    r_0.png -> upload ring (vs oracle/scene.py) | bh_train_step x 10, each step vs the oracle trainer | bh_refine_* at 5, 10 |
+    bh_splat_to_ply -> bh_splats_from_ply round trip.
+The fixture's bytes travel as tests/golden/test_dataset.npz (scripts/make_golden.py): /root/reference does not exist on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ply as oply, scene as oscene
+import util
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    d = np.load(os.path.join(util.GOLDEN_DIR, "test_dataset.npz"))
+    return dict(ply=d["init_ply"].tobytes(), rgba=d["r_0_rgba"], m=d["transform_matrix"], intr=d["intrinsics"])
+
+
+def test_oracle_reads_the_reference_point_cloud(fixture):
+    """CPU: the oracle's restatement of the importer on the one PLY the reference ships (ply_gaussian.rs:36-99, import.rs:289-405)"""
+    got = oply.load_splat_from_ply(fixture["ply"])
+    n = 100
+    assert got["transforms"].shape == (n, 10) and got["sh"].shape == (n, 1, 3) and got["raw_opac"].shape == (n,)
+    assert got["meta"]["total_splats"] == n and got["meta"]["sh_degree"] == 0
+    # rows: 3 little-endian floats + 4 bytes
+    body = fixture["ply"][fixture["ply"].index(b"end_header\n") + len(b"end_header\n"):]
+    rows = np.frombuffer(body, np.dtype([("xyz", "<f4", 3), ("rgba", "u1", 4)]), count=n)
+    assert np.array_equal(got["transforms"][:, :3], rows["xyz"])
+    assert np.array_equal(got["transforms"][:, 3:7], np.tile(np.float32([1, 0, 0, 0]), (n, 1)))      # absent rotation: identity (import.rs:372-376)
+    assert np.all(got["transforms"][:, 7:] == np.float32(-4.0)) and np.all(got["raw_opac"] == 0)      # absent scales / opacity defaults
+    want = (rows["rgba"][:, :3].astype(np.float32) / np.float32(254.0) - np.float32(0.5)) / np.float32(0.2820948)
+    assert np.allclose(got["sh"][:, 0, :], want, rtol=0, atol=1e-7)
+
+
+def test_camera_from_the_reference_transforms_json(fixture):
+    """CPU: OpenGL camera-to-world -> Brush pose; the fixture's camera looks at the point cloud (it sits in front of it)"""
+    cam = oscene.nerfstudio_frame_to_camera(fixture["m"], fixture["intr"])
+    assert (cam["img_w"], cam["img_h"]) == (50, 50) and cam["center_uv"] == (0.5, 0.5)
+    q = np.array(cam["rot_xyzw"], np.float64)
+    assert abs(np.linalg.norm(q) - 1.0) < 1e-6
+    # rotate +Z (Brush's forward) by q: must equal -(third column) of the file's matrix (OpenGL looks down -Z)
+    x, y, z, w = q
+    fwd = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+    assert np.allclose(fwd, -fixture["m"][:3, 2], atol=1e-6)
+    down = np.array([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)])
+    assert np.allclose(down, -fixture["m"][:3, 1], atol=1e-6)
+    assert np.allclose(cam["pos"], fixture["m"][:3, 3])
+    pts = oply.load_splat_from_ply(fixture["ply"])["transforms"][:, :3].astype(np.float64)
+    depth = (pts - np.array(cam["pos"])) @ fwd
+    assert depth.min() > 0.5, "every point of init.ply is in front of the fixture's camera"
+
+
+@pytest.mark.gpu
+def test_reference_fixture_end_to_end(dev, oracle_lib, fixture):
+    import torch
+    import brush_amd as ba
+    bo = oracle_lib
+    # ---- init.ply through the device importer
+    spl, meta = ba.load_splat_from_ply(fixture["ply"], device=dev)
+    want = oply.load_splat_from_ply(fixture["ply"])
+    assert meta.total_splats == 100 and meta.sh_degree == 0
+    assert np.array_equal(spl.transforms.cpu().numpy(), want["transforms"])
+    assert np.array_equal(spl.sh_coeffs.cpu().numpy(), want["sh"]) and np.array_equal(spl.raw_opacities.cpu().numpy(), want["raw_opac"])
+    # ---- the view: camera from transforms.json, pixels through the upload ring
+    cp = oscene.nerfstudio_frame_to_camera(fixture["m"], fixture["intr"])
+    w, h = cp["img_w"], cp["img_h"]
+    cam = util.hip_camera(ba, cp)
+    up = ba.BatchUploader(w * h, slots=2)
+    slot = up.submit(fixture["rgba"], premultiply=True)   # no mask file: AlphaMode::Transparent (load_image.rs:41-46)
+    packed, has_alpha = up.acquire(slot)
+    gt, wa = oscene.view_to_packed_data(fixture["rgba"], transparent_alpha=True)
+    assert has_alpha and wa and np.array_equal(util.u32(packed), gt)
+    batch = ba.SceneBatch(packed, cam, has_alpha=True, alpha_is_mask=False)
+    # ---- 10 steps, refine every 5 (integration.rs:62-68), each step against the oracle's composition of step()
+    cfg = ba.TrainConfig(total_train_iters=10, refine_every=5)
+    center, extent = ba.splat_bounds(spl)
+    median = ba.bounds_median_size(extent)
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=median)
+    trainer.set_bounds(center, extent)
+    otr = util.OracleTrainer(bo, cfg, median_scene_scale=median)
+    osc = {k: want[k].copy() for k in ("transforms", "sh", "raw_opac")}
+    ocam = bo.camera(**cp)
+    bg = (0.0, 0.0, 0.0)
+    losses, nv_seen = [], 0
+    for it in range(1, 11):
+        trainer.step(batch, spl, background=bg)
+        st = trainer.stats()
+        ref = otr.step(osc, ocam, gt, bg, has_alpha=True, alpha_is_mask=False)
+        losses.append(st.loss)
+        nv_seen = max(nv_seen, st.num_visible)
+        assert st.num_visible == ref["num_visible"] and st.num_intersections == ref["num_intersections"], it
+        assert abs(st.loss - ref["loss"]) <= 1e-5 * max(1.0, abs(ref["loss"])), it
+        k = it if it <= 5 else it - 5          # Adam steps since the (re)start of the moments compared below
+        tr = spl.transforms.cpu().numpy()
+        util.assert_adam_close(tr[:, 3:7], osc["transforms"][:, 3:7], cfg.lr_rotation, k, "rotation")
+        util.assert_adam_close(tr[:, 7:10], osc["transforms"][:, 7:10], cfg.lr_scale, k, "scale")
+        util.assert_adam_close(tr[:, 0:3], osc["transforms"][:, 0:3], ref["lr_mean"], k, "mean", extra_abs=1e-7)
+        util.assert_adam_close(spl.raw_opacities.cpu().numpy(), osc["raw_opac"], cfg.lr_opac, k, "opacity")
+        util.assert_adam_close(spl.sh_coeffs.cpu().numpy(), osc["sh"], cfg.lr_coeffs_dc, k, "sh")
+        if it % cfg.refine_every == 0:
+            spl, rstats = trainer.refine(it, spl, seed=77 + it)
+            assert rstats.total_splats == spl.num_splats() > 0
+            for t in (spl.transforms, spl.sh_coeffs, spl.raw_opacities):
+                assert bool(torch.isfinite(t).all())
+            if it < 10:
+                # the oracle continues from the refined state (which splats are sampled is not contractual: tests/test_gpu_refine.py)
+                osc = dict(transforms=spl.transforms.cpu().numpy().copy(), sh=spl.sh_coeffs.cpu().numpy().copy(), raw_opac=spl.raw_opacities.cpu().numpy().copy())
+                otr.state = dict(m1_t=trainer.state["m1_t"].cpu().numpy().copy(), m2_t=trainer.state["m2_t"].cpu().numpy().copy(),
+                                 m1_sh=trainer.state["m1_sh"].cpu().numpy().reshape(spl.num_splats(), -1).copy(), m2_sh=trainer.state["m2_sh"].cpu().numpy().copy(),
+                                 m1_o=trainer.state["m1_o"].cpu().numpy().reshape(-1, 1).copy(), m2_o=trainer.state["m2_o"].cpu().numpy().reshape(-1, 1).copy(),
+                                 refine=trainer.state["refine_weight_norm"].cpu().numpy().copy(), vis=trainer.state["vis_weight"].cpu().numpy().copy(),
+                                 screen=trainer.state["max_screen_size"].cpu().numpy().copy())
+    assert nv_seen > 0 and all(np.isfinite(losses)) and losses[4] < losses[0]
+    # ---- export (integration.rs:85-90: "an output file was created") and read it back
+    blob = ba.splat_to_ply(spl)
+    assert blob[:4] == b"ply\n" and len(blob) > 100
+    back, meta2 = ba.load_splat_from_ply(blob, device=dev)
+    assert meta2.total_splats == spl.num_splats()
+    assert np.array_equal(back.transforms.cpu().numpy()[:, :3], spl.transforms.cpu().numpy()[:, :3])
+    assert np.array_equal(back.sh_coeffs.cpu().numpy(), spl.sh_coeffs.cpu().numpy())
+    assert np.array_equal(back.raw_opacities.cpu().numpy(), spl.raw_opacities.cpu().numpy())
+    up.release(slot)
+    up.close()
