@@ -1,0 +1,231 @@
+"""The multi-rank paths at the world sizes they exist for (BASELINE.json configs[3]: 8 ranks data parallel over cameras;
+configs[4]: 8 ranks, one frame cut into strips of tile rows) — rehearsed on ONE GPU: `world` processes share the device and
+a gloo process group carries the buffers (the gpurun boxes have a single GPU; the collectives' arithmetic, the union
+listing, uneven strips, re-balancing, vis_weight counting and the dense fall-back do not care which transport sums).
+Contract: SURVEY.md §8e — all-reduced update == the oracle's step on the mean of the K single-view gradients, replicas
+bit-identical; a K-strip step == the single-GPU step."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from brush_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(world, target, args, timeout=900):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda r: r[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+    for p in procs:
+        assert p.exitcode == 0
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data parallel over cameras
+# ---------------------------------------------------------------------------------------------------------------
+def _dp_problem(name):
+    if name == "small":
+        n, w, h = 3000, 128, 96
+        sc = synth.make_scene(n, 0xD0, sh_degree=1, log_scale_range=(math.log(0.03), math.log(0.25)),
+                              tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), spread=1.8)
+        return sc, w, h, 2.0
+    sc, w, h = synth.config_scene("1m_1080p", 0)   # BASELINE.json configs[2] / [3]'s size
+    return sc, w, h, 5.0
+
+
+def _dp_cam(rank, world, w, h):
+    cp = synth.default_camera_params(w, h)
+    cp["rot_xyzw"] = util.quat_from_axis_angle((0, 1, 0), 0.12 / world * rank)   # K nearby views: the union stays a subset of the scene
+    return cp
+
+
+def _dp_worker(rank, world, port, q, problem, sparse, steps):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brush_amd as ba
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    sc, w, h, median = _dp_problem(problem)
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3 + rank).view(np.int32)).to(dev)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=median, process_group=dist.group.WORLD, sparse_exchange=sparse)
+    batch = ba.SceneBatch(gt, util.hip_camera(ba, _dp_cam(rank, world, w, h)))
+    rows, first = [], None
+    for _ in range(steps):
+        trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        rows.append(trainer.stats().exchange_rows)
+        if first is None:
+            first = (spl.transforms.cpu().numpy().copy(), spl.sh_coeffs.cpu().numpy().copy(), spl.raw_opacities.cpu().numpy().copy())
+    trainer.sync_refine_stats()
+    last = (spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy())
+    # (only rank 0 ships the big arrays; the others ship checksums — replicas must be bit-identical)
+    import hashlib
+    def digest(arrs):
+        hsh = hashlib.sha256()
+        for a in arrs:
+            hsh.update(np.ascontiguousarray(a).tobytes())
+        return hsh.hexdigest()
+    state = (trainer.state["vis_weight"].cpu().numpy(), trainer.state["refine_weight_norm"].cpu().numpy(), trainer.state["max_screen_size"].cpu().numpy())
+    payload = (first, state) if rank == 0 else None
+    q.put((rank, digest(first), digest(last), digest(state), rows, payload))
+    dist.destroy_process_group()
+
+
+def _check_against_oracle_mean(bo, problem, world, first, vis):
+    import brush_amd as ba
+    cfg = ba.TrainConfig()
+    sc, w, h, median = _dp_problem(problem)
+    extra = []
+    for r in range(1, world):
+        g = util.OracleTrainer(bo, cfg, median).step({k: v.copy() for k, v in sc.items()}, bo.camera(**_dp_cam(r, world, w, h)),
+                                                      synth.synthetic_gt_packed(w, h, seed=3 + r), (0.1, 0.2, 0.3), dry_run=True)
+        extra.append(g)
+    ot = util.OracleTrainer(bo, cfg, median)
+    ot.step(sc, bo.camera(**_dp_cam(0, world, w, h)), synth.synthetic_gt_packed(w, h, seed=3), (0.1, 0.2, 0.3), extra_grads=extra, world=world)
+    tr, sh, op = first
+    util.assert_adam_close(tr[:, 3:7], sc["transforms"][:, 3:7], cfg.lr_rotation, 1, "rotation")
+    util.assert_adam_close(tr[:, 7:10], sc["transforms"][:, 7:10], cfg.lr_scale, 1, "scale")
+    util.assert_adam_close(op, sc["raw_opac"], cfg.lr_opac, 1, "opacity")
+    util.assert_adam_close(sh, sc["sh"], cfg.lr_coeffs_dc, 1, "sh")
+    return ot
+
+
+@pytest.mark.parametrize("world,sparse", [(4, True), (4, False), (8, True), (8, False)])
+def test_dp_over_cameras_at_4_and_8_ranks_matches_the_oracle_mean_gradient(oracle_lib, world, sparse):
+    steps = 2
+    res = _run(world, _dp_worker, ("small", sparse, steps))
+    for key in (1, 2, 3):   # parameters after step 1, after the last step, refine statistics: identical on every rank
+        assert len({r[key] for r in res}) == 1, "replicas diverged (field %d)" % key
+    rows = res[0][4]
+    assert all(r[4] == rows for r in res)
+    first, (vis, norm, scr) = res[0][5]
+    n = first[0].shape[0]
+    if sparse:   # K nearby views: their union is a real subset of the scene -> compact rows on both steps
+        assert all(0 < r <= n // 2 for r in rows), rows
+    else:
+        assert rows == [0] * steps
+    assert vis.max() == float(world * steps)            # vis_weight counts (rank, step) views
+    ot = _check_against_oracle_mean(oracle_lib, "small", world, first, vis)
+    # after ONE step vis_weight = number of views that reached the splat: compare the two-step count's support
+    assert np.array_equal(ot.state["vis"] > 0, vis > 0) or np.mean((ot.state["vis"] > 0) != (vis > 0)) <= 2e-3
+
+
+def test_dp_4_ranks_at_1m_1080p_matches_the_oracle_mean_gradient(oracle_lib):
+    """the data-parallel step at configs[2]'s size: four 1 M-splat replicas on one GPU, mask-keyed exchange"""
+    world = 4
+    res = _run(world, _dp_worker, ("1m", True, 1), timeout=1500)
+    for key in (1, 2, 3):
+        assert len({r[key] for r in res}) == 1
+    rows = res[0][4]
+    first, (vis, norm, scr) = res[0][5]
+    assert 0 < rows[0] <= first[0].shape[0] // 2 and rows[0] == int((vis > 0).sum())
+    _check_against_oracle_mean(oracle_lib, "1m", world, first, vis)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one frame over 8 ranks
+# ---------------------------------------------------------------------------------------------------------------
+def _tile_problem():
+    n, w, h = 12000, 208, 400        # 25 tile rows over 8 ranks: strips of 4 and 3 rows before the first re-cut
+    sc = synth.make_scene(n, 0xE8, sh_degree=1, log_scale_range=(math.log(0.02), math.log(0.25)),
+                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), spread=2.0)
+    cp = synth.default_camera_params(w, h)
+    return sc, cp, w, h
+
+
+def _tile_worker(rank, world, port, q, strip_loss, sparse, steps):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brush_amd as ba
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    sc, cp, w, h = _tile_problem()
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=2.0, process_group=dist.group.WORLD, partition="tiles", sparse_exchange=sparse)
+    trainer.rebalance_every = 1
+    trainer.strip_loss = strip_loss
+    batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
+    losses, info, cuts = [], [], []
+    from brush_amd.parallel import tile_rows_for_rank
+    for _ in range(steps):
+        cuts.append(tile_rows_for_rank((h + 15) // 16, rank, world, trainer._row_weights))
+        trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        st = trainer.stats()
+        info.append((trainer._strip_loss_now, st.exchange_rows))
+        losses.append(trainer.reduce_loss(st))
+    trainer.sync_refine_stats()
+    q.put((rank, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(), losses,
+           trainer.state["vis_weight"].cpu().numpy(), trainer.state["refine_weight_norm"].cpu().numpy(), trainer._row_weights, info, cuts))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strip_loss,sparse", [(True, True), (False, True), (True, False)])
+def test_one_frame_over_8_uneven_rebalanced_strips_equals_the_single_gpu_step(dev, strip_loss, sparse):
+    import brush_amd as ba
+    world, steps = 8, 3
+    res = _run(world, _tile_worker, (strip_loss, sparse, steps))
+    r0 = res[0]
+    for r in res[1:]:
+        for a, b in zip(r0[1:7], r[1:7]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), "replicas diverged"
+        assert r[7] == r0[7]
+    # the strips tile the frame at every step, are uneven, and move when they are re-cut by blended intersections
+    for s in range(steps):
+        spans = [r[9][s] for r in res]
+        assert spans[0][0] == 0 and spans[-1][1] == 25 and all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+        assert all(e > b for b, e in spans)
+    assert len({e - b for b, e in [r[9][0] for r in res]}) > 1            # 25 rows over 8 ranks
+    assert [r[9][0] for r in res] != [r[9][steps - 1] for r in res]       # re-balanced
+    if sparse:
+        assert all(0 < x[1] for x in r0[8])
+    if strip_loss:   # wherever every strip is taller than the halo the strip-wise loss ran
+        assert any(x[0] for x in r0[8])
+    # single-GPU reference
+    sc, cp, w, h = _tile_problem()
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3).view(np.int32)).to(dev)
+    cfg = ba.TrainConfig()
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=2.0)
+    batch = ba.SceneBatch(gt, util.hip_camera(ba, cp))
+    losses = []
+    for _ in range(steps):
+        trainer.step(batch, spl, background=(0.1, 0.2, 0.3))
+        losses.append(trainer.stats().loss)
+    assert np.allclose(r0[4], losses, rtol=1e-5, atol=1e-7)
+    tr = spl.transforms.cpu().numpy()
+    util.assert_adam_close(r0[1][:, 3:7], tr[:, 3:7], cfg.lr_rotation, steps, "rotation")
+    util.assert_adam_close(r0[1][:, 7:10], tr[:, 7:10], cfg.lr_scale, steps, "scale")
+    util.assert_adam_close(r0[3], spl.raw_opacities.cpu().numpy(), cfg.lr_opac, steps, "opacity")
+    util.assert_adam_close(r0[2], spl.sh_coeffs.cpu().numpy(), cfg.lr_coeffs_dc, steps, "sh")
+    assert np.mean(r0[5] != trainer.state["vis_weight"].cpu().numpy()) <= 2e-3
+    ref_norm = trainer.state["refine_weight_norm"].cpu().numpy()
+    assert np.abs(r0[6] - ref_norm).max() <= 2e-3 * ref_norm.max() + 1e-12
