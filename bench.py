@@ -109,6 +109,95 @@ def dry_run(args):
     dist.destroy_process_group()
 
 
+def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args):
+    """Before anything is timed with N > 1 ranks: prove the exchange path that is about to be timed.
+      (1) all-reduce of ones through each available path (the library's RCCL communicator, the torch.distributed hook) == world;
+      (2) two train steps of a small scene from identical replicas through each path: parameters bit-identical across the
+          ranks, and equal between the two paths to 1e-6 (beyond that only where Adam turned a gradient that is summation-
+          order noise into a +-lr step: a bounded fraction).
+    Returns (use_native, record).  A failing native path falls back to the hook LOUDLY; if the hook fails too the run is
+    refused (non-zero exit, no JSON line).  A 60-s watchdog refuses a hung collective the same way."""
+    import threading
+    import torch.distributed as dist
+    t_start = time.perf_counter()
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(60.0):
+            sys.stderr.write("bench.py: exchange self-check did not finish within 60 s (hung collective?) - refusing to time this run\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=watchdog, daemon=True).start()
+    tile_mode = args.parallel == "tiles" and world > 1
+    n, w, h = 20000, 256, 256
+    scene = synth.make_scene(n, 0x5C, sh_degree=0, log_scale_range=(math.log(0.02), math.log(0.2)))
+    cp = synth.default_camera_params(w, h)
+    yaw = 0.0 if tile_mode else 0.03 * rank
+    cam = ba.Camera(position=cp["pos"], rotation=(0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0)), fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"])
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=11 + (0 if tile_mode else rank)).view("int32")).to(dev)
+    batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
+
+    def run_path(use_native):
+        ones = torch.ones(4096, device=dev)
+        if use_native:
+            ctx.allreduce_sum(ones)
+        else:
+            dist.all_reduce(ones)
+        torch.cuda.synchronize(dev)
+        if not bool((ones == float(world)).all()):
+            raise RuntimeError("all-reduce of ones gave %r ... expected %d everywhere" % (ones[:2].tolist(), world))
+        splats = ba.Splats(scene["transforms"].copy(), scene["sh"].copy(), scene["raw_opac"].copy(), device=dev)
+        tr = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=3.0, process_group=None if use_native else pg, ctx=ctx,
+                             partition=args.parallel, native_comm=use_native, sparse_exchange=args.exchange == "sparse", seed=0xB5EED)
+        for _ in range(2):
+            tr.step(batch, splats)
+        torch.cuda.synchronize(dev)
+        flat = torch.cat([splats.transforms.reshape(-1), splats.sh_coeffs.reshape(-1), splats.raw_opacities.reshape(-1)])
+        if not bool(torch.isfinite(flat).all()):
+            raise RuntimeError("non-finite parameters after two steps")
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if torch.equal(ref, flat) else 0], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        if int(same.item()) != 1:
+            raise RuntimeError("replicas are not bit-identical after two steps")
+        return flat
+
+    rec = {"world": world, "scene": "%d splats, %dx%d, 2 steps per path" % (n, w, h)}
+    results = {}
+    for name, use_native in (("native", True), ("torch", False)):
+        if use_native and (not native or tile_mode):
+            rec[name] = "not available" if not tile_mode else "not used (tile partition exchanges through the hooks)"
+            continue
+        try:
+            results[name] = run_path(use_native)
+            rec[name] = "ok"
+        except Exception as e:   # every rank must reach the same verdict: a failure anywhere fails the path everywhere
+            rec[name] = "FAILED: %s" % (e,)
+        bad = torch.tensor([0 if rec[name] == "ok" else 1], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and rec[name] == "ok":
+            rec[name] = "FAILED on another rank"
+            results.pop(name, None)
+    if "native" in results and "torch" in results:
+        d = (results["native"] - results["torch"]).abs()
+        rec["paths_max_abs_diff"] = float(d.max().item())
+        rec["paths_frac_beyond_1e-6"] = float((d > 1e-6).float().mean().item())
+        if rec["paths_frac_beyond_1e-6"] > 1e-3:
+            rec["native"] = "FAILED: disagrees with the torch.distributed path (%.3g of the parameters beyond 1e-6, max %.3g)" % (rec["paths_frac_beyond_1e-6"], rec["paths_max_abs_diff"])
+    use_native = native and rec.get("native") == "ok"
+    if native and not use_native:
+        sys.stderr.write("bench.py: the library communicator FAILED its self-check (%s) - timing the torch.distributed hook instead\n" % rec.get("native"))
+    if not use_native and rec.get("torch") != "ok":
+        sys.stderr.write("bench.py: no exchange path passed its self-check (%r) - refusing to time this run\n" % (rec,))
+        sys.stderr.flush()
+        os._exit(4)
+    rec["timed_path"] = "native" if use_native else "torch"
+    rec["seconds"] = round(time.perf_counter() - t_start, 2)
+    done.set()
+    return use_native, rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +288,9 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if native and int(ok.item()) == 0:
             native = False
+    selfcheck = None
+    if pg is not None:
+        native, selfcheck = exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args)
 
     def barrier():
         if pg is not None:
@@ -371,7 +463,8 @@ def main():
                        "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
                        "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
-            "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "rows_last_step": st.exchange_rows, "rows_total": n} if pg is not None else None),
+            "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "rows_last_step": st.exchange_rows, "rows_total": n,
+                          "selfcheck": selfcheck} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),

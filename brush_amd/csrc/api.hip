@@ -244,6 +244,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
     ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
     ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
+    ctx->knob_break_allreduce = getenv("BH_BREAK_ALLREDUCE") != nullptr;
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess ||

@@ -197,6 +197,7 @@ struct bh_ctx {
     // developer knobs (A/B measurements), read from the environment ONCE at bh_create
     bool knob_no_lpt = false;         // BH_NO_LPT: backward tiles in index order
     bool knob_force_exchange = false;       // BH_FORCE_PG: run the gradient-exchange path with a one-rank communicator too (overhead measurement)
+    bool knob_break_allreduce = false;      // BH_BREAK_ALLREDUCE: corrupt the library's all-reduce (the bench self-check must notice)
     bool knob_generic_depth_sort = false;   // BH_GENERIC_DEPTH_SORT: the forward's depth order by the generic 32-bit radix sort + scan
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
