@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-# BRUSH_HIP_LIB: developer override used to A/B kernel variants (scripts/ab_build.sh); still a HIP build.
+# BRUSH_HIP_LIB: developer override used to A/B kernel variants (scripts/ab.sh build); still a HIP build.
 LIB_PATH = os.environ.get("BRUSH_HIP_LIB") or os.path.join(_DIR, "libbrush_hip.so")
 
 FLAG_MIP = 1

@@ -595,7 +595,9 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
 #pragma unroll
     for (int w = 0; w < BK_WAVES; ++w) lo = min(lo, s_red[w]);
     __syncthreads();
-    const uint32_t passes = bits <= 8u ? 1u : 3u;
+    // (digits of at most 8 bits — the 256-entry tables — and an odd count: 1 pass up to 8 bits, 3 up to 24, 5 beyond.  K1 rejects
+    //  |z| > 1e10, which keeps a bucket's span below 2^24 today; the 5-pass case is there so that nothing depends on it.)
+    const uint32_t passes = bits <= 8u ? 1u : (bits <= 24u ? 3u : 5u);
     const uint32_t base_w = bits / passes, wide = bits % passes;
     uint32_t* src_k = a_keys; uint32_t* src_v = a_vals;
     uint32_t* dst_k = out_keys; uint32_t* dst_v = out_vals;

@@ -390,7 +390,9 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
         a.ty_base = a0;
         a.row_end = h;
         a.sum_src = nullptr; a.sum_n = 0; a.loss_out = nullptr; a.loss_host = nullptr;
-        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, (a1 - a0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, gy, a);
+        // (blocks are two tile rows tall: with an odd window the last block's lower half lies outside it — rows this rank may not
+        //  have rendered — and its loss partial is not stored: the limit is the window's end a1, not the image's gy)
+        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, (a1 - a0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a1, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
     }
     {

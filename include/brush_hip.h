@@ -330,8 +330,9 @@ typedef struct BhTrainBatch {
 typedef struct BhTrainStats {
     uint32_t num_visible, num_intersections;
     double lr_mean;
-    float loss; /* written by the next bh_sync on this ctx (the struct must stay alive until then);
-                   0 until then, and only the most recent step's stats are completed */
+    float loss; /* delivered by the next host wait on this ctx — bh_sync, bh_refine_plan, bh_splat_bounds (or the next
+                   bh_train_step, which replaces the pending delivery): the struct must stay alive until one of them has
+                   returned.  0 until then, and only the most recent step's stats are completed */
     uint32_t exchange_rows; /* exchange_mode 1: gradient rows in the compact block this step (0 = dense block was sent) */
 } BhTrainStats;
 
