@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract: see the task statement), including
   non_saturating — a second, non-headline measurement on a scene whose tiles do not saturate early
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -333,11 +334,16 @@ def main():
         # costs ~0.1 ms of host time per step, so the per-stage table comes from a separate untimed pass
         ctx.profile(2)
         ctx.profile_fetch()
+        # (the interpreter's cyclic collector stays out of the timed regions: a generation-2 sweep of this process' heap is a
+        #  30-50 ms host stall that lands on whichever call happens to cross its allocation threshold)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(steps):
             trainer.step(next_batch(), splats)
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         dominant = ctx.profile_fetch()
         stages = {}
         if with_stages:
@@ -370,16 +376,29 @@ def main():
             # blend into a packed rgba8 image, no visible[] / list shrinking / backward state; each call ends with the host having the
             # counts (the call's one readback), as the reference's render does.  Timed as wall time over back-to-back calls.
             fwd_only = {}
+            far0 = int(ctx.lib.bh_far_slices_queued(ctx._h))
             for mode, sliced in (("exact_lists", False), ("sliced_lists", True)):
                 for _ in range(5):
                     ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sliced)
                 torch.cuda.synchronize(dev)
                 reps = 50
+                per_call = []
+                gc.collect()
+                gc.disable()
                 t0 = time.perf_counter()
                 for _ in range(reps):
+                    tc = time.perf_counter()
                     ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sliced)
+                    per_call.append(time.perf_counter() - tc)
                 torch.cuda.synchronize(dev)
                 fwd_only[mode] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+                gc.enable()
+                if os.environ.get("BH_BENCH_DEBUG"):
+                    pc = sorted(per_call)
+                    print("forward_only %s: per-call host ms min %.3f median %.3f max %.3f (call %d)" % (mode, pc[0] * 1e3, pc[len(pc) // 2] * 1e3, pc[-1] * 1e3, per_call.index(pc[-1])), file=sys.stderr)
+                if sliced:
+                    fwd_only["near_share"] = round(float(ctx.lib.bh_last_list_share(ctx._h)), 4)
+                    fwd_only["far_slices_queued"] = int(ctx.lib.bh_far_slices_queued(ctx._h)) - far0
         return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, stages=stages, stats=st, isect_blended=isect_blended, loader=loader is not None,
                     list_share=list_share, forward_only=fwd_only)
 
@@ -529,7 +548,8 @@ def main():
             out["sh3"] = sh3
         if m.get("forward_only"):
             out["forward_only"] = {"workload": "%s, RasterPass::Forward (BASELINE.json configs[1]): packed rgba8 image, no backward state; ms per render call incl. its count readback" % args.workload,
-                                   "ms_exact_lists": m["forward_only"]["exact_lists"], "ms_sliced_lists": m["forward_only"]["sliced_lists"]}
+                                   "ms_exact_lists": m["forward_only"]["exact_lists"], "ms_sliced_lists": m["forward_only"]["sliced_lists"],
+                                   "near_share": m["forward_only"].get("near_share"), "far_slices_queued": m["forward_only"].get("far_slices_queued")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["scene"], m["cp"], w, h)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -758,6 +758,7 @@ int bh_set_list_slicing(bh_ctx* ctx, float near_share) {
 }
 
 float bh_last_list_share(bh_ctx* ctx) { return ctx ? ctx->last_slice_share : 0.0f; }
+uint32_t bh_far_slices_queued(bh_ctx* ctx) { return ctx ? ctx->far_launches : 0u; }
 
 // ---- backward ------------------------------------------------------------------
 int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,

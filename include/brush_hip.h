@@ -178,6 +178,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
+/* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far slice (diagnostics: on a scene that
+ * saturates, with the automatic share, this stops growing after the first frames) */
+uint32_t bh_far_slices_queued(bh_ctx* ctx);
 
 /* Backward of the last BH_FLAG_BWD_INFO forward on this ctx.  v_output [H,W,4].
  * All four outputs are dense and fully overwritten (zero where the splat got no
