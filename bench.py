@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the second (non-saturating scene) measurement")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run a short bench under rocprofv3 --pmc for the counter figures (use the committed CSVs, marked stale)")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage HIP-event pass (child runs under rocprofv3 use it)")
     ap.add_argument("--no-noise", action="store_true", help="leave out the two stochastic terms of the reference's default step (mean noise, background jitter)")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="N>1 gradient exchange: 'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in "
@@ -346,7 +347,7 @@ def main():
         gc.enable()
         dominant = ctx.profile_fetch()
         stages = {}
-        if with_stages:
+        if with_stages and not args.no_stages:
             ctx.profile(1)
             nst = min(steps, 10)
             for _ in range(nst):
@@ -467,11 +468,26 @@ def main():
         nv, ni = st.num_visible, st.num_intersections
         pixels, tiles = w * h, ((w + 15) // 16) * ((h + 15) // 16)
         sb = stage_bytes(n, nv, ni, m["isect_blended"], pixels, tiles, coeffs)
+        # per-stage GPU time: the kernels' own timestamps (a child run under rocprofv3 --kernel-trace) when rocprofv3 is there,
+        # else HIP events around each stage — which are host-bound while they record and read multi-launch stages too long
+        headline_n1 = args.workload == "1m_1080p" and args.sh_degree == 0 and not args.splats and world == 1 and args.feed == "resident"
+        ktrace = kernel_trace_inrun(args) if (headline_n1 and not args.no_pmc) else None
+        stage_ms = {name: ms / max(calls, 1) for name, (ms, calls) in m["stages"].items() if calls}
+        stage_src = "HIP events around each stage (host-bound while recording: multi-launch stages read long)"
+        if ktrace:
+            dom = stage_ms.get("RasterizeBackwards")
+            stage_ms = {k: v / 1e3 for k, v in ktrace["stages_us"].items()}
+            stage_src = "kernel timestamps: rocprofv3 --kernel-trace --stats over a %d-step child run of this command" % ktrace["steps"]
+            if dom:   # the dominant kernel: measured inside the parent's timed region (its launch carries its own events)
+                stage_ms["RasterizeBackwards"] = dom
+                m["stages"]["RasterizeBackwards"] = (dom, 1)
+            for k, v in stage_ms.items():
+                if k != "RasterizeBackwards":
+                    m["stages"][k] = (v, 1)
         stage_out = {}
-        for name, (ms, calls) in m["stages"].items():
-            if calls == 0 or (name == "ZeroGradBuffers" and ms / max(calls, 1) < 0.004):
+        for name, avg in stage_ms.items():
+            if name == "ZeroGradBuffers" and avg < 0.004:
                 continue   # an empty scope (the fills ride on K1 / K5): nothing to report
-            avg = ms / max(calls, 1)
             e = {"ms": round(avg, 4)}
             if name in sb and avg > 0:
                 e["MB"] = round(sb[name] / 1e6, 2)
@@ -485,6 +501,7 @@ def main():
         bwd_names = ["ZeroGradBuffers", "RasterizeBackwards", "ProjectBackwards"]
         fwd_ms = sum(stage_out[k]["ms"] for k in fwd_names if k in stage_out)
         bwd_ms = sum(stage_out[k]["ms"] for k in bwd_names if k in stage_out)
+        fwd_src = stage_src
         hbm, valu = blend_rooflines(m, steps)
         # the committed PMC passes were taken on the headline workload: no counter figure for any other
         headline = args.workload == "1m_1080p" and args.sh_degree == 0 and not args.splats and not tile_mode
@@ -534,6 +551,8 @@ def main():
                           "selfcheck": selfcheck} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
+            "fwd_bwd_source": fwd_src,
+            "kernel_trace": ({"steps": ktrace["steps"], "kernels": ktrace["kernels"]} if ktrace else None),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),
             "roofline": hbm,
             "roofline_valu": valu,
@@ -556,6 +575,57 @@ def main():
     if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+KERNEL_STAGE = (("project_forward_kernel", "ProjectSplats"), ("dsort_", "DepthSort"), ("map_gaussians_kernel", "MapGaussiansToIntersect"),
+                ("slice_count_kernel", "MapGaussiansToIntersect"), ("scan_", "MapGaussiansToIntersect"), ("radix_", "TileSort"),
+                ("tile_offsets_kernel", "GetTileOffsets"), ("rasterize_backward_kernel", "RasterizeBackwards"), ("rasterize_kernel", "Rasterize"),
+                ("loss_fused_forward_kernel", "ImageLoss"), ("loss_fused_backward_kernel", "ImageLossBackward"),
+                ("project_backward_kernel", "ProjectBackwards"), ("train_update_kernel", "OptimizerStep"), ("project_visible_kernel", "ProjectVisible"))
+
+
+def kernel_trace_inrun(args):
+    """Per-stage GPU time from the kernels' own timestamps: one child run of this command (100 steps) under
+    `rocprofv3 --kernel-trace --stats`, every library kernel's total duration / number of steps, summed by stage.  The HIP-event
+    stage table of the parent run brackets each stage with two event records and is host-bound while it does so (~30 records per
+    step): stages made of several short launches read up to 2x too long there.  Returns {stage: us per step} or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if os.environ.get("BH_BENCH_PMC_CHILD") == "1" or not shutil.which("rocprofv3"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bh_trace_", dir="/tmp")
+    env = dict(os.environ, BH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--no-stages",
+             "--lists", args.lists] + (["--no-noise"] if args.no_noise else [])
+    try:
+        p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--"] + child, cwd="/tmp", env=env,
+                           capture_output=True, text=True, timeout=300)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None
+        rows = list(csv.DictReader(open(files[0])))
+        steps = next((int(r["Calls"]) for r in rows if "train_update_kernel" in r["Name"]), 0)
+        if steps <= 0:
+            return None
+        per_stage, per_kernel = {}, {}
+        for r in rows:
+            name = r["Name"]
+            if "bh::" not in name:
+                continue
+            short = name.replace("void ", "").replace("bh::", "").split("(")[0]
+            us = float(r["TotalDurationNs"]) / 1e3 / steps
+            per_kernel[short] = {"us_per_step": round(us, 2), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "calls": int(r["Calls"])}
+            for key, stage in KERNEL_STAGE:
+                if key in short:
+                    per_stage[stage] = per_stage.get(stage, 0.0) + us
+                    break
+        return {"steps": steps, "stages_us": {k: round(v, 2) for k, v in per_stage.items()}, "kernels": per_kernel}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_inrun(args):

@@ -665,7 +665,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             }
             {
                 ProfScope ps(ctx, "TileSort");
-                if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted));
+                // (scratch sized for the whole list: the budget moves with every frame's feedback)
+                if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
                 else BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, tile_bits, tile_ids_sorted, isect_gids_sorted));
             }
         }

@@ -283,7 +283,7 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
 // the same with the number of pairs in device memory (host: only the bound n_max): n = min(*n_dev, n_max), 0 if *gate == 0
 // (gate may be NULL); the result is written *out_base elements into out_keys / out_vals (out_base may be NULL).  Not in place.
 int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
-                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals);
+                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals, uint32_t alloc_n = 0);
 // depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
 // order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.
 bool depth_sort_supported(uint32_t n);

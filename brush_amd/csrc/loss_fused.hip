@@ -83,6 +83,14 @@ namespace {
 constexpr int TW = 16, TH = 32;
 constexpr int SW = TW + 2 * HALO;   // 26
 constexpr int SR = TH + 2 * HALO;   // 42
+#ifndef BH_LOSS_HP
+#define BH_LOSS_HP (TW * 5)
+#endif
+#ifndef BH_LOSS_H2P
+#define BH_LOSS_H2P 24   /* 2 rows apart = 48 floats = 16 banks: the two output rows of a 32-lane half never share a bank (65.0 vs 66.2 us) */
+#endif
+constexpr int HP = BH_LOSS_HP;      // row pitch (floats) of pass A's horizontally blurred moments
+constexpr int H2P = BH_LOSS_H2P;    // ... of pass B's
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
                                                                 float* __restrict__ partials /*[3][3][H][W]*/,
                                                                 float* __restrict__ block_sums /*per 16-row tile row*/, uint32_t gy, FusedArgs a) {
     __shared__ float2 s_tile[3][SR * SW];          // (pred, gt_eff) per colour plane
-    __shared__ float s_h[SR * TW * 5];             // horizontally blurred moments of ONE plane
+    __shared__ float s_h[SR * HP];                 // horizontally blurred moments of ONE plane
     __shared__ float s_red[4];
     const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
                 sy += y[cc] * wc;
                 sy2 += yy[cc] * wc;
                 sxy += xy[cc] * wc;
-                float* op = &s_h[(r * TW + 2 * pair + o) * 5];
+                float* op = &s_h[r * HP + (2 * pair + o) * 5];
                 op[0] = sx; op[1] = sx2; op[2] = sy; op[3] = sy2; op[4] = sxy;
             }
         }
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
         float v[12][5];
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
-            const float* t = &s_h[((2 * ly + r) * TW + lx) * 5];
+            const float* t = &s_h[(2 * ly + r) * HP + lx * 5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[r][k] = t[k];
         }
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* _
                                                                  const float* __restrict__ partials /*[3][3][H][W]*/,
                                                                  float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
     __shared__ float s_part[3][SR * SW];       // chain * (dmu1, dsigma1, dsigma12) of ONE colour plane
-    __shared__ float s_h2[3][SR * TW];
+    __shared__ float s_h2[3][SR * H2P];
     // strip-wise loss: the launch covers pixel rows [row0, row1) (whole 16-row tile rows); blocks are 32 rows tall
     const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
@@ -313,14 +321,14 @@ __global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* _
 #pragma unroll
             for (int d = 1; d < 6; ++d) acc += (row[col - d] + row[col + d]) * a.taps.w[5 - d];
             acc += row[col] * a.taps.w[5];
-            s_h2[j][rem] = acc;
+            s_h2[j][r * H2P + (col - HALO)] = acc;
         }
         __syncthreads();
         float v[3][12];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 12; ++r) v[j][r] = s_h2[j][(2 * ly + r) * TW + lx];
+            for (int r = 0; r < 12; ++r) v[j][r] = s_h2[j][(2 * ly + r) * H2P + lx];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             float sres[3];

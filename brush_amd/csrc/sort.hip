@@ -270,8 +270,10 @@ __global__ __launch_bounds__(SORT_WG) void radix_scatter_kernel(const uint32_t* 
     }
 }
 
+// alloc_n >= n: what the scratch slots are sized for (a caller whose bound n moves from frame to frame passes its largest: the
+// arena only grows, and growing waits for the stream)
 static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
-                              uint32_t* out_keys, uint32_t* out_vals, const SortDyn& dyn) {
+                              uint32_t* out_keys, uint32_t* out_vals, const SortDyn& dyn, uint32_t alloc_n = 0) {
     if (bits > 32) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: bits must be <= 32");
     if (n == 0) return 0;
     const bool dynamic = dyn.n_dev || dyn.gate || dyn.out_base;
@@ -287,8 +289,11 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
     const uint32_t tile = SORT_WG * kpt;
     const uint32_t nblocks = (n + tile - 1) / tile;
     const size_t bytes = (size_t)n * 4;
+    if (alloc_n < n) alloc_n = n;
+    const size_t alloc_bytes = (size_t)alloc_n * 4;
+    const uint32_t alloc_blocks = (alloc_n + tile - 1) / tile;
     // [256] digit totals followed by the [256][nblocks] table
-    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * nblocks + RADIX) * 4);
+    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * alloc_blocks + RADIX) * 4);
     if (!totals) return BH_ERR_OOM;
     uint32_t* hist = totals + RADIX;
     // (a device-side length always takes the row scan: it walks only the live part of each row, however long the table)
@@ -301,13 +306,13 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
     const bool in_place = keys == out_keys || (vals && vals == out_vals);
     if (dynamic && in_place) return set_error(ctx, BH_ERR_INVALID_ARG, "radix_argsort: a device-length sort needs distinct input and output buffers");
     if (passes > 1 || in_place) {
-        sk[0] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, bytes);
-        sv[0] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, bytes);
+        sk[0] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, alloc_bytes);
+        sv[0] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, alloc_bytes);
         if (!sk[0] || !sv[0]) return BH_ERR_OOM;
     }
     if (passes > 2) {
-        sk[1] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_B, bytes);
-        sv[1] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_B, bytes);
+        sk[1] = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_B, alloc_bytes);
+        sv[1] = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_B, alloc_bytes);
         if (!sk[1] || !sv[1]) return BH_ERR_OOM;
     }
     const uint32_t* src_k = keys;
@@ -362,12 +367,12 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
 }
 
 int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
-                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals) {
+                      const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals, uint32_t alloc_n) {
     SortDyn dyn;
     dyn.n_dev = n_dev;
     dyn.gate = gate;
     dyn.out_base = out_base;
-    return radix_argsort_impl(ctx, keys, vals, n_max, bits, out_keys, out_vals, dyn);
+    return radix_argsort_impl(ctx, keys, vals, n_max, bits, out_keys, out_vals, dyn, alloc_n);
 }
 
 }  // namespace bh

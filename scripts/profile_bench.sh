@@ -5,10 +5,10 @@ TAG=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-pmc"
 # the kernel trace over a run long enough for the clocks to settle: with 13 steps the profiled process reads ~10 % slower
 # than an unprofiled one, with 200 the trace's averages and the bench's own events agree to 0.3 %
-LONG="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra"
+LONG="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $LONG > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace exit $?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.err
