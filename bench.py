@@ -113,9 +113,10 @@ def dry_run(args):
 def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args):
     """Before anything is timed with N > 1 ranks: prove the exchange path that is about to be timed.
       (1) all-reduce of ones through each available path (the library's RCCL communicator, the torch.distributed hook) == world;
+      (1b) all-reduce of a 56 MB rank-weighted integer pattern == its closed form, bit for bit;
       (2) two train steps of a small scene from identical replicas through each path: parameters bit-identical across the
           ranks, and equal between the two paths to 1e-6 (beyond that only where Adam turned a gradient that is summation-
-          order noise into a +-lr step: a bounded fraction).
+          order noise into a +-lr step: a bounded fraction; the fraction is recorded).
     Returns (use_native, record).  A failing native path falls back to the hook LOUDLY; if the hook fails too the run is
     refused (non-zero exit, no JSON line).  A 60-s watchdog refuses a hung collective the same way."""
     import threading
@@ -147,6 +148,18 @@ def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args
         torch.cuda.synchronize(dev)
         if not bool((ones == float(world)).all()):
             raise RuntimeError("all-reduce of ones gave %r ... expected %d everywhere" % (ones[:2].tolist(), world))
+        # ... and of a rank-dependent pattern the size of the real gradient block (56 MB): sum_r (r+1) * (i mod 4096) is exact in f32
+        big = (torch.arange(14 * 1024 * 1024, device=dev, dtype=torch.int32) % 4096).to(torch.float32)
+        want = big * float(world * (world + 1) // 2)
+        mine = big * float(rank + 1)
+        if use_native:
+            ctx.allreduce_sum(mine)
+        else:
+            dist.all_reduce(mine)
+        torch.cuda.synchronize(dev)
+        if not torch.equal(mine, want):
+            raise RuntimeError("all-reduce of a 56 MB rank-weighted pattern is wrong in %d places" % int((mine != want).sum().item()))
+        del big, want, mine
         splats = ba.Splats(scene["transforms"].copy(), scene["sh"].copy(), scene["raw_opac"].copy(), device=dev)
         tr = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=3.0, process_group=None if use_native else pg, ctx=ctx,
                              partition=args.parallel, native_comm=use_native, sparse_exchange=args.exchange == "sparse", seed=0xB5EED)
@@ -184,7 +197,9 @@ def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args
         d = (results["native"] - results["torch"]).abs()
         rec["paths_max_abs_diff"] = float(d.max().item())
         rec["paths_frac_beyond_1e-6"] = float((d > 1e-6).float().mean().item())
-        if rec["paths_frac_beyond_1e-6"] > 1e-3:
+        # (two runs of the SAME path already differ in ~0.1 % of the entries: the backward's float atomics order its sums differently
+        #  every launch and Adam turns a noise gradient's sign into a +-lr step; a wrong sum moves every visible splat)
+        if rec["paths_frac_beyond_1e-6"] > 2e-2:
             rec["native"] = "FAILED: disagrees with the torch.distributed path (%.3g of the parameters beyond 1e-6, max %.3g)" % (rec["paths_frac_beyond_1e-6"], rec["paths_max_abs_diff"])
     use_native = native and rec.get("native") == "ok"
     if native and not use_native:

