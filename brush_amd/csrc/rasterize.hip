@@ -217,6 +217,9 @@ struct SliceArgs {
     uint32_t* feedback = nullptr;           // [COUNTER_SLOTS][2]: max slots a saturated tile needed | listed pairs of unsaturated tiles
 };
 
+#ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
+__device__ unsigned long long g_k16_trace[65536 * 4];
+#endif
 template <bool BWD_INFO, bool SMOOTH, int PHASE>
 __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
@@ -227,6 +230,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
     if (local_tile >= u.num_tiles) return;
     const uint32_t tile = u.tile_begin + local_tile;
+#ifdef BH_K16_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     if (PHASE == 2) {
         if (*sl.unsat_count == 0u) return;                                     // the near slice finished the frame
         if ((sl.done_bits[tile >> 5] >> (tile & 31u)) & 1u) return;            // ... or this tile
@@ -364,6 +370,16 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
         }
     }
+#ifdef BH_K16_TRACE
+    if (lane == 0 && blockIdx.x < 65536u) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* tr = &g_k16_trace[(size_t)blockIdx.x * 4];
+        tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = ((unsigned long long)xcc << 32) | hwid; tr[3] = ((unsigned long long)tile << 32) | (last_useful - range_lo);
+    }
+#endif
     if (lane == 0) {
         if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
         uint32_t work = last_useful - range_lo;
@@ -734,3 +750,9 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
 }
 
 }  // namespace bh
+
+#ifdef BH_K16_TRACE
+extern "C" int bh_debug_k16_trace(unsigned long long* host_out, unsigned long long count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bh::g_k16_trace), count * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
