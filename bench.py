@@ -293,18 +293,32 @@ def main():
         ba.set_list_slicing(args.near_share, ctx)
     native = args.comm == "native" and not tile_mode and pg is not None
     if native:
+        import threading
         import torch.distributed as dist
         # rank 0's RCCL unique id travels over the process group that exists anyway (used for the barriers and the timing MAX)
         ids = [bytes(ba.Context.comm_unique_id()) if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0, device=dev)
-        try:
-            ctx.comm_init(rank, world, ids[0])
-        except Exception as e:  # both paths are RCCL; say which one ran (the line's "exchange.comm")
-            print("bench.py: library communicator unavailable (%s); using the torch.distributed exchange hook" % (e,), file=sys.stderr)
+        # ncclCommInitRank blocks until every rank has joined: run it beside a timer, so that a rendezvous that never completes
+        # (this communicator has never met more than one rank on hardware) costs 45 s and the native path, not the run
+        init_result = {}
+
+        def _init():
+            try:
+                ctx.comm_init(rank, world, ids[0])
+                init_result["ok"] = True
+            except Exception as e:  # both paths are RCCL; say which one ran (the line's "exchange.comm")
+                init_result["err"] = e
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(45.0)
+        if not init_result.get("ok"):
+            why = init_result.get("err", "no answer from ncclCommInitRank within 45 s")
+            print("bench.py: library communicator unavailable (%s); using the torch.distributed exchange hook" % (why,), file=sys.stderr)
             native = False
         ok = torch.tensor([1 if native else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if native and int(ok.item()) == 0:
+            print("bench.py: another rank could not create its library communicator; every rank uses the torch.distributed exchange hook", file=sys.stderr)
             native = False
     selfcheck = None
     if pg is not None:
