@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     // minus what has been replayed) and only ever uses it inside a dot product with the pixel's v_rgb, so the state kept here
     // is that dot product: S = remaining . v_rgb (one register and one fma per update instead of three).  T = 0: finished.
     float sS[4], sw[4];
-    float vox[4], voy[4], voz[4], v_o_w[4], inv_fa[4];
+    float vox[4], voy[4], voz[4], inv_fa[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
@@ -580,14 +580,16 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
             const float4 o = *reinterpret_cast<const float4*>(&out_img[pix]);
             const float4 vo = *reinterpret_cast<const float4*>(&v_output[pix]);
             const float t_final = 1.0f - o.w;
-            sS[q] = __builtin_fmaf(o.z - t_final * u.bg_b, vo.z, __builtin_fmaf(o.y - t_final * u.bg_g, vo.y, (o.x - t_final * u.bg_r) * vo.x));
+            // ... minus the pixel's constant term v_o_w = (v_A - bg . v_rgb) T_final, which only ever appears added to it (…:300-310):
+            // S' = remaining . v_rgb - v_o_w   (one register and one add per pixel-quadrant less)
+            const float v_o_w = (vo.w - (u.bg_r * vo.x + u.bg_g * vo.y + u.bg_b * vo.z)) * t_final;
+            sS[q] = __builtin_fmaf(o.z - t_final * u.bg_b, vo.z, __builtin_fmaf(o.y - t_final * u.bg_g, vo.y, (o.x - t_final * u.bg_r) * vo.x)) - v_o_w;
             sw[q] = 1.0f;
             vox[q] = vo.x; voy[q] = vo.y; voz[q] = vo.z;
-            v_o_w[q] = (vo.w - (u.bg_r * vo.x + u.bg_g * vo.y + u.bg_b * vo.z)) * t_final;
             inv_fa[q] = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
         } else {
             sS[q] = sw[q] = 0.0f;
-            vox[q] = voy[q] = voz[q] = v_o_w[q] = 0.0f;
+            vox[q] = voy[q] = voz[q] = 0.0f;
             inv_fa[q] = 1.0f;
         }
     }
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                         const float ra = __builtin_amdgcn_rcpf(one_m);
                         // (T c - remaining) . v_rgb = T (c . v_rgb) - S
                         const float cv = __builtin_fmaf(cb, voz[q], __builtin_fmaf(cgc, voy[q], cr * vox[q]));
-                        const float v_alpha_eff = (__builtin_fmaf(T, cv, -sS[q]) + v_o_w[q]) * ra;
+                        const float v_alpha_eff = __builtin_fmaf(T, cv, -sS[q]) * ra;
                         const float v_alpha = SMOOTH ? v_alpha_eff * (w_cut + alpha * alpha_cutoff_weight_deriv(alpha)) : v_alpha_eff;
                         // geometry / opacity / refine grads only below the alpha clamp (…:332)
                         const float v_sigma = (!CLAMP || alpha_raw <= 0.999f) ? -alpha * v_alpha : 0.0f;
