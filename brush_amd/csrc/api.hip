@@ -611,8 +611,15 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             const double prev = (double)ctx->prev_intersections;
             if (!ctx->had_forward || prev == 0.0) share = 0.25f;
             else if ((double)fb_unsat_pairs > 0.5 * prev) share = 1.0f;        // most of the list belongs to tiles that never saturate
-            else if (fb_need == 0u) share = 0.25f;
-            else share = (float)(1.25 * (double)fb_need / prev);
+            else if (fb_need == 0u && ctx->need_hint <= 0.0f) share = 0.25f;
+            else {
+                // what recent frames needed, not just the last one: a training loop cycles through its views, and a near slice
+                // sized for the shallowest of them sends every deeper one through the far slice (~150 us incl. the loss evaluated
+                // twice) — a larger near slice costs a few microseconds.  The memory fades by 10 % per frame.
+                const float now = (float)((double)fb_need / prev);
+                ctx->need_hint = now > ctx->need_hint * 0.9f ? now : ctx->need_hint * 0.9f;
+                share = 1.25f * ctx->need_hint;
+            }
             if (share > 0.7f) share = 1.0f;
         }
         if (share < 1.0f) {

@@ -181,6 +181,7 @@ struct bh_ctx {
     float slice_fraction = 0.0f;
     bool had_forward = false;         // a forward ran on this ctx before (its feedback words are meaningful)
     uint32_t prev_intersections = 0;  // ... and listed this many pairs
+    float need_hint = 0.0f;           // fading maximum of the share of the pair list recent frames' slowest saturating tile needed
     float last_slice_share = 1.0f;    // what the last sliced forward used (1 = one slice = the exact lists); diagnostics
     // The far slice costs ~12 launches even when every one of them is a no-op (~4.5 us each on this chip), so whether to queue
     // it is decided on the HOST where possible: far_direct = the previous sliced frame needed it -> queue it right away

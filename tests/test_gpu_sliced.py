@@ -236,3 +236,30 @@ def test_train_step_sliced_equals_exact(dev, sh_degree):
     util.assert_adam_close(res[True][3], res[False][3], cfg.lr_opac, 3, "opacity")
     util.assert_adam_close(res[True][2], res[False][2], cfg.lr_coeffs_dc, 3, "sh")
     assert np.mean(res[True][5] != res[False][5]) <= 2e-3
+
+
+def test_alternating_views_do_not_thrash_the_far_slice(dev):
+    """a shallow and a deep view in turn: the near slice is sized by what RECENT frames needed (a fading maximum), so after the
+    first round trip the deep view no longer falls through to the far slice every other frame"""
+    import brush_amd as ba
+    n, w, h = 60000, 320, 208
+    ctx = ba.Context(dev)
+    try:
+        sc, cp = _scene(n, w, h, 0x59, scales=(0.03, 0.3))
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        near_cam = util.hip_camera(ba, cp)
+        far = dict(cp)
+        far["pos"] = (0.0, 0.0, -6.0)          # from further away the splats are smaller on screen: tiles saturate deeper in the list
+        far_cam = util.hip_camera(ba, far)
+        ref = {}
+        for name, cam in (("near", near_cam), ("far", far_cam)):
+            ref[name] = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx)[0]
+        queued = []
+        for i in range(14):
+            name, cam = (("near", near_cam), ("far", far_cam))[i % 2]
+            img, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+            assert torch.equal(img, ref[name])
+            queued.append(int(ctx.lib.bh_far_slices_queued(ctx._h)))
+        assert queued[-1] - queued[3] <= 1, queued   # at most one more far slice after the first two rounds
+    finally:
+        ctx.close()
