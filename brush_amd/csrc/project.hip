@@ -556,7 +556,10 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     if (slice_info) {   // the near slice of a sliced frame: few, large splats (see SPW)
-        constexpr int SPW = 16;
+#ifndef BH_K5_SPW
+#define BH_K5_SPW 16
+#endif
+        constexpr int SPW = BH_K5_SPW;
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                            projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
