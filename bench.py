@@ -630,7 +630,7 @@ def kernel_trace_inrun(args):
              "--lists", args.lists] + (["--no-noise"] if args.no_noise else [])
     try:
         p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--"] + child, cwd="/tmp", env=env,
-                           capture_output=True, text=True, timeout=300)
+                           capture_output=True, text=True, timeout=120)
         files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
         if p.returncode != 0 or not files:
             return None
@@ -679,7 +679,7 @@ def pmc_inrun(args):
         for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             p = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=90)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return None

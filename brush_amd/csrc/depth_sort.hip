@@ -637,7 +637,10 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
 }
 
 // the fused path pays off while launches, not bytes, are the cost; beyond this the generic sort + scan run (6 M splats: 0.5 ms of an 8.7 ms step)
-constexpr uint32_t DSORT_MAX_N = 4u << 20;
+#ifndef BH_DSORT_MAX_N
+#define BH_DSORT_MAX_N (4u << 20)
+#endif
+constexpr uint32_t DSORT_MAX_N = BH_DSORT_MAX_N;
 bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n + DS_TILE - 1) / DS_TILE <= (uint32_t)DS_ROW_EPT * DS_WG; }
 
 // keys: [n] depth keys (culled = 0xFFFFFFFF); minmax: K1's [COUNTER_SLOTS][2] (max key, max ~key over visible splats);
