@@ -1082,16 +1082,30 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     const bool keyed = exchanging && batch->exchange_mode == 1 && n > 0;
     uint32_t* union_idx = nullptr;
     float* compact = nullptr;
+    bool flags_on_side = false;
     if (keyed) {
         ProfScope ps(ctx, "FlagExchange");
         const uint32_t nblk = (n + 4095u) / 4096u;
         auto* blocks = (uint32_t*)ensure(ctx, SLOT_EXCH_BLOCKS, ((size_t)nblk + 2) * 4);   // [nblk] block offsets, then the total
         union_idx = (uint32_t*)ensure(ctx, SLOT_EXCH_IDX, (size_t)n * 4);
         if (!blocks || !union_idx) return BH_ERR_OOM;   // (the compact block is sized once the union's size is known, below)
-        BH_TRY(sum_over_ranks(exch, (uint64_t)o_tr));
-        BH_TRY(launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx));
-        BH_HIP(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+        // The library's communicator runs this on its own stream: the flag sum (4 B per splat over xGMI), the union listing and the
+        // count's way to the host then overlap the backward on the ctx stream instead of standing in front of it; nothing on the
+        // ctx stream touches the flag section before the update, which waits for the side stream below.  (A caller's hook decides
+        // its own streams.)
+        flags_on_side = !hook && ctx->comm_stream != nullptr;
+        hipStream_t main_stream = ctx->stream;
+        if (flags_on_side) {
+            BH_HIP(ctx, hipEventRecord(ctx->comm_ev, main_stream));
+            BH_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ev, 0));
+            ctx->stream = ctx->comm_stream;   // (single-threaded ctx: the launchers below take the stream from it)
+        }
+        int rc = sum_over_ranks(exch, (uint64_t)o_tr);
+        if (rc == 0) rc = launch_union_index(ctx, s_visible, n, blocks, blocks + nblk, union_idx);
+        if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(reinterpret_cast<uint32_t*>(ctx->host_counters) + 8, blocks + nblk, 4, hipMemcpyDeviceToHost, ctx->stream), "flag count readback");
+        if (rc == 0) rc = check_hip(ctx, hipEventRecord(ctx->readback_ev, ctx->stream), "flag count event");
+        ctx->stream = main_stream;
+        BH_TRY(rc);
     }
 
     // ---- backward (train.rs:278)
@@ -1118,6 +1132,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
             float* g_ref = tile_mode ? s_refine : nullptr;
             const uint32_t c3 = 3 * C, k = 11 + c3 + (tile_mode ? 1u : 0u);
             BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+            if (flags_on_side) BH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->readback_ev, 0));   // the union list and the summed flags are the side stream's
             const uint32_t rows = reinterpret_cast<uint32_t*>(ctx->host_counters)[8];
             if (rows == 0) {
                 // no rank saw any splat: every gradient row is zero everywhere, nothing to send (same decision on all ranks)

@@ -111,6 +111,14 @@ int bh_comm_init(bh_ctx* ctx, int rank, int world, const void* unique_id) {
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
+    // side stream for the flag exchange (api.hip); without it the exchange simply stays on the ctx stream
+    if (hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->comm_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->comm_stream = nullptr;
+        ctx->comm_ev = nullptr;
+    }
     return 0;
 }
 
@@ -119,6 +127,8 @@ int bh_comm_destroy(bh_ctx* ctx) {
     if (!ctx->comm) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
+    if (ctx->comm_ev) { (void)hipEventDestroy(ctx->comm_ev); ctx->comm_ev = nullptr; }
     const int rc = rccl().CommDestroy((RcclComm)ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_world = 1;

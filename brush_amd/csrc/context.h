@@ -174,6 +174,10 @@ struct bh_ctx {
     bool grads_prezeroed = false, vcombined_prezeroed = false;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
+    // the library communicator's side stream: the mask-keyed exchange sums the visible flags and lists their union there,
+    // beside the backward on the ctx stream (api.hip); comm_ev marks "the forward is done" for it
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ev = nullptr;
     int comm_rank = 0, comm_world = 1;
     uint32_t* lpt = nullptr;          // longest-first tile order of the last BWD_INFO forward (rasterize.hip), or NULL
     // depth-sliced lists (BH_FLAG_SLICED_LISTS): share of the pair list the near slice takes.  <= 0: chosen per frame from the
@@ -345,7 +349,7 @@ int launch_fold_min_scale_backward(bh_ctx* ctx, const float* transforms, const f
 int launch_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const float* view_cams, uint32_t k, float factor, float* out);
 
 // comm.hip — in-place all-reduce of `count` floats over the ctx's RCCL communicator, on the ctx stream
-int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);
+int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);   // on ctx->stream
 
 // exchange.hip — compaction kernels of the mask-keyed gradient exchange
 int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* block_scratch /*[n/4096+2]*/, uint32_t* count_dev,
