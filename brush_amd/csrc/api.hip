@@ -512,6 +512,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     uint32_t nv = 0, ni = 0;
     uint32_t fb_need = 0;                  // previous forward: most exact-list slots any saturated tile needed
     unsigned long long fb_unsat_pairs = 0; // ... and pairs it listed for tiles that never saturated
+    uint32_t fb_unsat_tiles = 0;           // ... and how many such tiles there were (empty ones included)
     bool fused_scan = false;
     uint32_t* cum_early = nullptr;
     if (n > 0) {
@@ -572,12 +573,12 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         ni = (uint32_t)hc[1];
         // the previous forward's slicing hint came along in the same copy
         const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
-        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[2 * k] > fb_need) fb_need = hfb[2 * k]; fb_unsat_pairs += hfb[2 * k + 1]; }
+        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[3 * k] > fb_need) fb_need = hfb[3 * k]; fb_unsat_pairs += hfb[3 * k + 1]; fb_unsat_tiles += hfb[3 * k + 2]; }
     } else {   // no K1 to clear them on the way
         BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
         if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
         if (counter_pairs) {   // counter_phase does not flip without K1: clear what this frame's blend kernel will add to
-            BH_HIP(ctx, hipMemsetAsync(feedback_next, 0, COUNTER_SLOTS * 8, ctx->stream));
+            BH_HIP(ctx, hipMemsetAsync(feedback_next, 0, COUNTER_SLOTS * 12, ctx->stream));
         }
     }
 
@@ -621,6 +622,12 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 share = 1.25f * ctx->need_hint;
             }
             if (share > 0.7f) share = 1.0f;
+            // A frame with tiles that never saturate (a blank background: empty tiles count) needs its far slice EVERY time, and that
+            // costs about as much as listing and sorting 6 M pairs (~12 launches + the count walk over every far splat): slice only
+            // where the near slice saves more than that.  A one-slice frame's blend kernel reports the tiles too (above), so the
+            // decision follows the scene.
+            if (ctx->last_one_slice && ctx->had_forward) ctx->far_direct = fb_unsat_tiles != 0u;
+            if (share < 1.0f && ctx->far_direct && (1.0 - (double)share) * (double)ni < 6.0e6) share = 1.0f;
         }
         if (share < 1.0f) {
             const double b = (double)share * (double)ni;
@@ -755,6 +762,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     ctx->have_forward = true;
     ctx->had_forward = true;
     ctx->prev_intersections = ni;
+    ctx->last_one_slice = !sliced;
     return 0;
 }
 

@@ -74,16 +74,16 @@ constexpr int MAX_PROF = 32;
 constexpr uint32_t COUNTER_SLOTS = 128;
 // one counter set on the device:
 //   [COUNTER_SLOTS][2] u64  visible, intersections (K1's block totals)
-//   [COUNTER_SLOTS][2] u32  slicing feedback, written by the blend kernel of the forward BEFORE the one that accumulates into this
+//   [COUNTER_SLOTS][3] u32  slicing feedback, written by the blend kernel of the forward BEFORE the one that accumulates into this
 //                           set (rasterize.hip SliceArgs::feedback): max exact-list slots a saturated tile needed | pairs listed
-//                           for tiles that never saturated
+//                           for tiles that never saturated | number of such tiles (empty ones included)
 //   [COUNTER_SLOTS][2] u32  max depth key, max ~key over the visible splats: the key range the depth sort splits on.
 // The first two parts are read back together (one copy), the third stays on the device.
-constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8 + COUNTER_SLOTS * 8;
+constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12 + COUNTER_SLOTS * 8;
 constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
-constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 4;       // u32 index of the feedback part inside a set
-constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_SLOTS * 6;   // ... of the key-range part
-constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 8;
+constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 4;       // u32 index of the feedback part inside a set: [COUNTER_SLOTS][3]
+constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_SLOTS * 7;   // ... of the key-range part
+constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12;
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
@@ -184,6 +184,7 @@ struct bh_ctx {
     // previous frame's feedback (bh_set_list_slicing)
     float slice_fraction = 0.0f;
     bool had_forward = false;         // a forward ran on this ctx before (its feedback words are meaningful)
+    bool last_one_slice = true;       // ... and built one list per tile (exact path, or a sliced request that chose one slice)
     uint32_t prev_intersections = 0;  // ... and listed this many pairs
     float need_hint = 0.0f;           // fading maximum of the share of the pair list recent frames' slowest saturating tile needed
     float last_slice_share = 1.0f;    // what the last sliced forward used (1 = one slice = the exact lists); diagnostics

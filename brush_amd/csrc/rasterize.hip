@@ -214,7 +214,7 @@ struct SliceArgs {
     float* state = nullptr;                 // [H,W,4] raw rgb + signed T of those tiles
     const uint32_t* offsets_near = nullptr; // PHASE 2: the near slice's [T,2] table (shrunk ends: the tile's backward work so far)
     const uint32_t* cum = nullptr;          // cum_tiles_hit [Nv]: the exact list's slot ranges (feedback)
-    uint32_t* feedback = nullptr;           // [COUNTER_SLOTS][2]: max slots a saturated tile needed | listed pairs of unsaturated tiles
+    uint32_t* feedback = nullptr;           // [COUNTER_SLOTS][3]: max slots a saturated tile needed | listed pairs of unsaturated tiles | their number
 };
 
 #ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         // hint for the next frame's slicing (read back with its counters): how many slots of the exact list a tile needed before
         // it saturated (max over tiles), and how many pairs are listed for tiles that never saturate
         if (sl.feedback) {
-            uint32_t* fb = sl.feedback + 2u * (blockIdx.x & (COUNTER_SLOTS - 1u));
+            uint32_t* fb = sl.feedback + 3u * (blockIdx.x & (COUNTER_SLOTS - 1u));
             const uint32_t stop = BWD_INFO ? last_useful : reached;
             if (saturated) {
                 if (stop > range_lo) atomicMax(&fb[0], sl.cum[isect_gids[stop - 1u]]);
@@ -410,8 +410,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                     const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
                     if (n_hi > n_lo) atomicMax(&fb[0], sl.cum[isect_gids[n_hi - 1u]]);
                 }
-            } else if (listed) {
-                atomicAdd(&fb[1], listed);
+            } else {
+                if (listed) atomicAdd(&fb[1], listed);
+                atomicAdd(&fb[2], 1u);
             }
         }
     }

@@ -66,6 +66,10 @@ CONFIGS = {
     # pixels do not saturate after the first tenth of its list — the blend kernels then consume most of every list
     # (bench.py's second, non-headline measurement: their throughput on a scene that does not flatter them)
     "1m_1080p_lowopac": dict(n=1_000_000, w=1920, h=1080, seed=0xB1, log_scale_range=(math.log(0.005), math.log(0.05)), opacity_range=(0.02, 0.1)),
+    # NOT a BASELINE.json config: an object-centric frame — the configs[2] splats squeezed into the central half of the frustum, so
+    # that the outer tiles are empty (they never saturate: what a NeRF-synthetic view with a blank background looks like to the
+    # list builder)
+    "1m_1080p_centered": dict(n=1_000_000, w=1920, h=1080, seed=0xB1, log_scale_range=(math.log(0.005), math.log(0.05)), spread=0.5),
     # the SURVEY 8d "heavy" variant: scales U(ln 0.01, ln 0.1), I ~ 37 M
     "1m_1080p_heavy": dict(n=1_000_000, w=1920, h=1080, seed=0xB1, log_scale_range=(math.log(0.01), math.log(0.1))),
     # configs[4]: 6M splats, 4K
@@ -78,7 +82,7 @@ def config_scene(name, sh_degree=0, n=None):
     cam = default_camera_params(cfg["w"], cfg["h"])
     tans = (math.tan(cam["fov_x"] / 2.0), math.tan(cam["fov_y"] / 2.0))
     scene = make_scene(n or cfg["n"], cfg["seed"], sh_degree=sh_degree, log_scale_range=cfg["log_scale_range"],
-                       tan_half_fov=tans, opacity_range=cfg.get("opacity_range", (0.05, 0.95)))
+                       tan_half_fov=tans, opacity_range=cfg.get("opacity_range", (0.05, 0.95)), spread=cfg.get("spread", 1.1))
     return scene, cfg["w"], cfg["h"]
 
 

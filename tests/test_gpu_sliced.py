@@ -263,3 +263,28 @@ def test_alternating_views_do_not_thrash_the_far_slice(dev):
         assert queued[-1] - queued[3] <= 1, queued   # at most one more far slice after the first two rounds
     finally:
         ctx.close()
+
+
+def test_blank_background_keeps_one_slice_unless_the_saving_is_large(dev):
+    """an object-centric frame: the outer tiles are empty and never saturate, so a sliced frame needs its far slice every time —
+    about the price of listing 6 M pairs.  With a small pair list the automatic choice goes back to one slice after the first
+    probe (and stays there: a one-slice frame reports its never-saturating tiles too); images are the exact path's throughout."""
+    import brush_amd as ba
+    n, w, h = 60000, 320, 208
+    ctx = ba.Context(dev)
+    try:
+        sc = synth.make_scene(n, 0x5A, log_scale_range=(math.log(0.02), math.log(0.1)),
+                              tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), spread=0.45)
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        cam = util.hip_camera(ba, synth.default_camera_params(w, h))
+        ref, aux_e = ba.render_splats(spl, cam, (w, h), (0.2, 0.2, 0.2), ba.RasterPass.Backward, ctx=ctx)
+        assert float(ref[..., 3].min()) == 0.0                        # blank border: those tiles never saturate
+        shares = []
+        for _ in range(6):
+            img, aux = ba.render_splats(spl, cam, (w, h), (0.2, 0.2, 0.2), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+            assert torch.equal(img, ref) and torch.equal(aux.visible, aux_e.visible)
+            shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))
+        assert shares[-1] == 1.0 and shares[-2] == 1.0, shares
+        assert int(ctx.lib.bh_far_slices_queued(ctx._h)) <= 2
+    finally:
+        ctx.close()
