@@ -174,7 +174,11 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
 /* BH_FLAG_SLICED_LISTS: the near slice's share of the pair list.  near_share in (0, 1]: fixed (1 = never slice);
  * <= 0 (the default): chosen per frame from the previous forwards on this ctx — 1.25 x the slots the slowest saturating
  * tile of recent frames needed (a maximum that fades by 10 % per frame), a quarter of the list when there is no history,
- * one slice when most pairs belong to tiles that never saturate.  Results do not depend on the choice, only the time does. */
+ * one slice when most pairs belong to tiles that never saturate, or when some tiles never saturate (a blank background) and
+ * the near slice would save less than the far slice costs.  Results do not depend on the choice, only the time does.
+ * Note for bh_render_forward: a sliced frame that was not preceded by one needing its far slice makes the call wait for the
+ * near slice's blend (a 4-byte readback decides whether the far slice is queued); bh_train_step hides that wait behind its
+ * loss kernels. */
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
