@@ -167,20 +167,20 @@ ProfScope::~ProfScope() {
 // unsaturated tiles, so queueing it for a frame that does not need it is correct, just ~50 us of empty launches.
 int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
     const uint32_t* gate = j.slice_info + 2;
-    const uint32_t far_max = j.ni;   // the host's bound; the live count is far_cum[nv - 1] on the device
+    const uint32_t far_max = j.ni;   // the host's bound; the live count is slice_info[3] on the device (the emit kernel's last block)
     {
         ProfScope ps(ctx, "MapGaussiansToIntersect");
-        BH_TRY(launch_map_gaussians_far(ctx, j.nv, j.u, j.proj_by_gid, j.gfc, j.projected, j.cum, j.budget, j.done_bits, gate, j.far_counts, j.far_cum,
-                                        j.tile_ids, j.isect_gids));
+        BH_TRY(launch_map_gaussians_far(ctx, j.nv, j.u, j.proj_by_gid, j.gfc, j.projected, j.cum, j.budget, j.done_bits, gate, j.far_counts, j.far_block_totals,
+                                        j.far_group_totals, j.slice_info, j.tile_ids, j.isect_gids));
     }
     {
         ProfScope ps(ctx, "TileSort");
-        BH_TRY(radix_argsort_dev(ctx, j.tile_ids, j.isect_gids, far_max, j.far_cum + (j.nv - 1), gate, j.slice_info + 1, j.tile_bits, j.tile_ids_sorted,
+        BH_TRY(radix_argsort_dev(ctx, j.tile_ids, j.isect_gids, far_max, j.slice_info + 3, gate, j.slice_info + 1, j.tile_bits, j.tile_ids_sorted,
                                  j.isect_gids_sorted));
     }
     {
         ProfScope ps(ctx, "GetTileOffsets");
-        BH_TRY(launch_tile_offsets_dev(ctx, j.tile_ids_sorted, far_max, j.far_cum + (j.nv - 1), gate, j.slice_info + 1, j.num_tiles, j.tile_offsets_far));
+        BH_TRY(launch_tile_offsets_dev(ctx, j.tile_ids_sorted, far_max, j.slice_info + 3, gate, j.slice_info + 1, j.num_tiles, j.tile_offsets_far));
     }
     {
         ProfScope ps(ctx, "Rasterize");
@@ -496,11 +496,12 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
     const size_t visible_words = bwd_info ? ((ctx->ext_visible && ctx->ext_visible_floats) ? ctx->ext_visible_floats : npad) : 0;
-    // depth-sliced lists: [0] near-slice splats  [1] near-slice pairs  [2] tiles the near slice left unsaturated  [3] spare |
-    // done bits | far tile offsets [T,2].  Cleared by K1 with the tile table, whether or not this frame ends up slicing.
+    // depth-sliced lists: [0] near-slice splats  [1] near-slice pairs  [2] tiles the near slice left unsaturated  [3] far-slice pairs |
+    // done bits | far tile offsets [T,2] | far pairs per block group.  Cleared by K1 with the tile table, whether or not this frame ends up slicing.
     const bool want_sliced = (flags & BH_FLAG_SLICED_LISTS) != 0;
     const size_t slice_bit_words = ((size_t)num_tiles + 31) / 32;
-    const size_t slice_words = want_sliced ? 4 + slice_bit_words + (size_t)num_tiles * 2 : 0;
+    const size_t slice_group_words = (size_t)n / (256 * FAR_GROUP_BLOCKS) + 2;   // far pairs per group of count-kernel blocks
+    const size_t slice_words = want_sliced ? 4 + slice_bit_words + (size_t)num_tiles * 2 + slice_group_words : 0;
     uint32_t* slice_tab = nullptr;
     if (want_sliced) {
         slice_tab = (uint32_t*)ensure(ctx, SLOT_SLICE, slice_words * 4);
@@ -641,6 +642,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     uint32_t* slice_info = slice_tab;
     uint32_t* done_bits = slice_tab ? slice_tab + 4 : nullptr;
     uint32_t* tile_offsets_far = slice_tab ? slice_tab + 4 + slice_bit_words : nullptr;
+    uint32_t* far_group_totals = slice_tab ? slice_tab + 4 + slice_bit_words + (size_t)num_tiles * 2 : nullptr;
     uint32_t tile_bits = 0;
     while (tile_bits < 32 && (num_tiles >> tile_bits) != 0) tile_bits++;  // render.rs:228
     RasterSlice rs;
@@ -697,8 +699,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     } else {
         auto* state = (float*)ensure(ctx, SLOT_SLICE_STATE, pixels * 16);
         auto* far_counts = (uint32_t*)ensure(ctx, SLOT_SLICE_COUNTS, nvpad * 4);
-        auto* far_cum = (uint32_t*)ensure(ctx, SLOT_SLICE_CUM, nvpad * 4);
-        if (!state || !far_counts || !far_cum) return BH_ERR_OOM;
+        auto* far_block_totals = (uint32_t*)ensure(ctx, SLOT_SLICE_CUM, (nvpad / 256 + 2) * 4);
+        if (!state || !far_counts || !far_block_totals) return BH_ERR_OOM;
         rs.done_bits = done_bits;
         rs.unsat_count = slice_info + 2;
         rs.state = state;
@@ -715,7 +717,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         j.nv = nv; j.ni = ni; j.budget = budget; j.num_tiles = num_tiles; j.tile_bits = tile_bits;
         j.proj_by_gid = proj_by_gid; j.gfc = gfc; j.projected = projected; j.cum = cum;
         j.slice_info = slice_info; j.done_bits = done_bits; j.tile_offsets_far = tile_offsets_far;
-        j.far_counts = far_counts; j.far_cum = far_cum;
+        j.far_counts = far_counts; j.far_block_totals = far_block_totals; j.far_group_totals = far_group_totals;
         j.tile_ids = tile_ids; j.isect_gids = isect_gids; j.tile_ids_sorted = tile_ids_sorted; j.isect_gids_sorted = isect_gids_sorted;
         j.out_f32 = out_f32; j.out_u8 = out_u8; j.visible = visible; j.lpt = ctx->lpt; j.class_width = class_width; j.rs = rs;
         // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)

@@ -56,7 +56,7 @@ enum Slot : int {
     SLOT_EXCH_IDX,
     SLOT_EXCH_COMPACT,
     SLOT_PROJECTED_BY_GID,   // [N,9] projected records at their splat id (visible splats only)
-    SLOT_SLICE,              // depth-sliced forward: 4 control words | done bits [ceil(T/32)] | far tile offsets [T,2]
+    SLOT_SLICE,              // depth-sliced forward: 4 control words | done bits [ceil(T/32)] | far tile offsets [T,2] | far group totals
     SLOT_SLICE_STATE,        // [H,W,4] raw blend state of the tiles the near slice left unsaturated
     SLOT_SLICE_COUNTS,       // [Nv] live-tile hits per far splat / their inclusive scan
     SLOT_SLICE_CUM,
@@ -83,6 +83,7 @@ constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12 + C
 constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
 constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 4;       // u32 index of the feedback part inside a set: [COUNTER_SLOTS][3]
 constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_SLOTS * 7;   // ... of the key-range part
+constexpr uint32_t FAR_GROUP_BLOCKS = 64;   // far slice: count-kernel blocks per group total (<= the projection workgroup size)
 constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12;
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
@@ -131,7 +132,8 @@ struct FarJob {
     uint32_t* done_bits = nullptr;
     uint32_t* tile_offsets_far = nullptr;
     uint32_t* far_counts = nullptr;
-    uint32_t* far_cum = nullptr;
+    uint32_t* far_block_totals = nullptr;
+    uint32_t* far_group_totals = nullptr;   // zeroed by K1 with the slice table
     uint32_t* tile_ids = nullptr;
     uint32_t* isect_gids = nullptr;
     uint32_t* tile_ids_sorted = nullptr;
@@ -278,7 +280,7 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
                          float4* zero_span = nullptr, uint32_t zero_f4 = 0, uint32_t budget = 0xFFFFFFFFu, uint32_t* slice_info = nullptr);
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
-                             uint32_t* counts, uint32_t* far_cum, uint32_t* tile_ids, uint32_t* isect_gids);
+                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,

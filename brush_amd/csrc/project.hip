@@ -450,9 +450,10 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t* __restrict__ global_from_compact_gid, float* __restrict__ projected,
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4, uint32_t budget,
-    uint32_t* __restrict__ slice_info, const uint32_t* __restrict__ far_cum, const uint32_t* __restrict__ done_bits,
-    const uint32_t* __restrict__ gate) {
+    uint32_t* __restrict__ slice_info, const uint32_t* __restrict__ far_counts, const uint32_t* __restrict__ far_block_totals,
+    const uint32_t* __restrict__ far_group_totals, const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
+    __shared__ uint32_t s_far[2 * PROJ_WAVES];
     if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
     const uint32_t tid_lin = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
@@ -460,6 +461,37 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cg0 = (blockIdx.x * PROJ_WAVES + (uint32_t)wave) * (uint32_t)SPW;   // the wave's first splat
     const uint32_t cg = lane < SPW ? cg0 + (uint32_t)lane : 0xFFFFFFFFu;
+    // FAR: where this splat's pairs go = the far pairs of every block in front (slice_count_kernel's group and block totals, summed
+    // here: a few coalesced loads per thread instead of two scan launches) + the block-local exclusive scan of the per-splat counts
+    uint32_t far_base = 0, far_cnt = 0;
+    if (FAR) {
+        far_cnt = cg < nv ? far_counts[cg] : 0u;
+        uint32_t ahead = 0;
+        const uint32_t group = blockIdx.x / FAR_GROUP_BLOCKS;
+        for (uint32_t g = threadIdx.x; g < group; g += PROJ_WG) ahead += far_group_totals[g];
+        { const uint32_t b = group * FAR_GROUP_BLOCKS + threadIdx.x; if (threadIdx.x < FAR_GROUP_BLOCKS && b < blockIdx.x) ahead += far_block_totals[b]; }
+        uint32_t incl = far_cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ahead += __shfl_down(ahead, off);
+        if (lane == 63) s_far[wave] = incl;
+        if (lane == 0) s_far[PROJ_WAVES + wave] = ahead;
+        __syncthreads();
+        uint32_t before = 0, block_ahead = 0, block_total = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_WAVES; ++w) {
+            before += w < wave ? s_far[w] : 0u;
+            block_total += s_far[w];
+            block_ahead += s_far[PROJ_WAVES + w];
+        }
+        far_base = block_ahead + before + incl - far_cnt;
+        // the last block knows the far slice's size: the sort and the offsets kernel take it from here
+        if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0) slice_info[3] = block_ahead + block_total;
+    }
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
@@ -468,8 +500,8 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     if (cg < nv) {
         const uint32_t cum_end = cum_tiles_hit[cg];
         if (FAR) {
-            base = cg == 0 ? 0u : far_cum[cg - 1];
-            end = far_cum[cg];
+            base = far_base;
+            end = far_base + far_cnt;
             mine = cum_end > budget && end > base;
         } else {
             base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
@@ -521,8 +553,10 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
                                                              const uint32_t* __restrict__ global_from_compact_gid,
                                                              const uint32_t* __restrict__ cum_tiles_hit, uint32_t budget,
                                                              const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
-                                                             uint32_t* __restrict__ counts) {
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ block_totals,
+                                                             uint32_t* __restrict__ group_totals) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
+    __shared__ uint32_t s_tot[PROJ_WAVES];
     if (*gate == 0u) return;
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -548,6 +582,18 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
         hits = nb ? w.count[wrank] : 0u;
     }
     if (cg < nv) counts[cg] = hits;
+    uint32_t wsum = hits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wsum += __shfl_down(wsum, off);
+    if (lane == 0) s_tot[wave] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < PROJ_WAVES; ++w) t += s_tot[w];
+        block_totals[blockIdx.x] = t;
+        if (t) atomicAdd(group_totals + blockIdx.x / FAR_GROUP_BLOCKS, t);
+    }
 }
 
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
@@ -563,30 +609,31 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                            projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     } else {
         hipLaunchKernelGGL((map_gaussians_kernel<false, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                            projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     }
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
 }
 
-// The far slice of a depth-sliced forward: count -> scan -> emit, all three no-ops when *gate (the number of tiles the near
-// slice left unsaturated) is zero.  counts / far_cum: [nv] scratch.
+// The far slice of a depth-sliced forward: count -> emit (the scan between them is folded into the emit kernel), both no-ops when
+// *gate (the number of tiles the near slice left unsaturated) is zero.  counts: [nv], block_totals: [ceil(nv / 256)] scratch;
+// group_totals: [ceil(blocks / FAR_GROUP_BLOCKS)], zero on entry; slice_info[3] receives the number of far pairs.
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
-                             uint32_t* counts, uint32_t* far_cum, uint32_t* tile_ids, uint32_t* isect_gids) {
+                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids,
+                             uint32_t* isect_gids) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     hipLaunchKernelGGL(slice_count_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_y0, u.tile_y1, projected_by_gid, gid, cum_tiles_hit,
-                       budget, done_bits, gate, counts);
+                       budget, done_bits, gate, counts, block_totals, group_totals);
     BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
-    BH_TRY(prefix_sum(ctx, counts, nullptr, nv, far_cum, false, gate));
     hipLaunchKernelGGL((map_gaussians_kernel<true, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                       projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, (uint32_t*)nullptr, (const uint32_t*)far_cum,
-                       done_bits, gate);
+                       projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, slice_info, (const uint32_t*)counts,
+                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");
     return 0;
 }
