@@ -127,6 +127,7 @@ SYMBOLS = {
     "bh_set_list_slicing": (C.c_int, [C.c_void_p, C.c_float]),
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
+    "bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
     "bh_last_render_out": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),

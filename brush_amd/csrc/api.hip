@@ -244,6 +244,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
     ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
     ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
+    ctx->knob_zero_grads = getenv("BH_TRAIN_ZERO_GRADS") != nullptr;
     ctx->knob_break_allreduce = getenv("BH_BREAK_ALLREDUCE") != nullptr;
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
@@ -530,7 +531,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
             ctx->grads_prezeroed = false;
-            if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
+            if (bwd_info && !ctx->grad_row_mask && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
                 prep.span = reinterpret_cast<float4*>(ctx->ext_grad_begin);   // the train step's gradient span
                 prep.span_f4 = (uint32_t)(ctx->ext_grad_floats / 4);
@@ -798,7 +799,8 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "ZeroGradBuffers");
         // what the forward's kernels cleared on their way (K5: v_combined; K1: the train step's gradient span) is done
         const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
-        const bool vc_done = ctx->vcombined_prezeroed, span_done = ctx->grads_prezeroed && one_span;
+        // (grad_row_mask: the single-GPU train step reads only the rows K18 writes — nothing to clear)
+        const bool vc_done = ctx->vcombined_prezeroed, span_done = one_span && (ctx->grads_prezeroed || ctx->grad_row_mask);
         ctx->vcombined_prezeroed = false;
         ctx->grads_prezeroed = false;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
@@ -836,7 +838,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "ProjectBackwards");
         BH_TRY(launch_project_backward(ctx, ctx->uniforms, nv, ctx->flags & BH_FLAG_MIP, ctx->sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
-                                       v_raw_opacities, v_refine_weight));
+                                       v_raw_opacities, v_refine_weight, ctx->grad_row_mask));
     }
     return 0;
 }
@@ -968,6 +970,15 @@ int bh_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const
 
 }  // extern "C"
 
+extern "C" int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    const Buffer& s = ctx->slots[SLOT_GRADS];
+    if (!s.ptr || s.cap < 4) return set_error(ctx, BH_ERR_STATE, "debug_fill_train_scratch: no train step on this context yet");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.ptr), (int)pattern, s.cap / 4, ctx->stream));
+    return 0;
+}
+
 // ---- training step -------------------------------------------------------------
 extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
                              bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats) {
@@ -1017,6 +1028,14 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_max_radius = s_radius;
     ctx->ext_grad_begin = exch + o_tr;       // ... and the whole gradient span (padding included): K1 does both on its way
     ctx->ext_grad_floats = exch_count - o_tr;
+    // ... unless nobody but this step's own update reads the gradients (one GPU, no hook): then the span is not cleared at all.
+    // K18 writes the rows of the splats the blend used (`visible`), the update kernel takes every other row as zero — at SH
+    // degree 3 the zero-fill was most of K1's HBM traffic (236 of 330 MB per step at 1 M splats).
+    // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
+    // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
+    const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
+    const bool masked_grads = !exchanging && !batch->image_hook && !ctx->knob_zero_grads && n > 0;
+    ctx->grad_row_mask = masked_grads ? s_visible : nullptr;
     // depth-sliced lists: whether the far slice has to run is known once the near slice's blend has; a single-GPU step does not
     // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
     // (a tile-partitioned frame hands the image to its hook right after the forward: there the forward waits itself)
@@ -1028,6 +1047,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_max_radius = nullptr;
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
+    ctx->grad_row_mask = nullptr;
     BH_TRY(frc);
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
@@ -1081,9 +1101,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     // slice, if it had to run) is, so they are summed, the union of contributing splats is listed and its size starts travelling
     // to the host NOW — the backward hides the collective's latency and the readback, and the host finds the count ready
     const bool tile_mode = batch->image_hook != nullptr;
-    // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
-    // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
-    const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
     // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
     auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
         if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");
@@ -1124,9 +1141,11 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* g_op = exch + o_op;
     ctx->ext_grad_begin = g_tr;              // one zero-fill of the whole gradient span (padding included)
     ctx->ext_grad_floats = exch_count - o_tr;
+    ctx->grad_row_mask = masked_grads ? s_visible : nullptr;
     const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
+    ctx->grad_row_mask = nullptr;
     BH_TRY(brc);
     if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
         ProfScope ps(ctx, "FoldMinScaleBackward");
@@ -1181,7 +1200,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         // sh: DC at full lr, bands >= 1 scaled by 1/lr_coeffs_sh_scale
         BH_TRY(launch_train_update(ctx, st, g_tr, g_sh, g_op, s_refine, s_visible, s_radius, grad_scale, tile_mode, tab,
                                    (float)cfg->lr_coeffs_dc, 1.0f / cfg->lr_coeffs_sh_scale, (float)cfg->lr_opac, step, 0.9f, 0.999f, 1e-15f,
-                                   noise_fused ? &na : nullptr));
+                                   noise_fused ? &na : nullptr, masked_grads));
     }
     st->step_count = step;   // the update is queued: the step counts
     if (noise_on && !noise_fused) {

@@ -174,6 +174,9 @@ struct bh_ctx {
     // cleared on the way by the forward's kernels (K1: the gradient span, K5: v_combined) -> the backward skips its fills;
     // each flag is consumed by the next bh_render_backward
     bool grads_prezeroed = false, vcombined_prezeroed = false;
+    // single-GPU train step: the gradient span is NOT zero-filled; a row of it is meaningful iff this flag ([N], the forward's
+    // `visible`) is nonzero — K18 writes exactly those rows, the update kernel reads exactly those rows
+    const float* grad_row_mask = nullptr;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
     // the library communicator's side stream: the mask-keyed exchange sums the visible flags and lists their union there,
@@ -207,6 +210,7 @@ struct bh_ctx {
     bool knob_force_exchange = false;       // BH_FORCE_PG: run the gradient-exchange path with a one-rank communicator too (overhead measurement)
     bool knob_break_allreduce = false;      // BH_BREAK_ALLREDUCE: corrupt the library's all-reduce (the bench self-check must notice)
     bool knob_generic_depth_sort = false;   // BH_GENERIC_DEPTH_SORT: the forward's depth order by the generic 32-bit radix sort + scan
+    bool knob_zero_grads = false;     // BH_TRAIN_ZERO_GRADS: the single-GPU train step zero-fills its gradient span like the exchange path (A/B)
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
     bh::Profiler prof;
@@ -284,7 +288,7 @@ int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, co
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine);
+                            float* v_refine, const float* row_mask = nullptr);
 // sort.hip
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);
@@ -336,7 +340,7 @@ struct NoiseArgs { uint64_t seed; uint32_t step; float scale, clamp_abs; };
 int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
                         const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
                         bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
-                        float beta1, float beta2, float eps, const NoiseArgs* noise = nullptr);
+                        float beta1, float beta2, float eps, const NoiseArgs* noise = nullptr, bool masked_rows = false);
 int launch_gather_stats(bh_ctx* ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size,
                         const float* refine_weight, const float* visible, const float* screen_radius, uint64_t n);
 // samples == NULL: drawn on the device from (seed, step, splat)

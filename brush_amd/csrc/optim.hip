@@ -153,6 +153,7 @@ struct UpdateArgs {
     float gscale;          // 1/world for data parallel over cameras, else 1
     uint32_t n, sh_len;    // splats, 3*C
     uint32_t vis_clamp;    // tile-partitioned frame: visible arrives summed over strips -> min(v, 1)
+    uint32_t masked;       // the gradient tensors were not zero-filled: row i holds a gradient iff visible[i] != 0, else it is 0
     float tab_t[10];       // lr_mean x3, lr_rotation x4, lr_scale x3
     float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
     // visibility-gated noise on the means (train.rs:389-416) drawn on the device and added right behind the Adam update
@@ -180,7 +181,13 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
     float* s_g = s_dyn;                       // [rows][row_len + 1]
     float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
-    float* s_noise = s_v + (uint32_t)ROWS;            // [rows][3], only with noise_on
+    float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written (all rows, unless u.masked)
+    float* s_noise = s_mask + (uint32_t)ROWS;         // [rows][3], only with noise_on
+    const bool masked = u.masked != 0u;               // block-uniform
+    if (masked) {
+        if (threadIdx.x < (uint32_t)ROWS) s_mask[threadIdx.x] = (threadIdx.x < nrows && visible[row0 + threadIdx.x] != 0.0f) ? 1.0f : 0.0f;
+        __syncthreads();
+    }
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
@@ -188,28 +195,32 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     {
         const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
-            const float4 g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
+            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // (a float4 spans at most two rows: the first and the last component's; unwritten rows are not even loaded)
+            const uint32_t ra = (uint32_t)(((float)e + 0.5f) * rcp_len), rb = (uint32_t)(((float)(e + 3u) + 0.5f) * rcp_len);
+            if (!masked || s_mask[ra] != 0.0f || s_mask[rb] != 0.0f) g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t ee = e + k;
                 const uint32_t r = (uint32_t)(((float)ee + 0.5f) * rcp_len);  // ee / row_len, exact for ee < 2^16
-                s_g[r * pitch + (ee - r * row_len)] = gv[k] * u.gscale;
+                s_g[r * pitch + (ee - r * row_len)] = (masked && s_mask[r] == 0.0f) ? 0.0f : gv[k] * u.gscale;
             }
         }
         for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
             const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
-            s_g[r * pitch + (e - r * row_len)] = g_sh[sh_base + e] * u.gscale;
+            s_g[r * pitch + (e - r * row_len)] = (masked && s_mask[r] == 0.0f) ? 0.0f : g_sh[sh_base + e] * u.gscale;
         }
     }
     // ---- statistics + opacity: one splat per thread
     if (threadIdx.x < nrows) {
         const uint64_t i = row0 + threadIdx.x;
-        refine_weight_norm[i] = __builtin_fmaxf(refine_weight[i], refine_weight_norm[i]);
+        const bool written = !masked || visible[i] != 0.0f;
+        refine_weight_norm[i] = __builtin_fmaxf(written ? refine_weight[i] : 0.0f, refine_weight_norm[i]);
         const float v = u.vis_clamp ? __builtin_fminf(visible[i], 1.0f) : visible[i];
         vis_weight[i] = vis_weight[i] + v;
         max_screen_size[i] = __builtin_fmaxf(screen_radius[i], max_screen_size[i]);
-        const float g = g_o[i] * u.gscale;
+        const float g = written ? g_o[i] * u.gscale : 0.0f;
         float mm1 = a.first ? g * a.f1 : m1_o[i] * a.beta1 + g * a.f1;
         const float gsq = g * g;
         const float mm2 = a.first ? gsq * a.f2 : m2_o[i] * a.beta2 + gsq * a.f2;
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         auto one = [&](float g_raw, float m1v, float m2v, float pv, uint32_t e, float& o_m1, float& o_m2, float& o_p) {
             const uint32_t r = (e * 52429u) >> 19;  // e / 10 (e < 2560)
             const uint32_t c = e - r * 10u;
-            const float g = g_raw * u.gscale;
+            const float g = (masked && s_mask[r] == 0.0f) ? 0.0f : g_raw * u.gscale;
             const float mm1 = a.first ? g * a.f1 : m1v * a.beta1 + g * a.f1;
             const float gsq = g * g;
             const float mm2 = a.first ? gsq * a.f2 : m2v * a.beta2 + gsq * a.f2;
@@ -255,7 +266,8 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         const uint32_t vec_end = VEC ? (count & ~3u) : 0u;
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
             const uint64_t i = base + e;
-            const float4 g4 = *reinterpret_cast<const float4*>(&g_t[i]);
+            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (!masked || s_mask[(e * 52429u) >> 19] != 0.0f || s_mask[((e + 3u) * 52429u) >> 19] != 0.0f) g4 = *reinterpret_cast<const float4*>(&g_t[i]);
             float4 m14 = *reinterpret_cast<const float4*>(&m1_t[i]);
             float4 m24 = *reinterpret_cast<const float4*>(&m2_t[i]);
             float4 p4 = *reinterpret_cast<const float4*>(&transforms[i]);
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
 int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, const float* g_sh, const float* g_o,
                         const float* refine_weight, const float* visible, const float* screen_radius, float gscale,
                         bool vis_clamp, const float* tab_t, float lr_sh, float sh_rest_scale, float lr_opac, uint32_t t,
-                        float beta1, float beta2, float eps, const NoiseArgs* noise) {
+                        float beta1, float beta2, float eps, const NoiseArgs* noise, bool masked_rows) {
     const uint32_t n = st->n, C = (st->sh_degree + 1) * (st->sh_degree + 1);
     if (n == 0) return 0;
     if (t == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "adam: t is 1-based");
@@ -338,6 +350,7 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     u.a.first = t == 1 ? 1u : 0u;
     u.lr_sh = lr_sh; u.lr_opac = lr_opac; u.gscale = gscale;
     u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
+    u.masked = masked_rows ? 1u : 0u;
     u.noise_on = noise ? 1u : 0u;
     u.noise_step = noise ? noise->step : 0u;
     u.noise_scale = noise ? noise->scale : 0.0f;
@@ -349,7 +362,7 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     // SH degree 3: 0.368 ms @256, 0.300 @128, 0.290 @64, 0.327 @32; degree 0 is best at 256)
     uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
     if (ctx->knob_update_rows) rows = ctx->knob_update_rows;  // developer knob BH_UPDATE_ROWS (read once at bh_create)
-    const size_t lds = ((size_t)rows * (u.sh_len + 1) + rows + (noise ? 3 * rows : 0)) * sizeof(float);
+    const size_t lds = ((size_t)rows * (u.sh_len + 1) + 2 * rows + (noise ? 3 * rows : 0)) * sizeof(float);
     const unsigned nb = (unsigned)(((uint64_t)n + rows - 1) / rows);
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
     bool vec = true;

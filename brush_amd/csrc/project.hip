@@ -703,7 +703,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ sh_coeffs,
     const float* __restrict__ raw_opac, const uint32_t* __restrict__ global_from_compact_gid,
     const float* __restrict__ v_combined, float* __restrict__ v_transforms, float* __restrict__ v_coeffs,
-    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight) {
+    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const float* __restrict__ row_mask) {
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     if (cg >= nv) return;
     const uint32_t gid = global_from_compact_gid[cg];
@@ -712,7 +712,23 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 10; ++k) { g[k] = rg[k]; any = any || (g[k] != 0.0f); }
-    if (!any) return;
+    constexpr int C = (DEG + 1) * (DEG + 1);
+    if (!any) {
+        // dense outputs that nobody zero-filled (row_mask = the forward's `visible`, the single-GPU train step): the rows the
+        // consumer reads are those of the splats the blend used, and a splat it used can still come out with an all-zero
+        // gradient — that row is written here
+        if (row_mask && row_mask[gid] != 0.0f) {
+            float* vt = v_transforms + (size_t)gid * 10;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) vt[k] = 0.0f;
+            float* vc = v_coeffs + (size_t)gid * C * 3;
+#pragma unroll
+            for (int k = 0; k < C * 3; ++k) vc[k] = 0.0f;
+            v_raw_opac[gid] = 0.0f;
+            v_refine_weight[gid] = 0.0f;
+        }
+        return;
+    }
     const float* tr = transforms + (size_t)gid * 10;
     const Vec3A mean = v3(tr[0], tr[1], tr[2]);
     const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
@@ -721,7 +737,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     const Vec3A u_world = sub(mean, camera_pos(u));
     const float u_len = length(u_world);
     const Vec3A v = scale(u_world, 1.0f / u_len);
-    constexpr int C = (DEG + 1) * (DEG + 1);
     const Vec3A v_color = v3(g[5], g[6], g[7]);
     sh_coeffs_to_color_vjp<DEG>(v_coeffs + (size_t)gid * C * 3, v, v_color);
     const Vec3A v_v_sh = sh_color_viewdir_vjp<DEG>(sh_coeffs + (size_t)gid * C * 3, v, v_color);
@@ -764,14 +779,14 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 
 template <bool MIP, bool PINHOLE>
 static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
-                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr) {
+                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr, const float* rm) {
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
-        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr); break;
+        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
+        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
+        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
+        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
+        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_backward_kernel");
@@ -781,13 +796,13 @@ static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine) {
+                            float* v_refine, const float* row_mask) {
     if (nv == 0) return 0;
     if (u.model == CAM_PINHOLE)
-        return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
-                   : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
-    return mip ? launch_pb_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine)
-               : launch_pb_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine);
+        return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask)
+                   : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask);
+    return mip ? launch_pb_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask)
+               : launch_pb_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask);
 }
 
 }  // namespace bh

@@ -383,10 +383,17 @@ void bh_sample_background(uint64_t seed, uint32_t step, const float base[3] /*ho
 int bh_normal_samples(bh_ctx* ctx, uint64_t seed, uint32_t step, uint64_t n, float* out /*[n,3] device*/);
 void bh_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* state->step_count is advanced only when the call succeeds (a failed step applied no update and may be retried). */
+/* state->step_count is advanced only when the call succeeds (a failed step applied no update and may be retried).
+ * The gradients live in a scratch buffer of the ctx (the exchange buffer above).  With a hook or a communicator the whole
+ * buffer is defined when it is handed over (rows of splats the view did not use are zero: render_bwd.rs:123-138).  On one
+ * GPU without a hook nobody else reads it, and the step neither clears nor reads the rows of splats the view did not use
+ * (`visible` = 0): the update takes them as zero — same results, without 4 (11 + 3C) N bytes of zero-fill per step. */
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);
+/* Tests: overwrite that scratch buffer with a 32-bit pattern (e.g. a NaN) on the ctx stream — a step that then still
+ * produces the zero-filling step's results has not read a row it did not write.  BH_ERR_STATE before the first step. */
+int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern);
 
 /* ---- refine (densify / prune) ------------------------------------------------ */
 /* SplatTrainer::refine (brush-train/src/train.rs:431-893) in two calls, because the caller

@@ -1,0 +1,96 @@
+"""The single-GPU train step does not zero-fill its gradient span: K18 writes the rows of the splats the blend used, the
+update kernel takes every other row as zero (api.hip bh_train_step, `grad_row_mask`).  That must be invisible.  The span
+is filled with NaNs before every step (bh_debug_fill_train_scratch): one read of a row nobody wrote would poison a
+parameter, a moment or a statistic for good.  The results are then compared with the zero-filling step
+(BH_TRAIN_ZERO_GRADS, which is also what the multi-GPU exchange path runs) — to the run-to-run tolerance of a step, not
+bit for bit: the backward sums a splat's per-tile gradients with float atomics, so two runs of the SAME step already
+differ in the last bits."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from brush_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(w, h, k):
+    cp = synth.default_camera_params(w, h)
+    out = []
+    for i in range(k):
+        c = dict(cp)
+        # swing the camera so that every view sees a different subset (splats drop out of and into the frustum)
+        c["rot_xyzw"] = util.quat_from_axis_angle((0, 1, 0), math.radians(-35 + 70 * i / max(1, k - 1)))
+        out.append(c)
+    return out
+
+
+def _run(ba, dev, zero_fill, sc, cams, gt, sh_degree, mip, min_scale_views, steps, poison=False):
+    if zero_fill:
+        os.environ["BH_TRAIN_ZERO_GRADS"] = "1"
+    else:
+        os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
+    try:
+        ctx = ba.Context(dev)   # the knob is read once, at bh_create
+    finally:
+        os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
+    cfg = ba.TrainConfig()
+    cfg.render_mip = bool(mip)
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=3.0, ctx=ctx, seed=1234)
+    spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+    if min_scale_views:   # a 3D-filter floor: the fold's backward runs between K18 and the update, on written and unwritten rows alike
+        spl.with_min_scale(torch.full((spl.num_splats(),), 0.05, device=dev))
+    gt_t = torch.from_numpy(gt.view(np.int32)).to(dev)
+    for s in range(steps):
+        batch = ba.SceneBatch(gt_t, util.hip_camera(ba, cams[s % len(cams)]))
+        if poison and s > 0:
+            ctx.check(ctx.lib.bh_debug_fill_train_scratch(ctx._h, 0x7FC00000))   # quiet NaN in every word of the gradient scratch
+        trainer.step(batch, spl)
+    ctx.sync()
+    out = {"transforms": spl.transforms.clone(), "sh": spl.sh_coeffs.clone(), "opac": spl.raw_opacities.clone()}
+    out.update({k: v.clone() for k, v in trainer.state.items()})
+    stats = trainer.stats()
+    ctx.close()
+    return out, stats
+
+
+@pytest.mark.parametrize("sh_degree,mip,min_scale_views,n,w,h", [
+    (0, False, False, 20000, 320, 192),
+    (3, False, False, 12000, 256, 160),
+    (2, True, True, 8000, 200, 120),
+    (1, False, False, 300, 64, 48),    # fewer splats than one update block; ragged everything
+])
+def test_masked_rows_equal_zero_filled(dev, sh_degree, mip, min_scale_views, n, w, h):
+    import brush_amd as ba
+    sc = synth.make_scene(n, 0x51 + sh_degree, sh_degree=sh_degree, log_scale_range=(math.log(0.02), math.log(0.2)),
+                          tan_half_fov=(math.tan(math.radians(50)), math.tan(math.radians(50)) * h / w))
+    gt = synth.synthetic_gt_packed(w, h)
+    cams = _views(w, h, 4)
+    steps = 7
+    a, sa = _run(ba, dev, False, sc, cams, gt, sh_degree, mip, min_scale_views, steps, poison=True)
+    b, sb = _run(ba, dev, True, sc, cams, gt, sh_degree, mip, min_scale_views, steps)
+    c, sc2 = _run(ba, dev, True, sc, cams, gt, sh_degree, mip, min_scale_views, steps)   # the yardstick: the same path twice
+    assert 0 < sa.num_visible < n   # some rows are written, some are not
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()), k   # no NaN came through
+    assert abs(sa.num_visible - sb.num_visible) <= max(2, n // 2000)
+    assert abs(sa.loss - sb.loss) <= 1e-5 * max(1.0, abs(sb.loss))
+    cfg = ba.TrainConfig()
+    lr = {"transforms": max(cfg.lr_rotation, cfg.lr_scale), "sh": cfg.lr_coeffs_dc, "opac": cfg.lr_opac}
+    for k in ("transforms", "sh", "opac"):
+        # a row read as garbage (or as zero when it held a gradient) moves a parameter by about lr per step; run-to-run
+        # noise moves a handful of elements (a first-step sign flip of a ~0 gradient) and the rest by far less
+        d_ab = (a[k] - b[k]).abs()
+        d_bc = (b[k] - c[k]).abs()
+        assert float(d_ab.mean()) <= 2.0 * float(d_bc.mean()) + 1e-3 * lr[k], (k, float(d_ab.mean()), float(d_bc.mean()))
+        assert float((d_ab > 0.5 * lr[k]).float().mean()) <= 2.0 * float((d_bc > 0.5 * lr[k]).float().mean()) + 1e-3, k
+    for k in ("m1_t", "m2_t", "m1_sh", "m2_sh", "m1_o", "m2_o", "refine_weight_norm"):
+        ref = float(b[k].abs().max())
+        assert float((a[k] - b[k]).abs().max()) <= 4.0 * float((b[k] - c[k]).abs().max()) + 1e-3 * ref, k
+    assert float((a["vis_weight"] != b["vis_weight"]).float().mean()) <= 2e-3
+    # the scene is seen from four directions: the visibility pattern really changed between steps
+    assert float((a["vis_weight"] > 0).float().mean()) > float(sa.num_visible) / n
