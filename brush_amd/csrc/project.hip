@@ -86,6 +86,9 @@ struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are 
     }
 };
 
+// (One LDS atomic per hit lane in the counting callers: a variant in which the first lane of each splat's run of candidates adds
+// the run's hits — ballot + popcount, one plain LDS update per splat and step — measured the same, 58.1 vs 57.6 us: the walk is
+// bound by the ~60 VALU instructions of the test, two IEEE divisions among them, not by the LDS.)
 template <class OnHit, class Keep = KeepAllTiles>
 BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
                                OnHit on_hit, Keep keep = Keep{}) {
@@ -254,6 +257,12 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     if (gid < n) {
         const float* tr = transforms + (size_t)gid * 10;
         do {
+#ifdef BH_K1_NO_MATH   // measurement-only probe (wrong results: nothing is visible): the loads and the per-splat stores alone
+            float acc = raw_opacities[gid];
+            for (int k = 0; k < 10; ++k) acc += tr[k];
+            for (int k = 0; k < 3; ++k) acc += coeffs[(size_t)gid * ((DEG + 1) * (DEG + 1)) * 3 + k];
+            if (acc != 12345.678f) break;
+#endif
             mean = v3(tr[0], tr[1], tr[2]);
             const Vec3A mean_c = world_to_cam(mean, u);
             if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) break;
@@ -290,7 +299,11 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             visible = true;
         } while (false);
     }
+#ifdef BH_K1_NO_ROWS   // measurement-only probe (garbage image): the 36-byte projected rows are not written
+    if (visible && u.img_w == 0xFFFFFFFFu) {
+#else
     if (visible) {  // project_visible.rs:56-87
+#endif
         const Vec3A v = normalize(sub(mean, camera_pos(u)));
         constexpr int C = (DEG + 1) * (DEG + 1);
         const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
@@ -309,8 +322,12 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
+#ifdef BH_K1_NO_WALK   // measurement-only probe (wrong results: no splat hits a tile)
+    const uint32_t tiles_hit = nb == 0xFFFFFFFFu ? w.count[0] : 0u;
+#else
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); });
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
+#endif
     if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
