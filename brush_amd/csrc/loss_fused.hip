@@ -84,7 +84,11 @@ constexpr int TW = 16, TH = 32;
 constexpr int SW = TW + 2 * HALO;   // 26
 constexpr int SR = TH + 2 * HALO;   // 42
 #ifndef BH_LOSS_HP
-#define BH_LOSS_HP (TW * 5)
+/* 88, not TW * 5 = 80: a thread's rows are 2 * 88 = 176 floats = 48 banks apart, the four ly of a wave sit 0 / 48 / 32 / 16 banks
+   apart and lx * 5 covers every residue mod 16 once — the column pass's 60 reads per plane are conflict-free (80: the rows of ly and
+   ly + 2 share their banks).  Only with the block still at 40 KB = four per CU (s_h's last row unpadded, s_red inside it): 68.2 ->
+   63.5 us; at 41.0 KB (three blocks per CU) the same pitch cost +5 us. */
+#define BH_LOSS_HP 88
 #endif
 #ifndef BH_LOSS_H2P
 #define BH_LOSS_H2P 24   /* 2 rows apart = 48 floats = 16 banks: the two output rows of a 32-lane half never share a bank (65.0 vs 66.2 us) */
@@ -103,8 +107,10 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
                                                                 float* __restrict__ partials /*[3][3][H][W]*/,
                                                                 float* __restrict__ block_sums /*per 16-row tile row*/, uint32_t gy, FusedArgs a) {
     __shared__ float2 s_tile[3][SR * SW];          // (pred, gt_eff) per colour plane
-    __shared__ float s_h[SR * HP];                 // horizontally blurred moments of ONE plane
-    __shared__ float s_red[4];
+    // horizontally blurred moments of ONE plane; the last row carries no pitch padding: with HP = 88 the block is then
+    // exactly 40 KB = a quarter of the CU's LDS (conflict-free column reads AND four blocks per CU)
+    __shared__ float s_h[(SR - 1) * HP + TW * 5];
+    float* s_red = s_h;   // the four wave partials of the scalar loss reuse it after the last plane
     const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * TW + lx;
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
     float acc = acc_rgb * a.dl_rgb + acc_alpha * a.dl_alpha;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __syncthreads();   // every thread is done with the last plane's s_h
     if ((rank & 63) == 0) s_red[rank >> 6] = acc;
     __syncthreads();
     if (rank < 2) {
