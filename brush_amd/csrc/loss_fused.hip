@@ -154,7 +154,12 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
         __syncthreads();   // the tile is loaded (c == 0) / the previous plane's column pass is done with s_h
         // horizontal blur of (x, x^2, y, y^2, xy): 42 rows x 8 column PAIRS — an item loads the 12 pixels its two adjacent
         // outputs share once and squares each of them once
-        for (int i = rank; i < SR * (TW / 2); i += 256) {
+#ifdef BH_LOSSA_PROBE   // measurement-only (wrong results): 1 = no row pass, 2 = no column pass + SSIM, 3 = neither (tile load only)
+        const int probe_rows = (BH_LOSSA_PROBE == 1 || BH_LOSSA_PROBE == 3) ? (a.h == 0xFFFFFFFFu ? SR * (TW / 2) : 0) : SR * (TW / 2);
+#else
+        const int probe_rows = SR * (TW / 2);
+#endif
+        for (int i = rank; i < probe_rows; i += 256) {
             const int r = i / (TW / 2), pair = i - r * (TW / 2);
             const float2* row = &s_tile[c][r * SW + 2 * pair];   // row[k] = pixel at tile column 2*pair - HALO + k
             float x[12], y[12], xx[12], yy[12], xy[12];
@@ -188,6 +193,9 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
             }
         }
         __syncthreads();
+#if defined(BH_LOSSA_PROBE) && (BH_LOSSA_PROBE == 2 || BH_LOSSA_PROBE == 3)
+        if (a.h != 0xFFFFFFFFu) { acc_rgb += s_h[rank]; continue; }
+#endif
         // vertical blur: rows 2 ly .. 2 ly + 11 of s_h serve both outputs (output o: rows o .. o + 10, centre o + 5)
         float v[12][5];
 #pragma unroll
@@ -266,7 +274,10 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
 // ---------------------------------------------------------------------------
 // pass B
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
+#ifndef BH_LOSSB_WAVES
+#define BH_LOSSB_WAVES 1
+#endif
+__global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
                                                                  const float* __restrict__ partials /*[3][3][H][W]*/,
                                                                  float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
     __shared__ float s_part[3][SR * SW];       // chain * (dmu1, dsigma1, dsigma12) of ONE colour plane
@@ -306,21 +317,89 @@ __global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* _
         }
     }
     float out[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // block-uniform: rows of the partial planes can be fetched as aligned float4s
+#ifdef BH_LOSSB_NARROW   // A/B: the 4-byte loads of round 2
+    const bool wide_rows = false;
+#else
+    const bool wide_rows = (a.w & 3u) == 0u && (plane & 3u) == 0u && (reinterpret_cast<uintptr_t>(partials) & 15u) == 0;
+#endif
+    // A tile row is 26 floats from column tx0 - 5: fetched as the 8 aligned float4s from tx0 - 8 (128 contiguous bytes; W % 4 == 0,
+    // so a float4 lies entirely inside or outside the image) — 3 x 336 16-byte loads per colour instead of 3 x 1092 4-byte ones,
+    // four per thread, and they are issued one colour AHEAD into registers: a block is a chain of nine barrier-separated phases
+    // and only six blocks fit a CU, so a global round trip per colour standing in front of its blur passes was most of the
+    // block's life (probe builds: the plane loads cost 12-16 us, the two blur passes 11, the rest of the 65-us kernel was waiting).
+    constexpr int ROW_ITEMS = 3 * SR * 8;
+    auto fetch_rows = [&](const int c, float4 (&dst)[4]) {
+        const float* pc = partials + (size_t)(c * 3) * plane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = rank + 256 * t;
+            dst[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i < ROW_ITEMS) {
+                const int j = i / (SR * 8), rem = i - j * (SR * 8);
+                const int r = rem >> 3, k = rem & 7;
+                const int y = ty0 + r - HALO, x = tx0 - 8 + 4 * k;
+#if defined(BH_LOSSB_PROBE) && BH_LOSSB_PROBE == 4
+                const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w && a.h == 0xFFFFFFFFu;
+#else
+                const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
+#endif
+                if (in) dst[t] = *reinterpret_cast<const float4*>(&pc[(size_t)j * plane + (size_t)y * a.w + (size_t)x]);
+            }
+        }
+    };
+    auto stash_rows = [&](const float4 (&src)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = rank + 256 * t;
+            if (i < ROW_ITEMS) {
+                const int j = i / (SR * 8), rem = i - j * (SR * 8);
+                const int r = rem >> 3, k = rem & 7;
+                const float vv[4] = {src[t].x, src[t].y, src[t].z, src[t].w};
+                float* dst = &s_part[j][r * SW];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = 4 * k + u - 3;   // tile column of this component
+                    if (q >= 0 && q < SW) dst[q] = vv[u];
+                }
+            }
+        }
+    };
+    float4 pre[4];
+    if (wide_rows) fetch_rows(0, pre);
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
+#if defined(BH_LOSSB_PROBE) && BH_LOSSB_PROBE == 5   // no colour loop at all: the kernel's prologue + epilogue
+        if (a.h != 0xFFFFFFFFu) { out[0][c] = pv[0].x; out[1][c] = pv[1].y; continue; }
+#endif
         __syncthreads();   // the previous plane's column pass is done with the buffers
+#ifdef BH_LOSSB_NO_PREFETCH
+        if (wide_rows && c > 0) fetch_rows(c, pre);
+#endif
         const float* pc = partials + (size_t)(c * 3) * plane;
-        for (int i = rank; i < SR * SW; i += 256) {
-            const int r = i / SW, q = i - r * SW;
-            const int y = ty0 + r - HALO, x = tx0 + q - HALO;
-            const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
-            const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
-            s_part[0][i] = in ? pc[p] : 0.0f;
-            s_part[1][i] = in ? pc[plane + p] : 0.0f;
-            s_part[2][i] = in ? pc[2 * plane + p] : 0.0f;
+        if (wide_rows) {
+            stash_rows(pre);
+#ifndef BH_LOSSB_NO_PREFETCH
+            if (c < 2) fetch_rows(c + 1, pre);   // in flight while this plane goes through the two blur passes
+#endif
+        } else {
+            for (int i = rank; i < SR * SW; i += 256) {
+                const int r = i / SW, q = i - r * SW;
+                const int y = ty0 + r - HALO, x = tx0 + q - HALO;
+                const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
+                const size_t p = in ? (size_t)y * a.w + (size_t)x : 0;
+                s_part[0][i] = in ? pc[p] : 0.0f;
+                s_part[1][i] = in ? pc[plane + p] : 0.0f;
+                s_part[2][i] = in ? pc[2 * plane + p] : 0.0f;
+            }
         }
         __syncthreads();
-        for (int i = rank; i < 3 * SR * TW; i += 256) {
+#ifdef BH_LOSSB_PROBE   // measurement-only (wrong results): 1 = no row pass, 2 = no column pass, 3 = neither, 4 = zeros instead of the partial planes
+        const int probe_items = (BH_LOSSB_PROBE == 1 || BH_LOSSB_PROBE == 3) ? (a.h == 0xFFFFFFFFu ? 3 * SR * TW : 0) : 3 * SR * TW;
+#else
+        const int probe_items = 3 * SR * TW;
+#endif
+        for (int i = rank; i < probe_items; i += 256) {
             const int j = i / (SR * TW), rem = i - j * (SR * TW);
             const int r = rem / TW, col = (rem - r * TW) + HALO;
             const float* row = &s_part[j][r * SW];
@@ -331,6 +410,9 @@ __global__ __launch_bounds__(256) void loss_fused_backward_kernel(const float* _
             s_h2[j][r * H2P + (col - HALO)] = acc;
         }
         __syncthreads();
+#if defined(BH_LOSSB_PROBE) && (BH_LOSSB_PROBE == 2 || BH_LOSSB_PROBE == 3)
+        if (a.h != 0xFFFFFFFFu) { out[0][c] = s_h2[0][rank] + s_part[0][rank]; continue; }
+#endif
         float v[3][12];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
