@@ -181,13 +181,16 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
     float* s_g = s_dyn;                       // [rows][row_len + 1]
     float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
-    float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written (all rows, unless u.masked)
+    float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written (only with u.masked)
     float* s_noise = s_mask + (uint32_t)ROWS;         // [rows][3], only with noise_on
-    const bool masked = u.masked != 0u;               // block-uniform
-    if (masked) {
-        if (threadIdx.x < (uint32_t)ROWS) s_mask[threadIdx.x] = (threadIdx.x < nrows && visible[row0 + threadIdx.x] != 0.0f) ? 1.0f : 0.0f;
-        __syncthreads();
-    }
+    // masked (block-uniform): the gradient tensors were not zero-filled — row r of them counts iff visible[row0 + r] != 0.
+    // No barrier stands in front of what the block fetches: the SH staging below reads the flags it needs straight from global
+    // memory (its gradients are wanted last, two round trips hide) and skips the rows nobody wrote — they would come from
+    // cold HBM: +7 us at SH degree 3 when loaded and thrown away; the transforms' gradients are loaded unconditionally, their
+    // flags come through LDS from the per-splat section (which reads `visible` anyway), behind its barrier.  (Flags staged
+    // through LDS up front, every gradient load predicated on them: +6 us at SH degree 0.)
+    const bool masked = u.masked != 0u;
+    const float* vis_rows = visible + row0;
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
@@ -195,27 +198,29 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     {
         const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
-            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            // (a float4 spans at most two rows: the first and the last component's; unwritten rows are not even loaded)
+            // (a float4 spans at most two rows: the first and the last component's)
             const uint32_t ra = (uint32_t)(((float)e + 0.5f) * rcp_len), rb = (uint32_t)(((float)(e + 3u) + 0.5f) * rcp_len);
-            if (!masked || s_mask[ra] != 0.0f || s_mask[rb] != 0.0f) g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
+            const bool wa = !masked || vis_rows[ra] != 0.0f, wb = !masked || vis_rows[rb] != 0.0f;
+            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (wa || wb) g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t ee = e + k;
                 const uint32_t r = (uint32_t)(((float)ee + 0.5f) * rcp_len);  // ee / row_len, exact for ee < 2^16
-                s_g[r * pitch + (ee - r * row_len)] = (masked && s_mask[r] == 0.0f) ? 0.0f : gv[k] * u.gscale;
+                s_g[r * pitch + (ee - r * row_len)] = (r == ra ? wa : wb) ? gv[k] * u.gscale : 0.0f;
             }
         }
         for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
             const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
-            s_g[r * pitch + (e - r * row_len)] = (masked && s_mask[r] == 0.0f) ? 0.0f : g_sh[sh_base + e] * u.gscale;
+            s_g[r * pitch + (e - r * row_len)] = (!masked || vis_rows[r] != 0.0f) ? g_sh[sh_base + e] * u.gscale : 0.0f;
         }
     }
     // ---- statistics + opacity: one splat per thread
     if (threadIdx.x < nrows) {
         const uint64_t i = row0 + threadIdx.x;
         const bool written = !masked || visible[i] != 0.0f;
+        if (masked) s_mask[threadIdx.x] = written ? 1.0f : 0.0f;
         refine_weight_norm[i] = __builtin_fmaxf(written ? refine_weight[i] : 0.0f, refine_weight_norm[i]);
         const float v = u.vis_clamp ? __builtin_fminf(visible[i], 1.0f) : visible[i];
         vis_weight[i] = vis_weight[i] + v;
@@ -243,15 +248,15 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             s_noise[threadIdx.x * 3u + 2u] = nz[2];
         }
     }
-    if (u.noise_on) __syncthreads();   // block-uniform
+    if (u.noise_on || masked) __syncthreads();   // block-uniform
     // ---- transforms: full second moment, per-column lr
     {
         const uint32_t count = nrows * 10u;
         const uint64_t base = row0 * 10u;
-        auto one = [&](float g_raw, float m1v, float m2v, float pv, uint32_t e, float& o_m1, float& o_m2, float& o_p) {
+        auto one = [&](float g_raw, bool written, float m1v, float m2v, float pv, uint32_t e, float& o_m1, float& o_m2, float& o_p) {
             const uint32_t r = (e * 52429u) >> 19;  // e / 10 (e < 2560)
             const uint32_t c = e - r * 10u;
-            const float g = (masked && s_mask[r] == 0.0f) ? 0.0f : g_raw * u.gscale;
+            const float g = written ? g_raw * u.gscale : 0.0f;
             const float mm1 = a.first ? g * a.f1 : m1v * a.beta1 + g * a.f1;
             const float gsq = g * g;
             const float mm2 = a.first ? gsq * a.f2 : m2v * a.beta2 + gsq * a.f2;
@@ -266,15 +271,16 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         const uint32_t vec_end = VEC ? (count & ~3u) : 0u;
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
             const uint64_t i = base + e;
-            float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (!masked || s_mask[(e * 52429u) >> 19] != 0.0f || s_mask[((e + 3u) * 52429u) >> 19] != 0.0f) g4 = *reinterpret_cast<const float4*>(&g_t[i]);
+            const float4 g4 = *reinterpret_cast<const float4*>(&g_t[i]);
             float4 m14 = *reinterpret_cast<const float4*>(&m1_t[i]);
             float4 m24 = *reinterpret_cast<const float4*>(&m2_t[i]);
             float4 p4 = *reinterpret_cast<const float4*>(&transforms[i]);
-            one(g4.x, m14.x, m24.x, p4.x, e, m14.x, m24.x, p4.x);
-            one(g4.y, m14.y, m24.y, p4.y, e + 1, m14.y, m24.y, p4.y);
-            one(g4.z, m14.z, m24.z, p4.z, e + 2, m14.z, m24.z, p4.z);
-            one(g4.w, m14.w, m24.w, p4.w, e + 3, m14.w, m24.w, p4.w);
+            const uint32_t ra = (e * 52429u) >> 19, rb = ((e + 3u) * 52429u) >> 19;   // the float4's first and last row
+            const bool wa = !masked || s_mask[ra] != 0.0f, wb = !masked || s_mask[rb] != 0.0f;
+            one(g4.x, wa, m14.x, m24.x, p4.x, e, m14.x, m24.x, p4.x);
+            one(g4.y, (((e + 1u) * 52429u) >> 19) == ra ? wa : wb, m14.y, m24.y, p4.y, e + 1, m14.y, m24.y, p4.y);
+            one(g4.z, (((e + 2u) * 52429u) >> 19) == ra ? wa : wb, m14.z, m24.z, p4.z, e + 2, m14.z, m24.z, p4.z);
+            one(g4.w, wb, m14.w, m24.w, p4.w, e + 3, m14.w, m24.w, p4.w);
             *reinterpret_cast<float4*>(&m1_t[i]) = m14;
             *reinterpret_cast<float4*>(&m2_t[i]) = m24;
             *reinterpret_cast<float4*>(&transforms[i]) = p4;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         for (uint32_t e = vec_end + threadIdx.x; e < count; e += OPT_WG) {
             const uint64_t i = base + e;
             float o1, o2, op;
-            one(g_t[i], m1_t[i], m2_t[i], transforms[i], e, o1, o2, op);
+            one(g_t[i], !masked || s_mask[(e * 52429u) >> 19] != 0.0f, m1_t[i], m2_t[i], transforms[i], e, o1, o2, op);
             m1_t[i] = o1;
             m2_t[i] = o2;
             transforms[i] = op;
