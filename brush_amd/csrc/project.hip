@@ -44,7 +44,8 @@ constexpr int PROJ_WAVES = PROJ_WG / 64;
 // ---------------------------------------------------------------------------
 struct WalkLds {
     uint32_t count[64];   // by rank: hits per splat (K1) / emit cursor (K5)
-    float mx[64], my[64], c00[64], c01[64], c11[64], pt[64], rcp_w[64];   // by rank
+    float mx[64], my[64], c00[64], c01[64], c11[64], pt[64];   // by rank
+    uint32_t magic[64];   // by rank: ceil(2^32 / box width), 0 = divide the long way (walk_row)
     uint32_t box[64];     // by rank: min_x | min_y << 16   (tile grids up to 4095 x 4095: api.hip's image-size limit)
     uint32_t boxw[64];    // by rank: box width in tiles
     uint32_t start[64];   // by rank: first candidate of the splat
@@ -52,11 +53,24 @@ struct WalkLds {
     uint8_t flags[64];    // scratch strip for the per-step start marks
 };
 
-// i / bw for a candidate index inside a box: the float quotient is exact for boxes of up to ~1000 rows (error <= rows * 2^-22
-// against the 0.5 / bw margin) and at most one off for anything a 4095 x 4095 tile grid can hold (i < 2^24); one correction each
-// way makes it exact everywhere.
-BH_DEV uint32_t walk_row(uint32_t i, uint32_t bw, float rcp_w) {
-    uint32_t row = (uint32_t)(((float)i + 0.5f) * rcp_w);
+// i / bw for a candidate index inside a box.  The walk does this once per candidate, so it is a multiplication: with
+// m = ceil(2^32 / bw), mul_hi(i, m) = floor(i / bw) exactly as long as i * bw < 2^32 (e = m bw - 2^32 < bw and i e < 2^32 is the
+// classic condition) — walk_magic returns m when every index of the box satisfies that (any box of a 4K frame does by orders
+// of magnitude), else 0 and walk_row divides.  (Before: a float quotient + two exec-masked corrections, ~15 VALU ops and three
+// SALU exec swaps per candidate.)
+#ifdef BH_WALK_FLOAT_ROW   // A/B: the float quotient of rounds 1-3
+BH_DEV uint32_t walk_magic(uint32_t, uint32_t) { return 0u; }
+#else
+BH_DEV uint32_t walk_magic(uint32_t bw, uint32_t nb) {
+    if (bw < 2u || (unsigned long long)nb * bw >= (1ull << 32)) return 0u;
+    return 0xFFFFFFFFu / bw + 1u;
+}
+#endif
+BH_DEV uint32_t walk_row(uint32_t i, uint32_t bw, uint32_t magic) {
+    if (magic) return __umulhi(i, magic);
+    if (bw < 2u) return i;
+    // the float quotient is at most one off for anything a 4095 x 4095 tile grid can hold (i < 2^24); one correction each way
+    uint32_t row = (uint32_t)(((float)i + 0.5f) / (float)bw);
     if (row * bw > i) --row;
     else if ((row + 1u) * bw <= i) ++row;
     return row;
@@ -104,7 +118,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
         w.mx[rank] = mx; w.my[rank] = my;
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
-        w.rcp_w[rank] = 1.0f / (float)bb_w;
+        w.magic[rank] = walk_magic(bb_w, nb);
         w.box[rank] = bb.min_x | (bb.min_y << 16);
         w.boxw[rank] = bb_w;
         w.start[rank] = start;
@@ -135,8 +149,8 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t i = c - w.start[r];
             const uint32_t box = w.box[r];
             const uint32_t bw = w.boxw[r];
-            const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
-            const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
+            const uint32_t row = walk_row(i, bw, w.magic[r]);
+            const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
             if (keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
         }
@@ -166,7 +180,7 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
         w.mx[rank] = mx; w.my[rank] = my;
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
-        w.rcp_w[rank] = 1.0f / (float)bb_w;
+        w.magic[rank] = walk_magic(bb_w, nb);
         w.box[rank] = bb.min_x | (bb.min_y << 16);
         w.boxw[rank] = bb_w;
         w.start[rank] = start;
@@ -193,8 +207,8 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
             const uint32_t i = c - w.start[r];
             const uint32_t box = w.box[r];
             const uint32_t bw = w.boxw[r];
-            const uint32_t row = walk_row(i, bw, w.rcp_w[r]);
-            const uint32_t tx = (box & 0xFFFFu) + (i - row * bw);
+            const uint32_t row = walk_row(i, bw, w.magic[r]);
+            const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
             hit = keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
             tile = tx + ty * tile_bw;
