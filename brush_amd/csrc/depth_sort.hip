@@ -336,10 +336,14 @@ __global__ __launch_bounds__(DS_WG) void dsort_split_kernel(const uint32_t* __re
 }
 
 // ---- 2: one block per bucket: sort on the low bits, then the scan of the tile counts --------------------------------------------
-constexpr int BK_WG = 512;                     // 8 waves: two per SIMD, the only block on its CU (LDS)
+#ifndef BH_BK_WG
+#define BH_BK_WG 1024   /* 16 waves: four per SIMD, the only block on its CU (LDS).  512 (rounds 2-3): 39.5 us, 1024: 34.0 us — the
+                           kernel is one latency chain per bucket, the largest bucket sets its length, more waves shorten every link */
+#endif
+constexpr int BK_WG = BH_BK_WG;
 constexpr int BK_WAVES = BK_WG / 64;
 constexpr int BK_KPT = DS_TILE / BK_WG;        // scan / chunk granularity: 4096 elements, 8 per thread
-constexpr int FAST_CAP = 8192;                 // keys of a bucket that is sorted resident in LDS (two (key, id) buffers: ping-pong)
+constexpr int FAST_CAP = BK_WG <= 512 ? 8192 : 7168;   // keys of a bucket that is sorted resident in LDS (two (key, id) buffers: ping-pong)
 constexpr int FAST_NDIG = 512;                 // digits of up to 9 bits
 constexpr size_t FAST_LDS_WORDS = 4 * FAST_CAP + (BK_WAVES + 1) * FAST_NDIG;
 static_assert(FAST_LDS_WORDS * 4 >= sizeof(ChunkLds<BK_WG>), "the dynamic LDS block holds either path's arrays");
@@ -373,11 +377,11 @@ BH_DEV void bk_scan_counts(const uint32_t* vals, uint32_t size, const uint32_t* 
     for (uint32_t c = 0; c < nch; ++c) {
         const uint32_t first = c * DS_TILE;
         const uint32_t count = size - first < (uint32_t)DS_TILE ? size - first : (uint32_t)DS_TILE;
-        // thread t owns elements 8t .. 8t+7 of the chunk, staged through LDS (+1 word per 8: conflict-free) so the global side stays coalesced
+        // thread t owns elements 8t .. 8t+7 of the chunk, staged through LDS (+1 word per thread run: conflict-free) so the global side stays coalesced
 #pragma unroll
         for (int k = 0; k < BK_KPT; ++k) {
             const uint32_t e = k * BK_WG + tid;
-            stage[e + (e >> 3)] = e < count ? counts[vals[first + e]] : 0u;
+            stage[e + e / BK_KPT] = e < count ? counts[vals[first + e]] : 0u;
         }
         __syncthreads();
         uint32_t v[BK_KPT], tsum = 0;
@@ -391,7 +395,7 @@ BH_DEV void bk_scan_counts(const uint32_t* vals, uint32_t size, const uint32_t* 
 #pragma unroll
         for (int k = 0; k < BK_KPT; ++k) {
             const uint32_t e = k * BK_WG + tid;
-            if (e < count) cum_out[first + e] = stage[e + (e >> 3)];
+            if (e < count) cum_out[first + e] = stage[e + e / BK_KPT];
         }
         carry += total;
         __syncthreads();
@@ -501,14 +505,17 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             // (b) per digit (one per thread): wave cursors; exclusive scan of the digit totals
             {
                 uint32_t run = 0;
+                if (tid < FAST_NDIG) {
 #pragma unroll
-                for (int w = 0; w < BK_WAVES; ++w) {
-                    const uint32_t c = fcnt[w * FAST_NDIG + tid];
-                    fcnt[w * FAST_NDIG + tid] = run;
-                    run += c;
+                    for (int w = 0; w < BK_WAVES; ++w) {
+                        const uint32_t c = fcnt[w * FAST_NDIG + tid];
+                        fcnt[w * FAST_NDIG + tid] = run;
+                        run += c;
+                    }
                 }
                 uint32_t tot;
-                fdb[tid] = bk_excl_scan(run, tot, s_red);
+                const uint32_t ex = bk_excl_scan(run, tot, s_red);
+                if (tid < FAST_NDIG) fdb[tid] = ex;
             }
             __syncthreads();
             // (c) placement
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             const uint32_t v = fv[i];
             out_keys[start + i] = fk[i];
             out_vals[start + i] = v;
-            if (cum != nullptr) { const uint32_t e = i; spare[e + (e >> 3)] = counts[v]; }
+            if (cum != nullptr) { const uint32_t e = i; spare[e + e / BK_KPT] = counts[v]; }
         }
         DS_MARK(4);
         if (cum == nullptr) return;
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
 #pragma unroll
                 for (int k = 0; k < BK_KPT; ++k) {
                     const uint32_t e = first + tid * BK_KPT + k;
-                    v[k] = e < size ? spare[e + (e >> 3)] : 0u;
+                    v[k] = e < size ? spare[e + e / BK_KPT] : 0u;
                     tsum += v[k];
                 }
                 uint32_t total;
@@ -569,12 +576,12 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
                 for (int k = 0; k < BK_KPT; ++k) {
                     const uint32_t e = first + tid * BK_KPT + k;
                     run += v[k];
-                    if (e < size) spare[e + (e >> 3)] = run;
+                    if (e < size) spare[e + e / BK_KPT] = run;
                 }
                 carry += total;
             }
             __syncthreads();
-            for (uint32_t i = tid; i < size; i += BK_WG) cum[start + i] = spare[i + (i >> 3)];
+            for (uint32_t i = tid; i < size; i += BK_WG) cum[start + i] = spare[i + i / BK_KPT];
         }
         DS_MARK(5);
 #ifdef DS_DEBUG
