@@ -531,7 +531,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
             ctx->grads_prezeroed = false;
-            if (bwd_info && !ctx->grad_row_mask && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
+            if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
                 prep.span = reinterpret_cast<float4*>(ctx->ext_grad_begin);   // the train step's gradient span
                 prep.span_f4 = (uint32_t)(ctx->ext_grad_floats / 4);
@@ -799,8 +799,8 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "ZeroGradBuffers");
         // what the forward's kernels cleared on their way (K5: v_combined; K1: the train step's gradient span) is done
         const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
-        // (grad_row_mask: the single-GPU train step reads only the rows K18 writes — nothing to clear)
-        const bool vc_done = ctx->vcombined_prezeroed, span_done = one_span && (ctx->grads_prezeroed || ctx->grad_row_mask);
+        // (grad_rows_marked: the single-GPU train step reads only the rows K18 writes and marks — its forward cleared the marks)
+        const bool vc_done = ctx->vcombined_prezeroed, span_done = one_span && (ctx->grads_prezeroed || ctx->grad_rows_marked);
         ctx->vcombined_prezeroed = false;
         ctx->grads_prezeroed = false;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
@@ -838,7 +838,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         ProfScope ps(ctx, "ProjectBackwards");
         BH_TRY(launch_project_backward(ctx, ctx->uniforms, nv, ctx->flags & BH_FLAG_MIP, ctx->sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
-                                       v_raw_opacities, v_refine_weight, ctx->grad_row_mask));
+                                       v_raw_opacities, v_refine_weight, ctx->grad_rows_marked));
     }
     return 0;
 }
@@ -1028,14 +1028,18 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_max_radius = s_radius;
     ctx->ext_grad_begin = exch + o_tr;       // ... and the whole gradient span (padding included): K1 does both on its way
     ctx->ext_grad_floats = exch_count - o_tr;
-    // ... unless nobody but this step's own update reads the gradients (one GPU, no hook): then the span is not cleared at all.
-    // K18 writes the rows of the splats the blend used (`visible`), the update kernel takes every other row as zero — at SH
-    // degree 3 the zero-fill was most of K1's HBM traffic (236 of 330 MB per step at 1 M splats).
+    // ... unless nobody but this step's own update reads the gradients (one GPU, no hook): then only the refine-weight vector
+    // (N floats, the span's last section) is cleared.  K18 writes the rows of the splats that received a gradient and marks them in
+    // that vector's sign bit, the update kernel takes every unmarked row as zero — at SH degree 3 the zero-fill was most of K1's
+    // HBM traffic (236 of 330 MB per step at 1 M splats).
     // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
     // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
     const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
     const bool masked_grads = !exchanging && !batch->image_hook && !ctx->knob_zero_grads && n > 0;
-    ctx->grad_row_mask = masked_grads ? s_visible : nullptr;
+    if (masked_grads) {
+        ctx->ext_grad_begin = exch + o_ref;
+        ctx->ext_grad_floats = exch_count - o_ref;
+    }
     // depth-sliced lists: whether the far slice has to run is known once the near slice's blend has; a single-GPU step does not
     // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
     // (a tile-partitioned frame hands the image to its hook right after the forward: there the forward waits itself)
@@ -1047,7 +1051,6 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_max_radius = nullptr;
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
-    ctx->grad_row_mask = nullptr;
     BH_TRY(frc);
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
@@ -1141,11 +1144,11 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     float* g_op = exch + o_op;
     ctx->ext_grad_begin = g_tr;              // one zero-fill of the whole gradient span (padding included)
     ctx->ext_grad_floats = exch_count - o_tr;
-    ctx->grad_row_mask = masked_grads ? s_visible : nullptr;
+    ctx->grad_rows_marked = masked_grads;
     const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
-    ctx->grad_row_mask = nullptr;
+    ctx->grad_rows_marked = false;
     BH_TRY(brc);
     if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
         ProfScope ps(ctx, "FoldMinScaleBackward");

@@ -174,9 +174,9 @@ struct bh_ctx {
     // cleared on the way by the forward's kernels (K1: the gradient span, K5: v_combined) -> the backward skips its fills;
     // each flag is consumed by the next bh_render_backward
     bool grads_prezeroed = false, vcombined_prezeroed = false;
-    // single-GPU train step: the gradient span is NOT zero-filled; a row of it is meaningful iff this flag ([N], the forward's
-    // `visible`) is nonzero — K18 writes exactly those rows, the update kernel reads exactly those rows
-    const float* grad_row_mask = nullptr;
+    // single-GPU train step: of the gradient span only the refine-weight vector is zero-filled; K18 marks the splats whose rows it
+    // writes in that vector's sign bit, the update kernel reads exactly those rows
+    bool grad_rows_marked = false;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
     // the library communicator's side stream: the mask-keyed exchange sums the visible flags and lists their union there,
@@ -288,7 +288,7 @@ int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, co
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine, const float* row_mask = nullptr);
+                            float* v_refine, bool mark_written = false);
 // sort.hip
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);

@@ -153,7 +153,7 @@ struct UpdateArgs {
     float gscale;          // 1/world for data parallel over cameras, else 1
     uint32_t n, sh_len;    // splats, 3*C
     uint32_t vis_clamp;    // tile-partitioned frame: visible arrives summed over strips -> min(v, 1)
-    uint32_t masked;       // the gradient tensors were not zero-filled: row i holds a gradient iff visible[i] != 0, else it is 0
+    uint32_t masked;       // the gradient tensors were not zero-filled: row i holds a gradient iff the sign bit of refine_weight[i] is set (K18's mark), else it is 0
     float tab_t[10];       // lr_mean x3, lr_rotation x4, lr_scale x3
     float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
     // visibility-gated noise on the means (train.rs:389-416) drawn on the device and added right behind the Adam update
@@ -183,14 +183,15 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
     float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written (only with u.masked)
     float* s_noise = s_mask + (uint32_t)ROWS;         // [rows][3], only with noise_on
-    // masked (block-uniform): the gradient tensors were not zero-filled — row r of them counts iff visible[row0 + r] != 0.
-    // No barrier stands in front of what the block fetches: the SH staging below reads the flags it needs straight from global
+    // masked (block-uniform): the gradient tensors were not zero-filled — row r of them counts iff K18 marked the splat: the sign
+    // bit of its (non-negative) refine weight, a vector that WAS cleared.
+    // No barrier stands in front of what the block fetches: the SH staging below reads the marks it needs straight from global
     // memory (its gradients are wanted last, two round trips hide) and skips the rows nobody wrote — they would come from
     // cold HBM: +7 us at SH degree 3 when loaded and thrown away; the transforms' gradients are loaded unconditionally, their
-    // flags come through LDS from the per-splat section (which reads `visible` anyway), behind its barrier.  (Flags staged
-    // through LDS up front, every gradient load predicated on them: +6 us at SH degree 0.)
+    // marks come through LDS from the per-splat section (which reads the refine weight anyway), behind its barrier.  (Marks
+    // staged through LDS up front, every gradient load predicated on them: +6 us at SH degree 0.)
     const bool masked = u.masked != 0u;
-    const float* vis_rows = visible + row0;
+    const uint32_t* mark_rows = reinterpret_cast<const uint32_t*>(refine_weight) + row0;
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
             // (a float4 spans at most two rows: the first and the last component's)
             const uint32_t ra = (uint32_t)(((float)e + 0.5f) * rcp_len), rb = (uint32_t)(((float)(e + 3u) + 0.5f) * rcp_len);
-            const bool wa = !masked || vis_rows[ra] != 0.0f, wb = !masked || vis_rows[rb] != 0.0f;
+            const bool wa = !masked || (mark_rows[ra] >> 31) != 0u, wb = !masked || (mark_rows[rb] >> 31) != 0u;
             float4 g4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (wa || wb) g4 = *reinterpret_cast<const float4*>(&g_sh[sh_base + e]);
             const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -213,15 +214,17 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         }
         for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
             const uint32_t r = (uint32_t)(((float)e + 0.5f) * rcp_len);
-            s_g[r * pitch + (e - r * row_len)] = (!masked || vis_rows[r] != 0.0f) ? g_sh[sh_base + e] * u.gscale : 0.0f;
+            s_g[r * pitch + (e - r * row_len)] = (!masked || (mark_rows[r] >> 31) != 0u) ? g_sh[sh_base + e] * u.gscale : 0.0f;
         }
     }
     // ---- statistics + opacity: one splat per thread
     if (threadIdx.x < nrows) {
         const uint64_t i = row0 + threadIdx.x;
-        const bool written = !masked || visible[i] != 0.0f;
+        const float rw_raw = refine_weight[i];
+        const bool written = !masked || (f2u(rw_raw) >> 31) != 0u;
         if (masked) s_mask[threadIdx.x] = written ? 1.0f : 0.0f;
-        refine_weight_norm[i] = __builtin_fmaxf(written ? refine_weight[i] : 0.0f, refine_weight_norm[i]);
+        // (masked: K18 stored the weight with the sign bit as the mark; an unmarked entry is the zero the forward left)
+        refine_weight_norm[i] = __builtin_fmaxf(masked ? __builtin_fabsf(rw_raw) : rw_raw, refine_weight_norm[i]);
         const float v = u.vis_clamp ? __builtin_fminf(visible[i], 1.0f) : visible[i];
         vis_weight[i] = vis_weight[i] + v;
         max_screen_size[i] = __builtin_fmaxf(screen_radius[i], max_screen_size[i]);

@@ -572,6 +572,9 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t wave_total = __shfl(end, last_lane) - wave_base;
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
+#ifdef BH_K5_NO_WALK   // measurement-only probe (empty image): no candidate is visited, every slot leaves as a sentinel pair
+    nb = nb == 0xFFFFFFFFu ? 1u : 0u;
+#endif
     if (FAR) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
     else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
     (void)tile_bh;
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ sh_coeffs,
     const float* __restrict__ raw_opac, const uint32_t* __restrict__ global_from_compact_gid,
     const float* __restrict__ v_combined, float* __restrict__ v_transforms, float* __restrict__ v_coeffs,
-    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const float* __restrict__ row_mask) {
+    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const bool mark_written) {
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     if (cg >= nv) return;
     const uint32_t gid = global_from_compact_gid[cg];
@@ -744,22 +747,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) { g[k] = rg[k]; any = any || (g[k] != 0.0f); }
     constexpr int C = (DEG + 1) * (DEG + 1);
-    if (!any) {
-        // dense outputs that nobody zero-filled (row_mask = the forward's `visible`, the single-GPU train step): the rows the
-        // consumer reads are those of the splats the blend used, and a splat it used can still come out with an all-zero
-        // gradient — that row is written here
-        if (row_mask && row_mask[gid] != 0.0f) {
-            float* vt = v_transforms + (size_t)gid * 10;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) vt[k] = 0.0f;
-            float* vc = v_coeffs + (size_t)gid * C * 3;
-#pragma unroll
-            for (int k = 0; k < C * 3; ++k) vc[k] = 0.0f;
-            v_raw_opac[gid] = 0.0f;
-            v_refine_weight[gid] = 0.0f;
-        }
-        return;
-    }
+    if (!any) return;   // the row stays what it is: zero (the caller cleared the dense outputs) or, with mark_written, unmarked
     const float* tr = transforms + (size_t)gid * 10;
     const Vec3A mean = v3(tr[0], tr[1], tr[2]);
     const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
@@ -782,7 +770,10 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     const float os = sigmoid(raw_opac[gid]);
     v_raw_opac[gid] = filter_comp * g[8] * os * (1.0f - os);
     const float refine_clean = is_finite_f32(g[9]) ? g[9] : 0.0f;
-    v_refine_weight[gid] = clampf(refine_clean, 0.0f, 1.0e32f);
+    // mark_written (the single-GPU train step, which clears ONLY the refine-weight vector): the sign bit of the (non-negative)
+    // refine weight says "this splat's gradient rows were written this step" — the update kernel reads no other row
+    const float refine_w = clampf(refine_clean, 0.0f, 1.0e32f);
+    v_refine_weight[gid] = mark_written ? u2f(f2u(refine_w) | 0x80000000u) : refine_w;
     const Sym2 conic_inv = sym2_inverse(cov);
     const Sym2 v_inv = Sym2{g[2], g[3] * 0.5f, g[4]};
     const Sym2 v_cov2d = inverse2x2_vjp(conic_inv, v_inv);
@@ -810,7 +801,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 
 template <bool MIP, bool PINHOLE>
 static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
-                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr, const float* rm) {
+                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr, bool rm) {
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
         case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
@@ -827,7 +818,7 @@ static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine, const float* row_mask) {
+                            float* v_refine, bool row_mask) {
     if (nv == 0) return 0;
     if (u.model == CAM_PINHOLE)
         return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask)

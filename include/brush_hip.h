@@ -386,9 +386,9 @@ void bh_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 /* state->step_count is advanced only when the call succeeds (a failed step applied no update and may be retried).
  * The gradients live in a scratch buffer of the ctx (the exchange buffer above).  With a hook or a communicator the whole
  * buffer is defined when it is handed over (rows of splats the view did not use are zero: render_bwd.rs:123-138).  On one
- * GPU without a hook nobody else reads it, and the step does not clear the rows of splats the view did not use (`visible` = 0):
- * the update ignores whatever they hold and takes them as zero — same results, without 4 (11 + 3C) N bytes of zero-fill per
- * step. */
+ * GPU without a hook nobody else reads it, and the step clears only its refine-weight vector: the backward marks the splats
+ * whose gradient rows it writes (the sign bit of their refine weight), the update ignores whatever the other rows hold and takes
+ * them as zero — same results, without 4 (10 + 3C) N bytes of zero-fill per step. */
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);

@@ -1,5 +1,6 @@
-"""The single-GPU train step does not zero-fill its gradient span: K18 writes the rows of the splats the blend used, the
-update kernel takes every other row as zero (api.hip bh_train_step, `grad_row_mask`).  That must be invisible.  The span
+"""The single-GPU train step does not zero-fill its gradient span (only the refine-weight vector): K18 writes the rows of the
+splats that received a gradient and marks them in the sign bit of their refine weight, the update kernel takes every other row
+as zero (api.hip bh_train_step, `grad_rows_marked`).  That must be invisible.  The span
 is filled with NaNs before every step (bh_debug_fill_train_scratch): one read of a row nobody wrote would poison a
 parameter, a moment or a statistic for good.  The results are then compared with the zero-filling step
 (BH_TRAIN_ZERO_GRADS, which is also what the multi-GPU exchange path runs) — to the run-to-run tolerance of a step, not
