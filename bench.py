@@ -43,24 +43,29 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 VALU_PER_ISECT_STATIC = {"rasterize_backward_kernel": 249.4, "rasterize_kernel": 103.8}   # profiles/r2f_sq_counters.csv
 
 # stages whose working set the previous kernel left in the 256 MB Infinity Cache: their GB/s is not an HBM rate
-CACHE_RESIDENT = {"ProjectBackwards": "reads v_combined / writes into the gradient span K1 zero-filled, both still in the 256 MB Infinity Cache",
+CACHE_RESIDENT = {"ProjectBackwards": "reads v_combined (cleared by K5, accumulated by K17) / writes gradient rows the update reads next: still in the 256 MB Infinity Cache",
                   "OptimizerStep": "reads the gradient span the backward just wrote (Infinity-Cache resident at SH degree 0)"}
 
 
-def stage_bytes(n, nv, ni, ni_blended, pixels, tiles, coeffs):
-    """HBM bytes per stage: algorithmic (SURVEY.md §8d / DESIGN.md §5), except the two blend kernels, which are charged
-    only for the intersections they consume before every pixel of a tile saturates."""
+def stage_bytes(n, nv, ni, ni_blended, pixels, tiles, coeffs, list_share=1.0, grads_cleared=True):
+    """HBM bytes per stage: algorithmic (SURVEY.md §8d / DESIGN.md §5), except (i) the two blend kernels, which are charged
+    only for the intersections they consume before every pixel of a tile saturates, and (ii) what the depth-sliced lists do not
+    list: K5 / tile sort / offsets are charged for the near slice's pairs (list_share of ni; its splats taken as the same share
+    of nv).  grads_cleared: the step zero-fills its whole gradient span (the multi-GPU exchange paths) instead of the refine-weight
+    vector alone (one GPU)."""
     c = coeffs
+    ni_l = int(round(ni * list_share))
+    nv_l = int(round(nv * list_share))
     return {
-        # K1 also stores the projected record by splat id and clears visible + the train step's gradient span on its way
-        "ProjectSplats": 44 * n + 12 * n + 36 * nv + 4 * n + (48 + 12 * c) * n,
+        # K1 also stores the projected record by splat id and clears visible + (part of) the train step's gradient span on its way
+        "ProjectSplats": 44 * n + 12 * n + 36 * nv + 4 * n + ((48 + 12 * c) * n if grads_cleared else 4 * n),
         "DepthSort": 80 * nv,
         "PrefixSumGaussHits": 12 * nv,
         "ProjectVisible": (84 + 12 * c) * nv,   # separate launch only for frames without intersections
         # K5 also gathers the records into depth order (the former K4) and clears the backward's v_combined
-        "MapGaussiansToIntersect": 32 * nv + 8 * ni + 76 * nv + 40 * nv,
-        "TileSort": 40 * ni,
-        "GetTileOffsets": 4 * ni + 8 * tiles,
+        "MapGaussiansToIntersect": 4 * nv + 76 * nv_l + 8 * ni_l + 40 * nv,
+        "TileSort": 40 * ni_l,
+        "GetTileOffsets": 4 * ni_l + 8 * tiles,
         "Rasterize": 44 * ni_blended + 16 * pixels,
         "ImageLoss": (16 + 4 + 12) * pixels,
         "ImageLossBackward": (16 + 4 + 16) * pixels,
@@ -496,7 +501,8 @@ def main():
         ms_per_step = dt / steps * 1e3
         nv, ni = st.num_visible, st.num_intersections
         pixels, tiles = w * h, ((w + 15) // 16) * ((h + 15) // 16)
-        sb = stage_bytes(n, nv, ni, m["isect_blended"], pixels, tiles, coeffs)
+        sb = stage_bytes(n, nv, ni, m["isect_blended"], pixels, tiles, coeffs, list_share=m.get("list_share", 1.0),
+                         grads_cleared=(world > 1 or bool(os.environ.get("BH_FORCE_PG")) or bool(os.environ.get("BH_TRAIN_ZERO_GRADS"))))
         # per-stage GPU time: the kernels' own timestamps (a child run under rocprofv3 --kernel-trace) when rocprofv3 is there,
         # else HIP events around each stage — which are host-bound while they record and read multi-launch stages too long
         headline_n1 = args.workload == "1m_1080p" and args.sh_degree == 0 and not args.splats and world == 1 and args.feed == "resident"
