@@ -26,7 +26,10 @@ namespace bh {
 
 constexpr int DS_WG = 256;
 constexpr int DS_WAVES = DS_WG / 64;
-constexpr int DS_KPT = 16;
+#ifndef BH_DS_KPT
+#define BH_DS_KPT 16
+#endif
+constexpr int DS_KPT = BH_DS_KPT;
 constexpr int DS_TILE = DS_WG * DS_KPT;   // 4096 keys per chunk
 constexpr int DS_RADIX = 256;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
