@@ -95,3 +95,58 @@ def test_masked_rows_equal_zero_filled(dev, sh_degree, mip, min_scale_views, n, 
     assert float((a["vis_weight"] != b["vis_weight"]).float().mean()) <= 2e-3
     # the scene is seen from four directions: the visibility pattern really changed between steps
     assert float((a["vis_weight"] > 0).float().mean()) > float(sa.num_visible) / n
+
+
+def test_masked_and_exchange_steps_alternate(dev):
+    """One context, steps alternating between the single-GPU path (masked rows, scratch poisoned with NaNs in front of them) and
+    the exchange path (a hook: the whole span is zero-filled and handed over): neither leaves anything behind that the other
+    trips over — the run ends where an all-zero-filling run ends."""
+    import brush_amd as ba
+    from brush_amd import _ffi
+    n, w, h, sh_degree = 9000, 224, 144, 2
+    sc = synth.make_scene(n, 0x77, sh_degree=sh_degree, log_scale_range=(math.log(0.02), math.log(0.2)),
+                          tan_half_fov=(math.tan(math.radians(50)), math.tan(math.radians(50)) * h / w))
+    gt = synth.synthetic_gt_packed(w, h)
+    cams = _views(w, h, 4)
+    steps = 8
+    seen = []
+
+    def run(alternate):
+        if not alternate:
+            os.environ["BH_TRAIN_ZERO_GRADS"] = "1"
+        try:
+            ctx = ba.Context(dev)
+        finally:
+            os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
+        trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx, seed=99, sparse_exchange=False)
+        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+        gt_t = torch.from_numpy(gt.view(np.int32)).to(dev)
+
+        def hook_fn(_user, _ptr, count):   # one rank: the sum over the ranks is the buffer itself
+            seen.append(int(count))
+            return 0
+        hook = _ffi.GRAD_HOOK(hook_fn)
+        for s in range(steps):
+            with_hook = alternate and (s % 2 == 1)
+            trainer.pg, trainer._hook, trainer._world = ("one rank", hook, 1) if with_hook else (None, None, 1)
+            if alternate and not with_hook and s > 0:
+                ctx.check(ctx.lib.bh_debug_fill_train_scratch(ctx._h, 0x7FC00000))
+            trainer.step(ba.SceneBatch(gt_t, util.hip_camera(ba, cams[s % len(cams)])), spl)
+        ctx.sync()
+        out = {"transforms": spl.transforms.clone(), "sh": spl.sh_coeffs.clone(), "opac": spl.raw_opacities.clone()}
+        out.update({k: v.clone() for k, v in trainer.state.items()})
+        ctx.close()
+        return out
+
+    a = run(True)
+    b = run(False)
+    c = run(False)
+    assert len(seen) == steps // 2 and all(x > n for x in seen)   # the hook saw visible + the gradient sections
+    cfg = ba.TrainConfig()
+    lr = {"transforms": max(cfg.lr_rotation, cfg.lr_scale), "sh": cfg.lr_coeffs_dc, "opac": cfg.lr_opac}
+    for k in a:
+        assert bool(torch.isfinite(a[k]).all()), k
+    for k in ("transforms", "sh", "opac"):
+        d_ab, d_bc = (a[k] - b[k]).abs(), (b[k] - c[k]).abs()
+        assert float(d_ab.mean()) <= 2.0 * float(d_bc.mean()) + 1e-3 * lr[k], (k, float(d_ab.mean()), float(d_bc.mean()))
+        assert float((d_ab > 0.5 * lr[k]).float().mean()) <= 2.0 * float((d_bc > 0.5 * lr[k]).float().mean()) + 1e-3, k
