@@ -162,7 +162,7 @@ ProfScope::~ProfScope() {
 
 
 // ---- the far slice of a depth-sliced forward (see bh_render_forward) -------------------------------------------------------------
-// count -> scan -> emit the remaining splats into the tiles that still have live pixels, sort them behind the near list (absolute
+// count -> emit (the scan between them folded into the emit kernel) the remaining splats into the tiles that still have live pixels, sort them behind the near list (absolute
 // offsets: one array for the backward), blend from the parked state.  Every kernel is gated on the device by the number of
 // unsaturated tiles, so queueing it for a frame that does not need it is correct, just ~50 us of empty launches.
 int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
@@ -602,7 +602,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     // sorted list, at 6 M / 4K 1.7 %.  The splats are in depth order and cum_tiles_hit is their slot ranges, so "slot end <= budget"
     // is a NEAR slice of the depth order whose pairs are the first I0 slots of the exact list.  List + sort + blend that slice;
     // tiles whose pixels all saturated are final (one bit each); the FAR rest is listed only into tiles that are not
-    // (count -> scan -> emit against the bit table), sorted behind the near list and blended from the parked pixel state.
+    // (count -> emit against the bit table), sorted behind the near list and blended from the parked pixel state.
     // Everything the far slice launches is a no-op when no tile is left (a device-side gate: no host round trip).  Per pixel the
     // same splats are folded in the same order: out_img, visible[], the blended part of every list and the gradients are those
     // of the exact path.  The near slice's size comes from the PREVIOUS forward on this ctx (how many slots its slowest
