@@ -67,8 +67,10 @@ def stage_bytes(n, nv, ni, ni_blended, pixels, tiles, coeffs, list_share=1.0, gr
         "TileSort": 40 * ni_l,
         "GetTileOffsets": 4 * ni_l + 8 * tiles,
         "Rasterize": 44 * ni_blended + 16 * pixels,
-        "ImageLoss": (16 + 4 + 12) * pixels,
-        "ImageLossBackward": (16 + 4 + 16) * pixels,
+        # pass A: image + GT in, the nine SSIM-partial planes out; pass B: image + GT + the planes in (once: the halo re-read is
+        # not algorithmic), dL/dimg out  (loss_fused.hip)
+        "ImageLoss": (16 + 4 + 36) * pixels,
+        "ImageLossBackward": (16 + 4 + 36 + 16) * pixels,
         "RasterizeBackwards": 80 * ni_blended + 32 * pixels,
         "ProjectBackwards": (88 + 12 * c) * nv + (48 + 12 * c) * nv,
         "OptimizerStep": 28 * 11 * n + (20 * 3 * c + 8) * n + 36 * n,  # Adam x3 + refine statistics + noise, one launch
@@ -231,6 +233,13 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the second (non-saturating scene) measurement")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run a short bench under rocprofv3 --pmc for the counter figures (use the committed CSVs, marked stale)")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage HIP-event pass (child runs under rocprofv3 use it)")
+    ap.add_argument("--views", type=int, default=2,
+                    help="views each rank cycles through in the timed region (step k trains view k % V).  2 (the default) is the reference's own "
+                         "training bench: two cameras 2 units apart in x, alternating (crates/brush-bench-test/src/benches.rs:198-220); "
+                         "1 = one camera replayed (the round 1-3 headline); >= 3 = an orbit of V cameras")
+    ap.add_argument("--windows", type=int, default=3,
+                    help="timed windows of --steps steps each (barrier + synchronize on both sides of every window); the line reports the MEDIAN "
+                         "window as ms_per_step / value and all of them in `windows_ms_per_step`")
     ap.add_argument("--no-noise", action="store_true", help="leave out the two stochastic terms of the reference's default step (mean noise, background jitter)")
     ap.add_argument("--comm", choices=["torch", "native"], default="native",
                     help="N>1 gradient exchange: 'native' = the library's own RCCL communicator (bh_comm_init / built-in exchange in "
@@ -335,32 +344,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(workload, steps, warmup, with_stages, sh_degree=None):
-        """Time `steps` train steps of `workload`; returns a dict of raw measurements (rank-local)."""
+    def view_cameras(cp, nviews):
+        """The cameras one rank cycles through.  V = 2: the reference's training bench (benches.rs:198-220: camera positions
+        (0,0,z) and (2,0,z), identity rotation, batches[step % 2]) on the named config's camera; V >= 3: V cameras on a circle of
+        radius 1 around the named camera's position, each yawed to keep looking at the scene's centre line.  Rank r adds a small yaw
+        so that the ranks' gradients differ (data parallel over cameras); one frame split over the ranks uses the same camera."""
+        base = 0.0 if tile_mode else 0.02 * rank
+        cams = []
+        for v in range(nviews):
+            if nviews <= 2:
+                pos, yaw = (cp["pos"][0] + 2.0 * v, cp["pos"][1], cp["pos"][2]), base
+            else:
+                ang = 2.0 * math.pi * v / nviews
+                pos = (cp["pos"][0] + math.cos(ang) - 1.0, cp["pos"][1] + 0.5 * math.sin(ang), cp["pos"][2])
+                yaw = base - math.atan2(pos[0] - cp["pos"][0], 7.0)   # towards the scene's centre line at mid depth
+            rot = (0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0))
+            cams.append(ba.Camera(position=pos, rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"]))
+        return cams
+
+    def measure(workload, steps, warmup, with_stages, sh_degree=None, nviews=None, windows=1):
+        """Time `windows` windows of `steps` train steps of `workload`, cycling through `nviews` views; returns a dict of raw
+        measurements (rank-local; dt = the median window)."""
         sh_degree = args.sh_degree if sh_degree is None else sh_degree
+        nviews = max(1, args.views if nviews is None else nviews)
         scene, w, h = synth.config_scene(workload, sh_degree, n=args.splats or None)
         n = scene["transforms"].shape[0]
         coeffs = scene["sh"].shape[1]
         cp = synth.default_camera_params(w, h)
-        # one view per rank: rank r looks at the scene with a small extra yaw so the ranks'
-        # gradients differ (data parallel over cameras); rank 0 is the named config's camera
-        yaw = 0.0 if tile_mode else 0.02 * rank
-        rot = (0.0, math.sin(yaw / 2.0), 0.0, math.cos(yaw / 2.0))
-        cam = ba.Camera(position=cp["pos"], rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"])
+        cams = view_cameras(cp, nviews)
+        cam = cams[0]   # rank 0's first view is the named config's camera
         splats = ba.Splats(scene["transforms"], scene["sh"], scene["raw_opac"], device=dev)
-        gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + (0 if tile_mode else rank)).view(np.int32)).to(dev)
-        batch = ba.SceneBatch(gt, cam.uniforms((w, h)))
+        batches = []
+        for v, c in enumerate(cams):
+            gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + 100 * v + (0 if tile_mode else rank)).view(np.int32)).to(dev)
+            batches.append(ba.SceneBatch(gt, c.uniforms((w, h))))
+        batch = batches[0]
         # seed: the reference's default step draws the mean noise and jitters the background every step
         trainer = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
                                   native_comm=native, sparse_exchange=args.exchange == "sparse", seed=None if args.no_noise else 0xB5EED)
         loader = None
         if args.feed == "loader":
             rng = np.random.default_rng(1 + rank)
-            host_views = [(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), cam.uniforms((w, h))) for _ in range(6)]
+            host_views = [(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), cams[i % nviews].uniforms((w, h))) for i in range(max(6, nviews))]
             loader = ba.SceneLoader(host_views, seed=rank, slots=3, ctx=ctx)
+        counter = [0]
 
         def next_batch():
-            return loader.next_batch() if loader is not None else batch
+            if loader is not None:
+                return loader.next_batch()
+            b = batches[counter[0] % nviews]   # benches.rs:214: batches[step % batches.len()]
+            counter[0] += 1
+            return b
 
         for _ in range(warmup):
             trainer.step(next_batch(), splats)
@@ -373,36 +407,52 @@ def main():
         #  30-50 ms host stall that lands on whichever call happens to cross its allocation threshold)
         gc.collect()
         gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            trainer.step(next_batch(), splats)
-        barrier()
-        dt = time.perf_counter() - t0
+        sliced = args.lists == "sliced"
+        far0 = int(ctx.lib.bh_far_slices_queued(ctx._h))
+        shares = []
+        window_dt = []
+        for _ in range(max(1, windows)):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trainer.step(next_batch(), splats)
+                if sliced:
+                    shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))   # a host field: no synchronisation
+            barrier()
+            window_dt.append(time.perf_counter() - t0)
         gc.enable()
+        far_queued = int(ctx.lib.bh_far_slices_queued(ctx._h)) - far0
+        if pg is not None:   # every window: the slowest rank's time
+            import torch.distributed as dist
+            tmax = torch.tensor(window_dt, dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            window_dt = [float(x) for x in tmax.tolist()]
+        dt = sorted(window_dt)[len(window_dt) // 2]
         dominant = ctx.profile_fetch()
         stages = {}
         if with_stages and not args.no_stages:
             ctx.profile(1)
             nst = min(steps, 10)
             for _ in range(nst):
-                trainer.step(batch, splats)
+                trainer.step(next_batch(), splats)
             barrier()
             # per STEP, not per call: a sliced forward that needs its far slice enters some scopes twice
             stages = {k: (ms, nst) for k, (ms, calls) in ctx.profile_fetch().items()}
         stages.update(dominant)   # the dominant kernel's duration is the one measured inside the timed region
         ctx.profile(0)
         st = trainer.stats()
-        list_share = float(ctx.lib.bh_last_list_share(ctx._h)) if args.lists == "sliced" else 1.0
-        # how much of the per-tile lists the blend kernels actually consume before every pixel saturates (outside the
-        # timed region): the forward shrinks each tile's list end to its last useful splat
-        _, aux = ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
-        to = aux.tile_offsets.to(torch.int64)
-        isect_blended = int((to[:, 1] - to[:, 0]).clamp(min=0).sum().item())
-        if pg is not None:
-            import torch.distributed as dist
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
+        list_share = (sum(shares) / len(shares)) if shares else 1.0
+        # per view (outside the timed region): the counts, and how much of the per-tile lists the blend kernels actually consume
+        # before every pixel saturates — the forward shrinks each tile's list end to its last useful splat
+        per_view = []
+        for c in cams:
+            _, aux = ba.render_splats(splats, c, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
+            to = aux.tile_offsets.to(torch.int64)
+            per_view.append({"num_visible": aux.num_visible, "num_intersections": aux.num_intersections,
+                             "intersections_blended": int((to[:, 1] - to[:, 0]).clamp(min=0).sum().item())})
+            del aux, to
+        isect_blended = int(round(sum(v["intersections_blended"] for v in per_view) / len(per_view)))
+        nv_mean = int(round(sum(v["num_visible"] for v in per_view) / len(per_view)))
+        ni_mean = int(round(sum(v["num_intersections"] for v in per_view) / len(per_view)))
         if loader is not None:
             loader.close()
         fwd_only = None
@@ -411,10 +461,10 @@ def main():
             # blend into a packed rgba8 image, no visible[] / list shrinking / backward state; each call ends with the host having the
             # counts (the call's one readback), as the reference's render does.  Timed as wall time over back-to-back calls.
             fwd_only = {}
-            far0 = int(ctx.lib.bh_far_slices_queued(ctx._h))
-            for mode, sliced in (("exact_lists", False), ("sliced_lists", True)):
+            far1 = int(ctx.lib.bh_far_slices_queued(ctx._h))
+            for mode, sl in (("exact_lists", False), ("sliced_lists", True)):
                 for _ in range(5):
-                    ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sliced)
+                    ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sl)
                 torch.cuda.synchronize(dev)
                 reps = 50
                 per_call = []
@@ -423,7 +473,7 @@ def main():
                 t0 = time.perf_counter()
                 for _ in range(reps):
                     tc = time.perf_counter()
-                    ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sliced)
+                    ba.render_splats(splats, cam, (w, h), (0.0, 0.0, 0.0), ba.RasterPass.Forward, ctx=ctx, copy=False, sliced=sl)
                     per_call.append(time.perf_counter() - tc)
                 torch.cuda.synchronize(dev)
                 fwd_only[mode] = round((time.perf_counter() - t0) / reps * 1e3, 4)
@@ -431,15 +481,17 @@ def main():
                 if os.environ.get("BH_BENCH_DEBUG"):
                     pc = sorted(per_call)
                     print("forward_only %s: per-call host ms min %.3f median %.3f max %.3f (call %d)" % (mode, pc[0] * 1e3, pc[len(pc) // 2] * 1e3, pc[-1] * 1e3, per_call.index(pc[-1])), file=sys.stderr)
-                if sliced:
+                if sl:
                     fwd_only["near_share"] = round(float(ctx.lib.bh_last_list_share(ctx._h)), 4)
-                    fwd_only["far_slices_queued"] = int(ctx.lib.bh_far_slices_queued(ctx._h)) - far0
-        return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, stages=stages, stats=st, isect_blended=isect_blended, loader=loader is not None,
-                    list_share=list_share, forward_only=fwd_only)
+                    fwd_only["far_slices_queued"] = int(ctx.lib.bh_far_slices_queued(ctx._h)) - far1
+        return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, window_dt=window_dt, stages=stages, stats=st, isect_blended=isect_blended,
+                    nv=nv_mean, ni=ni_mean, per_view=per_view, nviews=nviews, loader=loader is not None, list_share=list_share,
+                    near_share_min=min(shares) if shares else 1.0, near_share_max=max(shares) if shares else 1.0, far_slices_queued=far_queued,
+                    timed_steps=steps * max(1, windows), forward_only=fwd_only)
 
     def blend_rooflines(m, steps):
         """HBM and VALU rooflines of the two blend kernels from one measurement."""
-        nv, ni, ib = m["stats"].num_visible, m["stats"].num_intersections, m["isect_blended"]
+        nv, ni, ib = m["nv"], m["ni"], m["isect_blended"]
         pixels = m["w"] * m["h"]
         dom_ms = m["stages"].get("RasterizeBackwards", (0.0, 0))
         dom_ms = dom_ms[0] / max(dom_ms[1], 1)
@@ -448,6 +500,9 @@ def main():
         ach = touched / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
         hbm = {"bound": "hbm (reported because the contract asks for it: the kernel is VALU-issue bound, see roofline_valu)", "kernel": "rasterize_backward_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": touched, "avg_launch_ms": round(dom_ms, 4),
+               "avg_launch_ms_clock": "HIP events carried by the kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events on the ctx stream), every launch "
+                                      "of the timed windows, mean over them and over the views; the rocprofv3 trace of the child run reads the same kernel ~10 % "
+                                      "shorter (kernel_trace.kernels: begin/end timestamps of the dispatch without the packet's completion signal) - this figure is the conservative one",
                "intersections_listed": ni, "intersections_blended": ib,
                "frac_listed": round(listed / 1e9 / (dom_ms * 1e-3) / HBM_PEAK_GBS, 4) if dom_ms > 0 else 0.0,
                "note": "achieved = bytes the launch touches (80 B per BLENDED intersection + 32 B per pixel) / measured duration. frac_listed is the "
@@ -468,7 +523,23 @@ def main():
                           "G_pixel_splat_evals_per_s": round(256.0 * ib / 1e9 / (ms * 1e-3), 1)}
         return hbm, valu
 
-    m = measure(args.workload, args.steps, args.warmup, "forward_only" if (world == 1 and not args.no_extra) else True)
+    m = measure(args.workload, args.steps, args.warmup, "forward_only" if (world == 1 and not args.no_extra) else True, windows=args.windows)
+
+    # the round 1-3 headline (ONE camera replayed: the slicing feedback, the tile order and every cache see the same frame every
+    # step) next to the multi-view number, and an 8-view orbit
+    view_runs = None
+    if world == 1 and not args.no_extra and args.feed == "resident" and not args.splats:
+        view_runs = {}
+        for nvw in (1, 8):
+            if nvw == args.views:
+                continue
+            vs = max(10, min(args.steps, 40))
+            mv = measure(args.workload, vs, 2 * nvw, False, nviews=nvw, windows=1)
+            view_runs["views_%d" % nvw] = {"views": nvw, "steps": vs, "ms_per_step": round(mv["dt"] / vs * 1e3, 4), "views_per_s": round(vs / mv["dt"], 2),
+                                           "near_share_min": round(mv["near_share_min"], 4), "near_share_max": round(mv["near_share_max"], 4),
+                                           "far_slices_queued": mv["far_slices_queued"],
+                                           "num_intersections_per_view": [v["num_intersections"] for v in mv["per_view"]],
+                                           "intersections_blended_per_view": [v["intersections_blended"] for v in mv["per_view"]]}
 
     extra = None
     if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats:
@@ -478,10 +549,10 @@ def main():
         est = me["stats"]
         extra = {"workload": "1m_1080p_lowopac: the configs[2] scene with opacities U(0.02, 0.1) instead of U(0.05, 0.95) — tiles do not saturate early, "
                              "the blend kernels consume %.0f %% of every list (NOT a BASELINE.json config; context for the blend kernels only)"
-                             % (100.0 * me["isect_blended"] / max(est.num_intersections, 1)),
+                             % (100.0 * me["isect_blended"] / max(me["ni"], 1)),
                  "steps": ex_steps, "ms_per_step": round(me["dt"] / ex_steps * 1e3, 4), "views_per_s": round(ex_steps / me["dt"], 2),
-                 "num_visible": est.num_visible, "num_intersections": est.num_intersections, "intersections_blended": me["isect_blended"],
-                 "list_share": me["list_share"],
+                 "views": me["nviews"], "num_visible": me["nv"], "num_intersections": me["ni"], "intersections_blended": me["isect_blended"],
+                 "list_share": me["list_share"], "far_slices_queued": me["far_slices_queued"],
                  "roofline": ehbm, "roofline_valu": evalu,
                  "stages_ms": {k: round(ms / max(c, 1), 4) for k, (ms, c) in me["stages"].items()}}
 
@@ -491,15 +562,34 @@ def main():
         m3 = measure("1m_1080p", s3_steps, 3, True, sh_degree=3)
         sh3 = {"workload": "1m_1080p at SH degree 3 (the reference's ModelConfig default, 16 coefficients per splat)", "steps": s3_steps,
                "ms_per_step": round(m3["dt"] / s3_steps * 1e3, 4), "views_per_s": round(s3_steps / m3["dt"], 2),
-               "num_visible": m3["stats"].num_visible, "num_intersections": m3["stats"].num_intersections, "list_share": m3["list_share"],
+               "views": m3["nviews"], "num_visible": m3["nv"], "num_intersections": m3["ni"], "list_share": m3["list_share"], "far_slices_queued": m3["far_slices_queued"],
                "stages_ms": {k: round(ms / max(c, 1), 4) for k, (ms, c) in m3["stages"].items()}}
+
+    per_rank = None
+    if pg is not None:
+        # what every rank put on the wire in its last step (an all-reduce moves ~2 (N-1)/N of its payload per rank): the first
+        # SCALE record should be readable without a second run
+        import torch.distributed as dist
+        st_r = m["stats"]
+        c3 = 3 * m["coeffs"]
+        pad4 = lambda x: (x + 3) & ~3   # noqa: E731
+        dense_bytes = 4 * (pad4(m["n"]) + pad4(10 * m["n"]) + pad4(c3 * m["n"]) + pad4(m["n"]) + (pad4(m["n"]) if tile_mode else 0))
+        if args.exchange == "sparse" and st_r.exchange_rows > 0:
+            payload = 4 * pad4(m["n"]) + 4 * st_r.exchange_rows * (11 + c3 + (1 if tile_mode else 0))
+        else:
+            payload = dense_bytes
+        mine = {"rank": rank, "rows_last_step": int(st_r.exchange_rows), "allreduce_payload_bytes_last_step": int(payload),
+                "dense_payload_bytes": int(dense_bytes), "num_visible": int(st_r.num_visible), "num_intersections": int(st_r.num_intersections),
+                "ms_per_step_local": round(m["dt"] / args.steps * 1e3, 4), "far_slices_queued": m["far_slices_queued"]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         steps = args.steps
         dt, st = m["dt"], m["stats"]
         n, w, h, coeffs = m["n"], m["w"], m["h"], m["coeffs"]
         ms_per_step = dt / steps * 1e3
-        nv, ni = st.num_visible, st.num_intersections
+        nv, ni = m["nv"], m["ni"]   # means over the views of the timed region
         pixels, tiles = w * h, ((w + 15) // 16) * ((h + 15) // 16)
         sb = stage_bytes(n, nv, ni, m["isect_blended"], pixels, tiles, coeffs, list_share=m.get("list_share", 1.0),
                          grads_cleared=(world > 1 or bool(os.environ.get("BH_FORCE_PG")) or bool(os.environ.get("BH_TRAIN_ZERO_GRADS"))))
@@ -575,15 +665,24 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not m["loader"] else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
+            "windows_ms_per_step": [round(x / steps * 1e3, 4) for x in m["window_dt"]],
+            "windows_spread": round((max(m["window_dt"]) - min(m["window_dt"])) / max(dt, 1e-12), 4),
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
-                       "num_visible": nv, "num_intersections": ni,
-                       "lists": ("depth-sliced: near slice = %.3f of the pair list (chosen from the previous step's feedback), the far slice only into tiles "
+                       "views": m["nviews"],
+                       "view_cycle": ("step k trains view k %% %d; " % m["nviews"]) + ("two cameras 2 units apart in x as crates/brush-bench-test/src/benches.rs:198-220" if m["nviews"] == 2 else
+                                                                                   ("one camera replayed" if m["nviews"] == 1 else "an orbit of cameras on a circle of radius 1")),
+                       "num_visible": nv, "num_intersections": ni, "per_view": m["per_view"],
+                       "near_share": {"min": round(m["near_share_min"], 4), "max": round(m["near_share_max"], 4), "mean": round(m["list_share"], 4),
+                                      "of": "every step of the timed windows"} if args.lists == "sliced" else None,
+                       "far_slices_queued": m["far_slices_queued"] if args.lists == "sliced" else None,
+                       "timed_steps": m["timed_steps"],
+                       "lists": ("depth-sliced: near slice = %.3f of the pair list on average (chosen from the previous steps' feedback), the far slice only into tiles "
                                  "it left unsaturated; image / gradients identical to the exact lists" % m["list_share"]) if args.lists == "sliced" else "exact (every pair listed and sorted)",
                        "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
                        "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
             "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "rows_last_step": st.exchange_rows, "rows_total": n,
-                          "selfcheck": selfcheck} if pg is not None else None),
+                          "per_rank": per_rank, "selfcheck": selfcheck} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "fwd_bwd_source": fwd_src,
@@ -596,6 +695,8 @@ def main():
                          "note": "sum of the per-stage bytes (blend kernels: touched bytes) / ms_per_step"},
             "stages": stage_out,
         }
+        if view_runs:
+            out["other_view_counts"] = view_runs
         if extra is not None:
             out["non_saturating"] = extra
         if sh3 is not None:
@@ -613,7 +714,7 @@ def main():
 
 
 KERNEL_STAGE = (("project_forward_kernel", "ProjectSplats"), ("dsort_", "DepthSort"), ("map_gaussians_kernel", "MapGaussiansToIntersect"),
-                ("slice_count_kernel", "MapGaussiansToIntersect"), ("scan_", "MapGaussiansToIntersect"), ("radix_", "TileSort"),
+                ("slice_count_kernel", "MapGaussiansToIntersect"), ("radix_", "TileSort"), ("scan_", "MapGaussiansToIntersect"),
                 ("tile_offsets_kernel", "GetTileOffsets"), ("rasterize_backward_kernel", "RasterizeBackwards"), ("rasterize_kernel", "Rasterize"),
                 ("loss_fused_forward_kernel", "ImageLoss"), ("loss_fused_backward_kernel", "ImageLossBackward"),
                 ("project_backward_kernel", "ProjectBackwards"), ("train_update_kernel", "OptimizerStep"), ("project_visible_kernel", "ProjectVisible"))
@@ -633,7 +734,7 @@ def kernel_trace_inrun(args):
     tmp = tempfile.mkdtemp(prefix="bh_trace_", dir="/tmp")
     env = dict(os.environ, BH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--no-stages",
-             "--lists", args.lists] + (["--no-noise"] if args.no_noise else [])
+             "--lists", args.lists, "--views", str(args.views), "--windows", "1"] + (["--no-noise"] if args.no_noise else [])
     try:
         p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--"] + child, cwd="/tmp", env=env,
                            capture_output=True, text=True, timeout=120)
@@ -678,7 +779,8 @@ def pmc_inrun(args):
     per_launch, blended = collections.defaultdict(dict), None
     tmp = tempfile.mkdtemp(prefix="bh_pmc_", dir="/tmp")
     env = dict(os.environ, BH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--lists", args.lists]
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "4", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--lists", args.lists,
+             "--views", str(args.views), "--windows", "1"]
     if args.no_noise:
         child.append("--no-noise")
     try:

@@ -1,7 +1,7 @@
 """BASELINE.json full sizes: 1 M splats @ 1920x1080 (configs[1], configs[2]) and 6 M @ 3840x2160 (configs[4]).
 Checked against the oracle directly at the full size — forward stage by stage (bit-exact), the whole backward and one
-whole train step at SH degree 0 and 3 (configs[2]: "grads checked vs reference") — and through size-independent
-properties.  configs[3] (NeRF-synthetic lego) needs a dataset that is not in this container: untestable here."""
+whole train step at SH degree 0 and 3 (configs[2]: "grads checked vs reference") and at 6 M / 4K / SH 3 (configs[4] on one
+GPU) — and through size-independent properties.  configs[3] (NeRF-synthetic lego) needs a dataset that is not in this container: untestable here."""
 import math
 
 import numpy as np
@@ -213,16 +213,27 @@ def test_1m_1080p_full_backward_and_step_vs_oracle(dev, oracle_lib, sh_degree):
     assert not moved[otr.state["vis"] == 0].any() and moved.sum() > 10_000
 
 
-def test_6m_4k_sh3_forward_stagewise_exact_vs_oracle(dev, oracle_lib):
-    """BASELINE.json configs[4] (6 M splats, 3840x2160, SH degree 3) on one GPU: every stage output of the forward
-    bit-identical to the oracle — counts, depth order, scan, projected records, (tile, splat) lists before and after the
-    tile sort, tile offsets (incl. the shrunk ends), visible flags — and the image to 1e-6."""
+def test_6m_4k_sh3_forward_backward_step_vs_oracle(dev, oracle_lib):
+    """BASELINE.json configs[4] (6 M splats, 3840x2160, SH degree 3) on one GPU, all of it against the oracle at the full size:
+    (1) every stage output of the forward bit-identical — counts, depth order, scan, projected records, (tile, splat) lists before
+        and after the tile sort, tile offsets (incl. the shrunk ends), visible flags — and the image to 1e-6;
+    (2) the whole backward of a random v_output: v_combined per lane, all four dense gradient tensors, the zero pattern
+        (reference semantics: bwd/kernels/rasterize_backwards.rs:101-390, project_backwards.rs:101-254), per tensor AND per element;
+    (3) ONE complete SplatTrainer step (forward with the depth-sliced lists, L1+SSIM loss, backward, statistics, Adam) vs the
+        oracle's composition of the same step: loss, counts, every parameter, the RefineRecord."""
     import brush_amd as ba
+    from test_gpu_backward import assert_grads_match
     sc, w, h = synth.config_scene("6m_4k", 3)
     cp = synth.default_camera_params(w, h)
-    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
-    img, aux = ba.render_splats(spl, util.hip_camera(ba, cp), (w, h), (0.1, 0.2, 0.3), ba.RasterPass.Backward)
-    ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=(0.1, 0.2, 0.3))
+    cam = util.hip_camera(ba, cp)
+    bg = (0.1, 0.2, 0.3)
+    spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+    rng = np.random.default_rng(64)
+    v = (rng.uniform(-1, 1, (h, w, 4)) / (h * w)).astype(np.float32)
+    res = ba.render_splats_bwd(spl, cam, (w, h), bg, torch.from_numpy(v).to(dev))
+    img, aux = res["img"], res["aux"]
+    ocam = oracle_lib.camera(**cp)
+    ref = oracle_lib.Render().forward(ocam, sc["transforms"], sc["sh"], sc["raw_opac"], bg=bg)
     assert aux.num_visible == ref.num_visible and aux.num_intersections == ref.num_intersections
     nv = aux.num_visible
     assert np.array_equal(util.u32(aux.intersect_counts), ref.get("intersect_counts"))
@@ -236,6 +247,36 @@ def test_6m_4k_sh3_forward_stagewise_exact_vs_oracle(dev, oracle_lib):
     assert np.array_equal(aux.visible.cpu().numpy(), ref.get("visible"))
     d = np.abs(img.cpu().numpy() - ref.image())
     assert d.max() <= 1e-6, "L-inf %g" % d.max()
+    del d, img, aux
+    # ---- (2) the backward
+    ref.backward(v)
+    assert_grads_match(res, ref)
+    del res, ref, v
+    # ---- (3) one full train step
+    gt = synth.synthetic_gt_packed(w, h)
+    cfg = ba.TrainConfig()
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=5.0)
+    otr = util.OracleTrainer(oracle_lib, cfg, median_scene_scale=5.0)
+    osc = {k: a.copy() for k, a in sc.items()}
+    batch = ba.SceneBatch(torch.from_numpy(gt.view(np.int32)).to(dev), cam)
+    trainer.step(batch, spl, background=bg)
+    st = trainer.stats()
+    o = otr.step(osc, ocam, gt, bg)
+    assert st.num_visible == o["num_visible"] and st.num_intersections == o["num_intersections"]
+    assert abs(st.loss - o["loss"]) <= 1e-5 * max(1.0, abs(o["loss"]))
+    assert abs(st.lr_mean - o["lr_mean"]) <= 1e-12
+    tr = spl.transforms.cpu().numpy()
+    util.assert_adam_close(tr[:, 3:7], osc["transforms"][:, 3:7], cfg.lr_rotation, 1, "rotation")
+    util.assert_adam_close(tr[:, 7:10], osc["transforms"][:, 7:10], cfg.lr_scale, 1, "scale")
+    util.assert_adam_close(tr[:, 0:3], osc["transforms"][:, 0:3], o["lr_mean"], 1, "mean", extra_abs=1e-7)
+    util.assert_adam_close(spl.raw_opacities.cpu().numpy(), osc["raw_opac"], cfg.lr_opac, 1, "opacity")
+    util.assert_adam_close(spl.sh_coeffs.cpu().numpy(), osc["sh"], cfg.lr_coeffs_dc, 1, "sh")
+    s = trainer.state
+    assert np.array_equal(s["vis_weight"].cpu().numpy(), otr.state["vis"])
+    assert np.array_equal(s["max_screen_size"].cpu().numpy(), otr.state["screen"])
+    assert util.rel_linf(s["refine_weight_norm"].cpu().numpy(), otr.state["refine"]) <= 1e-4
+    moved = np.any(tr != sc["transforms"], axis=1)
+    assert not moved[otr.state["vis"] == 0].any() and moved.sum() > 10_000
 
 
 @pytest.mark.parametrize("share", [0.0, 0.04])

@@ -294,3 +294,168 @@ def test_one_6m_4k_sh3_frame_over_4_strips_equals_the_single_gpu_step(dev):
     util.assert_adam_close(tr[:, 7:10], spl.transforms[::997, 7:10].cpu().numpy(), cfg.lr_scale, steps, "scale")
     util.assert_adam_close(op, spl.raw_opacities[::997].cpu().numpy(), cfg.lr_opac, steps, "opacity")
     util.assert_adam_close(sh, spl.sh_coeffs[::997].cpu().numpy(), cfg.lr_coeffs_dc, steps, "sh")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[3]'s code path across ranks: data parallel over cameras AND refine in one loop
+# (crates/brush-train/src/train.rs:431-663; SURVEY.md §8e: "rank 0 must decide ... or all ranks share a seeded RNG")
+# ---------------------------------------------------------------------------------------------------------------
+_LOOP_VIEWS = 5          # the ranks cycle through V views: rank r trains view (step * K + r) % V
+
+
+def _loop_view(v, w, h):
+    cp = synth.default_camera_params(w, h)
+    cp["rot_xyzw"] = util.quat_from_axis_angle((0, 1, 0), 0.03 * v)
+    cp["pos"] = (0.15 * v, 0.0, 0.0)
+    return cp, synth.synthetic_gt_packed(w, h, seed=3 + v)
+
+
+def _loop_cfg(ba):
+    # thresholds low enough that the 3-step RefineRecord of this small scene selects splits of every kind
+    return ba.TrainConfig(growth_grad_threshold=2e-6, split_at_screen_size=0.12)
+
+
+def _digest(arrs):
+    import hashlib
+    hsh = hashlib.sha256()
+    for a in arrs:
+        hsh.update(np.ascontiguousarray(a).tobytes())
+    return hsh.hexdigest()
+
+
+def _loop_worker(rank, world, port, q, steps_a, steps_b):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brush_amd as ba
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    sc, w, h, median = _dp_problem("small")
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    views = []
+    for v in range(_LOOP_VIEWS):
+        cp, gt = _loop_view(v, w, h)
+        views.append(ba.SceneBatch(torch.from_numpy(gt.view(np.int32)).to(dev), util.hip_camera(ba, cp)))
+    trainer = ba.SplatTrainer(_loop_cfg(ba), median_scene_scale=median, process_group=dist.group.WORLD, sparse_exchange=True)
+    bg = (0.1, 0.2, 0.3)
+
+    def params(s):
+        return [s.transforms.cpu().numpy().copy(), s.sh_coeffs.cpu().numpy().copy(), s.raw_opacities.cpu().numpy().copy()]
+
+    def adam():
+        return {k: trainer.state[k].cpu().numpy().copy() for k in ("m1_t", "m2_t", "m1_sh", "m2_sh", "m1_o", "m2_o")}
+
+    step = 0
+    for _ in range(steps_a):
+        trainer.step(views[(step * world + rank) % _LOOP_VIEWS], spl, background=bg)
+        step += 1
+    trainer.stats()
+    trainer.sync_refine_stats()      # MAX over the ranks (refine() does it again: idempotent)
+    before = params(spl)
+    moments_before = adam()
+    record = {k: trainer.state[k].cpu().numpy().copy() for k in ("refine_weight_norm", "vis_weight", "max_screen_size")}
+    new, rs = trainer.refine(steps_a, spl)      # seed derived from the iteration: the same on every rank
+    plan = {k: v.cpu().numpy().copy() for k, v in trainer.last_refine_plan.items()}
+    after = params(new)
+    moments_after = adam()
+    bounds, median_after = trainer.bounds, trainer.median_scene_scale
+    for _ in range(steps_b):
+        trainer.step(views[(step * world + rank) % _LOOP_VIEWS], new, background=bg)
+        step += 1
+    trainer.stats()
+    final = params(new)
+    digs = (_digest(before + list(moments_before.values()) + list(record.values())),
+            _digest(after + list(moments_after.values()) + [plan["keep"], plan["split"]]), _digest(final))
+    payload = dict(before=before, moments_before=moments_before, record=record, plan=plan, after=after, moments_after=moments_after, final=final,
+                   stats=(rs.num_added, rs.num_pruned, rs.total_splats), bounds=bounds, median_after=median_after) if rank == 0 else None
+    q.put((rank, digs, new.num_splats(), payload))
+    dist.destroy_process_group()
+
+
+def _oracle_dp_steps(bo, cfg, median, scene, state, step0, world, nsteps, w, h):
+    """`nsteps` data-parallel steps on the oracle: every step is rank 0's view with the other ranks' single-view gradients added and
+    the mean taken (OracleTrainer.step(extra_grads, world)); returns the trainer (scene is updated in place)."""
+    ot = util.OracleTrainer(bo, cfg, median)
+    ot.state, ot.step_count = state, step0
+    bg = (0.1, 0.2, 0.3)
+    for s in range(nsteps):
+        step = step0 + s
+        extra = []
+        for r in range(1, world):
+            cp, gt = _loop_view((step * world + r) % _LOOP_VIEWS, w, h)
+            probe = util.OracleTrainer(bo, cfg, median)
+            probe.state, probe.step_count = ot.state, ot.step_count    # dry_run: reads nothing from it, changes nothing
+            extra.append(probe.step({k: v.copy() for k, v in scene.items()}, bo.camera(**cp), gt, bg, dry_run=True))
+        cp, gt = _loop_view((step * world) % _LOOP_VIEWS, w, h)
+        ot.step(scene, bo.camera(**cp), gt, bg, extra_grads=extra, world=world)
+    return ot
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_steps_refine_steps_replicas_identical_and_match_the_oracle(oracle_lib, world):
+    """K ranks x (N steps over cycling views -> MAX-reduce of the RefineRecord -> refine(seed) -> N more steps): the replicas are
+    bit-identical before the refine, after it (parameters, Adam moments, the plan itself) and after the further steps; the
+    splat count, every parameter and the RefineRecord follow the oracle trainer fed the mean gradients, and the refine follows
+    the oracle's refine given the same plan."""
+    import brush_amd as ba
+    from oracle import refine as orf
+    steps_a, steps_b = 3, 2
+    res = _run(world, _loop_worker, (steps_a, steps_b))
+    for k in range(3):
+        assert len({r[1][k] for r in res}) == 1, "replicas diverged (%s)" % ("before refine", "after refine", "after the further steps")[k]
+    assert len({r[2] for r in res}) == 1
+    p = res[0][3]
+    cfg = _loop_cfg(ba)
+    sc, w, h, median = _dp_problem("small")
+    n, C = sc["transforms"].shape[0], sc["sh"].shape[1]
+    # ---- phase A vs the oracle's mean-gradient steps
+    osc = {k: v.copy() for k, v in sc.items()}
+    z = lambda *s: np.zeros(s, np.float32)  # noqa: E731
+    ost = dict(m1_t=z(n, 10), m2_t=z(n, 10), m1_sh=z(n, C * 3), m2_sh=z(n), m1_o=z(n, 1), m2_o=z(n, 1), refine=z(n), vis=z(n), screen=z(n))
+    ot = _oracle_dp_steps(oracle_lib, cfg, median, osc, ost, 0, world, steps_a, w, h)
+    tr, sh, op = p["before"]
+    util.assert_adam_close(tr[:, 3:7], osc["transforms"][:, 3:7], cfg.lr_rotation, steps_a, "rotation")
+    util.assert_adam_close(tr[:, 7:10], osc["transforms"][:, 7:10], cfg.lr_scale, steps_a, "scale")
+    util.assert_adam_close(op, osc["raw_opac"], cfg.lr_opac, steps_a, "opacity")
+    util.assert_adam_close(sh, osc["sh"], cfg.lr_coeffs_dc, steps_a, "sh")
+    rec = p["record"]
+    assert rec["vis_weight"].max() <= float(world * steps_a) and np.mean(rec["vis_weight"] != ot.state["vis"]) <= 2e-3
+    # (after the first step the two trajectories differ by Adam's +-lr sign flips on noise gradients: radii agree closely, not bitwise)
+    assert np.mean(np.abs(rec["max_screen_size"] - ot.state["screen"]) > 1e-3 * np.maximum(ot.state["screen"], 1e-6)) <= 2e-3
+    assert np.abs(rec["refine_weight_norm"] - ot.state["refine"]).max() <= 2e-3 * ot.state["refine"].max() + 1e-12
+    # ---- the refine: decisions and tensors vs the oracle's refine, given the replicas' state and the plan they all took
+    keep, split = p["plan"]["keep"].astype(bool), p["plan"]["split"].astype(bool)
+    bounds0 = orf.bounds_from_pos(0.8, tr[:, :3])      # the trainer had no bounds yet: refine takes them from the splats (train.rs:485)
+    mask, _bad = orf.prune_mask(tr, sh, op, bounds0[0], bounds0[1])
+    assert np.array_equal(keep, ~mask)
+    rcfg = dict(split_at_screen_size=cfg.split_at_screen_size, growth_grad_threshold=cfg.growth_grad_threshold,
+                growth_select_fraction=cfg.growth_select_fraction, iter=steps_a, total_train_iters=cfg.total_train_iters, opac_decay=cfg.opac_decay)
+    bc = orf.budget_counts(n, keep, rec["vis_weight"], rec["refine_weight_norm"], rec["max_screen_size"], rcfg)
+    vis = rec["vis_weight"] > 0
+    assert not (split & ~keep).any() and not (split & ~((keep & vis) | bc["oversized"] | bc["above"])).any()
+    added, pruned, total = p["stats"]
+    assert pruned == int(mask.sum()) and added == int(split.sum()) and total == bc["n_keep"] + added == res[0][2]
+    assert added > 0, "the scene was set up so that the refine splits something"
+    mb = p["moments_before"]
+    state = dict(transforms=tr, sh=sh, raw_opac=op, **mb)
+    ref = orf.apply(state, keep, split, rcfg, rec["max_screen_size"])
+    got = dict(transforms=p["after"][0], sh=p["after"][1], raw_opac=p["after"][2], **p["moments_after"])
+    for k, r in ref.items():
+        assert got[k].shape == r.shape, k
+        assert np.allclose(got[k], r, rtol=2e-5, atol=2e-5), (k, float(np.abs(got[k] - r).max()))
+    c, e = orf.bounds_from_pos(0.8, ref["transforms"][:, :3])
+    assert np.allclose(p["bounds"][0], c, atol=1e-6) and np.allclose(p["bounds"][1], e, atol=1e-6)
+    # ---- phase B: the oracle continues from the refined replica state (same count, same moments, fresh RefineRecord)
+    n2 = total
+    osc2 = dict(transforms=p["after"][0].copy(), sh=p["after"][1].copy(), raw_opac=p["after"][2].copy())
+    ma = p["moments_after"]
+    ost2 = dict(m1_t=ma["m1_t"].copy(), m2_t=ma["m2_t"].copy(), m1_sh=ma["m1_sh"].reshape(n2, C * 3).copy(), m2_sh=ma["m2_sh"].copy(),
+                m1_o=ma["m1_o"].reshape(n2, 1).copy(), m2_o=ma["m2_o"].reshape(n2, 1).copy(), refine=z(n2), vis=z(n2), screen=z(n2))
+    _oracle_dp_steps(oracle_lib, cfg, p["median_after"], osc2, ost2, steps_a, world, steps_b, w, h)
+    tr2, sh2, op2 = p["final"]
+    assert tr2.shape[0] == n2
+    util.assert_adam_close(tr2[:, 3:7], osc2["transforms"][:, 3:7], cfg.lr_rotation, steps_b, "rotation after refine")
+    util.assert_adam_close(tr2[:, 7:10], osc2["transforms"][:, 7:10], cfg.lr_scale, steps_b, "scale after refine")
+    util.assert_adam_close(op2, osc2["raw_opac"], cfg.lr_opac, steps_b, "opacity after refine")
+    util.assert_adam_close(sh2, osc2["sh"], cfg.lr_coeffs_dc, steps_b, "sh after refine")
