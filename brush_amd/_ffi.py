@@ -119,6 +119,9 @@ SYMBOLS = {
     "bh_last_error": (C.c_char_p, [C.c_void_p]),
     "bh_sync": (C.c_int, [C.c_void_p]),
     "bh_version": (C.c_char_p, []),
+    "bh_abi_version": (C.c_uint32, []),
+    "bh_struct_size": (C.c_uint32, [C.c_uint32]),
+    "bh_last_list_counts": (C.c_int, [C.c_void_p, u32p, u32p]),
     "bh_camera_setup": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BhCamera)]),
     "bh_camera_setup_model": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(BhCamera)]),
     "bh_fov_to_focal": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
@@ -172,6 +175,10 @@ SYMBOLS = {
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
 }
 
+ABI_VERSION = 4   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
+# bh_struct_size index -> mirror (the BH_STRUCT_* order of the header)
+STRUCT_MIRRORS = (BhCamera, BhRenderOut, BhLossConfig, BhTrainConfig, BhTrainState, BhTrainBatch, BhTrainStats, BhRefineConfig, BhRefineStats, BhPlyInfo)
+
 _lib = None
 
 
@@ -193,5 +200,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # ABI guard: the library fills these structs with ITS layout; a mirror of another revision would be overrun
+    if lib.bh_abi_version() != ABI_VERSION:
+        raise BrushHipError("%s speaks ABI %d, this binding ABI %d" % (LIB_PATH, lib.bh_abi_version(), ABI_VERSION))
+    for i, mirror in enumerate(STRUCT_MIRRORS):
+        if lib.bh_struct_size(i) != C.sizeof(mirror):
+            raise BrushHipError("%s: sizeof(%s) is %d in the library, %d in this binding" % (LIB_PATH, mirror.__name__, lib.bh_struct_size(i), C.sizeof(mirror)))
     _lib = lib
     return lib

@@ -213,6 +213,24 @@ extern "C" {
 
 const char* bh_version(void) { return "brush_hip 0.1 (gfx950)"; }
 
+uint32_t bh_abi_version(void) { return BH_ABI_VERSION; }
+
+uint32_t bh_struct_size(uint32_t which) {
+    switch (which) {
+        case BH_STRUCT_CAMERA: return (uint32_t)sizeof(BhCamera);
+        case BH_STRUCT_RENDER_OUT: return (uint32_t)sizeof(BhRenderOut);
+        case BH_STRUCT_LOSS_CONFIG: return (uint32_t)sizeof(BhLossConfig);
+        case BH_STRUCT_TRAIN_CONFIG: return (uint32_t)sizeof(BhTrainConfig);
+        case BH_STRUCT_TRAIN_STATE: return (uint32_t)sizeof(BhTrainState);
+        case BH_STRUCT_TRAIN_BATCH: return (uint32_t)sizeof(BhTrainBatch);
+        case BH_STRUCT_TRAIN_STATS: return (uint32_t)sizeof(BhTrainStats);
+        case BH_STRUCT_REFINE_CONFIG: return (uint32_t)sizeof(BhRefineConfig);
+        case BH_STRUCT_REFINE_STATS: return (uint32_t)sizeof(BhRefineStats);
+        case BH_STRUCT_PLY_INFO: return (uint32_t)sizeof(BhPlyInfo);
+        default: return 0u;
+    }
+}
+
 bh_ctx* bh_create(int device, void* stream, int own_stream) {
     bh_ctx* ctx = new (std::nothrow) bh_ctx();
     if (!ctx) return nullptr;
@@ -246,6 +264,12 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
     ctx->knob_zero_grads = getenv("BH_TRAIN_ZERO_GRADS") != nullptr;
     ctx->knob_break_allreduce = getenv("BH_BREAK_ALLREDUCE") != nullptr;
+    if (ctx->knob_break_allreduce)   // a test hook (bench.py's exchange self-check must catch it): never silent
+        fprintf(stderr, "brush_hip: BH_BREAK_ALLREDUCE is set - every all-reduce of this context's communicator is deliberately CORRUPTED (test hook)\n");
+    if (const char* e = getenv("BH_TEST_FAIL_LOSS_AT")) {   // test hook (tests/test_gpu_sliced.py): the k-th train step on this ctx fails between its forward and its loss
+        ctx->knob_fail_loss_at = (uint32_t)atoi(e);
+        if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
+    }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess ||
@@ -851,6 +875,24 @@ int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out) {
     return 0;
 }
 
+int bh_last_list_counts(bh_ctx* ctx, uint32_t* near_pairs, uint32_t* far_pairs) {
+    if (!ctx || !near_pairs || !far_pairs) return BH_ERR_INVALID_ARG;
+    if (!ctx->have_forward) return set_error(ctx, BH_ERR_STATE, "no forward render on this context yet");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    *near_pairs = ctx->last.num_intersections;
+    *far_pairs = 0u;
+    if (!ctx->last.tile_offsets_far) return 0;   // one slice: the exact lists
+    // slice_info (SLOT_SLICE): [0] near splats  [1] near pairs  [2] tiles the near slice left unsaturated  [3] far pairs
+    uint32_t info[4] = {0u, 0u, 0u, 0u};
+    BH_HIP(ctx, hipMemcpyAsync(info, ctx->slots[SLOT_SLICE].ptr, sizeof info, hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    deliver_pending_loss(ctx);
+    *near_pairs = info[1];
+    *far_pairs = info[2] ? info[3] : 0u;
+    return 0;
+}
+
 const float* bh_last_v_combined(bh_ctx* ctx) { return ctx ? (const float*)ctx->slots[SLOT_V_COMBINED].ptr : nullptr; }
 
 // ---- primitives ----------------------------------------------------------------
@@ -1052,6 +1094,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
     BH_TRY(frc);
+    // masked gradients rely on last step's row marks (sign bits of the refine-weight vector) being gone: K1 clears the vector on
+    // its way when the span is float4-addressable (always, with the pad4 layout and hipMalloc's alignment) - not an implicit
+    // invariant: if it could not, clear it here
+    if (masked_grads && !ctx->grads_prezeroed) BH_HIP(ctx, hipMemsetAsync(exch + o_ref, 0, (exch_count - o_ref) * sizeof(float), ctx->stream));
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
     if (batch->image_hook) {
@@ -1090,6 +1136,8 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         }
         return launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host);
     };
+    if (ctx->knob_fail_loss_at && ++ctx->train_steps_seen == ctx->knob_fail_loss_at)   // (the forward is queued, a deferred far slice may be pending)
+        return set_error(ctx, BH_ERR_OOM, "train_step: injected failure between the forward and the loss (BH_TEST_FAIL_LOSS_AT)");
     BH_TRY(queue_loss());
     if (ctx->far_job.pending) {
         // The loss above ran on the near slice's image, which is the frame's image unless some tile was left unsaturated — the

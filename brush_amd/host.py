@@ -347,9 +347,24 @@ def _forward(ctx, splats, camera, img_size, background, pass_, sliced=False):
     return cam, out, (r_t, r_o)
 
 
-def _aux_from(out, n, w, h, device, copy):
+def last_list_counts(ctx: Optional["Context"] = None, device=None):
+    """(near_pairs, far_pairs) the last forward on `ctx` actually listed (bh_last_list_counts; blocking): the pair lists of a
+    depth-sliced forward hold that many defined entries, not num_intersections."""
+    ctx = ctx or get_context(device)
+    a, b = C.c_uint32(), C.c_uint32()
+    ctx.check(ctx.lib.bh_last_list_counts(ctx._h, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
+def _aux_from(out, n, w, h, device, copy, ctx=None):
     nv, ni, T = out.num_visible, out.num_intersections, out.num_tiles
     i32, f32 = torch.int32, torch.float32
+    listed = ni
+    if out.tile_offsets_far and copy and ctx is not None:
+        # depth-sliced lists: only the near slice's pairs and, behind them, the far slice's are defined (copies are trimmed to
+        # them; copy=False views keep the arena's length and cost no readback)
+        near, far = last_list_counts(ctx)
+        listed = min(ni, near + far)
 
     def mk(ptr, shape, dt):
         v = _view(ptr, shape, dt, device)
@@ -360,8 +375,8 @@ def _aux_from(out, n, w, h, device, copy):
         max_radius=mk(out.max_radius, (n,), f32),
         tile_offsets=mk(out.tile_offsets, (T, 2), i32),
         projected_splats=mk(out.projected, (nv, 9), f32),
-        compact_gid_from_isect=mk(out.compact_gid_from_isect, (ni,), i32),
-        tile_id_from_isect=mk(out.tile_id_from_isect, (ni,), i32),
+        compact_gid_from_isect=mk(out.compact_gid_from_isect, (listed,), i32),
+        tile_id_from_isect=mk(out.tile_id_from_isect, (listed,), i32),
         global_from_compact_gid=mk(out.global_from_compact_gid, (nv,), i32),
         cum_tiles_hit=mk(out.cum_tiles_hit, (nv,), i32),
         intersect_counts=mk(out.intersect_counts, (n,), i32),
@@ -389,7 +404,7 @@ def render_splats(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), 
         img = _view(out.out_img_packed, (h, w), torch.int32, splats.device)
     if copy:
         img = img.clone()
-    return img, _aux_from(out, splats.num_splats(), w, h, splats.device, copy)
+    return img, _aux_from(out, splats.num_splats(), w, h, splats.device, copy, ctx)
 
 
 def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pass_: RasterPass = RasterPass.Backward,
@@ -405,7 +420,7 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
         camera = camera.uniforms((w, h), tile_rows)
     _, out, (r_t, r_o) = _forward(ctx, splats, camera, (w, h), background, pass_, sliced)
     img = _view(out.out_img, (h, w, 4), torch.float32, dev).clone()
-    aux = _aux_from(out, splats.num_splats(), w, h, dev, True)
+    aux = _aux_from(out, splats.num_splats(), w, h, dev, True, ctx)
     if callable(v_output):
         v_output = v_output(img)
     v_output = _f32c(v_output, dev).reshape(h, w, 4)

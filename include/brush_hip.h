@@ -141,6 +141,20 @@ typedef struct BhRenderOut {
     uint32_t list_budget;
 } BhRenderOut;
 
+/* ---- ABI guard -------------------------------------------------------------- */
+/* The structs of this header are passed by pointer and filled / read with the layout the LIBRARY was built with; a binding
+ * built against another revision would be overrun (BhRenderOut, BhTrainBatch and BhTrainConfig have grown).  A binding
+ * checks once, at load time: bh_abi_version() == the BH_ABI_VERSION it was written against, and bh_struct_size(i) == the
+ * size of its own mirror of struct i (brush_amd/_ffi.py and include/brush_hip.hpp do; INTEGRATION.md shows the Rust side). */
+#define BH_ABI_VERSION 4u
+enum {
+    BH_STRUCT_CAMERA = 0, BH_STRUCT_RENDER_OUT, BH_STRUCT_LOSS_CONFIG, BH_STRUCT_TRAIN_CONFIG, BH_STRUCT_TRAIN_STATE,
+    BH_STRUCT_TRAIN_BATCH, BH_STRUCT_TRAIN_STATS, BH_STRUCT_REFINE_CONFIG, BH_STRUCT_REFINE_STATS, BH_STRUCT_PLY_INFO,
+    BH_STRUCT_COUNT
+};
+uint32_t bh_abi_version(void);
+uint32_t bh_struct_size(uint32_t which); /* sizeof(struct BH_STRUCT_*) in the library; 0 for an unknown index */
+
 /* ---- context ------------------------------------------------------------- */
 /* own_stream != 0: the ctx creates (and owns) a non-blocking stream; `stream` is
  * ignored.  own_stream == 0: submit on the caller's `stream` (a hipStream_t; NULL
@@ -185,6 +199,12 @@ float bh_last_list_share(bh_ctx* ctx);
 /* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far slice (diagnostics: on a scene that
  * saturates, with the automatic share, this stops growing after the first frames) */
 uint32_t bh_far_slices_queued(bh_ctx* ctx);
+
+/* How many pairs the last forward on this ctx actually LISTED: compact_gid_from_isect / tile_id_from_isect hold near_pairs
+ * entries sorted by tile, then far_pairs entries sorted by tile; everything behind near_pairs + far_pairs is undefined.
+ * Exact lists (no BH_FLAG_SLICED_LISTS, or a frame that chose one slice): near_pairs = num_intersections, far_pairs = 0.
+ * Blocking (the counts live on the device: one 16-byte readback); BH_ERR_STATE without a forward. */
+int bh_last_list_counts(bh_ctx* ctx, uint32_t* near_pairs /*host*/, uint32_t* far_pairs /*host*/);
 
 /* Backward of the last BH_FLAG_BWD_INFO forward on this ctx.  v_output [H,W,4].
  * All four outputs are dense and fully overwritten (zero where the splat got no

@@ -90,8 +90,21 @@ std::vector<T> download(const T* dev, size_t n) {
 // ---- context: one per thread / per GPU (brush-async/src/lib.rs:1-17) ---------------------------------------
 class Context {
   public:
-    explicit Context(int device = 0) : h_(bh_create(device, nullptr, /*own_stream=*/1)) {
+    explicit Context(int device = 0) : h_(nullptr) {
+        check_abi();
+        h_ = bh_create(device, nullptr, /*own_stream=*/1);
         if (!h_) throw Error(BH_ERR_HIP, "bh_create failed: no HIP device " + std::to_string(device));
+    }
+    // the library fills the header's structs with the layout IT was built with: refuse a library of another revision
+    static void check_abi() {
+        if (bh_abi_version() != BH_ABI_VERSION)
+            throw Error(BH_ERR_UNSUPPORTED, "libbrush_hip.so speaks ABI " + std::to_string(bh_abi_version()) + ", this header ABI " + std::to_string(BH_ABI_VERSION));
+        const size_t mine[BH_STRUCT_COUNT] = {sizeof(BhCamera), sizeof(BhRenderOut), sizeof(BhLossConfig), sizeof(BhTrainConfig), sizeof(BhTrainState),
+                                              sizeof(BhTrainBatch), sizeof(BhTrainStats), sizeof(BhRefineConfig), sizeof(BhRefineStats), sizeof(BhPlyInfo)};
+        for (uint32_t i = 0; i < BH_STRUCT_COUNT; ++i)
+            if (bh_struct_size(i) != mine[i])
+                throw Error(BH_ERR_UNSUPPORTED, "libbrush_hip.so: struct " + std::to_string(i) + " is " + std::to_string(bh_struct_size(i)) + " bytes in the library, " +
+                                                    std::to_string(mine[i]) + " in this header");
     }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;

@@ -288,3 +288,186 @@ def test_blank_background_keeps_one_slice_unless_the_saving_is_large(dev):
         assert int(ctx.lib.bh_far_slices_queued(ctx._h)) <= 2
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the slicing state machine under random call sequences (include/brush_hip.h: "Results do not depend on the choice")
+# ---------------------------------------------------------------------------------------------------------------
+def _fuzz_scenes(dev):
+    import brush_amd as ba
+    w, h = 208, 160
+    tans = (math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w)
+    mk = lambda n, seed, **kw: synth.make_scene(n, seed, tan_half_fov=tans, **kw)  # noqa: E731
+    raw = {
+        "saturating": mk(9000, 0x61, log_scale_range=(math.log(0.03), math.log(0.3))),
+        "non_saturating": mk(9000, 0x62, log_scale_range=(math.log(0.01), math.log(0.05)), opacity_range=(0.01, 0.05)),
+        "blank_background": mk(9000, 0x63, log_scale_range=(math.log(0.02), math.log(0.15)), spread=0.45),
+        "forty": mk(40, 0x64, log_scale_range=(math.log(0.05), math.log(0.4))),
+        "sh2": mk(5000, 0x65, sh_degree=2, log_scale_range=(math.log(0.03), math.log(0.3))),
+        "empty": dict(transforms=np.zeros((0, 10), np.float32), sh=np.zeros((0, 1, 3), np.float32), raw_opac=np.zeros((0,), np.float32)),
+    }
+    return raw, w, h
+
+
+def _fuzz_camera(ba, rng, w, h):
+    cp = synth.default_camera_params(w, h)
+    cp["pos"] = (float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-0.3, 0.3)), float(rng.choice([0.0, 0.0, -3.0, 1.0])))
+    cp["rot_xyzw"] = util.quat_from_axis_angle((0, 1, 0), float(rng.uniform(-0.2, 0.2)))
+    return util.hip_camera(ba, cp)
+
+
+def _grads_close(a, b, what):
+    for k in ("v_transforms", "v_sh_coeffs", "v_raw_opacities", "v_refine_weight"):
+        x, y = a[k].cpu().numpy().reshape(-1), b[k].cpu().numpy().reshape(-1)
+        scale = max(float(np.abs(y).max()), 1e-20)
+        assert float(np.abs(x - y).max()) <= 5e-6 * scale, (what, k, float(np.abs(x - y).max()) / scale)   # the float atomics' order only
+
+
+def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
+    """One long random walk over the public calls on ONE ctx — renders (exact / sliced x Forward / Backward / SmoothCutoff, whole
+    frames and strips), backwards, train steps (with and without an exchange hook), bh_set_list_slicing, changing scenes
+    (saturating, non-saturating, blank background, 40 splats, empty) and cameras: every result equals the same call on a FRESH
+    ctx (bit for bit: images, counts, flags; gradients to the float atomics' order; updates to Adam's sign flips on noise).
+    The host-side slicing state (far_job.pending, gate_learn, far_direct, need_hint, last_one_slice) may only change WHEN work
+    is done, never WHAT comes out."""
+    import brush_amd as ba
+    from brush_amd import _ffi
+    rng = np.random.default_rng(0xF022)
+    raw, w, h = _fuzz_scenes(dev)
+    names = list(raw)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+    noop_hook = _ffi.GRAD_HOOK(lambda _u, _p, _c: 0)    # one rank: the sum over the ranks is the buffer itself
+    A = ba.Context(dev)
+    n_ops = 420
+    kinds = {"render": 0, "backward": 0, "step": 0, "slicing": 0}
+    try:
+        for it in range(n_ops):
+            op = rng.choice(["render", "render", "backward", "step", "slicing"])
+            kinds[op] += 1
+            if op == "slicing":
+                share = float(rng.choice([0.0, 0.0, 0.02, 0.1, 0.4, 1.0]))
+                ba.set_list_slicing(share, A)
+                cur_share = share
+                continue
+            name = names[int(rng.integers(len(names)))]
+            if name == "empty" and op != "render":   # (the Python mirror cannot hand over zero-sized output tensors)
+                name = "forty"
+            sc = raw[name]
+            cam = _fuzz_camera(ba, rng, w, h)
+            bg = tuple(float(x) for x in rng.choice([0.0, 0.2, 0.7], 3))
+            sliced = bool(rng.integers(2))
+            F = ba.Context(dev)
+            try:
+                if 'cur_share' in locals():
+                    ba.set_list_slicing(cur_share, F)       # the SHARE is an input; the history is what differs
+                if op == "render":
+                    pass_ = [ba.RasterPass.Forward, ba.RasterPass.Backward, ba.RasterPass.BackwardSmoothCutoff][int(rng.integers(3))]
+                    rows = None
+                    if rng.integers(4) == 0:
+                        a = int(rng.integers(0, (h + 15) // 16 - 1))
+                        rows = (a, int(rng.integers(a + 1, (h + 15) // 16 + 1)))
+                    outs = []
+                    for ctx in (A, F):
+                        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+                        img, aux = ba.render_splats(spl, cam, (w, h), bg, pass_, ctx=ctx, tile_rows=rows, sliced=sliced)
+                        if rows is not None:
+                            img = img[rows[0] * 16:min(rows[1] * 16, h)]
+                        outs.append((img, aux))
+                    (ia, xa), (ib, xb) = outs
+                    what = (it, op, name, str(pass_), rows, sliced)
+                    assert torch.equal(ia, ib), what
+                    assert (xa.num_visible, xa.num_intersections) == (xb.num_visible, xb.num_intersections), what
+                    assert torch.equal(xa.max_radius, xb.max_radius) and torch.equal(xa.global_from_compact_gid, xb.global_from_compact_gid), what
+                    if pass_.bwd_info():
+                        assert torch.equal(xa.visible, xb.visible), what
+                        for t, (la, lb) in enumerate(zip(_blended_lists(xa), _blended_lists(xb))):
+                            # the two contexts may have cut the slices elsewhere: the same blended list up to useless tail entries
+                            assert (len(la) == 0) == (len(lb) == 0) and (len(la) == 0 or la[-1] == lb[-1]), (what, t)
+                elif op == "backward":
+                    v_out = torch.from_numpy((rng.normal(size=(h, w, 4)) / (h * w)).astype(np.float32)).to(dev)
+                    smooth = bool(rng.integers(4) == 0)
+                    pass_ = ba.RasterPass.BackwardSmoothCutoff if smooth else ba.RasterPass.Backward
+                    res = []
+                    for ctx in (A, F):
+                        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+                        res.append(ba.render_splats_bwd(spl, cam, (w, h), bg, v_out, pass_, ctx=ctx, sliced=sliced))
+                    assert torch.equal(res[0]["img"], res[1]["img"]), (it, op, name)
+                    _grads_close(res[0], res[1], (it, op, name, sliced, smooth))
+                else:   # a train step from the same state on both contexts
+                    with_hook = bool(rng.integers(3) == 0)
+                    exact = bool(rng.integers(4) == 0)
+                    finals = []
+                    for ctx in (A, F):
+                        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+                        tr = ba.SplatTrainer(ba.TrainConfig(exact_lists=exact), median_scene_scale=3.0, ctx=ctx, sparse_exchange=bool(it % 2))
+                        if with_hook:
+                            tr.pg, tr._hook, tr._world = "one rank", noop_hook, 1
+                        tr.step(ba.SceneBatch(gt, cam), spl, background=bg)
+                        st = tr.stats(ctx)
+                        finals.append((st, spl.transforms.cpu().numpy(), spl.sh_coeffs.cpu().numpy(), spl.raw_opacities.cpu().numpy(),
+                                       tr.state["vis_weight"].cpu().numpy(), tr.state["max_screen_size"].cpu().numpy()))
+                    (sa, ta, ha, oa, va, ra), (sb, tb, hb, ob, vb, rb) = finals
+                    what = (it, op, name, with_hook, exact)
+                    assert (sa.num_visible, sa.num_intersections) == (sb.num_visible, sb.num_intersections), what
+                    assert abs(sa.loss - sb.loss) <= 1e-6 * max(1.0, abs(sb.loss)), what
+                    assert np.array_equal(va, vb) and np.array_equal(ra, rb), what
+                    cfg = ba.TrainConfig()
+                    if sc["transforms"].shape[0] >= 5000:
+                        util.assert_adam_close(ta[:, 3:7], tb[:, 3:7], cfg.lr_rotation, 1, what)
+                        util.assert_adam_close(ta[:, 7:10], tb[:, 7:10], cfg.lr_scale, 1, what)
+                        util.assert_adam_close(oa, ob, cfg.lr_opac, 1, what)
+                        util.assert_adam_close(ha, hb, cfg.lr_coeffs_dc, 1, what)
+                    else:   # 40 splats: one +-lr sign flip on a noise gradient is already 0.6 % of the entries - bound the size only
+                        assert np.abs(ta[:, 3:7] - tb[:, 3:7]).max() <= 2.1 * cfg.lr_rotation and np.abs(oa - ob).max() <= 2.1 * cfg.lr_opac, what
+            finally:
+                F.close()
+        assert min(kinds.values()) >= 30, kinds
+    finally:
+        A.close()
+
+
+def test_a_step_that_fails_behind_its_near_slice_leaves_the_ctx_usable(dev):
+    """bh_train_step queues the near slice, defers the far-slice decision behind the loss kernels (far_job.pending) and THEN fails
+    (an injected BH_ERR_OOM in front of the loss: BH_TEST_FAIL_LOSS_AT).  The step must not count (a failed step applied no
+    update), and everything that follows on the ctx — the retried step, a render, a backward — must equal a fresh ctx's."""
+    import os
+    import brush_amd as ba
+    raw, w, h = _fuzz_scenes(dev)
+    sc = raw["saturating"]
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+    cam = util.hip_camera(ba, synth.default_camera_params(w, h))
+    bg = (0.1, 0.2, 0.3)
+    os.environ["BH_TEST_FAIL_LOSS_AT"] = "3"
+    try:
+        A = ba.Context(dev)
+    finally:
+        del os.environ["BH_TEST_FAIL_LOSS_AT"]
+    F = ba.Context(dev)
+    try:
+        runs = {}
+        for key, ctx in (("A", A), ("F", F)):
+            spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+            tr = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx)
+            losses, failed = [], 0
+            while tr.step_count < 4:
+                # steps 1-2: automatic share, every tile finishes in the near slice -> the host decides (far_job.pending) from now on;
+                # from step 3 (the one that fails on A): a near slice that leaves most tiles unsaturated -> the pending decision is "yes"
+                ba.set_list_slicing(0.0 if tr.step_count < 2 else 0.03, ctx)
+                try:
+                    tr.step(ba.SceneBatch(gt, cam), spl, background=bg)
+                    losses.append(tr.stats(ctx).loss)
+                except ba.BrushHipError as e:
+                    assert "injected failure" in str(e)
+                    failed += 1
+                    assert tr.step_count == 2, "a failed step must not count"
+            img, aux = ba.render_splats(spl, cam, (w, h), bg, ba.RasterPass.Backward, ctx=ctx, sliced=True)
+            runs[key] = (losses, failed, spl.transforms.cpu().numpy(), spl.raw_opacities.cpu().numpy(), img, aux.visible)
+        assert runs["A"][1] == 1 and runs["F"][1] == 0
+        assert len(runs["A"][0]) == len(runs["F"][0]) == 4
+        assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(runs["A"][0], runs["F"][0]))
+        cfg = ba.TrainConfig()
+        util.assert_adam_close(runs["A"][2][:, 3:7], runs["F"][2][:, 3:7], cfg.lr_rotation, 4, "rotation")
+        util.assert_adam_close(runs["A"][3], runs["F"][3], cfg.lr_opac, 4, "opacity")
+    finally:
+        A.close()
+        F.close()
