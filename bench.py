@@ -237,6 +237,7 @@ def main():
                     help="views each rank cycles through in the timed region (step k trains view k % V).  2 (the default) is the reference's own "
                          "training bench: two cameras 2 units apart in x, alternating (crates/brush-bench-test/src/benches.rs:198-220); "
                          "1 = one camera replayed (the round 1-3 headline); >= 3 = an orbit of V cameras")
+    ap.add_argument("--no-view-ids", action="store_true", help="do not tell the library which view a batch is (BhTrainBatch.view_id = 0): all views share one per-tile cut table (A/B)")
     ap.add_argument("--windows", type=int, default=3,
                     help="timed windows of --steps steps each (barrier + synchronize on both sides of every window); the line reports the MEDIAN "
                          "window as ms_per_step / value and all of them in `windows_ms_per_step`")
@@ -377,7 +378,8 @@ def main():
         batches = []
         for v, c in enumerate(cams):
             gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=7 + 100 * v + (0 if tile_mode else rank)).view(np.int32)).to(dev)
-            batches.append(ba.SceneBatch(gt, c.uniforms((w, h))))
+            # view ids: what a loader knows anyway (the view's index in the dataset + 1) — keys the per-tile depth cuts of the forward
+            batches.append(ba.SceneBatch(gt, c.uniforms((w, h)), view_id=(0 if args.no_view_ids else v + 1)))
         batch = batches[0]
         # seed: the reference's default step draws the mean noise and jitters the background every step
         trainer = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
@@ -676,8 +678,9 @@ def main():
                                       "of": "every step of the timed windows"} if args.lists == "sliced" else None,
                        "far_slices_queued": m["far_slices_queued"] if args.lists == "sliced" else None,
                        "timed_steps": m["timed_steps"],
-                       "lists": ("depth-sliced: near slice = %.3f of the pair list on average (chosen from the previous steps' feedback), the far slice only into tiles "
-                                 "it left unsaturated; image / gradients identical to the exact lists" % m["list_share"]) if args.lists == "sliced" else "exact (every pair listed and sorted)",
+                       "lists": ("per-tile depth cuts keyed by view id%s: the near pass lists %.3f of the pairs on average (per tile: what the tile needed at the view's "
+                                 "previous visit + a margin), a far pass finishes tiles the forecast missed; image / gradients identical to the exact lists"
+                                 % (" (OFF: --no-view-ids, one shared table)" if args.no_view_ids else "", m["list_share"])) if args.lists == "sliced" else "exact (every pair listed and sorted)",
                        "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
                        "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
@@ -734,7 +737,7 @@ def kernel_trace_inrun(args):
     tmp = tempfile.mkdtemp(prefix="bh_trace_", dir="/tmp")
     env = dict(os.environ, BH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--no-stages",
-             "--lists", args.lists, "--views", str(args.views), "--windows", "1"] + (["--no-noise"] if args.no_noise else [])
+             "--lists", args.lists, "--views", str(args.views), "--windows", "1"] + (["--no-noise"] if args.no_noise else []) + (["--no-view-ids"] if args.no_view_ids else [])
     try:
         p = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "trace", "--"] + child, cwd="/tmp", env=env,
                            capture_output=True, text=True, timeout=120)
@@ -780,7 +783,7 @@ def pmc_inrun(args):
     tmp = tempfile.mkdtemp(prefix="bh_pmc_", dir="/tmp")
     env = dict(os.environ, BH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "4", "--no-cpu-baseline", "--no-extra", "--no-pmc", "--lists", args.lists,
-             "--views", str(args.views), "--windows", "1"]
+             "--views", str(args.views), "--windows", "1"] + (["--no-view-ids"] if args.no_view_ids else [])
     if args.no_noise:
         child.append("--no-noise")
     try:

@@ -23,6 +23,6 @@ from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
     render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
-    splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader, set_list_slicing, last_list_counts,
+    splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader, set_list_slicing, last_list_counts, set_view_id,
 )
 from ._ffi import BrushHipError  # noqa: F401

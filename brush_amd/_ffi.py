@@ -96,6 +96,7 @@ class BhTrainBatch(C.Structure):
         ("camera", BhCamera), ("gt_packed", C.c_void_p), ("has_alpha", C.c_int32), ("alpha_is_mask", C.c_int32),
         ("background", C.c_float * 3), ("noise_samples", C.c_void_p), ("device_noise", C.c_int32), ("noise_seed", C.c_uint64),
         ("image_hook", C.c_void_p), ("image_hook_user", C.c_void_p), ("exchange_mode", C.c_int32), ("strip_loss", C.c_int32),
+        ("view_id", C.c_uint32),
     ]
 
 
@@ -128,6 +129,7 @@ SYMBOLS = {
     "bh_focal_to_fov": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
     "bh_render_forward": (C.c_int, [C.c_void_p, C.POINTER(BhCamera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, fp, C.c_uint32, C.POINTER(BhRenderOut)]),
     "bh_set_list_slicing": (C.c_int, [C.c_void_p, C.c_float]),
+    "bh_set_view_id": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
     "bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -171,7 +171,7 @@ int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
     {
         ProfScope ps(ctx, "MapGaussiansToIntersect");
         BH_TRY(launch_map_gaussians_far(ctx, j.nv, j.u, j.proj_by_gid, j.gfc, j.projected, j.cum, j.budget, j.done_bits, gate, j.far_counts, j.far_block_totals,
-                                        j.far_group_totals, j.slice_info, j.tile_ids, j.isect_gids));
+                                        j.far_group_totals, j.slice_info, j.tile_ids, j.isect_gids, j.zcut, j.depth_keys_sorted));
     }
     {
         ProfScope ps(ctx, "TileSort");
@@ -191,6 +191,59 @@ int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
     return 0;
 }
 
+// The per-tile depth-cut table of view `id` for a (tile_bw x tile_bh) grid: created (all ZCUT_ALL = "list everything") on first
+// use, re-created when the grid changes, the least recently used one evicted beyond MAX_VIEW_STATES.
+static ViewState* view_state(bh_ctx* ctx, uint32_t id, uint32_t tile_bw, uint32_t tile_bh) {
+    auto it = ctx->views.find(id);
+    if (it != ctx->views.end() && (it->second.tile_bw != tile_bw || it->second.tile_bh != tile_bh)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(it->second.zcut);
+        ctx->views.erase(it);
+        it = ctx->views.end();
+    }
+    if (it == ctx->views.end()) {
+        if (ctx->views.size() >= MAX_VIEW_STATES) {
+            auto old = ctx->views.begin();
+            for (auto k = ctx->views.begin(); k != ctx->views.end(); ++k)
+                if (k->second.last_used < old->second.last_used) old = k;
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(old->second.zcut);
+            if (ctx->gate_view == &old->second) ctx->gate_view = nullptr;
+            if (ctx->far_job.view == &old->second) ctx->far_job.view = nullptr;
+            ctx->views.erase(old);
+        }
+        ViewState vs;
+        vs.tile_bw = tile_bw;
+        vs.tile_bh = tile_bh;
+        const size_t words = (size_t)tile_bw * tile_bh;
+        if (hipMalloc((void**)&vs.zcut, (words ? words : 1) * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut), (int)ZCUT_ALL, words ? words : 1, ctx->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(vs.zcut);
+            return nullptr;
+        }
+        it = ctx->views.emplace(id, vs).first;
+    }
+    it->second.last_used = ++ctx->view_clock;
+    return &it->second;
+}
+
+// Outcome of a per-tile-cut frame of `vs`: did its far pass have to run (= the forecast failed for some tile)?  One miss is
+// normal — the far pass has just corrected the table.  Three misses within the view's last eight cut frames (alternating cameras
+// sharing one table, a scene that changes faster than the margin) and the view's next eight frames are rendered with complete
+// lists, each of them re-seeding the table.
+static void view_outcome(ViewState* vs, bool missed) {
+    if (!vs) return;
+    vs->penalty = ((vs->penalty << 1) | (missed ? 1u : 0u)) & 0xFFu;   // (the history of the last eight cut frames, one bit each)
+    if (__builtin_popcount(vs->penalty) >= 3) {
+        vs->exact_frames = 8u;
+        vs->penalty = 0u;
+    }
+}
+
 // A sliced forward that left the decision to the host: wait for the near slice's gate word and queue the far slice only if some
 // tile is still unsaturated.  *launched (optional) tells the caller whether out_img changed after the near slice.
 int finish_far_slice(bh_ctx* ctx, bool* launched) {
@@ -199,7 +252,11 @@ int finish_far_slice(bh_ctx* ctx, bool* launched) {
     ctx->far_job.pending = false;
     BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
     const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
-    ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
+    if (ctx->far_job.zcut) {   // per-tile cuts: the far pass corrects the table, the next frame of the view is predicted again
+        view_outcome(ctx->far_job.view, unsat != 0u);
+    } else {
+        ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
+    }
     if (unsat == 0u) return 0;
     if (launched) *launched = true;
     return enqueue_far_slice(ctx, ctx->far_job);
@@ -292,6 +349,8 @@ void bh_destroy(bh_ctx* ctx) {
     for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (auto& b : ctx->slots)
         if (b.ptr) (void)hipFree(b.ptr);
+    for (auto& kv : ctx->views)
+        if (kv.second.zcut) (void)hipFree(kv.second.zcut);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
     if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
@@ -526,7 +585,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     const bool want_sliced = (flags & BH_FLAG_SLICED_LISTS) != 0;
     const size_t slice_bit_words = ((size_t)num_tiles + 31) / 32;
     const size_t slice_group_words = (size_t)n / (256 * FAR_GROUP_BLOCKS) + 2;   // far pairs per group of count-kernel blocks
-    const size_t slice_words = want_sliced ? 4 + slice_bit_words + (size_t)num_tiles * 2 + slice_group_words : 0;
+    const size_t slice_words = want_sliced ? SLICE_CTRL_WORDS + slice_bit_words + (size_t)num_tiles * 2 + slice_group_words : 0;
     uint32_t* slice_tab = nullptr;
     if (want_sliced) {
         slice_tab = (uint32_t*)ensure(ctx, SLOT_SLICE, slice_words * 4);
@@ -534,8 +593,31 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     }
     // where THIS forward's blend kernel leaves its slicing hint: the feedback words of the counter set the NEXT forward reads back
     uint32_t* feedback_next = counter_pairs ? counter_pairs + counter_set_words * ((ctx->counter_phase & 1u) ^ 1u) + COUNTER_FB_WORD : nullptr;
+    // ---- per-tile depth cuts (BH_FLAG_SLICED_LISTS with the automatic share) ------------------------------------------------
+    // A training loop comes back to each of its views every V steps with parameters that moved by a learning rate: how deep every
+    // TILE of the view had to go last time is a near-exact forecast of how deep it has to go now.  So every blend launch leaves,
+    // per tile, the depth key of the last splat the tile needed + a margin (rasterize.hip) in a table that belongs to the VIEW
+    // (bh_set_view_id / BhTrainBatch.view_id), and the view's next frame lists a (splat, tile) pair only if the splat is at or in
+    // front of the tile's cut: K1 counts those hits beside the exact ones (same walk), the scan runs over the near counts, K5 /
+    // tile sort / offsets handle ~a tenth of the pairs — per tile, so a frame with thin or empty regions (whose tiles keep
+    // "everything", i.e. their own short lists) is cut as deep as a frame that saturates everywhere.  Correctness does not rest
+    // on the forecast: a tile that is still live behind an incomplete list is parked, and the far pass lists the pairs BEHIND the
+    // cut for exactly those tiles (same machinery as the slot-budget slices below); the table is then corrected by that pass.
+    ViewState* view = nullptr;
+    bool cut_active = false;
+    if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
+        view = view_state(ctx, ctx->view_id, u.tile_bw, u.tile_bh);
+        if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
+        if (view->seeded && view->exact_frames == 0u) cut_active = true;
+        else if (view->exact_frames) view->exact_frames--;
+    }
+    uint32_t* near_counts = nullptr;
+    if (cut_active) {
+        near_counts = (uint32_t*)ensure(ctx, SLOT_NEAR_COUNTS, npad * 4);
+        if (!near_counts) return BH_ERR_OOM;
+    }
 
-    uint32_t nv = 0, ni = 0;
+    uint32_t nv = 0, ni = 0, near_total = 0;
     uint32_t fb_need = 0;                  // previous forward: most exact-list slots any saturated tile needed
     unsigned long long fb_unsat_pairs = 0; // ... and pairs it listed for tiles that never saturated
     uint32_t fb_unsat_tiles = 0;           // ... and how many such tiles there were (empty ones included)
@@ -562,7 +644,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 ctx->grads_prezeroed = true;
             }
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
-                                          proj_by_gid, counters, prep));
+                                          proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts));
             ctx->counter_phase ^= 1u;
             ctx->counters_ready = true;
         }
@@ -582,7 +664,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 // cum slot is sized for n here because the visible count is not known yet
                 cum_early = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, npad * 4);
                 if (!cum_early) return BH_ERR_OOM;
-                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, isect_counts, n, depths_sorted, gfc, cum_early));
+                // (per-tile cuts: the scan of the NEAR counts = the slot ranges of the near pass's list)
+                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
@@ -592,11 +675,12 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             ctx->gate_learn = false;
             ctx->far_direct = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD] != 0u;
         }
-        unsigned long long hc[2] = {0ull, 0ull};
-        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { hc[0] += hslots[2 * k]; hc[1] += hslots[2 * k + 1]; }
+        unsigned long long hc[3] = {0ull, 0ull, 0ull};
+        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { hc[0] += hslots[COUNTER_K1_U64 * k]; hc[1] += hslots[COUNTER_K1_U64 * k + 1]; hc[2] += hslots[COUNTER_K1_U64 * k + 2]; }
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
         nv = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
+        near_total = cut_active ? (uint32_t)hc[2] : ni;
         // the previous forward's slicing hint came along in the same copy
         const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
         for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[3 * k] > fb_need) fb_need = hfb[3 * k]; fb_unsat_pairs += hfb[3 * k + 1]; fb_unsat_tiles += hfb[3 * k + 2]; }
@@ -632,47 +716,47 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     // of the exact path.  The near slice's size comes from the PREVIOUS forward on this ctx (how many slots its slowest
     // saturating tile needed, + 25 %), or from bh_set_list_slicing; scenes that do not saturate keep the single exact list.
     uint32_t budget = ni;   // == ni: one slice, the exact lists
+    bool sliced = false;
     if (want_sliced && ni > 0) {
-        float share = ctx->slice_fraction;
-        if (!(share > 0.0f)) {
-            const double prev = (double)ctx->prev_intersections;
-            if (!ctx->had_forward || prev == 0.0) share = 0.25f;
-            else if ((double)fb_unsat_pairs > 0.5 * prev) share = 1.0f;        // most of the list belongs to tiles that never saturate
-            else if (fb_need == 0u && ctx->need_hint <= 0.0f) share = 0.25f;
-            else {
-                // what recent frames needed, not just the last one: a training loop cycles through its views, and a near slice
-                // sized for the shallowest of them sends every deeper one through the far slice (~150 us incl. the loss evaluated
-                // twice) — a larger near slice costs a few microseconds.  The memory fades by 10 % per frame.
-                const float now = (float)((double)fb_need / prev);
-                ctx->need_hint = now > ctx->need_hint * 0.9f ? now : ctx->need_hint * 0.9f;
-                share = 1.25f * ctx->need_hint;
+        const float share = ctx->slice_fraction;
+        if (share > 0.0f) {   // a fixed share of the pair list (bh_set_list_slicing: tests, A/B): the slot-budget slices
+            if (share < 1.0f) {
+                const double b = (double)share * (double)ni;
+                const uint32_t floor_b = ni < 1024u ? ni : 1024u;
+                budget = b < (double)floor_b ? floor_b : (uint32_t)b;
+                if (budget > ni) budget = ni;
             }
-            if (share > 0.7f) share = 1.0f;
-            // A frame with tiles that never saturate (a blank background: empty tiles count) needs its far slice EVERY time, and that
-            // costs about as much as listing and sorting 6 M pairs (~12 launches + the count walk over every far splat): slice only
-            // where the near slice saves more than that.  A one-slice frame's blend kernel reports the tiles too (above), so the
-            // decision follows the scene.
-            if (ctx->last_one_slice && ctx->had_forward) ctx->far_direct = fb_unsat_tiles != 0u;
-            if (share < 1.0f && ctx->far_direct && (1.0 - (double)share) * (double)ni < 6.0e6) share = 1.0f;
+            sliced = budget < ni;
+            ctx->last_slice_share = (float)((double)budget / (double)ni);
+        } else if (cut_active && near_total < ni) {   // per-tile depth cuts from this view's last frame
+            sliced = true;
+            budget = near_total;
+            ctx->last_slice_share = (float)((double)near_total / (double)ni);
+        } else {
+            // no history for this view yet (or its forecast keeps failing, or it cut nothing): complete lists; the blend
+            // kernel seeds / refreshes the view's table
+            ctx->last_slice_share = 1.0f;
         }
-        if (share < 1.0f) {
-            const double b = (double)share * (double)ni;
-            const uint32_t floor_b = ni < 1024u ? ni : 1024u;
-            budget = b < (double)floor_b ? floor_b : (uint32_t)b;
-            if (budget > ni) budget = ni;
-        }
-        ctx->last_slice_share = (float)((double)budget / (double)ni);
     }
-    const bool sliced = budget < ni;
+    (void)fb_need; (void)fb_unsat_pairs; (void)fb_unsat_tiles;
+    const bool by_cut = cut_active && sliced;           // this frame's lists end at the per-tile cuts
+    const uint32_t* zcut_lists = cut_active ? view->zcut : nullptr;   // (cut_active but not sliced: the cut removed nothing — K5 still filters, and keeps everything)
     uint32_t* slice_info = slice_tab;
-    uint32_t* done_bits = slice_tab ? slice_tab + 4 : nullptr;
-    uint32_t* tile_offsets_far = slice_tab ? slice_tab + 4 + slice_bit_words : nullptr;
-    uint32_t* far_group_totals = slice_tab ? slice_tab + 4 + slice_bit_words + (size_t)num_tiles * 2 : nullptr;
+    uint32_t* done_bits = slice_tab ? slice_tab + SLICE_CTRL_WORDS : nullptr;
+    uint32_t* tile_offsets_far = slice_tab ? slice_tab + SLICE_CTRL_WORDS + slice_bit_words : nullptr;
+    uint32_t* far_group_totals = slice_tab ? slice_tab + SLICE_CTRL_WORDS + slice_bit_words + (size_t)num_tiles * 2 : nullptr;
     uint32_t tile_bits = 0;
     while (tile_bits < 32 && (num_tiles >> tile_bits) != 0) tile_bits++;  // render.rs:228
     RasterSlice rs;
     rs.cum = cum;
-    rs.feedback = feedback_next;
+    rs.feedback = nullptr;   // (the slot-budget heuristics that read it are gone: the automatic mode cuts per tile)
+    (void)feedback_next;
+    if (view) {   // every forward of a view refreshes its table
+        rs.zcut = view->zcut;
+        rs.depth_keys_sorted = depths_sorted;
+        rs.nv = nv;
+        rs.cut_active = by_cut;
+    }
     // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
     const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
     const float class_width_raw = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
@@ -684,7 +768,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (nv > 0) {
         if (!fused_scan) {
             ProfScope ps(ctx, "PrefixSumGaussHits");
-            BH_TRY(prefix_sum(ctx, isect_counts, gfc, nv, cum, false));
+            BH_TRY(prefix_sum(ctx, cut_active ? near_counts : isect_counts, gfc, nv, cum, false));
         }
         if (ni == 0) {   // nothing to map: only the record gather is left (K5 does it on its way otherwise)
             ProfScope ps(ctx, "ProjectVisible");
@@ -701,20 +785,27 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                     if (!vc) return BH_ERR_OOM;
                     ctx->vcombined_prezeroed = true;
                 }
-                BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u,
-                                            sliced ? budget : 0xFFFFFFFFu, sliced ? slice_info : nullptr));
+                if (zcut_lists && near_total == 0u) {
+                    ctx->vcombined_prezeroed = false;   // no pair in front of any cut: nothing to emit (and K5 does not run to clear v_combined)
+                } else {
+                    BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u,
+                                                (sliced && !by_cut) ? budget : 0xFFFFFFFFu, (sliced || zcut_lists) ? slice_info : nullptr, zcut_lists,
+                                                zcut_lists ? depths_sorted : nullptr));
+                }
             }
             {
                 ProfScope ps(ctx, "TileSort");
-                // (scratch sized for the whole list: the budget moves with every frame's feedback)
-                if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
+                // (scratch sized for the whole list: the near list's length moves from frame to frame)
+                if (zcut_lists) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, near_total, nullptr, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
+                else if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
                 else BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, tile_bits, tile_ids_sorted, isect_gids_sorted));
             }
         }
     }
     {
         ProfScope ps(ctx, "GetTileOffsets");   // K1 cleared the table (or a fill did, for n == 0)
-        if (sliced) BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, budget, slice_info + 1, nullptr, nullptr, num_tiles, tile_offsets));
+        if (zcut_lists) BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, near_total, num_tiles, tile_offsets, /*pre_zeroed=*/true));
+        else if (sliced) BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, budget, slice_info + 1, nullptr, nullptr, num_tiles, tile_offsets));
         else BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, ni, num_tiles, tile_offsets, /*pre_zeroed=*/true));
     }
     if (!sliced) {
@@ -730,6 +821,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         rs.unsat_count = slice_info + 2;
         rs.state = state;
         rs.offsets_near = tile_offsets;
+        rs.live_bands = slice_info + 4;
         {
             ProfScope ps(ctx, "Rasterize");
             BH_TRY(launch_rasterize(ctx, u, background, bwd_info, smooth, isect_gids_sorted, tile_offsets, projected, gfc, out_f32, out_u8, visible, ctx->lpt,
@@ -745,9 +837,14 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         j.far_counts = far_counts; j.far_block_totals = far_block_totals; j.far_group_totals = far_group_totals;
         j.tile_ids = tile_ids; j.isect_gids = isect_gids; j.tile_ids_sorted = tile_ids_sorted; j.isect_gids_sorted = isect_gids_sorted;
         j.out_f32 = out_f32; j.out_u8 = out_u8; j.visible = visible; j.lpt = ctx->lpt; j.class_width = class_width; j.rs = rs;
+        j.zcut = by_cut ? view->zcut : nullptr;
+        j.depth_keys_sorted = by_cut ? depths_sorted : nullptr;
+        j.view = by_cut ? view : nullptr;
         // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)
         BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->far_direct) {
+        // (per-tile cuts: the forecast is expected to hold, and a far pass that had to run has corrected the table — the host decides
+        //  every time, bh_train_step hides the wait behind its loss kernels)
+        if (ctx->far_direct && !by_cut) {
             BH_TRY(enqueue_far_slice(ctx, j));
             ctx->gate_learn = true;
         } else {
@@ -777,7 +874,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     r.intersect_counts = isect_counts;
     r.depths_sorted = (float*)depths_sorted;
     r.tile_offsets_far = sliced ? tile_offsets_far : nullptr;
-    r.list_budget = budget;
+    r.list_budget = budget;   // (per-tile cuts: the pairs the near pass listed)
     *out = r;
     ctx->last = r;
     ctx->cam = *cam;
@@ -790,6 +887,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     ctx->had_forward = true;
     ctx->prev_intersections = ni;
     ctx->last_one_slice = !sliced;
+    if (view) view->seeded = true;   // this frame's blend kernels (incl. a far pass, if one runs) leave what every tile needed
     return 0;
 }
 
@@ -797,6 +895,12 @@ int bh_set_list_slicing(bh_ctx* ctx, float near_share) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     if (near_share != near_share || near_share > 1.0f) return set_error(ctx, BH_ERR_INVALID_ARG, "set_list_slicing: the near slice's share must be <= 1 (<= 0: automatic)");
     ctx->slice_fraction = near_share > 0.0f ? near_share : 0.0f;
+    return 0;
+}
+
+int bh_set_view_id(bh_ctx* ctx, uint32_t view_id) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    ctx->view_id = view_id;
     return 0;
 }
 
@@ -1086,8 +1190,11 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
     // (a tile-partitioned frame hands the image to its hook right after the forward: there the forward waits itself)
     ctx->defer_far = !batch->image_hook;
+    const uint32_t caller_view = ctx->view_id;
+    ctx->view_id = batch->view_id;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
                                       batch->background, flags, &ro);
+    ctx->view_id = caller_view;
     ctx->defer_far = false;
     ctx->ext_visible = nullptr;
     ctx->ext_max_radius = nullptr;

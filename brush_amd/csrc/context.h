@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/brush_hip.h"
@@ -56,10 +57,11 @@ enum Slot : int {
     SLOT_EXCH_IDX,
     SLOT_EXCH_COMPACT,
     SLOT_PROJECTED_BY_GID,   // [N,9] projected records at their splat id (visible splats only)
-    SLOT_SLICE,              // depth-sliced forward: 4 control words | done bits [ceil(T/32)] | far tile offsets [T,2] | far group totals
+    SLOT_SLICE,              // depth-sliced forward: 8 control words (SLICE_CTRL_WORDS) | done bits [ceil(T/32)] | far tile offsets [T,2] | far group totals
     SLOT_SLICE_STATE,        // [H,W,4] raw blend state of the tiles the near slice left unsaturated
     SLOT_SLICE_COUNTS,       // [Nv] live-tile hits per far splat / their inclusive scan
     SLOT_SLICE_CUM,
+    SLOT_NEAR_COUNTS,        // [N] tiles hit per splat at or in front of the tile's depth cut (per-tile cut lists)
     SLOT_COUNT
 };
 
@@ -73,18 +75,23 @@ constexpr int MAX_PROF = 32;
 // K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
 constexpr uint32_t COUNTER_SLOTS = 128;
 // one counter set on the device:
-//   [COUNTER_SLOTS][2] u64  visible, intersections (K1's block totals)
+//   [COUNTER_SLOTS][3] u64  visible, intersections, near intersections (K1's block totals; the third only with a per-tile depth cut:
+//                           the pairs the near pass will list, see ViewState)
 //   [COUNTER_SLOTS][3] u32  slicing feedback, written by the blend kernel of the forward BEFORE the one that accumulates into this
 //                           set (rasterize.hip SliceArgs::feedback): max exact-list slots a saturated tile needed | pairs listed
 //                           for tiles that never saturated | number of such tiles (empty ones included)
 //   [COUNTER_SLOTS][2] u32  max depth key, max ~key over the visible splats: the key range the depth sort splits on.
 // The first two parts are read back together (one copy), the third stays on the device.
-constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12 + COUNTER_SLOTS * 8;
+constexpr uint32_t COUNTER_K1_U64 = 3;                        // u64 words per slot of K1's block totals
+constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 8 * COUNTER_K1_U64 + COUNTER_SLOTS * 12 + COUNTER_SLOTS * 8;
 constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
-constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 4;       // u32 index of the feedback part inside a set: [COUNTER_SLOTS][3]
-constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_SLOTS * 7;   // ... of the key-range part
+constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 2 * COUNTER_K1_U64;   // u32 index of the feedback part inside a set: [COUNTER_SLOTS][3]
+constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_FB_WORD + COUNTER_SLOTS * 3;   // ... of the key-range part
+// control words of SLOT_SLICE: [0] near-slice splats  [1] near pairs  [2] tiles the near pass left live  [3] far pairs
+// [4] live column bands  [5] live row bands (32 bands per axis; the far pass skips splats whose box misses them)  [6..7] spare
+constexpr uint32_t SLICE_CTRL_WORDS = 8;
 constexpr uint32_t FAR_GROUP_BLOCKS = 64;   // far slice: count-kernel blocks per group total (<= the projection workgroup size)
-constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 16 + COUNTER_SLOTS * 12;
+constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 8 * COUNTER_K1_U64 + COUNTER_SLOTS * 12;
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
@@ -107,6 +114,20 @@ struct Profiler {
     hipEvent_t ext_a = nullptr, ext_b = nullptr;
 };
 
+// Per-view state of the per-tile depth cut (BH_FLAG_SLICED_LISTS, automatic mode; api.hip has the whole story): for every tile the
+// depth key behind which the tile needed no splat the last time THIS view was rendered (+ a margin), 0xFFFFFFFF = list everything.
+// Written in place by the blend kernel of every forward of the view, read by K1 / K5 / the far pass of its next one.
+constexpr uint32_t ZCUT_ALL = 0xFFFFFFFFu;
+struct ViewState {
+    uint32_t* zcut = nullptr;       // [tile_bw * tile_bh] device
+    uint32_t tile_bw = 0, tile_bh = 0;
+    bool seeded = false;            // a forward of this view has written the table
+    uint32_t exact_frames = 0;      // frames to render with complete lists before the cut is trusted again (the forecast kept failing)
+    uint32_t penalty = 0;           // one bit per recent cut frame: its far pass had to run (api.hip view_outcome)
+    uint64_t last_used = 0;         // LRU stamp
+};
+constexpr size_t MAX_VIEW_STATES = 4096;
+
 // scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
 struct RasterSlice {
     uint32_t* done_bits = nullptr;
@@ -115,6 +136,14 @@ struct RasterSlice {
     const uint32_t* offsets_near = nullptr;
     const uint32_t* cum = nullptr;
     uint32_t* feedback = nullptr;
+    // per-tile depth cut: the view's table (read: is the tile's near list complete?  written: what the tile needed this time),
+    // the depth keys in compact order and their number (to turn "last useful splat + margin" into a key); cut_active: the lists of
+    // this frame were built against the table (else it is only written)
+    uint32_t* zcut = nullptr;
+    const uint32_t* depth_keys_sorted = nullptr;
+    uint32_t nv = 0;
+    bool cut_active = false;
+    uint32_t* live_bands = nullptr;   // the two band words of the slice table (SLICE_CTRL_WORDS): sliced phases only
 };
 
 // The far slice of a depth-sliced forward, ready to be queued: everything launch_* needs (api.hip enqueue_far_slice).
@@ -144,6 +173,10 @@ struct FarJob {
     uint32_t* lpt = nullptr;
     float class_width = 8.0f;
     RasterSlice rs{};
+    // per-tile cut lists: the far pass lists, for tiles still live, every pair BEHIND the tile's cut (all visible splats take part)
+    const uint32_t* zcut = nullptr;
+    const uint32_t* depth_keys_sorted = nullptr;
+    ViewState* view = nullptr;      // whose prediction failed if the far pass has to run
 };
 
 }  // namespace bh
@@ -201,6 +234,11 @@ struct bh_ctx {
     bool defer_far = false;           // set by bh_train_step around its forward: return with far_job.pending instead of waiting
     bool gate_learn = false;          // a gate word copied out by a far_direct frame has not been looked at yet
     uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice
+    // per-tile depth cuts (automatic slicing): one table per view id (bh_set_view_id / BhTrainBatch.view_id; 0 = the ctx's own slot)
+    std::unordered_map<uint32_t, bh::ViewState> views;
+    uint32_t view_id = 0;
+    uint64_t view_clock = 0;
+    bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
     bh::FarJob far_job;
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
@@ -277,16 +315,19 @@ struct ForwardPrep {
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep);
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep, const uint32_t* zcut = nullptr,
+                           uint32_t* near_counts = nullptr);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 // budget: only splats whose slot range ends at or below it are emitted (the near slice of a depth-sliced forward; 0xFFFFFFFF =
 // all); slice_info (device, 2 words) then receives the slice's splat count and pair count.
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
-                         float4* zero_span = nullptr, uint32_t zero_f4 = 0, uint32_t budget = 0xFFFFFFFFu, uint32_t* slice_info = nullptr);
+                         float4* zero_span = nullptr, uint32_t zero_f4 = 0, uint32_t budget = 0xFFFFFFFFu, uint32_t* slice_info = nullptr,
+                         const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr);
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
-                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids);
+                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids,
+                             const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,

@@ -50,6 +50,8 @@ struct WalkLds {
     uint32_t boxw[64];    // by rank: box width in tiles
     uint32_t start[64];   // by rank: first candidate of the splat
     uint32_t lane_of[64]; // by rank: the lane (splat slot) it came from
+    uint32_t zkey[64];    // by rank: the splat's depth key (per-tile depth cuts: near / far is decided per (splat, tile))
+    uint32_t near[64];    // by rank: hits at or in front of their tile's cut (K1)
     uint8_t flags[64];    // scratch strip for the per-step start marks
 };
 
@@ -90,13 +92,29 @@ BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 // (valid when nb > 0): per-splat results are read back from w.count[rank].
 // keep(tx, ty) is evaluated BEFORE the contribution test: the depth-sliced forward's second slice walks only the tiles that are
 // still unsaturated (a bit test against a 1 KB table instead of the ellipse-rectangle test); K1 / the exact path keep everything.
-struct KeepAllTiles { BH_DEV bool operator()(uint32_t, uint32_t) const { return true; } };
+struct KeepAllTiles { BH_DEV bool operator()(const WalkLds&, uint32_t, uint32_t, uint32_t) const { return true; } };
 struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are final
     const uint32_t* done_bits;
     uint32_t tile_bw;
-    BH_DEV bool operator()(uint32_t tx, uint32_t ty) const {
+    BH_DEV bool operator()(const WalkLds&, uint32_t, uint32_t tx, uint32_t ty) const {
         const uint32_t t = tx + ty * tile_bw;
         return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u;
+    }
+};
+// Per-tile depth cuts (api.hip): the NEAR list of a tile holds the splats whose depth key is <= the tile's cut ...
+struct KeepNearOfCut {
+    const uint32_t* zcut;
+    uint32_t tile_bw;
+    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return w.zkey[r] <= zcut[tx + ty * tile_bw]; }
+};
+// ... and the FAR pass lists, for tiles that still have live pixels, the ones behind it
+struct KeepLiveBehindCut {
+    const uint32_t* done_bits;
+    const uint32_t* zcut;
+    uint32_t tile_bw;
+    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const {
+        const uint32_t t = tx + ty * tile_bw;
+        return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u && w.zkey[r] > zcut[t];
     }
 };
 
@@ -105,7 +123,7 @@ struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are 
 // bound by the ~60 VALU instructions of the test, two IEEE divisions among them, not by the LDS.)
 template <class OnHit, class Keep = KeepAllTiles>
 BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
-                               OnHit on_hit, Keep keep = Keep{}) {
+                               OnHit on_hit, Keep keep = Keep{}, uint32_t zkey = 0u) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
     const bool nz = nb > 0u;
@@ -115,6 +133,8 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
     const uint32_t bb_w = bb.max_x - bb.min_x;
     if (nz) {
         w.count[rank] = 0;
+        w.near[rank] = 0;
+        w.zkey[rank] = zkey;
         w.mx[rank] = mx; w.my[rank] = my;
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
@@ -152,7 +172,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
-            if (keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
+            if (keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
         }
         before += (uint32_t)__popcll(marks);
     }
@@ -168,7 +188,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
 template <class Keep = KeepAllTiles>
 BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
                                     uint32_t wave_base, uint32_t wave_total, uint32_t tile_bw, uint32_t cg0, uint32_t* __restrict__ tile_ids,
-                                    uint32_t* __restrict__ isect_gids, Keep keep = Keep{}) {
+                                    uint32_t* __restrict__ isect_gids, Keep keep = Keep{}, uint32_t zkey = 0u) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
     const bool nz = nb > 0u;
@@ -177,6 +197,7 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
     const uint32_t rank = (uint32_t)__popcll(nzmask & below);
     const uint32_t bb_w = bb.max_x - bb.min_x;
     if (nz) {
+        w.zkey[rank] = zkey;
         w.mx[rank] = mx; w.my[rank] = my;
         w.c00[rank] = conic.c00; w.c01[rank] = conic.c01; w.c11[rank] = conic.c11;
         w.pt[rank] = pt;
@@ -210,7 +231,7 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
-            hit = keep(tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
+            hit = keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
             tile = tx + ty * tile_bw;
             owner = cg0 + w.lane_of[r];
         }
@@ -247,10 +268,12 @@ template <bool MIP, bool PINHOLE, int DEG>
 __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ coeffs,
     const float* __restrict__ raw_opacities, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts,
-    float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters, ForwardPrep prep) {
+    float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters, ForwardPrep prep,
+    const uint32_t* __restrict__ zcut, uint32_t* __restrict__ near_counts) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
+    __shared__ uint32_t s_near[PROJ_WAVES];
     __shared__ uint32_t s_kmax[PROJ_WAVES];
     __shared__ uint32_t s_nmax[PROJ_WAVES];
     const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
@@ -339,13 +362,23 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 #ifdef BH_K1_NO_WALK   // measurement-only probe (wrong results: no splat hits a tile)
     const uint32_t tiles_hit = nb == 0xFFFFFFFFu ? w.count[0] : 0u;
 #else
-    const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); });
+    // per-tile depth cuts (zcut != NULL, wave-uniform): a hit also counts for the NEAR list if the splat is at or in front of its
+    // tile's cut - K5 lists exactly those pairs (same keys, same table, same test)
+    const uint32_t tile_bw = u.tile_bw;
+    const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
+        atomicAdd(&w.count[r], 1u);
+        if (zcut && w.zkey[r] <= zcut[tx + ty * tile_bw]) atomicAdd(&w.near[r], 1u);
+    }, KeepAllTiles{}, key);
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
+    const uint32_t near_hit = (nb && zcut) ? w.near[wrank] : 0u;
 #endif
     if (gid < n) {
         depth_keys[gid] = key;
         isect_counts[gid] = tiles_hit;
         max_radius[gid] = radius;
+#ifndef BH_K1_NO_WALK
+        if (zcut) near_counts[gid] = near_hit;
+#endif
     }
     // block totals -> two global atomics per block (the reference does two per splat), spread over COUNTER_SLOTS
     // (visible, hits) pairs that the host adds up: 7814 atomics on ONE pair of addresses serialise at ~7 ns each on
@@ -354,6 +387,14 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     uint32_t wave_hits = tiles_hit;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
+    uint32_t wave_near = 0;
+#ifndef BH_K1_NO_WALK
+    if (zcut) {   // wave-uniform
+        wave_near = near_hit;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wave_near += __shfl_down(wave_near, off);
+    }
+#endif
     // range of the visible depth keys, for the depth sort's split (depth_sort.hip): maxima of key and of ~key
     uint32_t kmax = visible ? key : 0u, nmax = visible ? ~key : 0u;
 #pragma unroll
@@ -364,18 +405,20 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     if (lane == 0) {
         s_vis[wave] = (uint32_t)__popcll(ball);
         s_hit[wave] = wave_hits;
+        s_near[wave] = wave_near;
         s_kmax[wave] = kmax;
         s_nmax[wave] = nmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t v = 0, h = 0, km = 0, nm = 0;
+        uint32_t v = 0, h = 0, nh = 0, km = 0, nm = 0;
 #pragma unroll
-        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; km = max(km, s_kmax[k]); nm = max(nm, s_nmax[k]); }
+        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; nh += s_near[k]; km = max(km, s_kmax[k]); nm = max(nm, s_nmax[k]); }
         const uint32_t sl = blockIdx.x & (COUNTER_SLOTS - 1u);
-        unsigned long long* slot = counters + 2u * sl;
+        unsigned long long* slot = counters + COUNTER_K1_U64 * sl;
         if (v) atomicAdd(&slot[0], (unsigned long long)v);
         if (h) atomicAdd(&slot[1], (unsigned long long)h);
+        if (nh) atomicAdd(&slot[2], (unsigned long long)nh);
         if (v) {
             uint32_t* mm = reinterpret_cast<uint32_t*>(counters) + COUNTER_MINMAX_WORD + 2u * sl;
             atomicMax(&mm[0], km);
@@ -386,14 +429,15 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 
 template <bool MIP, bool PINHOLE>
 static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_t deg, const float* t, const float* sh, const float* ro,
-                         uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64, const ForwardPrep& prep) {
+                         uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64, const ForwardPrep& prep,
+                         const uint32_t* zcut, uint32_t* near_counts) {
     const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
-        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
-        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
-        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
-        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep); break;
+        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
@@ -402,7 +446,8 @@ static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_
 
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& want) {
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& want, const uint32_t* zcut, uint32_t* near_counts) {
+    if (zcut && !near_counts) return set_error(ctx, BH_ERR_INVALID_ARG, "project_forward: a depth-cut table needs the near-count output");
     // what the grid cannot cover (tiny scenes under a large tile table, n == 0) is cleared with plain fills
     ForwardPrep prep = want;
     const size_t covered = (size_t)((n + PROJ_WG - 1) / PROJ_WG) * PROJ_WG;
@@ -429,10 +474,10 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
     }
     auto* c64 = reinterpret_cast<unsigned long long*>(counters);
     const bool pinhole = u.model == CAM_PINHOLE;
-    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
-    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
-    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
-    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep);
+    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
 }
 
 // ---------------------------------------------------------------------------
@@ -482,10 +527,14 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t* __restrict__ cum_tiles_hit, uint32_t* __restrict__ tile_id_from_isect,
     uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4, uint32_t budget,
     uint32_t* __restrict__ slice_info, const uint32_t* __restrict__ far_counts, const uint32_t* __restrict__ far_block_totals,
-    const uint32_t* __restrict__ far_group_totals, const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate) {
+    const uint32_t* __restrict__ far_group_totals, const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
+    const uint32_t* __restrict__ zcut, const uint32_t* __restrict__ depth_keys_sorted) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_far[2 * PROJ_WAVES];
     if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
+    // zcut != NULL (wave-uniform): per-tile depth cuts instead of one slot budget — cum_tiles_hit is then the scan of K1's NEAR
+    // counts, the near pass (FAR = false) emits the pairs at or in front of their tile's cut, the far pass the ones behind it
+    // into tiles that still have live pixels; every visible splat may take part in either
     const uint32_t tid_lin = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
     for (size_t i = tid_lin; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -526,14 +575,20 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
-    uint32_t base = 0, end = 0, nb = 0;
+    uint32_t base = 0, end = 0, nb = 0, zkey = 0;
     bool mine = false;   // this lane's splat belongs to the slice being emitted (and, FAR, still reaches a live tile)
     if (cg < nv) {
         const uint32_t cum_end = cum_tiles_hit[cg];
+        if (zcut) zkey = depth_keys_sorted[cg];
         if (FAR) {
             base = far_base;
             end = far_base + far_cnt;
-            mine = cum_end > budget && end > base;
+            mine = (zcut != nullptr || cum_end > budget) && end > base;
+        } else if (zcut) {
+            base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+            end = cum_end;
+            mine = end > base;
+            if (slice_info && cg + 1u == nv) { slice_info[0] = nv; slice_info[1] = cum_end; }   // the far pass sorts behind the near list
         } else {
             base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
             end = cum_end;
@@ -575,30 +630,46 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
 #ifdef BH_K5_NO_WALK   // measurement-only probe (empty image): no candidate is visited, every slot leaves as a sentinel pair
     nb = nb == 0xFFFFFFFFu ? 1u : 0u;
 #endif
-    if (FAR) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
-    else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
+    if (FAR) {
+        if (zcut) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveBehindCut{done_bits, zcut, tile_bw}, zkey);
+        else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
+    } else {
+        if (zcut) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepNearOfCut{zcut, tile_bw}, zkey);
+        else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
+    }
     (void)tile_bh;
 }
 
 // Second slice, pass 1: how many LIVE tiles (done bit clear) does each far splat reach?  counts[cg] = 0 for the near slice.
 // Same walk, same test as K1 / K5 (only the tile filter in front of it), so the emit pass cannot disagree with the count.
-__global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint32_t tile_bw, uint32_t tile_y0, uint32_t tile_y1,
+// bit b set = band b of 32 equal bands of the `extent` tiles along one axis overlaps [lo, hi)
+BH_DEV uint32_t band_of(uint32_t t, uint32_t extent) { return (t * 32u) / extent; }   // t < extent <= 4095: no overflow
+BH_DEV uint32_t band_mask(uint32_t lo, uint32_t hi, uint32_t extent) {
+    const uint32_t b0 = band_of(lo, extent), b1 = band_of(hi - 1u, extent);
+    return (0xFFFFFFFFu >> (31u - (b1 - b0))) << b0;
+}
+
+__global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint32_t tile_bw, uint32_t tile_bh, uint32_t tile_y0, uint32_t tile_y1,
                                                              const float* __restrict__ projected_by_gid,
                                                              const uint32_t* __restrict__ global_from_compact_gid,
                                                              const uint32_t* __restrict__ cum_tiles_hit, uint32_t budget,
                                                              const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ block_totals,
-                                                             uint32_t* __restrict__ group_totals) {
+                                                             uint32_t* __restrict__ group_totals, const uint32_t* __restrict__ zcut,
+                                                             const uint32_t* __restrict__ depth_keys_sorted, const uint32_t* __restrict__ live_bands) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_tot[PROJ_WAVES];
     if (*gate == 0u) return;
+    // which 1/32 bands of tile columns / rows hold a live tile (the blend kernel ORs them together as it parks tiles): a splat whose
+    // box misses them all reaches no live tile and is not walked — with few live tiles that is nearly every splat
+    const uint32_t live_cols = live_bands[0], live_rows = live_bands[1];
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
-    uint32_t nb = 0;
-    if (cg < nv && cum_tiles_hit[cg] > budget) {
+    uint32_t nb = 0, zkey = 0;
+    if (cg < nv && (zcut != nullptr || cum_tiles_hit[cg] > budget)) {
         const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
         xy_x = src[0]; xy_y = src[1];
         conic = Sym2{src[2], src[3], src[4]};
@@ -607,12 +678,18 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
         compute_bbox_extent(conic, pt, ex, ey);
         bb = get_tile_bbox(xy_x, xy_y, ex, ey, tile_bw, tile_y0, tile_y1);
         nb = (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x);
+        if (nb) {
+            if ((band_mask(bb.min_x, bb.max_x, tile_bw) & live_cols) == 0u || (band_mask(bb.min_y, bb.max_y, tile_bh) & live_rows) == 0u) nb = 0u;
+        }
+        if (zcut) zkey = depth_keys_sorted[cg];
     }
     WalkLds& w = s_walk[wave];
     uint32_t hits = 0;
     if (__ballot(nb > 0u) != 0ull) {
-        const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); },
-                                              KeepLiveTiles{done_bits, tile_bw});
+        auto count_hit = [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); };
+        uint32_t wrank;
+        if (zcut) wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, count_hit, KeepLiveBehindCut{done_bits, zcut, tile_bw}, zkey);
+        else wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, count_hit, KeepLiveTiles{done_bits, tile_bw});
         hits = nb ? w.count[wrank] : 0u;
     }
     if (cg < nv) counts[cg] = hits;
@@ -632,9 +709,12 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
 
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
-                         float4* zero_span, uint32_t zero_f4, uint32_t budget, uint32_t* slice_info) {
+                         float4* zero_span, uint32_t zero_f4, uint32_t budget, uint32_t* slice_info, const uint32_t* zcut,
+                         const uint32_t* depth_keys_sorted) {
     if (nv == 0) return 0;
+    if (zcut && (!slice_info || !depth_keys_sorted)) return set_error(ctx, BH_ERR_INVALID_ARG, "map_gaussians: a depth-cut table needs the slice words and the sorted keys");
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
+    const uint32_t* nul = nullptr;
     if (slice_info) {   // the near slice of a sliced frame: few, large splats (see SPW)
 #ifndef BH_K5_SPW
 #define BH_K5_SPW 16
@@ -642,12 +722,10 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
         constexpr int SPW = BH_K5_SPW;
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, zcut, depth_keys_sorted);
     } else {
         hipLaunchKernelGGL((map_gaussians_kernel<false, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
     }
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
@@ -655,19 +733,21 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
 
 // The far slice of a depth-sliced forward: count -> emit (the scan between them is folded into the emit kernel), both no-ops when
 // *gate (the number of tiles the near slice left unsaturated) is zero.  counts: [nv], block_totals: [ceil(nv / 256)] scratch;
-// group_totals: [ceil(blocks / FAR_GROUP_BLOCKS)], zero on entry; slice_info[3] receives the number of far pairs.
+// group_totals: [ceil(blocks / FAR_GROUP_BLOCKS)], zero on entry; slice_info[3] receives the number of far pairs, slice_info[4..5]
+// hold the live column / row bands.  zcut != NULL: per-tile depth cuts (every visible splat takes part, a pair is far if it lies
+// behind its tile's cut); else the splats behind the slot budget.
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
                              uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids,
-                             uint32_t* isect_gids) {
+                             uint32_t* isect_gids, const uint32_t* zcut, const uint32_t* depth_keys_sorted) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
-    hipLaunchKernelGGL(slice_count_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_y0, u.tile_y1, projected_by_gid, gid, cum_tiles_hit,
-                       budget, done_bits, gate, counts, block_totals, group_totals);
+    hipLaunchKernelGGL(slice_count_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid, cum_tiles_hit,
+                       budget, done_bits, gate, counts, block_totals, group_totals, zcut, depth_keys_sorted, (const uint32_t*)(slice_info + 4));
     BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
     hipLaunchKernelGGL((map_gaussians_kernel<true, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                        projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, slice_info, (const uint32_t*)counts,
-                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate);
+                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate, zcut, depth_keys_sorted);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");
     return 0;
 }

@@ -215,6 +215,15 @@ struct SliceArgs {
     const uint32_t* offsets_near = nullptr; // PHASE 2: the near slice's [T,2] table (shrunk ends: the tile's backward work so far)
     const uint32_t* cum = nullptr;          // cum_tiles_hit [Nv]: the exact list's slot ranges (feedback)
     uint32_t* feedback = nullptr;           // [COUNTER_SLOTS][3]: max slots a saturated tile needed | listed pairs of unsaturated tiles | their number
+    // per-tile depth cuts (api.hip): zcut[tile] = the depth key behind which the tile's NEAR list was cut (ZCUT_ALL: complete).
+    // Every phase that finishes a tile writes what it needed THIS time into the table (the view's next frame lists against it);
+    // cut_active: this frame's lists were built against the table, so an unsaturated tile with a complete list is final in PHASE 1.
+    uint32_t* zcut = nullptr;
+    const uint32_t* depth_keys_sorted = nullptr;   // [nv] depth keys in compact (depth) order
+    uint32_t nv = 0;
+    uint32_t cut_active = 0;
+    uint32_t* live_bands = nullptr;         // [2]: 32 bands of tile columns | rows that hold a parked tile (PHASE 1 ORs, the far pass reads)
+    uint32_t tile_bh = 0;
 };
 
 #ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
@@ -334,7 +343,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     const bool live_end = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
     const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
 
-    if (PHASE == 1 && !saturated) {
+    // (per-tile depth cuts: a tile whose near list was NOT cut holds everything there is — unsaturated or not, it is final)
+    const bool near_complete = PHASE == 1 && sl.cut_active != 0u && sl.zcut[tile] == ZCUT_ALL;
+    if (PHASE == 1 && !saturated && !near_complete) {
         // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -345,6 +356,11 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         if (lane == 0) {
             if (BWD_INFO) tile_offsets[tile * 2 + 1] = last_useful;
             atomicAdd(sl.unsat_count, 1u);
+            if (sl.live_bands) {   // where the live tiles are: the far pass walks only splats whose box reaches these bands
+                const uint32_t ttx = tile % u.tile_bw, tty = tile / u.tile_bw;
+                atomicOr(&sl.live_bands[0], 1u << ((ttx * 32u) / u.tile_bw));
+                atomicOr(&sl.live_bands[1], 1u << ((tty * 32u) / sl.tile_bh));
+            }
         }
         return;
     }
@@ -399,6 +415,27 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                 lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
             }
         }
+        // per-tile depth cut for this view's NEXT frame: a saturated tile needs the splats up to its last useful one — plus a margin
+        // of a quarter more of the depth order (parameters move between two visits of a view) — and nothing behind; a tile that
+        // did not saturate needs everything there is.  forward-only passes keep no last_useful: `reached` (>= it) is used.
+        if (sl.zcut) {
+            uint32_t newcut = ZCUT_ALL;
+            if (saturated && sl.nv) {
+                const uint32_t stop = BWD_INFO ? last_useful : reached;
+                uint32_t g = 0xFFFFFFFFu;
+                if (stop > range_lo) g = isect_gids[stop - 1u];
+                else if (PHASE == 2) {   // (saturated by the near list's last splats, nothing blended here)
+                    const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
+                    if (n_hi > n_lo) g = isect_gids[n_hi - 1u];
+                }
+                if (g != 0xFFFFFFFFu) {
+                    const uint32_t margin = (g >> 2) > 64u ? (g >> 2) : 64u;
+                    const uint32_t g2 = g + margin < sl.nv ? g + margin : sl.nv - 1u;
+                    newcut = sl.depth_keys_sorted[g2];
+                }
+            }
+            sl.zcut[tile] = newcut;
+        }
         // hint for the next frame's slicing (read back with its counters): how many slots of the exact list a tile needed before
         // it saturated (max over tiles), and how many pairs are listed for tiles that never saturate
         if (sl.feedback) {
@@ -448,7 +485,14 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.offsets_near = slice->offsets_near;
         sl.cum = slice->cum;
         sl.feedback = slice->feedback;
+        sl.zcut = slice->zcut;
+        sl.depth_keys_sorted = slice->depth_keys_sorted;
+        sl.nv = slice->nv;
+        sl.cut_active = slice->cut_active ? 1u : 0u;
+        sl.live_bands = slice->live_bands;
+        sl.tile_bh = vu.tile_bh;
     }
+    if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;

@@ -327,6 +327,13 @@ def set_list_slicing(near_share: float, ctx: Optional["Context"] = None, device=
     ctx.check(ctx.lib.bh_set_list_slicing(ctx._h, float(near_share)))
 
 
+def set_view_id(view_id: int, ctx: Optional["Context"] = None, device=None):
+    """The view the following forwards on `ctx` render (bh_set_view_id; sticky, 0 = unknown): selects the per-tile depth-cut
+    table that sliced forwards read and refresh."""
+    ctx = ctx or get_context(device)
+    ctx.check(ctx.lib.bh_set_view_id(ctx._h, int(view_id)))
+
+
 def _forward(ctx, splats, camera, img_size, background, pass_, sliced=False):
     if img_size[0] <= 0 or img_size[1] <= 0:
         raise BrushHipError("Can't render images with 0 size.")  # render.rs:50-53
@@ -679,6 +686,7 @@ class SceneBatch:
     camera: Camera
     has_alpha: bool = False
     alpha_is_mask: bool = False
+    view_id: int = 0   # which view of the dataset this is (index + 1; 0 = unknown): keys the per-tile depth cuts (BhTrainBatch.view_id)
 
     def img_size(self):
         return tuple(self.img_packed.shape)  # (h, w)
@@ -769,6 +777,7 @@ class SceneLoader:
         import queue
         import threading
         self.views = [v for i, v in enumerate(views) if i % world == rank]
+        self.view_ids = [i + 1 for i in range(len(views)) if i % world == rank]   # dataset index + 1 (0 = "unknown view")
         if not self.views:
             raise ValueError("Need at least one view in dataset")  # scene_loader.rs:130
         self._own_uploader = uploader is None
@@ -840,7 +849,7 @@ class SceneLoader:
         slot, idx, cam, mask = item
         packed, has_alpha = self.up.acquire(slot)
         self._held = slot
-        b = SceneBatch(packed, cam, has_alpha=has_alpha, alpha_is_mask=mask)
+        b = SceneBatch(packed, cam, has_alpha=has_alpha, alpha_is_mask=mask, view_id=self.view_ids[idx])
         b.view_index = idx
         return b
 
@@ -1055,6 +1064,7 @@ class SplatTrainer:
             b.device_noise, b.noise_seed = 1, self.seed
         stats = _ffi.BhTrainStats()
         b.exchange_mode = 1 if (self.sparse_exchange and (self.pg is not None or self.native_comm)) else 0
+        b.view_id = int(getattr(batch, "view_id", 0)) & 0xFFFFFFFF
         hook, scale = None, 1.0
         if self.native_comm:
             scale = 1.0 / ctx.comm_world()

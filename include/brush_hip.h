@@ -185,19 +185,28 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
                       const float* transforms, const float* sh_coeffs, const float* raw_opacities,
                       const float* background /*host [3]*/, uint32_t flags, BhRenderOut* out /*host*/);
 
-/* BH_FLAG_SLICED_LISTS: the near slice's share of the pair list.  near_share in (0, 1]: fixed (1 = never slice);
- * <= 0 (the default): chosen per frame from the previous forwards on this ctx — 1.25 x the slots the slowest saturating
- * tile of recent frames needed (a maximum that fades by 10 % per frame), a quarter of the list when there is no history,
- * one slice when most pairs belong to tiles that never saturate, or when some tiles never saturate (a blank background) and
- * the near slice would save less than the far slice costs.  Results do not depend on the choice, only the time does.
- * Note for bh_render_forward: a sliced frame that was not preceded by one needing its far slice makes the call wait for the
- * near slice's blend (a 4-byte readback decides whether the far slice is queued); bh_train_step hides that wait behind its
- * loss kernels. */
+/* BH_FLAG_SLICED_LISTS: how the near lists are cut.
+ *   near_share <= 0 (the default): PER TILE, from the last frame of the same view on this ctx (bh_set_view_id).  Every blend
+ *     launch records, per tile, the depth behind which the tile needed no splat (+ a quarter more of the depth order as a
+ *     margin; "everything" for a tile that did not saturate); the view's next frame lists a (splat, tile) pair only if the
+ *     splat lies at or in front of the tile's cut — typically a tenth of the pairs, whatever the frame looks like (a blank
+ *     background or thin regions keep their own short lists whole).  A tile that is still live behind a cut list is finished
+ *     by the far pass (the pairs behind the cut, for those tiles only), which also corrects the table; a view's first frame,
+ *     and frames after repeated misses, are rendered with complete lists.
+ *   near_share in (0, 1]: ONE cut for the whole frame — the first near_share of the exact list's slots (splats in depth order);
+ *     1 = never slice.  Tests and A/B measurements.
+ * Results do not depend on the choice, only the time does.  Under a per-tile cut cum_tiles_hit is the scan of the near counts.
+ * Note for bh_render_forward: a sliced frame makes the call wait for the near pass's blend (a 4-byte readback decides whether
+ * the far pass is queued); bh_train_step hides that wait behind its loss kernels. */
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
+/* The view the following forwards on this ctx render (sticky; 0 = unknown, the default): selects the per-tile depth-cut table
+ * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.  One
+ * table is 4 bytes per tile; the 4096 most recently used views are kept. */
+int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
-/* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far slice (diagnostics: on a scene that
- * saturates, with the automatic share, this stops growing after the first frames) */
+/* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far pass (diagnostics: with view ids and
+ * slowly moving parameters this stops growing after each view's first frames) */
 uint32_t bh_far_slices_queued(bh_ctx* ctx);
 
 /* How many pairs the last forward on this ctx actually LISTED: compact_gid_from_isect / tile_id_from_isect hold near_pairs
@@ -352,6 +361,11 @@ typedef struct BhTrainBatch {
      * 5-px SSIM window) above and below this rank's strip; the loss kernels run on the strip (pass A one tile row wider),
      * BhTrainStats.loss is the strip's share of the frame's mean loss (sum the ranks' values). */
     int32_t strip_loss;
+    /* Which view of the dataset this batch is (any stable non-zero number, e.g. its index + 1; 0 = unknown).  Only the TIME of a
+     * step depends on it: the forward keeps, per view id, how deep every tile had to go the last time that view was rendered
+     * and lists only that much of every tile the next time (bh_set_view_id).  Without ids all frames share one table, which
+     * works for one repeated camera and turns itself off for alternating ones. */
+    uint32_t view_id;
 } BhTrainBatch;
 
 typedef struct BhTrainStats {

@@ -283,8 +283,9 @@ def test_6m_4k_sh3_forward_backward_step_vs_oracle(dev, oracle_lib):
 def test_1m_1080p_sliced_lists_vs_oracle(dev, oracle_lib, scene_1m, share):
     """BH_FLAG_SLICED_LISTS at configs[2]'s size against the oracle's exact pipeline: image, visible flags and counts exact,
     every tile's blended list (near segment + far segment) == the oracle's shrunk list, gradients within the stated 1e-4.
-    share 0 = the automatic choice (no history: a quarter of the list, every tile done in the near slice); 0.04 leaves about
-    half of the tiles to the far slice."""
+    share 0 = the automatic choice: per-tile depth cuts from the view's previous frame (the first frame seeds them with complete
+    lists, the compared one lists what every tile needed + a margin); 0.04 = one cut for the whole frame that leaves about half
+    of the tiles to the far slice."""
     import brush_amd as ba
     from test_gpu_backward import assert_grads_match
     sc, w, h = scene_1m
@@ -296,9 +297,13 @@ def test_1m_1080p_sliced_lists_vs_oracle(dev, oracle_lib, scene_1m, share):
     ctx = ba.Context(dev)   # fresh: no slicing history
     try:
         ba.set_list_slicing(share, ctx)
+        if share == 0.0:   # the view's first frame: complete lists, seeds the per-tile cuts
+            ba.render_splats(spl, util.hip_camera(ba, cp), (w, h), bg, ba.RasterPass.Backward, ctx=ctx, sliced=True, copy=False)
         res = ba.render_splats_bwd(spl, util.hip_camera(ba, cp), (w, h), bg, torch.from_numpy(v).to(dev), ctx=ctx, sliced=True)
         aux = res["aux"]
         assert aux.tile_offsets_far is not None and aux.list_budget < aux.num_intersections
+        if share == 0.0:
+            assert aux.list_budget < 0.3 * aux.num_intersections, "per-tile cuts list %d of %d pairs" % (aux.list_budget, aux.num_intersections)
         ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=bg)
         ref.backward(v)
         assert aux.num_visible == ref.num_visible and aux.num_intersections == ref.num_intersections
