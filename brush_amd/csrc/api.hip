@@ -231,15 +231,17 @@ static ViewState* view_state(bh_ctx* ctx, uint32_t id, uint32_t tile_bw, uint32_
     return &it->second;
 }
 
-// Outcome of a per-tile-cut frame of `vs`: did its far pass have to run (= the forecast failed for some tile)?  One miss is
-// normal — the far pass has just corrected the table.  Three misses within the view's last eight cut frames (alternating cameras
-// sharing one table, a scene that changes faster than the margin) and the view's next eight frames are rendered with complete
-// lists, each of them re-seeding the table.
-static void view_outcome(ViewState* vs, bool missed) {
+// Outcome of a per-tile-cut frame of `vs`: did its far pass have to run (= the forecast failed for some tile)?  A miss now and
+// then is normal and cheap (the far pass lists a few pairs for a few tiles and corrects the table).  Six misses within the
+// view's last eight cut frames (alternating cameras sharing one table, a scene that changes faster than the margin) and the view's
+// next eight frames are rendered with complete lists, each of them re-seeding the table.
+static void view_outcome(ViewState* vs, bool missed, bool shared_table) {
     if (!vs) return;
     vs->penalty = ((vs->penalty << 1) | (missed ? 1u : 0u)) & 0xFFu;   // (the history of the last eight cut frames, one bit each)
-    if (__builtin_popcount(vs->penalty) >= 3) {
-        vs->exact_frames = 8u;
+    // the table of view id 0 is shared by every frame that names no view: alternating cameras miss on every other frame there,
+    // each miss a far pass over MANY tiles — three misses are enough, and the table stays untrusted for longer
+    if (__builtin_popcount(vs->penalty) >= (shared_table ? 3 : 6)) {
+        vs->exact_frames = shared_table ? 32u : 8u;
         vs->penalty = 0u;
     }
 }
@@ -253,7 +255,7 @@ int finish_far_slice(bh_ctx* ctx, bool* launched) {
     BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
     const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
     if (ctx->far_job.zcut) {   // per-tile cuts: the far pass corrects the table, the next frame of the view is predicted again
-        view_outcome(ctx->far_job.view, unsat != 0u);
+        view_outcome(ctx->far_job.view, unsat != 0u, ctx->far_job.view_shared);
     } else {
         ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
     }
@@ -327,6 +329,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         ctx->knob_fail_loss_at = (uint32_t)atoi(e);
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
+    if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess ||
@@ -612,9 +615,15 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         else if (view->exact_frames) view->exact_frames--;
     }
     uint32_t* near_counts = nullptr;
+    uint32_t* far_epoch = nullptr;
+    if (++ctx->frame_id == 0u) ctx->frame_id = 1u;
     if (cut_active) {
         near_counts = (uint32_t*)ensure(ctx, SLOT_NEAR_COUNTS, npad * 4);
-        if (!near_counts) return BH_ERR_OOM;
+        const size_t had = ctx->slots[SLOT_FAR_EPOCH].cap;
+        far_epoch = (uint32_t*)ensure(ctx, SLOT_FAR_EPOCH, (size_t)num_tiles * 4);
+        if (!near_counts || !far_epoch) return BH_ERR_OOM;
+        // (a fresh block holds garbage that could pass for a frame id: zero = "never")
+        if (ctx->slots[SLOT_FAR_EPOCH].cap != had) BH_HIP(ctx, hipMemsetAsync(far_epoch, 0, ctx->slots[SLOT_FAR_EPOCH].cap, ctx->stream));
     }
 
     uint32_t nv = 0, ni = 0, near_total = 0;
@@ -644,7 +653,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 ctx->grads_prezeroed = true;
             }
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
-                                          proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts));
+                                          proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts, far_epoch, ctx->frame_id));
             ctx->counter_phase ^= 1u;
             ctx->counters_ready = true;
         }
@@ -756,6 +765,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         rs.depth_keys_sorted = depths_sorted;
         rs.nv = nv;
         rs.cut_active = by_cut;
+        rs.far_epoch = far_epoch;
+        rs.frame_id = ctx->frame_id;
+        rs.margin_pct = ctx->knob_cut_margin_pct;
     }
     // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
     const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
@@ -840,6 +852,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         j.zcut = by_cut ? view->zcut : nullptr;
         j.depth_keys_sorted = by_cut ? depths_sorted : nullptr;
         j.view = by_cut ? view : nullptr;
+        j.view_shared = ctx->view_id == 0u;
         // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)
         BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
         // (per-tile cuts: the forecast is expected to hold, and a far pass that had to run has corrected the table — the host decides
@@ -1245,11 +1258,14 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     };
     if (ctx->knob_fail_loss_at && ++ctx->train_steps_seen == ctx->knob_fail_loss_at)   // (the forward is queued, a deferred far slice may be pending)
         return set_error(ctx, BH_ERR_OOM, "train_step: injected failure between the forward and the loss (BH_TEST_FAIL_LOSS_AT)");
+    // A view whose forecast missed recently decides FIRST (the host waits for the near pass's blend, ~15 us of bubble) instead of
+    // queueing loss kernels that a far pass would make worthless (~120 us)
+    if (ctx->far_job.pending && ctx->far_job.view && ctx->far_job.view->penalty != 0u) BH_TRY(finish_far_slice(ctx, nullptr));
     BH_TRY(queue_loss());
     if (ctx->far_job.pending) {
         // The loss above ran on the near slice's image, which is the frame's image unless some tile was left unsaturated — the
-        // host finds out while it runs.  Then (rare on scenes that saturate: the near slice is sized with a margin from the last
-        // frame) the far slice is queued and the loss is evaluated again on the finished image.
+        // host finds out while it runs.  Then (rare: the near lists carry a margin over what the view needed last time)
+        // the far slice is queued and the loss is evaluated again on the finished image.
         bool far_ran = false;
         BH_TRY(finish_far_slice(ctx, &far_ran));
         if (far_ran) BH_TRY(queue_loss());

@@ -62,6 +62,7 @@ enum Slot : int {
     SLOT_SLICE_COUNTS,       // [Nv] live-tile hits per far splat / their inclusive scan
     SLOT_SLICE_CUM,
     SLOT_NEAR_COUNTS,        // [N] tiles hit per splat at or in front of the tile's depth cut (per-tile cut lists)
+    SLOT_FAR_EPOCH,          // [T] the last frame (ctx->frame_id) in which K1 saw a pair BEHIND the tile's cut: == this frame -> the tile's near list is incomplete
     SLOT_COUNT
 };
 
@@ -144,6 +145,9 @@ struct RasterSlice {
     uint32_t nv = 0;
     bool cut_active = false;
     uint32_t* live_bands = nullptr;   // the two band words of the slice table (SLICE_CTRL_WORDS): sliced phases only
+    const uint32_t* far_epoch = nullptr;   // [T] (SLOT_FAR_EPOCH) and the frame's id: which near lists are incomplete
+    uint32_t frame_id = 0;
+    uint32_t margin_pct = 150;        // depth-order margin behind a tile's last useful splat, in % of its rank
 };
 
 // The far slice of a depth-sliced forward, ready to be queued: everything launch_* needs (api.hip enqueue_far_slice).
@@ -177,6 +181,7 @@ struct FarJob {
     const uint32_t* zcut = nullptr;
     const uint32_t* depth_keys_sorted = nullptr;
     ViewState* view = nullptr;      // whose prediction failed if the far pass has to run
+    bool view_shared = false;       // ... and whether that is the table of view id 0 (shared by all frames without an id)
 };
 
 }  // namespace bh
@@ -239,6 +244,8 @@ struct bh_ctx {
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
+    uint32_t frame_id = 0;                // forwards on this ctx so far (never 0 in use): stamps SLOT_FAR_EPOCH
+    uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
     bh::FarJob far_job;
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
@@ -316,7 +323,7 @@ struct ForwardPrep {
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
                            float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep, const uint32_t* zcut = nullptr,
-                           uint32_t* near_counts = nullptr);
+                           uint32_t* near_counts = nullptr, uint32_t* far_epoch = nullptr, uint32_t frame_id = 0);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 // budget: only splats whose slot range ends at or below it are emitted (the near slice of a depth-sliced forward; 0xFFFFFFFF =
 // all); slice_info (device, 2 words) then receives the slice's splat count and pair count.

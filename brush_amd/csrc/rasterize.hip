@@ -224,6 +224,9 @@ struct SliceArgs {
     uint32_t cut_active = 0;
     uint32_t* live_bands = nullptr;         // [2]: 32 bands of tile columns | rows that hold a parked tile (PHASE 1 ORs, the far pass reads)
     uint32_t tile_bh = 0;
+    const uint32_t* far_epoch = nullptr;    // [T]: == frame_id where K1 saw a pair behind the tile's cut (the near list is incomplete)
+    uint32_t frame_id = 0;
+    uint32_t margin_pct = 150;
 };
 
 #ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
 
     // (per-tile depth cuts: a tile whose near list was NOT cut holds everything there is — unsaturated or not, it is final)
-    const bool near_complete = PHASE == 1 && sl.cut_active != 0u && sl.zcut[tile] == ZCUT_ALL;
+    const bool near_complete = PHASE == 1 && sl.cut_active != 0u && sl.far_epoch[tile] != sl.frame_id;
     if (PHASE == 1 && !saturated && !near_complete) {
         // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
 #pragma unroll
@@ -429,8 +432,12 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                     if (n_hi > n_lo) g = isect_gids[n_hi - 1u];
                 }
                 if (g != 0xFFFFFFFFu) {
-                    const uint32_t margin = (g >> 2) > 64u ? (g >> 2) : 64u;
-                    const uint32_t g2 = g + margin < sl.nv ? g + margin : sl.nv - 1u;
+                    // (how deep a tile has to go is set by its SLOWEST pixel — an extreme value that jumps when a few small splats
+                    //  move, and the default step moves them on purpose: the margin is generous, the lists still a fraction)
+                    // (a tile the far pass had to finish has just shown that it is volatile: three times the margin)
+                    const unsigned long long mraw = (unsigned long long)g * sl.margin_pct / 100ull * (PHASE == 2 ? 3ull : 1ull);
+                    const uint32_t margin = mraw > 128ull ? (mraw < 0x7FFFFFFFull ? (uint32_t)mraw : 0x7FFFFFFFu) : 128u;
+                    const uint32_t g2 = (unsigned long long)g + margin < sl.nv ? g + margin : sl.nv - 1u;
                     newcut = sl.depth_keys_sorted[g2];
                 }
             }
@@ -491,7 +498,11 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.cut_active = slice->cut_active ? 1u : 0u;
         sl.live_bands = slice->live_bands;
         sl.tile_bh = vu.tile_bh;
+        sl.far_epoch = slice->far_epoch;
+        sl.frame_id = slice->frame_id;
+        sl.margin_pct = slice->margin_pct;
     }
+    if (sl.cut_active && !sl.far_epoch) return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: per-tile cuts without the far-epoch table");
     if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
