@@ -215,12 +215,14 @@ static ViewState* view_state(bh_ctx* ctx, uint32_t id, uint32_t tile_bw, uint32_
         ViewState vs;
         vs.tile_bw = tile_bw;
         vs.tile_bh = tile_bh;
-        const size_t words = (size_t)tile_bw * tile_bh;
-        if (hipMalloc((void**)&vs.zcut, (words ? words : 1) * 4) != hipSuccess) {
+        const size_t words = (size_t)tile_bw * tile_bh ? (size_t)tile_bw * tile_bh : 1;
+        // [T] depth cuts (all "everything") | [T] per-tile work of the last frame (all zero)
+        if (hipMalloc((void**)&vs.zcut, 2 * words * 4) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
-        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut), (int)ZCUT_ALL, words ? words : 1, ctx->stream) != hipSuccess) {
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut), (int)ZCUT_ALL, words, ctx->stream) != hipSuccess ||
+            hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut + words), 0, words, ctx->stream) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(vs.zcut);
             return nullptr;
@@ -329,6 +331,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         ctx->knob_fail_loss_at = (uint32_t)atoi(e);
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
+    if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
@@ -616,6 +619,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     }
     uint32_t* near_counts = nullptr;
     uint32_t* far_epoch = nullptr;
+    uint32_t* tile_order = nullptr;
     if (++ctx->frame_id == 0u) ctx->frame_id = 1u;
     if (cut_active) {
         near_counts = (uint32_t*)ensure(ctx, SLOT_NEAR_COUNTS, npad * 4);
@@ -645,6 +649,16 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.tile_words = num_tiles * 2 + 8 * 16;
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
+            if (view && ctx->knob_k16_order && n >= 8u * 256u) {   // the forward blend's tile order from the view's last per-tile work (K1's blocks 0..7 sort it: the grid must have them)
+                const uint32_t win_t = u.tile_bw * (u.tile_y1 - u.tile_y0);
+                tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, (size_t)8 * ((win_t + 7u) / 8u) * 4);
+                if (!tile_order) return BH_ERR_OOM;
+                prep.order_work = view->zcut + (size_t)num_tiles;
+                prep.order_out = tile_order;
+                prep.order_tiles = win_t;
+                prep.order_tile_begin = u.tile_bw * u.tile_y0;
+                prep.order_mode = ctx->knob_k16_order;
+            }
             ctx->grads_prezeroed = false;
             if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
@@ -768,6 +782,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         rs.far_epoch = far_epoch;
         rs.frame_id = ctx->frame_id;
         rs.margin_pct = ctx->knob_cut_margin_pct;
+        rs.work = view->zcut + (size_t)num_tiles;
+        rs.order = tile_order;
+        rs.order_mode = ctx->knob_k16_order;
     }
     // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
     const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);

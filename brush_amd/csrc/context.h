@@ -62,6 +62,7 @@ enum Slot : int {
     SLOT_SLICE_COUNTS,       // [Nv] live-tile hits per far splat / their inclusive scan
     SLOT_SLICE_CUM,
     SLOT_NEAR_COUNTS,        // [N] tiles hit per splat at or in front of the tile's depth cut (per-tile cut lists)
+    SLOT_TILE_ORDER,         // [8][ceil(T/8)] the forward blend's block -> tile map: every XCD band's tiles by descending forecast work
     SLOT_FAR_EPOCH,          // [T] the last frame (ctx->frame_id) in which K1 saw a pair BEHIND the tile's cut: == this frame -> the tile's near list is incomplete
     SLOT_COUNT
 };
@@ -120,7 +121,8 @@ struct Profiler {
 // Written in place by the blend kernel of every forward of the view, read by K1 / K5 / the far pass of its next one.
 constexpr uint32_t ZCUT_ALL = 0xFFFFFFFFu;
 struct ViewState {
-    uint32_t* zcut = nullptr;       // [tile_bw * tile_bh] device
+    uint32_t* zcut = nullptr;       // [tile_bw * tile_bh] device; directly behind it: work[tile_bw * tile_bh], the splats every tile blended at the
+                                    // view's last frame (the forward blend's tile order, rasterize.hip)
     uint32_t tile_bw = 0, tile_bh = 0;
     bool seeded = false;            // a forward of this view has written the table
     uint32_t exact_frames = 0;      // frames to render with complete lists before the cut is trusted again (the forecast kept failing)
@@ -147,6 +149,9 @@ struct RasterSlice {
     uint32_t* live_bands = nullptr;   // the two band words of the slice table (SLICE_CTRL_WORDS): sliced phases only
     const uint32_t* far_epoch = nullptr;   // [T] (SLOT_FAR_EPOCH) and the frame's id: which near lists are incomplete
     uint32_t frame_id = 0;
+    uint32_t* work = nullptr;              // [T] the view's per-tile blended counts: written by every phase that finishes a tile
+    const uint32_t* order = nullptr;       // [8][ceil(Tw/8)] block -> local tile of this launch (K1 sorted each XCD band by the view's last work), or NULL
+    uint32_t order_mode = 1;
     uint32_t margin_pct = 150;        // depth-order margin behind a tile's last useful splat, in % of its rank
 };
 
@@ -245,6 +250,7 @@ struct bh_ctx {
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
     uint32_t frame_id = 0;                // forwards on this ctx so far (never 0 in use): stamps SLOT_FAR_EPOCH
+    uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
     bh::FarJob far_job;
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
@@ -319,6 +325,11 @@ struct ForwardPrep {
     uint32_t span_f4 = 0;
     uint32_t* slice_table = nullptr;              // depth-sliced forward: control words + done bits + far tile offsets
     uint32_t slice_words = 0;
+    // the forward blend's tile order: blocks 0..7 sort the tiles of XCD band b by the view's last per-tile work (descending)
+    const uint32_t* order_work = nullptr;         // [T] (global tile ids), or NULL
+    uint32_t* order_out = nullptr;                // [8][ceil(order_tiles/8)] local tile ids, 0xFFFFFFFF behind a short band
+    uint32_t order_tiles = 0, order_tile_begin = 0;
+    uint32_t order_mode = 1;                      // 1: descending work   2: dealt (consecutive blocks take every 8th rank)
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,

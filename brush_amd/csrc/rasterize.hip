@@ -227,6 +227,13 @@ struct SliceArgs {
     const uint32_t* far_epoch = nullptr;    // [T]: == frame_id where K1 saw a pair behind the tile's cut (the near list is incomplete)
     uint32_t frame_id = 0;
     uint32_t margin_pct = 150;
+    // tile order: all one-wave tiles of a frame are resident at once, so the launch lasts as long as the SIMD whose eight tiles sum
+    // to the most work.  order[band][rank] (K1: every XCD band's tiles sorted by the work they had at the view's last frame) makes
+    // consecutive blocks take tiles of steadily decreasing work: whichever regular pattern deals blocks to SIMDs, each SIMD's tiles
+    // are spread over the whole range instead of being eight neighbours.  work[tile]: what this frame's tiles blended, for next time.
+    const uint32_t* order = nullptr;
+    uint32_t order_mode = 1;
+    uint32_t* work = nullptr;
 };
 
 #ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
@@ -239,7 +246,18 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
                                                       float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    const uint32_t local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+    uint32_t local_tile;
+    if (sl.order) {
+        const uint32_t per = (u.num_tiles + 7u) / 8u;
+        uint32_t j = blockIdx.x >> 3;
+        if (sl.order_mode == 2u) {   // dealt: consecutive blocks of a band take every seg-th rank (the grid covers 8 * seg ranks per band)
+            const uint32_t seg = (per + 7u) / 8u;
+            j = (j & 7u) * seg + (j >> 3);
+        }
+        local_tile = j < per ? sl.order[(blockIdx.x & 7u) * per + j] : 0xFFFFFFFFu;
+    } else {
+        local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+    }
     if (local_tile >= u.num_tiles) return;
     const uint32_t tile = u.tile_begin + local_tile;
 #ifdef BH_K16_TRACE
@@ -401,13 +419,14 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
 #endif
     if (lane == 0) {
         if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
-        uint32_t work = last_useful - range_lo;
+        uint32_t work = (BWD_INFO ? last_useful : reached) - range_lo;
         uint32_t listed = range_hi - range_lo;
         if (PHASE == 2) {   // the tile's backward work / list = what both slices contributed
             const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
             work += n_hi - n_lo;
             listed += n_hi - n_lo;
         }
+        if (sl.work) sl.work[tile] = work;   // the forecast of this tile's work at the view's next frame
         // rasterize.rs:183-189: shrink the tile's end to one past the last useful splat
         if (BWD_INFO) {
             tile_offsets[tile * 2 + 1] = last_useful;
@@ -501,13 +520,17 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.far_epoch = slice->far_epoch;
         sl.frame_id = slice->frame_id;
         sl.margin_pct = slice->margin_pct;
+        sl.order = slice->order;
+        sl.order_mode = slice->order_mode;
+        sl.work = slice->work;
     }
     if (sl.cut_active && !sl.far_epoch) return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: per-tile cuts without the far-epoch table");
     if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;
-    const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
+    uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
+    if (sl.order && sl.order_mode == 2u) nblocks = (((u.num_tiles + 7u) / 8u + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
     const dim3 grid(nblocks);
     if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
