@@ -618,16 +618,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         else if (view->exact_frames) view->exact_frames--;
     }
     uint32_t* near_counts = nullptr;
-    uint32_t* far_epoch = nullptr;
     uint32_t* tile_order = nullptr;
-    if (++ctx->frame_id == 0u) ctx->frame_id = 1u;
     if (cut_active) {
         near_counts = (uint32_t*)ensure(ctx, SLOT_NEAR_COUNTS, npad * 4);
-        const size_t had = ctx->slots[SLOT_FAR_EPOCH].cap;
-        far_epoch = (uint32_t*)ensure(ctx, SLOT_FAR_EPOCH, (size_t)num_tiles * 4);
-        if (!near_counts || !far_epoch) return BH_ERR_OOM;
-        // (a fresh block holds garbage that could pass for a frame id: zero = "never")
-        if (ctx->slots[SLOT_FAR_EPOCH].cap != had) BH_HIP(ctx, hipMemsetAsync(far_epoch, 0, ctx->slots[SLOT_FAR_EPOCH].cap, ctx->stream));
+        if (!near_counts) return BH_ERR_OOM;
     }
 
     uint32_t nv = 0, ni = 0, near_total = 0;
@@ -667,7 +661,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
                 ctx->grads_prezeroed = true;
             }
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
-                                          proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts, far_epoch, ctx->frame_id));
+                                          proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts));
             ctx->counter_phase ^= 1u;
             ctx->counters_ready = true;
         }
@@ -779,8 +773,6 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         rs.depth_keys_sorted = depths_sorted;
         rs.nv = nv;
         rs.cut_active = by_cut;
-        rs.far_epoch = far_epoch;
-        rs.frame_id = ctx->frame_id;
         rs.margin_pct = ctx->knob_cut_margin_pct;
         rs.work = view->zcut + (size_t)num_tiles;
         rs.order = tile_order;

@@ -63,7 +63,6 @@ enum Slot : int {
     SLOT_SLICE_CUM,
     SLOT_NEAR_COUNTS,        // [N] tiles hit per splat at or in front of the tile's depth cut (per-tile cut lists)
     SLOT_TILE_ORDER,         // [8][ceil(T/8)] the forward blend's block -> tile map: every XCD band's tiles by descending forecast work
-    SLOT_FAR_EPOCH,          // [T] the last frame (ctx->frame_id) in which K1 saw a pair BEHIND the tile's cut: == this frame -> the tile's near list is incomplete
     SLOT_COUNT
 };
 
@@ -119,7 +118,10 @@ struct Profiler {
 // Per-view state of the per-tile depth cut (BH_FLAG_SLICED_LISTS, automatic mode; api.hip has the whole story): for every tile the
 // depth key behind which the tile needed no splat the last time THIS view was rendered (+ a margin), 0xFFFFFFFF = list everything.
 // Written in place by the blend kernel of every forward of the view, read by K1 / K5 / the far pass of its next one.
-constexpr uint32_t ZCUT_ALL = 0xFFFFFFFFu;
+// Bit 0 of an entry is not part of the cut: K1 sets it when it meets a pair BEHIND the cut ("this tile's near list is incomplete
+// this frame"), the blend kernel reads it and rewrites the entry with the bit clear.  Cuts are compared without it (zcut_near).
+constexpr uint32_t ZCUT_ALL = 0xFFFFFFFEu;
+BH_DEV bool zcut_near(uint32_t key, uint32_t cut) { return (key >> 1) <= (cut >> 1); }
 struct ViewState {
     uint32_t* zcut = nullptr;       // [tile_bw * tile_bh] device; directly behind it: work[tile_bw * tile_bh], the splats every tile blended at the
                                     // view's last frame (the forward blend's tile order, rasterize.hip)
@@ -147,8 +149,6 @@ struct RasterSlice {
     uint32_t nv = 0;
     bool cut_active = false;
     uint32_t* live_bands = nullptr;   // the two band words of the slice table (SLICE_CTRL_WORDS): sliced phases only
-    const uint32_t* far_epoch = nullptr;   // [T] (SLOT_FAR_EPOCH) and the frame's id: which near lists are incomplete
-    uint32_t frame_id = 0;
     uint32_t* work = nullptr;              // [T] the view's per-tile blended counts: written by every phase that finishes a tile
     const uint32_t* order = nullptr;       // [8][ceil(Tw/8)] block -> local tile of this launch (K1 sorted each XCD band by the view's last work), or NULL
     uint32_t order_mode = 1;
@@ -249,7 +249,6 @@ struct bh_ctx {
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
-    uint32_t frame_id = 0;                // forwards on this ctx so far (never 0 in use): stamps SLOT_FAR_EPOCH
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
     bh::FarJob far_job;
@@ -333,8 +332,8 @@ struct ForwardPrep {
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep, const uint32_t* zcut = nullptr,
-                           uint32_t* near_counts = nullptr, uint32_t* far_epoch = nullptr, uint32_t frame_id = 0);
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& prep, uint32_t* zcut = nullptr,
+                           uint32_t* near_counts = nullptr);
 int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_gid, const uint32_t* gid, float* projected);
 // budget: only splats whose slot range ends at or below it are emitted (the near slice of a depth-sliced forward; 0xFFFFFFFF =
 // all); slice_info (device, 2 words) then receives the slice's splat count and pair count.

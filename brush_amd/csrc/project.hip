@@ -106,7 +106,7 @@ struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are 
 struct KeepNearOfCut {
     const uint32_t* zcut;
     uint32_t tile_bw;
-    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return w.zkey[r] <= zcut[tx + ty * tile_bw]; }
+    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return zcut_near(w.zkey[r], zcut[tx + ty * tile_bw]); }
 };
 // ... and the FAR pass lists, for tiles that still have live pixels, the ones behind it
 struct KeepLiveBehindCut {
@@ -115,7 +115,7 @@ struct KeepLiveBehindCut {
     uint32_t tile_bw;
     BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const {
         const uint32_t t = tx + ty * tile_bw;
-        return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u && w.zkey[r] > zcut[t];
+        return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u && !zcut_near(w.zkey[r], zcut[t]);
     }
 };
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     ViewUniforms u, uint32_t n, const float* __restrict__ transforms, const float* __restrict__ coeffs,
     const float* __restrict__ raw_opacities, uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ isect_counts,
     float* __restrict__ max_radius, float* __restrict__ projected_by_gid, unsigned long long* __restrict__ counters, ForwardPrep prep,
-    const uint32_t* __restrict__ zcut, uint32_t* __restrict__ near_counts, uint32_t* __restrict__ far_epoch, uint32_t frame_id) {
+    uint32_t* __restrict__ zcut, uint32_t* __restrict__ near_counts) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
@@ -410,16 +410,19 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     const uint32_t tiles_hit = nb == 0xFFFFFFFFu ? w.count[0] : 0u;
 #else
     // per-tile depth cuts (zcut != NULL, wave-uniform): a hit also counts for the NEAR list if the splat is at or in front of its
-    // tile's cut - K5 lists exactly those pairs (same keys, same table, same test).  A hit BEHIND the cut stamps the tile with this
-    // frame's id (a plain store, every writer writes the same value; checked first so that a tile is stamped about once): the blend
-    // kernel then knows whose near list is incomplete — an unstamped tile holds everything there is, whatever its cut says.
+    // tile's cut - K5 lists exactly those pairs (same keys, same table, same test).  A hit BEHIND the cut sets bit 0 of the tile's
+    // entry — the bit is not part of the cut, and the other 31 bits do not change while K1 runs, so every writer stores the SAME
+    // word: a plain store (an atomic OR here cost 36 us: the value just loaded comes from a CU's L1, stays stale there, and
+    // every later hit of the tile repeated the atomic).  The blend kernel then knows whose near list is incomplete — an
+    // unmarked tile holds everything there is, however its cut reads.
     const uint32_t tile_bw = u.tile_bw;
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
         atomicAdd(&w.count[r], 1u);
         if (zcut) {
             const uint32_t t = tx + ty * tile_bw;
-            if (w.zkey[r] <= zcut[t]) atomicAdd(&w.near[r], 1u);
-            else if (far_epoch[t] != frame_id) far_epoch[t] = frame_id;
+            const uint32_t cut = zcut[t];
+            if (zcut_near(w.zkey[r], cut)) atomicAdd(&w.near[r], 1u);
+            else if ((cut & 1u) == 0u) zcut[t] = cut | 1u;
         }
     }, KeepAllTiles{}, key);
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
@@ -483,14 +486,14 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 template <bool MIP, bool PINHOLE>
 static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_t deg, const float* t, const float* sh, const float* ro,
                          uint32_t* keys, uint32_t* counts, float* radius, float* proj, unsigned long long* c64, const ForwardPrep& prep,
-                         const uint32_t* zcut, uint32_t* near_counts, uint32_t* far_epoch, uint32_t frame_id) {
+                         uint32_t* zcut, uint32_t* near_counts) {
     const dim3 grid((n + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts, far_epoch, frame_id); break;
-        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts, far_epoch, frame_id); break;
-        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts, far_epoch, frame_id); break;
-        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts, far_epoch, frame_id); break;
-        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts, far_epoch, frame_id); break;
+        case 0: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 0>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 1: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 1>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 2: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 2>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 3: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 3>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
+        case 4: hipLaunchKernelGGL((project_forward_kernel<MIP, PINHOLE, 4>), grid, block, 0, ctx->stream, u, n, t, sh, ro, keys, counts, radius, proj, c64, prep, zcut, near_counts); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_forward_kernel");
@@ -499,9 +502,8 @@ static int launch_pf_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, uint32_
 
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
-                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& want, const uint32_t* zcut, uint32_t* near_counts,
-                           uint32_t* far_epoch, uint32_t frame_id) {
-    if (zcut && (!near_counts || !far_epoch)) return set_error(ctx, BH_ERR_INVALID_ARG, "project_forward: a depth-cut table needs the near-count output");
+                           float* projected_by_gid, uint32_t* counters, const ForwardPrep& want, uint32_t* zcut, uint32_t* near_counts) {
+    if (zcut && !near_counts) return set_error(ctx, BH_ERR_INVALID_ARG, "project_forward: a depth-cut table needs the near-count output");
     // what the grid cannot cover (tiny scenes under a large tile table, n == 0) is cleared with plain fills
     ForwardPrep prep = want;
     const size_t covered = (size_t)((n + PROJ_WG - 1) / PROJ_WG) * PROJ_WG;
@@ -528,10 +530,10 @@ int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool 
     }
     auto* c64 = reinterpret_cast<unsigned long long*>(counters);
     const bool pinhole = u.model == CAM_PINHOLE;
-    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts, far_epoch, frame_id);
-    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts, far_epoch, frame_id);
-    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts, far_epoch, frame_id);
-    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts, far_epoch, frame_id);
+    if (mip && pinhole) return launch_pf_deg<true, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    if (pinhole) return launch_pf_deg<false, true>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    if (mip) return launch_pf_deg<true, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
+    return launch_pf_deg<false, false>(ctx, u, n, sh_degree, transforms, sh, raw_opac, depth_keys, isect_counts, max_radius, projected_by_gid, c64, prep, zcut, near_counts);
 }
 
 // ---------------------------------------------------------------------------

@@ -224,8 +224,6 @@ struct SliceArgs {
     uint32_t cut_active = 0;
     uint32_t* live_bands = nullptr;         // [2]: 32 bands of tile columns | rows that hold a parked tile (PHASE 1 ORs, the far pass reads)
     uint32_t tile_bh = 0;
-    const uint32_t* far_epoch = nullptr;    // [T]: == frame_id where K1 saw a pair behind the tile's cut (the near list is incomplete)
-    uint32_t frame_id = 0;
     uint32_t margin_pct = 150;
     // tile order: all one-wave tiles of a frame are resident at once, so the launch lasts as long as the SIMD whose eight tiles sum
     // to the most work.  order[band][rank] (K1: every XCD band's tiles sorted by the work they had at the view's last frame) makes
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
 
     // (per-tile depth cuts: a tile whose near list was NOT cut holds everything there is — unsaturated or not, it is final)
-    const bool near_complete = PHASE == 1 && sl.cut_active != 0u && sl.far_epoch[tile] != sl.frame_id;
+    const bool near_complete = PHASE == 1 && sl.cut_active != 0u && (sl.zcut[tile] & 1u) == 0u;   // (bit 0: K1 met a pair behind the cut)
     if (PHASE == 1 && !saturated && !near_complete) {
         // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
 #pragma unroll
@@ -457,7 +455,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                     const unsigned long long mraw = (unsigned long long)g * sl.margin_pct / 100ull * (PHASE == 2 ? 3ull : 1ull);
                     const uint32_t margin = mraw > 128ull ? (mraw < 0x7FFFFFFFull ? (uint32_t)mraw : 0x7FFFFFFFu) : 128u;
                     const uint32_t g2 = (unsigned long long)g + margin < sl.nv ? g + margin : sl.nv - 1u;
-                    newcut = sl.depth_keys_sorted[g2];
+                    newcut = sl.depth_keys_sorted[g2] & ~1u;   // (bit 0 is the "incomplete" mark of the table's next frame: clear)
                 }
             }
             sl.zcut[tile] = newcut;
@@ -517,14 +515,11 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.cut_active = slice->cut_active ? 1u : 0u;
         sl.live_bands = slice->live_bands;
         sl.tile_bh = vu.tile_bh;
-        sl.far_epoch = slice->far_epoch;
-        sl.frame_id = slice->frame_id;
         sl.margin_pct = slice->margin_pct;
         sl.order = slice->order;
         sl.order_mode = slice->order_mode;
         sl.work = slice->work;
     }
-    if (sl.cut_active && !sl.far_epoch) return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: per-tile cuts without the far-epoch table");
     if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
