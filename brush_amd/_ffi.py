@@ -130,6 +130,7 @@ SYMBOLS = {
     "bh_render_forward": (C.c_int, [C.c_void_p, C.POINTER(BhCamera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, fp, C.c_uint32, C.POINTER(BhRenderOut)]),
     "bh_set_list_slicing": (C.c_int, [C.c_void_p, C.c_float]),
     "bh_set_view_id": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bh_set_list_cut_threshold": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
     "bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32]),

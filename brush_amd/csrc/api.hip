@@ -331,6 +331,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         ctx->knob_fail_loss_at = (uint32_t)atoi(e);
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
+    if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
@@ -614,7 +615,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
         view = view_state(ctx, ctx->view_id, u.tile_bw, u.tile_bh);
         if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
-        if (view->seeded && view->exact_frames == 0u) cut_active = true;
+        // (a frame with few pairs has nothing to save: the near count in K1 and an occasional far pass cost more than listing and
+        //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
+        if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) cut_active = true;
         else if (view->exact_frames) view->exact_frames--;
     }
     uint32_t* near_counts = nullptr;
@@ -909,7 +912,10 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     ctx->had_forward = true;
     ctx->prev_intersections = ni;
     ctx->last_one_slice = !sliced;
-    if (view) view->seeded = true;   // this frame's blend kernels (incl. a far pass, if one runs) leave what every tile needed
+    if (view) {   // this frame's blend kernels (incl. a far pass, if one runs) leave what every tile needed
+        view->seeded = true;
+        view->last_pairs = ni;
+    }
     return 0;
 }
 
@@ -917,6 +923,12 @@ int bh_set_list_slicing(bh_ctx* ctx, float near_share) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     if (near_share != near_share || near_share > 1.0f) return set_error(ctx, BH_ERR_INVALID_ARG, "set_list_slicing: the near slice's share must be <= 1 (<= 0: automatic)");
     ctx->slice_fraction = near_share > 0.0f ? near_share : 0.0f;
+    return 0;
+}
+
+int bh_set_list_cut_threshold(bh_ctx* ctx, uint32_t min_pairs) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    ctx->cut_min_pairs = min_pairs;
     return 0;
 }
 

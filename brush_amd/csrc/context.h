@@ -130,7 +130,9 @@ struct ViewState {
     uint32_t exact_frames = 0;      // frames to render with complete lists before the cut is trusted again (the forecast kept failing)
     uint32_t penalty = 0;           // one bit per recent cut frame: its far pass had to run (api.hip view_outcome)
     uint64_t last_used = 0;         // LRU stamp
+    uint32_t last_pairs = 0;        // num_intersections of the view's last frame
 };
+constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
 constexpr size_t MAX_VIEW_STATES = 4096;
 
 // scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
@@ -249,6 +251,7 @@ struct bh_ctx {
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
+    uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
     bh::FarJob far_job;

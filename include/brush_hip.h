@@ -203,6 +203,11 @@ int bh_set_list_slicing(bh_ctx* ctx, float near_share);
  * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.  One
  * table is 4 bytes per tile; the 4096 most recently used views are kept. */
 int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
+/* Per-tile cuts pay when there are lists to shorten: a view whose last frame had fewer than min_pairs intersections keeps
+ * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional far pass cost more than
+ * listing and sorting everything; 0 = always cut).  The environment variable BH_CUT_MIN_PAIRS sets the initial value of new
+ * contexts (the test suite, whose scenes are small, sets 0). */
+int bh_set_list_cut_threshold(bh_ctx* ctx, uint32_t min_pairs);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
 /* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far pass (diagnostics: with view ids and

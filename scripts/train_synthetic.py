@@ -125,7 +125,7 @@ def run(args, log=print):
         return float(np.mean([psnr(render_u8(s, c), r) for c, r in zip(eval_cams, eval_ref)]))
     p0 = eval_psnr(spl)
     cfg = ba.TrainConfig(total_train_iters=args.steps, refine_every=args.refine_every, growth_stop_iter=int(args.steps * 0.8),
-                         max_splats=args.gt_splats * 2)
+                         max_splats=args.gt_splats * 2, exact_lists=args.exact_lists)
     trainer = ba.SplatTrainer(cfg, process_group=pg)
     trainer.set_bounds(*ba.splat_bounds(spl))
     focal = ba.fov_to_focal(fov, w)
@@ -137,10 +137,15 @@ def run(args, log=print):
     gen.manual_seed(1234)  # identical noise on every rank keeps the replicas identical
     t0 = time.perf_counter()
     stats_log = []
+    ctx = ba.get_context(dev)
+    shares, far0 = [], int(ctx.lib.bh_far_slices_queued(ctx._h))
     for it in range(1, args.steps + 1):
         batch = loader.next_batch()
+        if args.no_view_ids:
+            batch.view_id = 0
         noise = torch.randn(spl.num_splats(), 3, device=dev, generator=gen)
         trainer.step(batch, spl, noise_samples=noise)
+        shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))
         if it % args.refine_every == 0 and it < args.steps:
             spl, rs = trainer.refine(it, spl)
             stats_log.append((it, rs.total_splats, rs.num_pruned, rs.num_added))
@@ -158,10 +163,16 @@ def run(args, log=print):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), "replicas diverged"
         dist.destroy_process_group()
+    far = int(ctx.lib.bh_far_slices_queued(ctx._h)) - far0
     if rank == 0:
         log("PSNR on held-out views: %.2f dB -> %.2f dB; final loss %.5f; %d splats; %.1f steps/s x %d ranks" %
             (p0, p1, loss, spl.num_splats(), args.steps / dt, world))
-    return dict(psnr_before=p0, psnr_after=p1, loss=loss, splats=spl.num_splats(), refines=stats_log, steps_per_s=args.steps / dt)
+        # the forward's per-tile depth cuts over a whole training run (views cycling, refine every N steps): how much of the pair
+        # lists was built, how often a view's forecast missed (a far pass) and how many frames ran with complete lists
+        log("lists: mean share %.3f of the pairs, %d frames with complete lists, %d far passes in %d steps" %
+            (float(np.mean(shares)), sum(1 for x in shares if x >= 1.0), far, args.steps))
+    return dict(psnr_before=p0, psnr_after=p1, loss=loss, splats=spl.num_splats(), refines=stats_log, steps_per_s=args.steps / dt,
+                mean_list_share=float(np.mean(shares)), far_passes=far)
 
 
 def parse(argv=None):
@@ -174,6 +185,8 @@ def parse(argv=None):
     ap.add_argument("--sh-degree", type=int, default=1)
     ap.add_argument("--refine-every", type=int, default=100)
     ap.add_argument("--filter3d", action="store_true")
+    ap.add_argument("--exact-lists", action="store_true", help="BhTrainConfig.exact_lists: the reference's full per-tile lists (A/B)")
+    ap.add_argument("--no-view-ids", action="store_true", help="do not tell the library which view a batch is (A/B)")
     return ap.parse_args(argv)
 
 

@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# per-tile depth cuts (include/brush_hip.h: bh_set_list_cut_threshold) are only applied to frames with >= 1.5 M intersections by
+# default; the parity suite's scenes are small, and it is the mechanism that has to be covered: every context of this session
+# (and of the processes it spawns) cuts whatever the frame's size.  tests/test_gpu_sliced.py checks the default threshold itself.
+os.environ.setdefault("BH_CUT_MIN_PAIRS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

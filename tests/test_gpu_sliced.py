@@ -345,6 +345,28 @@ def test_a_view_that_changed_behind_its_cuts_is_finished_by_the_far_pass(dev):
         ctx.close()
 
 
+def test_small_frames_keep_complete_lists_by_default(dev):
+    """bh_set_list_cut_threshold: a view whose last frame had fewer pairs than the threshold (default 1.5 M) is not cut"""
+    import brush_amd as ba
+    n, w, h = 30000, 320, 208
+    sc, cp = _scene(n, w, h, 0x5D, scales=(0.03, 0.3))
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    ctx = ba.Context(dev)
+    try:
+        ctx.check(ctx.lib.bh_set_list_cut_threshold(ctx._h, 1500000))
+        shares = []
+        for _ in range(3):
+            _, aux = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+            shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))
+        assert aux.num_intersections < 1500000 and shares == [1.0, 1.0, 1.0]
+        ctx.check(ctx.lib.bh_set_list_cut_threshold(ctx._h, 0))
+        ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        assert float(ctx.lib.bh_last_list_share(ctx._h)) < 1.0
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("sh_degree", [0, 2])
 def test_train_steps_over_cycling_views_with_ids_equal_exact_lists(dev, sh_degree):
     """three views in turn, five rounds: the default step (per-tile cuts keyed by view id) and the exact_lists step follow the same
