@@ -45,7 +45,7 @@ class BhRenderOut(C.Structure):
         ("compact_gid_from_isect", C.c_void_p), ("tile_id_from_isect", C.c_void_p),
         ("global_from_compact_gid", C.c_void_p), ("cum_tiles_hit", C.c_void_p),
         ("intersect_counts", C.c_void_p), ("depths_sorted", C.c_void_p),
-        ("tile_offsets_far", C.c_void_p), ("list_budget", C.c_uint32),
+        ("tile_offsets_far", C.c_void_p), ("list_budget", C.c_uint32), ("num_listed_splats", C.c_uint32),
     ]
 
 
@@ -178,7 +178,7 @@ SYMBOLS = {
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
 }
 
-ABI_VERSION = 4   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
+ABI_VERSION = 5   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
 # bh_struct_size index -> mirror (the BH_STRUCT_* order of the header)
 STRUCT_MIRRORS = (BhCamera, BhRenderOut, BhLossConfig, BhTrainConfig, BhTrainState, BhTrainBatch, BhTrainStats, BhRefineConfig, BhRefineStats, BhPlyInfo)
 

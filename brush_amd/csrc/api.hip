@@ -171,7 +171,7 @@ int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
     {
         ProfScope ps(ctx, "MapGaussiansToIntersect");
         BH_TRY(launch_map_gaussians_far(ctx, j.nv, j.u, j.proj_by_gid, j.gfc, j.projected, j.cum, j.budget, j.done_bits, gate, j.far_counts, j.far_block_totals,
-                                        j.far_group_totals, j.slice_info, j.tile_ids, j.isect_gids, j.zcut, j.depth_keys_sorted));
+                                        j.far_group_totals, j.slice_info, j.tile_ids, j.isect_gids));
     }
     {
         ProfScope ps(ctx, "TileSort");
@@ -248,19 +248,43 @@ static void view_outcome(ViewState* vs, bool missed, bool shared_table) {
     }
 }
 
-// A sliced forward that left the decision to the host: wait for the near slice's gate word and queue the far slice only if some
-// tile is still unsaturated.  *launched (optional) tells the caller whether out_img changed after the near slice.
+static int forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_degree, const float* transforms, const float* sh_coeffs,
+                        const float* raw_opacities, const float* background, uint32_t flags, BhRenderOut* out, bool allow_cut);
+
+// A sliced forward that left the decision to the host: wait for the near pass's gate word.  Slot-budget slices: queue the far slice
+// if some tile is still unsaturated.  Per-tile cuts: there is no far pass (only the splats that own a near pair were sorted) — a
+// tile that is still live behind a cut list means the view's forecast failed, and the whole forward is run again with complete
+// lists (which also re-seeds the view's table).  *launched (optional) tells the caller whether out_img changed after the near pass.
 int finish_far_slice(bh_ctx* ctx, bool* launched) {
     if (launched) *launched = false;
     if (!ctx->far_job.pending) return 0;
     ctx->far_job.pending = false;
     BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
     const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
-    if (ctx->far_job.zcut) {   // per-tile cuts: the far pass corrects the table, the next frame of the view is predicted again
-        view_outcome(ctx->far_job.view, unsat != 0u, ctx->far_job.view_shared);
-    } else {
-        ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
+    if (ctx->far_job.by_cut) {
+        FarJob& j = ctx->far_job;
+        view_outcome(j.view, unsat != 0u, j.view_shared);
+        if (unsat == 0u) return 0;
+        if (launched) *launched = true;
+        ctx->far_launches++;
+        // the same call again, with the redirections of the train step that were in force and the same view, complete lists
+        const FarJob keep = j;
+        struct Saved { float* ev; float* er; size_t evf; float* eg; size_t egf; uint32_t vid; bool defer; } sv{ctx->ext_visible, ctx->ext_max_radius, ctx->ext_visible_floats,
+                                                                                                      ctx->ext_grad_begin, ctx->ext_grad_floats, ctx->view_id, ctx->defer_far};
+        ctx->ext_visible = keep.ext_visible; ctx->ext_max_radius = keep.ext_max_radius; ctx->ext_visible_floats = keep.ext_visible_floats;
+        ctx->ext_grad_begin = keep.ext_grad_begin; ctx->ext_grad_floats = keep.ext_grad_floats;
+        ctx->view_id = keep.view_id;
+        ctx->defer_far = false;
+        BhRenderOut again;
+        const int rc = forward_impl(ctx, &keep.cam, keep.n, keep.sh_degree, keep.transforms, keep.sh_coeffs, keep.raw_opacities, keep.bg, keep.flags, &again,
+                                    /*allow_cut=*/false);
+        ctx->ext_visible = sv.ev; ctx->ext_max_radius = sv.er; ctx->ext_visible_floats = sv.evf;
+        ctx->ext_grad_begin = sv.eg; ctx->ext_grad_floats = sv.egf;
+        ctx->view_id = sv.vid;
+        ctx->defer_far = sv.defer;
+        return rc;
     }
+    ctx->far_direct = unsat != 0u;   // ... and the next sliced frame starts from what this one needed
     if (unsat == 0u) return 0;
     if (launched) *launched = true;
     return enqueue_far_slice(ctx, ctx->far_job);
@@ -332,6 +356,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
     if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
+    ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
@@ -559,6 +584,15 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     if ((flags & BH_FLAG_SMOOTH_CUTOFF) && !(flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_INVALID_ARG, "smooth cutoff requires the backward pass flag");
     BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));   // (a deferred decision nobody collected)
+    return forward_impl(ctx, cam, n, sh_degree, transforms, sh_coeffs, raw_opacities, background, flags, out, /*allow_cut=*/true);
+}
+
+}  // extern "C"
+
+// The forward pipeline (arguments validated by bh_render_forward).  allow_cut = false: complete lists whatever the view's table says
+// (the second attempt after a failed forecast, finish_far_slice).
+int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_degree, const float* transforms, const float* sh_coeffs,
+                            const float* raw_opacities, const float* background, uint32_t flags, BhRenderOut* out, bool allow_cut) {
     ctx->have_forward = false;
     ctx->vcombined_prezeroed = false;   // set below only by the kernels of THIS forward
     ctx->grads_prezeroed = false;
@@ -617,7 +651,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
         // (a frame with few pairs has nothing to save: the near count in K1 and an occasional far pass cost more than listing and
         //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
-        if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) cut_active = true;
+        if (!allow_cut) {
+            // (the forecast has just failed: this attempt re-seeds the table)
+        } else if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) cut_active = true;
         else if (view->exact_frames) view->exact_frames--;
     }
     uint32_t* near_counts = nullptr;
@@ -627,7 +663,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         if (!near_counts) return BH_ERR_OOM;
     }
 
-    uint32_t nv = 0, ni = 0, near_total = 0;
+    uint32_t nv = 0, ni = 0, near_total = 0, nv_true = 0;
     uint32_t fb_need = 0;                  // previous forward: most exact-list slots any saturated tile needed
     unsigned long long fb_unsat_pairs = 0; // ... and pairs it listed for tiles that never saturated
     uint32_t fb_unsat_tiles = 0;           // ... and how many such tiles there were (empty ones included)
@@ -646,6 +682,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             prep.tile_words = num_tiles * 2 + 8 * 16;
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
+            prep.list_all_visible = ctx->knob_cut_sort_all;
             if (view && ctx->knob_k16_order && n >= 8u * 256u) {   // the forward blend's tile order from the view's last per-tile work (K1's blocks 0..7 sort it: the grid must have them)
                 const uint32_t win_t = u.tile_bw * (u.tile_y1 - u.tile_y0);
                 tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, (size_t)8 * ((win_t + 7u) / 8u) * 4);
@@ -695,12 +732,16 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
             ctx->gate_learn = false;
             ctx->far_direct = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD] != 0u;
         }
-        unsigned long long hc[3] = {0ull, 0ull, 0ull};
-        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { hc[0] += hslots[COUNTER_K1_U64 * k]; hc[1] += hslots[COUNTER_K1_U64 * k + 1]; hc[2] += hslots[COUNTER_K1_U64 * k + 2]; }
+        unsigned long long hc[4] = {0ull, 0ull, 0ull, 0ull};
+        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k)
+            for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) hc[c] += hslots[COUNTER_K1_U64 * k + c];
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
-        nv = (uint32_t)hc[0];
+        nv_true = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
         near_total = cut_active ? (uint32_t)hc[2] : ni;
+        // per-tile cuts: only the splats that own a pair in front of some cut were given a real depth key (K1): the compact
+        // arrays, K5's grid, the backward's accumulator and K18 are sized for THEM; num_visible stays the reference's count
+        nv = cut_active ? (uint32_t)hc[3] : nv_true;   // (BH_CUT_SORT_ALL: K1 then listed every visible splat, hc[3] == hc[0])
         // the previous forward's slicing hint came along in the same copy
         const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
         for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[3 * k] > fb_need) fb_need = hfb[3 * k]; fb_unsat_pairs += hfb[3 * k + 1]; fb_unsat_tiles += hfb[3 * k + 2]; }
@@ -861,10 +902,16 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         j.far_counts = far_counts; j.far_block_totals = far_block_totals; j.far_group_totals = far_group_totals;
         j.tile_ids = tile_ids; j.isect_gids = isect_gids; j.tile_ids_sorted = tile_ids_sorted; j.isect_gids_sorted = isect_gids_sorted;
         j.out_f32 = out_f32; j.out_u8 = out_u8; j.visible = visible; j.lpt = ctx->lpt; j.class_width = class_width; j.rs = rs;
-        j.zcut = by_cut ? view->zcut : nullptr;
-        j.depth_keys_sorted = by_cut ? depths_sorted : nullptr;
+        j.by_cut = by_cut;
         j.view = by_cut ? view : nullptr;
         j.view_shared = ctx->view_id == 0u;
+        if (by_cut) {   // what a second attempt with complete lists needs (finish_far_slice)
+            j.cam = *cam;
+            j.n = n; j.sh_degree = sh_degree; j.flags = flags; j.view_id = ctx->view_id;
+            j.transforms = transforms; j.sh_coeffs = sh_coeffs; j.raw_opacities = raw_opacities;
+            j.ext_visible = ctx->ext_visible; j.ext_max_radius = ctx->ext_max_radius; j.ext_visible_floats = ctx->ext_visible_floats;
+            j.ext_grad_begin = ctx->ext_grad_begin; j.ext_grad_floats = ctx->ext_grad_floats;
+        }
         // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)
         BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
         // (per-tile cuts: the forecast is expected to hold, and a far pass that had to run has corrected the table — the host decides
@@ -875,12 +922,20 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
         } else {
             BH_HIP(ctx, hipEventRecord(ctx->gate_ev, ctx->stream));
             j.pending = true;
-            if (!ctx->defer_far) BH_TRY(finish_far_slice(ctx, nullptr));
+            if (!ctx->defer_far) {
+                bool again = false;
+                BH_TRY(finish_far_slice(ctx, &again));
+                if (by_cut && again) {   // the forecast failed and the frame was rendered a second time, with complete lists: that is the result
+                    *out = ctx->last;
+                    return 0;
+                }
+            }
         }
     }
 
     BhRenderOut r{};
-    r.num_visible = nv;
+    r.num_visible = nv_true;
+    r.num_listed_splats = nv;
     r.num_intersections = ni;
     r.num_tiles = num_tiles;
     r.tile_bw = u.tile_bw;
@@ -902,6 +957,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     r.list_budget = budget;   // (per-tile cuts: the pairs the near pass listed)
     *out = r;
     ctx->last = r;
+    ctx->last_listed_splats = nv;
     ctx->cam = *cam;
     ctx->uniforms = u;
     ctx->n = n;
@@ -918,6 +974,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
     }
     return 0;
 }
+
+extern "C" {
 
 int bh_set_list_slicing(bh_ctx* ctx, float near_share) {
     if (!ctx) return BH_ERR_INVALID_ARG;
@@ -953,7 +1011,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     const BhRenderOut& r = ctx->last;
-    const uint32_t n = ctx->n, nv = r.num_visible, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
+    const uint32_t n = ctx->n, nv = r.num_listed_splats, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
     const size_t nvpad = nv ? nv : 1;
     auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4 + 16);   // + room to clear whole float4s
     if (!v_combined) return BH_ERR_OOM;
@@ -1281,7 +1339,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         return set_error(ctx, BH_ERR_OOM, "train_step: injected failure between the forward and the loss (BH_TEST_FAIL_LOSS_AT)");
     // A view whose forecast missed recently decides FIRST (the host waits for the near pass's blend, ~15 us of bubble) instead of
     // queueing loss kernels that a far pass would make worthless (~120 us)
-    if (ctx->far_job.pending && ctx->far_job.view && ctx->far_job.view->penalty != 0u) BH_TRY(finish_far_slice(ctx, nullptr));
+    if (ctx->far_job.pending && ctx->far_job.view && ctx->far_job.view->penalty != 0u) {
+        BH_TRY(finish_far_slice(ctx, nullptr));
+        ro = ctx->last;   // (a second attempt replaces the frame's outputs)
+    }
     BH_TRY(queue_loss());
     if (ctx->far_job.pending) {
         // The loss above ran on the near slice's image, which is the frame's image unless some tile was left unsaturated — the
@@ -1289,7 +1350,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         // the far slice is queued and the loss is evaluated again on the finished image.
         bool far_ran = false;
         BH_TRY(finish_far_slice(ctx, &far_ran));
-        if (far_ran) BH_TRY(queue_loss());
+        if (far_ran) {
+            ro = ctx->last;
+            BH_TRY(queue_loss());
+        }
     }
 
     // ---- multi-GPU exchange, part 1 (mask-keyed mode, exchange.hip): the visible flags are final once the forward (incl. a far

@@ -76,14 +76,14 @@ constexpr int MAX_PROF = 32;
 // K1's block totals land in slot (block % COUNTER_SLOTS); the host adds the slots up after the readback
 constexpr uint32_t COUNTER_SLOTS = 128;
 // one counter set on the device:
-//   [COUNTER_SLOTS][3] u64  visible, intersections, near intersections (K1's block totals; the third only with a per-tile depth cut:
-//                           the pairs the near pass will list, see ViewState)
+//   [COUNTER_SLOTS][4] u64  visible, intersections, near intersections, near splats (K1's block totals; the last two only with
+//                           per-tile depth cuts: the pairs the near pass will list and the splats that own them, see ViewState)
 //   [COUNTER_SLOTS][3] u32  slicing feedback, written by the blend kernel of the forward BEFORE the one that accumulates into this
 //                           set (rasterize.hip SliceArgs::feedback): max exact-list slots a saturated tile needed | pairs listed
 //                           for tiles that never saturated | number of such tiles (empty ones included)
 //   [COUNTER_SLOTS][2] u32  max depth key, max ~key over the visible splats: the key range the depth sort splits on.
 // The first two parts are read back together (one copy), the third stays on the device.
-constexpr uint32_t COUNTER_K1_U64 = 3;                        // u64 words per slot of K1's block totals
+constexpr uint32_t COUNTER_K1_U64 = 4;                        // u64 words per slot of K1's block totals
 constexpr size_t COUNTER_SET_BYTES = COUNTER_SLOTS * 8 * COUNTER_K1_U64 + COUNTER_SLOTS * 12 + COUNTER_SLOTS * 8;
 constexpr uint32_t COUNTER_SET_U64 = (uint32_t)(COUNTER_SET_BYTES / 8);
 constexpr uint32_t COUNTER_FB_WORD = COUNTER_SLOTS * 2 * COUNTER_K1_U64;   // u32 index of the feedback part inside a set: [COUNTER_SLOTS][3]
@@ -184,11 +184,22 @@ struct FarJob {
     uint32_t* lpt = nullptr;
     float class_width = 8.0f;
     RasterSlice rs{};
-    // per-tile cut lists: the far pass lists, for tiles still live, every pair BEHIND the tile's cut (all visible splats take part)
-    const uint32_t* zcut = nullptr;
-    const uint32_t* depth_keys_sorted = nullptr;
-    ViewState* view = nullptr;      // whose prediction failed if the far pass has to run
+    // per-tile cut lists: only the splats with a pair in front of some cut were sorted and listed, so there is no far pass — if a
+    // tile is still live behind a cut list the forecast has failed and the whole forward is run again with complete lists
+    // (api.hip finish_far_slice).  Its arguments, and the train step's redirections that were in force:
+    bool by_cut = false;
+    ViewState* view = nullptr;      // whose prediction failed
     bool view_shared = false;       // ... and whether that is the table of view id 0 (shared by all frames without an id)
+    BhCamera cam{};
+    uint32_t n = 0, sh_degree = 0, flags = 0, view_id = 0;
+    const float* transforms = nullptr;
+    const float* sh_coeffs = nullptr;
+    const float* raw_opacities = nullptr;
+    float* ext_visible = nullptr;
+    float* ext_max_radius = nullptr;
+    size_t ext_visible_floats = 0;
+    float* ext_grad_begin = nullptr;
+    size_t ext_grad_floats = 0;
 };
 
 }  // namespace bh
@@ -245,13 +256,15 @@ struct bh_ctx {
     bool far_direct = false;
     bool defer_far = false;           // set by bh_train_step around its forward: return with far_job.pending instead of waiting
     bool gate_learn = false;          // a gate word copied out by a far_direct frame has not been looked at yet
-    uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice
+    uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice / had to be run again with complete lists
+    uint32_t last_listed_splats = 0;  // compact entries of the last forward (== num_visible unless per-tile cuts listed a subset)
     // per-tile depth cuts (automatic slicing): one table per view id (bh_set_view_id / BhTrainBatch.view_id; 0 = the ctx's own slot)
     std::unordered_map<uint32_t, bh::ViewState> views;
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
+    bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
     bh::FarJob far_job;
@@ -332,6 +345,7 @@ struct ForwardPrep {
     uint32_t* order_out = nullptr;                // [8][ceil(order_tiles/8)] local tile ids, 0xFFFFFFFF behind a short band
     uint32_t order_tiles = 0, order_tile_begin = 0;
     uint32_t order_mode = 1;                      // 1: descending work   2: dealt (consecutive blocks take every 8th rank)
+    bool list_all_visible = false;                // A/B knob BH_CUT_SORT_ALL: per-tile cuts sort and number EVERY visible splat
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,
                            const float* sh, const float* raw_opac, uint32_t* depth_keys, uint32_t* isect_counts, float* max_radius,
@@ -346,8 +360,7 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
                          const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr);
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
-                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids,
-                             const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr);
+                             uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
                             const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,

@@ -107,10 +107,14 @@ __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __res
     for (int i = tid; i < DS_WAVES * DS_RADIX; i += DS_WG) { (&s_hist[0][0])[i] = 0; (&s_csum[0][0])[i] = 0; }
     const DepthSplit sp = depth_split(minmax, s_red);   // (contains the barrier behind the clears)
     const uint32_t base = blockIdx.x * DS_TILE;
+    // culled keys (digit 255) are neither counted nor moved: nothing reads the order's tail behind the visible splats, and with
+    // per-tile cuts three quarters of the keys are culled — their LDS atomics would all land on one counter
     auto count_one = [&](uint32_t key, uint32_t cnt) {
         const uint32_t d = depth_digit(key, sp);
-        atomicAdd(&s_hist[wave][d], 1u);
-        if (d != 255u) atomicAdd(&s_csum[wave][d], cnt);
+        if (d != 255u) {
+            atomicAdd(&s_hist[wave][d], 1u);
+            atomicAdd(&s_csum[wave][d], cnt);
+        }
     };
     if (base + (uint32_t)DS_TILE <= n && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(counts)) & 15u) == 0) {
         // every chunk but the last: 16-byte loads (which thread counts which key is irrelevant to a histogram)
@@ -297,10 +301,10 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
             const uint32_t kk = L.keys[e];
             const uint32_t d = digit(kk);
             const uint32_t pos = L.gofs[d] + e;
-            // alt_*: where digit 255 goes instead (the split sends the culled splats, which need no further sorting, straight to the output)
-            const bool alt = alt_k != nullptr && d == 255u;
-            (alt ? alt_k : dst_k)[pos] = kk;
-            (alt ? alt_v : dst_v)[pos] = L.vals[e];
+            // alt_* != NULL (the depth split): digit 255 = the culled splats, whose place in the order nobody reads — not written at all
+            if (alt_k != nullptr && d == 255u) continue;
+            dst_k[pos] = kk;
+            dst_v[pos] = L.vals[e];
         }
     }
     __syncthreads();

@@ -102,21 +102,11 @@ struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are 
         return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u;
     }
 };
-// Per-tile depth cuts (api.hip): the NEAR list of a tile holds the splats whose depth key is <= the tile's cut ...
+// Per-tile depth cuts (api.hip): the list of a tile holds the splats whose depth key is <= the tile's cut
 struct KeepNearOfCut {
     const uint32_t* zcut;
     uint32_t tile_bw;
     BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return zcut_near(w.zkey[r], zcut[tx + ty * tile_bw]); }
-};
-// ... and the FAR pass lists, for tiles that still have live pixels, the ones behind it
-struct KeepLiveBehindCut {
-    const uint32_t* done_bits;
-    const uint32_t* zcut;
-    uint32_t tile_bw;
-    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const {
-        const uint32_t t = tx + ty * tile_bw;
-        return ((done_bits[t >> 5] >> (t & 31u)) & 1u) == 0u && !zcut_near(w.zkey[r], zcut[t]);
-    }
 };
 
 // (One LDS atomic per hit lane in the counting callers: a variant in which the first lane of each splat's run of candidates adds
@@ -275,6 +265,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     __shared__ uint32_t s_vis[PROJ_WAVES];
     __shared__ uint32_t s_hit[PROJ_WAVES];
     __shared__ uint32_t s_near[PROJ_WAVES];
+    __shared__ uint32_t s_listed[PROJ_WAVES];
     __shared__ uint32_t s_kmax[PROJ_WAVES];
     __shared__ uint32_t s_nmax[PROJ_WAVES];
     const uint32_t gid = blockIdx.x * PROJ_WG + threadIdx.x;
@@ -428,8 +419,16 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
     const uint32_t near_hit = (nb && zcut) ? w.near[wrank] : 0u;
 #endif
+    // per-tile cuts: a visible splat without a single pair in front of a cut takes no part in this frame's lists — it gets the
+    // culled key, so the depth sort (whose stable order IS the compaction) numbers and orders only the splats that own a near
+    // pair: a quarter of the visible ones at the bench workload.  It still counts as visible (the reference's num_visible).
+#ifndef BH_K1_NO_WALK
+    const bool listed = visible && (!zcut || near_hit > 0u || prep.list_all_visible);
+#else
+    const bool listed = visible;
+#endif
     if (gid < n) {
-        depth_keys[gid] = key;
+        depth_keys[gid] = listed ? key : 0xFFFFFFFFu;
         isect_counts[gid] = tiles_hit;
         max_radius[gid] = radius;
 #ifndef BH_K1_NO_WALK
@@ -440,6 +439,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // (visible, hits) pairs that the host adds up: 7814 atomics on ONE pair of addresses serialise at ~7 ns each on
     // this chip (cross-XCD atomics execute at the memory side) and held the kernel's retirement back by 53 us
     const unsigned long long ball = __ballot(visible);
+    const unsigned long long lball = __ballot(listed);
     uint32_t wave_hits = tiles_hit;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     }
 #endif
     // range of the visible depth keys, for the depth sort's split (depth_sort.hip): maxima of key and of ~key
-    uint32_t kmax = visible ? key : 0u, nmax = visible ? ~key : 0u;
+    uint32_t kmax = listed ? key : 0u, nmax = listed ? ~key : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
@@ -462,20 +462,22 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         s_vis[wave] = (uint32_t)__popcll(ball);
         s_hit[wave] = wave_hits;
         s_near[wave] = wave_near;
+        s_listed[wave] = (uint32_t)__popcll(lball);
         s_kmax[wave] = kmax;
         s_nmax[wave] = nmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t v = 0, h = 0, nh = 0, km = 0, nm = 0;
+        uint32_t v = 0, h = 0, nh = 0, ls = 0, km = 0, nm = 0;
 #pragma unroll
-        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; nh += s_near[k]; km = max(km, s_kmax[k]); nm = max(nm, s_nmax[k]); }
+        for (int k = 0; k < PROJ_WAVES; ++k) { v += s_vis[k]; h += s_hit[k]; nh += s_near[k]; ls += s_listed[k]; km = max(km, s_kmax[k]); nm = max(nm, s_nmax[k]); }
         const uint32_t sl = blockIdx.x & (COUNTER_SLOTS - 1u);
         unsigned long long* slot = counters + COUNTER_K1_U64 * sl;
         if (v) atomicAdd(&slot[0], (unsigned long long)v);
         if (h) atomicAdd(&slot[1], (unsigned long long)h);
         if (nh) atomicAdd(&slot[2], (unsigned long long)nh);
-        if (v) {
+        if (ls && zcut) atomicAdd(&slot[3], (unsigned long long)ls);
+        if (ls) {
             uint32_t* mm = reinterpret_cast<uint32_t*>(counters) + COUNTER_MINMAX_WORD + 2u * sl;
             atomicMax(&mm[0], km);
             atomicMax(&mm[1], nm);
@@ -588,9 +590,8 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_far[2 * PROJ_WAVES];
     if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
-    // zcut != NULL (wave-uniform): per-tile depth cuts instead of one slot budget — cum_tiles_hit is then the scan of K1's NEAR
-    // counts, the near pass (FAR = false) emits the pairs at or in front of their tile's cut, the far pass the ones behind it
-    // into tiles that still have live pixels; every visible splat may take part in either
+    // zcut != NULL (wave-uniform; FAR = false only): per-tile depth cuts instead of one slot budget — the compact splats are the
+    // ones that own a pair in front of some cut, cum_tiles_hit is the scan of K1's near counts, and exactly those pairs are emitted
     const uint32_t tid_lin = blockIdx.x * PROJ_WG + threadIdx.x;
     // housekeeping for the backward: clear its v_combined accumulator on the way (coalesced, fire-and-forget)
     for (size_t i = tid_lin; i < zero_f4; i += (size_t)gridDim.x * PROJ_WG) zero_span[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
         if (FAR) {
             base = far_base;
             end = far_base + far_cnt;
-            mine = (zcut != nullptr || cum_end > budget) && end > base;
+            mine = cum_end > budget && end > base;
         } else if (zcut) {
             base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
             end = cum_end;
@@ -687,8 +688,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     nb = nb == 0xFFFFFFFFu ? 1u : 0u;
 #endif
     if (FAR) {
-        if (zcut) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveBehindCut{done_bits, zcut, tile_bw}, zkey);
-        else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
+        (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
     } else {
         if (zcut) (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepNearOfCut{zcut, tile_bw}, zkey);
         else (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect);
@@ -711,8 +711,7 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
                                                              const uint32_t* __restrict__ cum_tiles_hit, uint32_t budget,
                                                              const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ block_totals,
-                                                             uint32_t* __restrict__ group_totals, const uint32_t* __restrict__ zcut,
-                                                             const uint32_t* __restrict__ depth_keys_sorted, const uint32_t* __restrict__ live_bands) {
+                                                             uint32_t* __restrict__ group_totals, const uint32_t* __restrict__ live_bands) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_tot[PROJ_WAVES];
     if (*gate == 0u) return;
@@ -724,8 +723,8 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
     float xy_x = 0.0f, xy_y = 0.0f, pt = 0.0f;
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
-    uint32_t nb = 0, zkey = 0;
-    if (cg < nv && (zcut != nullptr || cum_tiles_hit[cg] > budget)) {
+    uint32_t nb = 0;
+    if (cg < nv && cum_tiles_hit[cg] > budget) {
         const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
         xy_x = src[0]; xy_y = src[1];
         conic = Sym2{src[2], src[3], src[4]};
@@ -737,15 +736,12 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
         if (nb) {
             if ((band_mask(bb.min_x, bb.max_x, tile_bw) & live_cols) == 0u || (band_mask(bb.min_y, bb.max_y, tile_bh) & live_rows) == 0u) nb = 0u;
         }
-        if (zcut) zkey = depth_keys_sorted[cg];
     }
     WalkLds& w = s_walk[wave];
     uint32_t hits = 0;
     if (__ballot(nb > 0u) != 0ull) {
-        auto count_hit = [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); };
-        uint32_t wrank;
-        if (zcut) wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, count_hit, KeepLiveBehindCut{done_bits, zcut, tile_bw}, zkey);
-        else wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, count_hit, KeepLiveTiles{done_bits, tile_bw});
+        const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); },
+                                              KeepLiveTiles{done_bits, tile_bw});
         hits = nb ? w.count[wrank] : 0u;
     }
     if (cg < nv) counts[cg] = hits;
@@ -790,20 +786,19 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
 // The far slice of a depth-sliced forward: count -> emit (the scan between them is folded into the emit kernel), both no-ops when
 // *gate (the number of tiles the near slice left unsaturated) is zero.  counts: [nv], block_totals: [ceil(nv / 256)] scratch;
 // group_totals: [ceil(blocks / FAR_GROUP_BLOCKS)], zero on entry; slice_info[3] receives the number of far pairs, slice_info[4..5]
-// hold the live column / row bands.  zcut != NULL: per-tile depth cuts (every visible splat takes part, a pair is far if it lies
-// behind its tile's cut); else the splats behind the slot budget.
+// hold the live column / row bands.
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
                              uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids,
-                             uint32_t* isect_gids, const uint32_t* zcut, const uint32_t* depth_keys_sorted) {
+                             uint32_t* isect_gids) {
     if (nv == 0) return 0;
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     hipLaunchKernelGGL(slice_count_kernel, grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid, cum_tiles_hit,
-                       budget, done_bits, gate, counts, block_totals, group_totals, zcut, depth_keys_sorted, (const uint32_t*)(slice_info + 4));
+                       budget, done_bits, gate, counts, block_totals, group_totals, (const uint32_t*)(slice_info + 4));
     BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
     hipLaunchKernelGGL((map_gaussians_kernel<true, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                        projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, slice_info, (const uint32_t*)counts,
-                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate, zcut, depth_keys_sorted);
+                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");
     return 0;
 }

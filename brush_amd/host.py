@@ -310,9 +310,11 @@ class RenderAux:
     intersect_counts: torch.Tensor
     depths_sorted: torch.Tensor
     # depth-sliced lists (render_splats(..., sliced=True), the train step's default): the far slice's [T,2] segment table, or
-    # None when the lists are the exact ones; list_budget = exact-list slots the near slice covered
+    # None when the lists are the exact ones; list_budget = pairs the near pass listed; num_listed_splats = entries of the compact
+    # arrays (per-tile cuts sort and number only the splats that own a listed pair: a sub-sequence of the full depth order)
     tile_offsets_far: Optional[torch.Tensor] = None
     list_budget: int = 0
+    num_listed_splats: int = 0
 
     def validate(self, num_splats):
         # render_aux.rs:30-45
@@ -365,6 +367,7 @@ def last_list_counts(ctx: Optional["Context"] = None, device=None):
 
 def _aux_from(out, n, w, h, device, copy, ctx=None):
     nv, ni, T = out.num_visible, out.num_intersections, out.num_tiles
+    nl = out.num_listed_splats   # entries of the compact (depth-ordered) arrays: == nv unless per-tile cuts listed a subset of the splats
     i32, f32 = torch.int32, torch.float32
     listed = ni
     if out.tile_offsets_far and copy and ctx is not None:
@@ -381,15 +384,16 @@ def _aux_from(out, n, w, h, device, copy, ctx=None):
         visible=mk(out.visible, (n,), f32) if out.visible else None,
         max_radius=mk(out.max_radius, (n,), f32),
         tile_offsets=mk(out.tile_offsets, (T, 2), i32),
-        projected_splats=mk(out.projected, (nv, 9), f32),
+        projected_splats=mk(out.projected, (nl, 9), f32),
         compact_gid_from_isect=mk(out.compact_gid_from_isect, (listed,), i32),
         tile_id_from_isect=mk(out.tile_id_from_isect, (listed,), i32),
-        global_from_compact_gid=mk(out.global_from_compact_gid, (nv,), i32),
-        cum_tiles_hit=mk(out.cum_tiles_hit, (nv,), i32),
+        global_from_compact_gid=mk(out.global_from_compact_gid, (nl,), i32),
+        cum_tiles_hit=mk(out.cum_tiles_hit, (nl,), i32),
         intersect_counts=mk(out.intersect_counts, (n,), i32),
-        depths_sorted=mk(out.depths_sorted, (nv,), f32),
+        depths_sorted=mk(out.depths_sorted, (nl,), f32),
         tile_offsets_far=mk(out.tile_offsets_far, (T, 2), i32) if out.tile_offsets_far else None,
         list_budget=int(out.list_budget),
+        num_listed_splats=int(nl),
     )
 
 
@@ -441,7 +445,7 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     if splats.min_scale is not None:  # chain through the fold (the autodiff of bwd/burn_glue.rs:260-270)
         ctx.check(ctx.lib.bh_fold_min_scale_backward(ctx._h, _ptr(splats.transforms), _ptr(splats.raw_opacities), _ptr(splats.min_scale), n,
                                                      _ptr(v_t), _ptr(v_op)))
-    vc = _view(ctx.lib.bh_last_v_combined(ctx._h), (max(out.num_visible, 1), 10), torch.float32, dev).clone()
+    vc = _view(ctx.lib.bh_last_v_combined(ctx._h), (max(out.num_listed_splats, 1), 10), torch.float32, dev).clone()
     return dict(img=img, aux=aux, v_transforms=v_t, v_sh_coeffs=v_sh, v_raw_opacities=v_op, v_refine_weight=v_rf, v_combined=vc)
 
 

@@ -137,8 +137,12 @@ typedef struct BhRenderOut {
     /* BH_FLAG_SLICED_LISTS and the frame was actually sliced: [T,2] start,end of each tile's far-slice segment (absolute
      * indices into compact_gid_from_isect; 0,0 for tiles the near slice finished); NULL otherwise */
     uint32_t* tile_offsets_far;
-    /* slots of the exact list the near slice covers (== num_intersections: one slice, the lists are the exact ones) */
+    /* pairs the near pass listed (== num_intersections: the lists are the exact ones) */
     uint32_t list_budget;
+    /* entries of the compact (depth-ordered) arrays — global_from_compact_gid, depths_sorted, cum_tiles_hit, projected and the
+     * compact ids inside compact_gid_from_isect.  == num_visible, except under BH_FLAG_SLICED_LISTS with per-tile cuts: then only
+     * the splats that own a listed pair are sorted and numbered (a sub-sequence of the full depth order). */
+    uint32_t num_listed_splats;
 } BhRenderOut;
 
 /* ---- ABI guard -------------------------------------------------------------- */
@@ -146,7 +150,7 @@ typedef struct BhRenderOut {
  * built against another revision would be overrun (BhRenderOut, BhTrainBatch and BhTrainConfig have grown).  A binding
  * checks once, at load time: bh_abi_version() == the BH_ABI_VERSION it was written against, and bh_struct_size(i) == the
  * size of its own mirror of struct i (brush_amd/_ffi.py and include/brush_hip.hpp do; INTEGRATION.md shows the Rust side). */
-#define BH_ABI_VERSION 4u
+#define BH_ABI_VERSION 5u
 enum {
     BH_STRUCT_CAMERA = 0, BH_STRUCT_RENDER_OUT, BH_STRUCT_LOSS_CONFIG, BH_STRUCT_TRAIN_CONFIG, BH_STRUCT_TRAIN_STATE,
     BH_STRUCT_TRAIN_BATCH, BH_STRUCT_TRAIN_STATS, BH_STRUCT_REFINE_CONFIG, BH_STRUCT_REFINE_STATS, BH_STRUCT_PLY_INFO,

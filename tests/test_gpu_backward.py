@@ -46,9 +46,28 @@ def run_both(ba, bo, dev, scene, cp, w, h, v_out, bg=(0.0, 0.0, 0.0), pass_=None
     return res, ref
 
 
+def _v_combined_in_oracle_rows(res, ref):
+    """The HIP accumulator in the oracle's row numbering.  A frame rendered with per-tile cuts numbers only the splats that own a
+    listed pair (BhRenderOut.num_listed_splats, a sub-sequence of the full depth order); the others blended nowhere: zero rows."""
+    vc = res["v_combined"].cpu().numpy().reshape(-1, 10)
+    aux = res["aux"]
+    nv = ref.num_visible
+    if getattr(aux, "num_listed_splats", nv) == nv and vc.shape[0] == max(nv, 1):
+        return vc.reshape(-1)
+    gfc_h = util.u32(aux.global_from_compact_gid)
+    gfc_o = ref.get("global_from_compact_gid")[:nv]
+    pos = np.full(int(gfc_o.max()) + 1 if nv else 1, -1, np.int64)
+    pos[gfc_o] = np.arange(nv)
+    rows = pos[gfc_h]
+    assert np.all(rows >= 0) and np.all(np.diff(rows) > 0), "listed splats are not a sub-sequence of the depth order"
+    full = np.zeros((max(nv, 1), 10), np.float32)
+    full[rows] = vc[:gfc_h.size]
+    return full.reshape(-1)
+
+
 def assert_grads_match(res, ref, tol=GRAD_TOL):
     n = res["v_transforms"].shape[0]
-    pairs = [("v_combined", res["v_combined"].cpu().numpy().reshape(-1), ref.get("v_combined")),
+    pairs = [("v_combined", _v_combined_in_oracle_rows(res, ref), ref.get("v_combined")),
              ("v_transforms", res["v_transforms"].cpu().numpy().reshape(-1), ref.get("v_transforms")),
              ("v_sh", res["v_sh_coeffs"].cpu().numpy().reshape(-1), ref.get("v_coeffs")),
              ("v_raw_opac", res["v_raw_opacities"].cpu().numpy(), ref.get("v_raw_opac")),

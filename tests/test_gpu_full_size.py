@@ -310,9 +310,10 @@ def test_1m_1080p_sliced_lists_vs_oracle(dev, oracle_lib, scene_1m, share):
         assert np.abs(res["img"].cpu().numpy() - ref.image()).max() <= 1e-6
         assert np.array_equal(aux.visible.cpu().numpy(), ref.get("visible"))
         assert np.array_equal(aux.max_radius.cpu().numpy(), ref.get("max_radius"))
-        gids = util.u32(aux.compact_gid_from_isect)
+        # (global splat ids: per-tile cuts number only the splats that own a listed pair)
+        gids = util.u32(aux.global_from_compact_gid)[util.u32(aux.compact_gid_from_isect)]
         near, far = util.u32(aux.tile_offsets).reshape(-1, 2), util.u32(aux.tile_offsets_far).reshape(-1, 2)
-        og, oo = ref.get("compact_gid_from_isect"), ref.get("tile_offsets").reshape(-1, 2)
+        og, oo = ref.get("global_from_compact_gid")[ref.get("compact_gid_from_isect")], ref.get("tile_offsets").reshape(-1, 2)
         two_segments = 0
         for t in range(near.shape[0]):
             mine = gids[near[t, 0]:max(near[t, 0], near[t, 1])]
