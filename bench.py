@@ -4,7 +4,11 @@
 A "step" is one SplatTrainer.step (forward render -> L1+SSIM loss -> backward ->
 statistics -> Adam + the visibility-gated mean noise, background jittered: the reference's
 default step, train.rs:176-429) on ONE 1920x1080 view of the 1 M-splat synthetic scene
-(BASELINE.json configs[2]), inputs already resident in HBM.
+(BASELINE.json configs[2]), inputs already resident in HBM.  The timed loop is the
+reference's own training bench (crates/brush-bench-test/src/benches.rs:198-220): TWO views, the
+second camera 2 units to the right, step k trains view k % 2 (--views V for other counts); every
+batch carries its view id, as a loader's batches do.  --windows (3) windows of --steps steps are
+timed, each bracketed by barrier + synchronize; the line reports the median window.
 
 --gpus N: data parallel over cameras, one rank per GPU, gradients all-reduced over RCCL between
 backward and Adam (weak scaling).  Started either by `python -m torch.distributed.run ... bench.py

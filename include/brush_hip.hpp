@@ -210,6 +210,7 @@ struct RenderAux {  // render_aux.rs:17-68: host scalars + ctx-owned device poin
     BhRenderOut raw{};
     uint32_t img_w = 0, img_h = 0, num_splats = 0;
     uint32_t num_visible() const { return raw.num_visible; }
+    uint32_t num_listed_splats() const { return raw.num_listed_splats; }   // entries of the compact (depth-ordered) arrays
     uint32_t num_intersections() const { return raw.num_intersections; }
     std::vector<float> image() const { return download(raw.out_img, (size_t)img_w * img_h * 4); }             // [H,W,4] f32
     std::vector<uint32_t> image_packed() const { return download(raw.out_img_packed, (size_t)img_w * img_h); }  // [H,W] rgba8
@@ -354,6 +355,7 @@ struct SceneBatch {  // brush-dataset/src/scene.rs:139-147
     uint32_t img_w = 0, img_h = 0;
     bool has_alpha = false, alpha_is_mask = false;
     Camera camera;
+    uint32_t view_id = 0;  // which view of the dataset this is (its index + 1; 0 = unknown): keys the forward's per-tile depth cuts (time only)
 };
 
 struct TrainStepStats { uint32_t num_visible, num_intersections; double lr_mean; float loss; };
@@ -380,6 +382,7 @@ class SplatTrainer {
         b.gt_packed = batch.img_packed;
         b.has_alpha = batch.has_alpha;
         b.alpha_is_mask = batch.alpha_is_mask;
+        b.view_id = batch.view_id;
         for (int k = 0; k < 3; ++k) b.background[k] = background ? background[k] : cfg_.background_color[k];
         if (!background && have_seed_) bh_sample_background(seed_, step_count_ + 1, cfg_.background_color, cfg_.background_noise_strength, b.background);
         b.noise_samples = noise_samples;
