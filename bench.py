@@ -390,8 +390,13 @@ def main():
                                   native_comm=native, sparse_exchange=args.exchange == "sparse", seed=None if args.no_noise else 0xB5EED)
         loader = None
         if args.feed == "loader":
-            rng = np.random.default_rng(1 + rank)
-            host_views = [(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), cams[i % nviews].uniforms((w, h))) for i in range(max(6, nviews))]
+            # the SAME views and ground-truth images as the resident feed (so that the two rates differ by the feed alone), as decoded
+            # host RGB8 arrays: every step uploads one through the pinned ring, the copy stream and the device packing kernel
+            host_views = []
+            for v, c in enumerate(cams):
+                packed = synth.synthetic_gt_packed(w, h, seed=7 + 100 * v + (0 if tile_mode else rank))
+                rgb = np.stack([(packed >> np.uint32(8 * k)) & np.uint32(255) for k in range(3)], axis=-1).astype(np.uint8)
+                host_views.append((np.ascontiguousarray(rgb), c.uniforms((w, h))))
             loader = ba.SceneLoader(host_views, seed=rank, slots=3, ctx=ctx)
         counter = [0]
 

@@ -1337,9 +1337,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
     };
     if (ctx->knob_fail_loss_at && ++ctx->train_steps_seen == ctx->knob_fail_loss_at)   // (the forward is queued, a deferred far slice may be pending)
         return set_error(ctx, BH_ERR_OOM, "train_step: injected failure between the forward and the loss (BH_TEST_FAIL_LOSS_AT)");
-    // A view whose forecast missed recently decides FIRST (the host waits for the near pass's blend, ~15 us of bubble) instead of
-    // queueing loss kernels that a far pass would make worthless (~120 us)
-    if (ctx->far_job.pending && ctx->far_job.view && ctx->far_job.view->penalty != 0u) {
+    // A view whose forecast keeps missing (two of its last eight cut frames) decides FIRST — the host waits for the near pass's blend,
+    // ~15 us of bubble — instead of queueing loss kernels that a second attempt would make worthless (~120 us).  One isolated miss
+    // does not switch: eight bubbles cost more than the one wasted loss they would insure against at a 3 % miss rate.
+    if (ctx->far_job.pending && ctx->far_job.view && __builtin_popcount(ctx->far_job.view->penalty) >= 2) {
         BH_TRY(finish_far_slice(ctx, nullptr));
         ro = ctx->last;   // (a second attempt replaces the frame's outputs)
     }
