@@ -79,6 +79,18 @@ BH_DEV Vec3A sh_coeffs_to_color(const float* __restrict__ c, Vec3A v) {
     return color;
 }
 
+// the same with the DC coefficient already in registers (K1 fetches it with the splat's other inputs)
+template <int DEG>
+BH_DEV Vec3A sh_coeffs_to_color_dc(const float* __restrict__ c, Vec3A v, const float (&dc)[3]) {
+    constexpr int C = (DEG + 1) * (DEG + 1);
+    float b[25];
+    sh_basis<DEG>(v, b);
+    Vec3A color = scale(Vec3A{dc[0], dc[1], dc[2]}, b[0]);
+#pragma unroll
+    for (int k = 1; k < C; ++k) color = add(color, scale(Vec3A{c[3 * k], c[3 * k + 1], c[3 * k + 2]}, b[k]));
+    return color;
+}
+
 // sh.rs:277-355: v_coeff_k = vc * basis_k.
 template <int DEG>
 BH_DEV void sh_coeffs_to_color_vjp(float* __restrict__ vcoef, Vec3A v, Vec3A vc) {

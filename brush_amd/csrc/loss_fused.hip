@@ -115,36 +115,63 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * TW + lx;
     const size_t plane = (size_t)a.h * a.w;
-    for (int i = rank; i < SR * SW; i += 256) {
-        const int r = i / SW, q = i - r * SW;
-        const int y = ty0 + r - HALO, x = tx0 + q - HALO;
-        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w) {  // zero padding (lib.rs:110-176)
-            const size_t p = (size_t)y * a.w + (size_t)x;
-            pv = *reinterpret_cast<const float4*>(&img[p * 4]);
-            const uint32_t val = gt[p];
-            const float ga = gt_ch(val, 3);
-            g0 = gt_ch(val, 0); g1 = gt_ch(val, 1); g2 = gt_ch(val, 2);
-            if (a.composite) {
-                g0 = g0 + (1.0f - ga) * a.bg[0];
-                g1 = g1 + (1.0f - ga) * a.bg[1];
-                g2 = g2 + (1.0f - ga) * a.bg[2];
-            }
-        }
-        s_tile[0][i] = make_float2(pv.x, g0);
-        s_tile[1][i] = make_float2(pv.y, g1);
-        s_tile[2][i] = make_float2(pv.z, g2);
-    }
-    // this thread's two pixels
+    // Every global load of the block's prologue — the tile's (image, GT) pixels, five per thread, and the GT alpha of the thread's
+    // two outputs — is issued before the first one is consumed: as a rolled loop with a load, a wait and three LDS stores per
+    // trip the prologue was SEVEN dependent global round trips (the "tile load alone" of the round-3 probes: 23 of the 64 us).
+    constexpr int TILE_LOADS = (SR * SW + 255) / 256;
+    float lx3[TILE_LOADS][3];
+    uint32_t lval[TILE_LOADS];
+    bool lin[TILE_LOADS];
     const int pxx = tx0 + lx;
     const int py[2] = {ty0 + 2 * ly, ty0 + 2 * ly + 1};
     const bool inside[2] = {pxx < (int)a.w && py[0] < (int)a.h, pxx < (int)a.w && py[1] < (int)a.h};
+    uint32_t own_val[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; ++k) {
+        const int i = rank + 256 * k;
+        const int r = i / SW, q = i - r * SW;
+        const int y = ty0 + r - HALO, x = tx0 + q - HALO;
+        lin[k] = i < SR * SW && y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;   // zero padding (lib.rs:110-176)
+        // (UNCONDITIONAL loads from a clamped, always valid address, masked afterwards: a load under `if` ends in a wait where
+        //  the branches join, which serialises the five again)
+        const int yc = y < 0 ? 0 : (y >= (int)a.h ? (int)a.h - 1 : y), xc = x < 0 ? 0 : (x >= (int)a.w ? (int)a.w - 1 : x);
+        const size_t p = (size_t)yc * a.w + (size_t)xc;
+        const float* ip = &img[p * 4];
+        lx3[k][0] = ip[0]; lx3[k][1] = ip[1]; lx3[k][2] = ip[2];
+        lval[k] = gt[p];
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int yc = py[o] >= (int)a.h ? (int)a.h - 1 : py[o], xc = pxx >= (int)a.w ? (int)a.w - 1 : pxx;
+        own_val[o] = gt[(size_t)yc * a.w + (size_t)xc];
+    }
+#pragma unroll
+    for (int k = 0; k < TILE_LOADS; ++k) {
+        const int i = rank + 256 * k;
+        if (i < SR * SW) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (!lin[k]) lx3[k][0] = lx3[k][1] = lx3[k][2] = 0.0f;
+            if (lin[k]) {
+                const uint32_t val = lval[k];
+                const float ga = gt_ch(val, 3);
+                g0 = gt_ch(val, 0); g1 = gt_ch(val, 1); g2 = gt_ch(val, 2);
+                if (a.composite) {
+                    g0 = g0 + (1.0f - ga) * a.bg[0];
+                    g1 = g1 + (1.0f - ga) * a.bg[1];
+                    g2 = g2 + (1.0f - ga) * a.bg[2];
+                }
+            }
+            s_tile[0][i] = make_float2(lx3[k][0], g0);
+            s_tile[1][i] = make_float2(lx3[k][1], g1);
+            s_tile[2][i] = make_float2(lx3[k][2], g2);
+        }
+    }
+    // this thread's two pixels
     float ga[2] = {0.f, 0.f}, chain[2] = {0.f, 0.f};
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         if (inside[o]) {
-            ga[o] = gt_ch(gt[(size_t)py[o] * a.w + (size_t)pxx], 3);
+            ga[o] = gt_ch(own_val[o], 3);
             chain[o] = a.mask ? a.dl_rgb * ga[o] : a.dl_rgb;
         }
     }

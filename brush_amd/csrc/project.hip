@@ -329,13 +329,31 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     Sym2 conic = Sym2{0.0f, 0.0f, 0.0f};
     TileBbox bb = TileBbox{0, 0, 0, 0};
     Vec3A mean = v3(0.0f, 0.0f, 0.0f);
+    // Every input of the splat is fetched up front, unconditionally (a clamped row for the grid's tail): behind the cull tests the
+    // loads were SEVEN dependent global round trips (mean -> test -> scale x -> scale y -> scale z -> quaternion -> opacity -> SH),
+    // one wait each.  The 14 % of splats that are culled early read 44 bytes they would not have needed.
+    const uint32_t gsafe = gid < n ? gid : (n ? n - 1u : 0u);
+    float tr[10];
+    {
+        const float* trp = transforms + (size_t)gsafe * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tr[k] = trp[k];
+    }
+    float raw_opac = raw_opacities[gsafe];
+    constexpr int C_ALL = (DEG + 1) * (DEG + 1);
+    // the SH DC term of every splat; the higher bands (up to 72 more floats) only for the visible ones, below
+    float sh_dc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sh_dc[k] = coeffs[(size_t)gsafe * C_ALL * 3 + k];
+    // (an empty asm that "uses" all fourteen values: without it the compiler sinks the later loads back behind the first cull test)
+    asm volatile("" : "+v"(tr[0]), "+v"(tr[1]), "+v"(tr[2]), "+v"(tr[3]), "+v"(tr[4]), "+v"(tr[5]), "+v"(tr[6]), "+v"(tr[7]), "+v"(tr[8]), "+v"(tr[9]),
+                      "+v"(raw_opac), "+v"(sh_dc[0]), "+v"(sh_dc[1]), "+v"(sh_dc[2]));
     if (gid < n) {
-        const float* tr = transforms + (size_t)gid * 10;
         do {
 #ifdef BH_K1_NO_MATH   // measurement-only probe (wrong results: nothing is visible): the loads and the per-splat stores alone
-            float acc = raw_opacities[gid];
+            float acc = raw_opac;
             for (int k = 0; k < 10; ++k) acc += tr[k];
-            for (int k = 0; k < 3; ++k) acc += coeffs[(size_t)gid * ((DEG + 1) * (DEG + 1)) * 3 + k];
+            for (int k = 0; k < 3; ++k) acc += sh_dc[k];
             if (acc != 12345.678f) break;
 #endif
             mean = v3(tr[0], tr[1], tr[2]);
@@ -347,7 +365,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             const Quat qu = Quat{tr[3], tr[4], tr[5], tr[6]};
             const float qn = qdot(qu, qu);
             if (!(qn >= 1.0e-6f && is_finite_f32(qn))) break;
-            const float raw_opac = raw_opacities[gid];
             if (!is_finite_f32(raw_opac)) break;
             const Quat q = qnormalize(qu);
             const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 #endif
         const Vec3A v = normalize(sub(mean, camera_pos(u)));
         constexpr int C = (DEG + 1) * (DEG + 1);
-        const Vec3A raw = sh_coeffs_to_color<DEG>(coeffs + (size_t)gid * C * 3, v);
+        const Vec3A raw = sh_coeffs_to_color_dc<DEG>(coeffs + (size_t)gid * C * 3, v, sh_dc);
         const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
         float* o = projected_by_gid + (size_t)gid * 9;
         o[0] = mx;
@@ -635,19 +652,24 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t base = 0, end = 0, nb = 0, zkey = 0;
     bool mine = false;   // this lane's splat belongs to the slice being emitted (and, FAR, still reaches a live tile)
     if (cg < nv) {
-        const uint32_t cum_end = cum_tiles_hit[cg];
+        // (the lane's independent loads side by side — its slot range, its depth key, its splat id — not one wait each)
+        uint32_t cum_end = cum_tiles_hit[cg];
+        uint32_t cum_prev = cum_tiles_hit[cg == 0u ? 0u : cg - 1u];
+        uint32_t my_gid = global_from_compact_gid[cg];
         if (zcut) zkey = depth_keys_sorted[cg];
+        asm volatile("" : "+v"(cum_end), "+v"(cum_prev), "+v"(my_gid), "+v"(zkey));
+        if (cg == 0u) cum_prev = 0u;
         if (FAR) {
             base = far_base;
             end = far_base + far_cnt;
             mine = cum_end > budget && end > base;
         } else if (zcut) {
-            base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+            base = cum_prev;
             end = cum_end;
             mine = end > base;
             if (slice_info && cg + 1u == nv) { slice_info[0] = nv; slice_info[1] = cum_end; }   // the far pass sorts behind the near list
         } else {
-            base = cg == 0 ? 0u : cum_tiles_hit[cg - 1];
+            base = cum_prev;
             end = cum_end;
             mine = cum_end <= budget;
             if (slice_info) {   // where the near slice ends (the next splat's range does not fit, or there is none)
@@ -657,7 +679,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
             }
         }
         if (mine) {
-            const float* src = projected_by_gid + (size_t)global_from_compact_gid[cg] * 9;
+            const float* src = projected_by_gid + (size_t)my_gid * 9;
             float p[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) p[k] = src[k];
@@ -871,15 +893,26 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const bool mark_written) {
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     if (cg >= nv) return;
-    const uint32_t gid = global_from_compact_gid[cg];
+    uint32_t gid = global_from_compact_gid[cg];
     const float* rg = v_combined + (size_t)cg * 10;
     float g[10];
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { g[k] = rg[k]; any = any || (g[k] != 0.0f); }
+    for (int k = 0; k < 10; ++k) g[k] = rg[k];
+    asm volatile("" : "+v"(gid));   // (the splat id travels with the accumulator row, not behind the test on it)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) any = any || (g[k] != 0.0f);
     constexpr int C = (DEG + 1) * (DEG + 1);
     if (!any) return;   // the row stays what it is: zero (the caller cleared the dense outputs) or, with mark_written, unmarked
-    const float* tr = transforms + (size_t)gid * 10;
+    // the splat's inputs side by side (they were six dependent round trips: mean, scale x, y, z, quaternion, opacity)
+    float tr[10];
+    {
+        const float* trp = transforms + (size_t)gid * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tr[k] = trp[k];
+    }
+    float raw_o = raw_opac[gid];
+    asm volatile("" : "+v"(tr[0]), "+v"(tr[1]), "+v"(tr[2]), "+v"(tr[3]), "+v"(tr[4]), "+v"(tr[5]), "+v"(tr[6]), "+v"(tr[7]), "+v"(tr[8]), "+v"(tr[9]), "+v"(raw_o));
     const Vec3A mean = v3(tr[0], tr[1], tr[2]);
     const Vec3A scl = v3(bh_expf(tr[7]), bh_expf(tr[8]), bh_expf(tr[9]));
     const Quat qu = Quat{tr[3], tr[4], tr[5], tr[6]};
@@ -898,7 +931,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     const Sym2 raw_cov = calc_cov2d<PINHOLE>(scl, q, mean_c, u);
     float filter_comp;
     const Sym2 cov = compensate_cov2d<MIP>(raw_cov, filter_comp);
-    const float os = sigmoid(raw_opac[gid]);
+    const float os = sigmoid(raw_o);
     v_raw_opac[gid] = filter_comp * g[8] * os * (1.0f - os);
     const float refine_clean = is_finite_f32(g[9]) ? g[9] : 0.0f;
     // mark_written (the single-GPU train step, which clears ONLY the refine-weight vector): the sign bit of the (non-negative)
