@@ -646,13 +646,23 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     // is that dot product: S = remaining . v_rgb (one register and one fma per update instead of three).  T = 0: finished.
     float sS[4], sw[4];
     float vox[4], voy[4], voz[4], inv_fa[4];
+    // (the eight pixel loads side by side, from clamped — always valid — addresses, masked afterwards: under `if (inside)` they
+    //  were four dependent global round trips at the head of every tile)
+    float4 o4[4], vo4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
+        const uint32_t pxc = px < u.img_w ? px : u.img_w - 1u, pyc = py < u.img_h ? py : u.img_h - 1u;
+        const size_t pix = ((size_t)pxc + (size_t)pyc * u.img_w) * 4;
+        o4[q] = *reinterpret_cast<const float4*>(&out_img[pix]);
+        vo4[q] = *reinterpret_cast<const float4*>(&v_output[pix]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
         if (px < u.img_w && py < u.img_h) {
-            const size_t pix = ((size_t)px + (size_t)py * u.img_w) * 4;
-            const float4 o = *reinterpret_cast<const float4*>(&out_img[pix]);
-            const float4 vo = *reinterpret_cast<const float4*>(&v_output[pix]);
+            const float4 o = o4[q];
+            const float4 vo = vo4[q];
             const float t_final = 1.0f - o.w;
             // ... minus the pixel's constant term v_o_w = (v_A - bg . v_rgb) T_final, which only ever appears added to it (…:300-310):
             // S' = remaining . v_rgb - v_o_w   (one register and one add per pixel-quadrant less)
