@@ -358,6 +358,38 @@ def test_a_view_that_changed_behind_its_cuts_is_rendered_again_with_complete_lis
         ctx.close()
 
 
+def test_view_tables_survive_eviction_and_resolution_changes(dev):
+    """the ctx keeps the 4096 most recently used view tables: a view that was evicted is simply seeded again; a view id that comes
+    back at another resolution (another tile grid) gets a fresh table — the images are the exact path's throughout"""
+    import brush_amd as ba
+    n, w, h = 6000, 160, 112
+    sc, cp = _scene(n, w, h, 0x5E, scales=(0.03, 0.3))
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    ctx = ba.Context(dev)
+    try:
+        ref, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx)
+        ref2, _ = ba.render_splats(spl, cam, (w * 2, h * 2), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx)
+        for vid in range(1, 4301):           # more ids than the ctx keeps tables for
+            ba.set_view_id(vid, ctx)
+            img, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx, sliced=True, copy=(vid % 500 == 0))
+            if vid % 500 == 0:
+                assert torch.equal(img, ref), vid
+        shares = []
+        for vid in (1, 4300, 4300, 1, 1):    # 1 was evicted long ago: seeded again, then cut; 4300 still has its table
+            ba.set_view_id(vid, ctx)
+            img, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx, sliced=True)
+            assert torch.equal(img, ref), vid
+            shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))
+        assert shares[0] == 1.0 and shares[1] < 1.0 and shares[4] < 1.0, shares
+        for size, want in (((w * 2, h * 2), ref2), ((w, h), ref), ((w * 2, h * 2), ref2), ((w * 2, h * 2), ref2)):   # one id, two tile grids
+            ba.set_view_id(7, ctx)
+            img, _ = ba.render_splats(spl, cam, size, (0, 0, 0), ba.RasterPass.Forward, ctx=ctx, sliced=True)
+            assert torch.equal(img, want), size
+    finally:
+        ctx.close()
+
+
 def test_small_frames_keep_complete_lists_by_default(dev):
     """bh_set_list_cut_threshold: a view whose last frame had fewer pairs than the threshold (default 1.5 M) is not cut"""
     import brush_amd as ba
