@@ -357,6 +357,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     }
     if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
     ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
+    ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
@@ -706,23 +707,29 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             ctx->counters_ready = true;
         }
         // the one mid-pipeline readback (render.rs:146-168).  The depth sort covers all n splats
-        // and needs neither count, so it is queued behind the copy BEFORE the host waits: the GPU
-        // sorts while the host reads the counts, sizes the buffers and queues the rest.
+        // and needs neither count, so it is queued BEFORE the host waits: the GPU sorts while the
+        // host reads the counts, sizes the buffers and queues the rest.
         auto* hslots = reinterpret_cast<unsigned long long*>(ctx->host_counters + 16);
-        BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_read_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+        fused_scan = depth_sort_supported(n) && !ctx->knob_generic_depth_sort;
+        // (the sort's first kernel adds the counter slots up and stores the sums into the pinned block itself; only the generic
+        //  sort path still needs a copy launch between K1 and the sort)
+        const bool sums_on_device = fused_scan && !ctx->knob_readback_copy;
+        if (!sums_on_device) {
+            BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_read_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+        }
         {
             ProfScope ps(ctx, "DepthSort");
             // culled splats carry key 0xFFFFFFFF and sort behind every visible one:
             // the stable sort is also the (deterministic) compaction.
-            fused_scan = depth_sort_supported(n) && !ctx->knob_generic_depth_sort;
             if (fused_scan) {
                 // ... and the scan of the tile counts in depth order rides on its last kernel (depth_sort.hip); the arena's
                 // cum slot is sized for n here because the visible count is not known yet
                 cum_early = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, npad * 4);
                 if (!cum_early) return BH_ERR_OOM;
                 // (per-tile cuts: the scan of the NEAR counts = the slot ranges of the near pass's list)
-                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early));
+                BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early,
+                                       sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
@@ -733,8 +740,18 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             ctx->far_direct = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD] != 0u;
         }
         unsigned long long hc[4] = {0ull, 0ull, 0ull, 0ull};
-        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k)
-            for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) hc[c] += hslots[COUNTER_K1_U64 * k + c];
+        if (sums_on_device) {
+            const volatile unsigned long long* hs = hslots;
+            for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) hc[c] = hs[c];
+            const volatile uint32_t* hfb = reinterpret_cast<const volatile uint32_t*>(hslots) + 2 * COUNTER_K1_U64;
+            fb_need = hfb[0]; fb_unsat_pairs = hfb[1]; fb_unsat_tiles = hfb[2];   // the previous forward's slicing hint
+        } else {
+            for (uint32_t k = 0; k < COUNTER_SLOTS; ++k)
+                for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) hc[c] += hslots[COUNTER_K1_U64 * k + c];
+            // the previous forward's slicing hint came along in the same copy
+            const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
+            for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[3 * k] > fb_need) fb_need = hfb[3 * k]; fb_unsat_pairs += hfb[3 * k + 1]; fb_unsat_tiles += hfb[3 * k + 2]; }
+        }
         if (hc[1] > 0xFFFFFFFFull) return set_error(ctx, BH_ERR_UNSUPPORTED, "more than 2^32-1 tile intersections");
         nv_true = (uint32_t)hc[0];
         ni = (uint32_t)hc[1];
@@ -742,9 +759,6 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         // per-tile cuts: only the splats that own a pair in front of some cut were given a real depth key (K1): the compact
         // arrays, K5's grid, the backward's accumulator and K18 are sized for THEM; num_visible stays the reference's count
         nv = cut_active ? (uint32_t)hc[3] : nv_true;   // (BH_CUT_SORT_ALL: K1 then listed every visible splat, hc[3] == hc[0])
-        // the previous forward's slicing hint came along in the same copy
-        const uint32_t* hfb = reinterpret_cast<const uint32_t*>(hslots) + COUNTER_FB_WORD;
-        for (uint32_t k = 0; k < COUNTER_SLOTS; ++k) { if (hfb[3 * k] > fb_need) fb_need = hfb[3 * k]; fb_unsat_pairs += hfb[3 * k + 1]; fb_unsat_tiles += hfb[3 * k + 2]; }
     } else {   // no K1 to clear them on the way
         BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
         if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
@@ -884,6 +898,13 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         if (!state || !far_counts || !far_block_totals) return BH_ERR_OOM;
         rs.done_bits = done_bits;
         rs.unsat_count = slice_info + 2;
+        if (!ctx->knob_readback_copy) {
+            // how many tiles are left, for the host (to decide now, or to learn for the next frame: context.h far_direct): the
+            // blend kernel stores into the pinned word itself.  Nothing of an earlier frame can still write it — every frame's
+            // count readback waited behind the previous frame's blend.
+            rs.gate_host = ctx->host_counters + HOST_GATE_WORD;
+            *reinterpret_cast<volatile uint32_t*>(rs.gate_host) = 0u;
+        }
         rs.state = state;
         rs.offsets_near = tile_offsets;
         rs.live_bands = slice_info + 4;
@@ -912,8 +933,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             j.ext_visible = ctx->ext_visible; j.ext_max_radius = ctx->ext_max_radius; j.ext_visible_floats = ctx->ext_visible_floats;
             j.ext_grad_begin = ctx->ext_grad_begin; j.ext_grad_floats = ctx->ext_grad_floats;
         }
-        // how many tiles are left: to the host, either to decide now or to learn for the next frame (context.h far_direct)
-        BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->knob_readback_copy)
+            BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
         // (per-tile cuts: the forecast is expected to hold, and a far pass that had to run has corrected the table — the host decides
         //  every time, bh_train_step hides the wait behind its loss kernels)
         if (ctx->far_direct && !by_cut) {

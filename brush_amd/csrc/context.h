@@ -93,6 +93,8 @@ constexpr uint32_t COUNTER_MINMAX_WORD = COUNTER_FB_WORD + COUNTER_SLOTS * 3;   
 constexpr uint32_t SLICE_CTRL_WORDS = 8;
 constexpr uint32_t FAR_GROUP_BLOCKS = 64;   // far slice: count-kernel blocks per group total (<= the projection workgroup size)
 constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 8 * COUNTER_K1_U64 + COUNTER_SLOTS * 12;
+// ... or, when the depth sort's first kernel adds the slots up on the device: [COUNTER_K1_U64] u64 totals | [3] u32 feedback
+constexpr uint32_t HOST_SUM_WORDS = 2 * COUNTER_K1_U64 + 3;
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
@@ -139,6 +141,7 @@ constexpr size_t MAX_VIEW_STATES = 4096;
 struct RasterSlice {
     uint32_t* done_bits = nullptr;
     uint32_t* unsat_count = nullptr;
+    uint32_t* gate_host = nullptr;   // pinned host word: the near pass stores 1 there when it parks a tile (the host's copy of unsat_count != 0)
     float* state = nullptr;
     const uint32_t* offsets_near = nullptr;
     const uint32_t* cum = nullptr;
@@ -264,6 +267,7 @@ struct bh_ctx {
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
+    bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
     bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
@@ -373,10 +377,11 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
 int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
                       const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals, uint32_t alloc_n = 0);
 // depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
-// order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.
+// order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.  rb_*: the first launch also adds
+// up counter set rb_set into the pinned host words rb_host (HOST_SUM_WORDS) and rb_done is recorded behind it.
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum);
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 // gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);

@@ -96,14 +96,57 @@ BH_DEV unsigned long long ds_match(uint32_t d) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// The mid-pipeline readback (render.rs:146-168) without a copy launch: K1's counter set (context.h: [COUNTER_SLOTS] block totals +
+// the previous frame's slicing feedback) is added up by one wave of the first kernel queued behind K1 and stored straight into
+// the pinned host block — [4] u64 totals | [3] u32 feedback (max need, unsaturated pairs, unsaturated tiles).  A blit kernel
+// between K1 and the sort cost 4.5 us of device time plus its two launch gaps in every frame.
+BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __restrict__ host_sums, int lane) {
+    const unsigned long long* c64 = reinterpret_cast<const unsigned long long*>(set);
+    unsigned long long tot[COUNTER_K1_U64];
+#pragma unroll
+    for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) tot[c] = 0ull;
+    uint32_t need = 0, pairs = 0, tiles = 0;
+    for (uint32_t k = (uint32_t)lane; k < COUNTER_SLOTS; k += 64u) {
+#pragma unroll
+        for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) tot[c] += c64[COUNTER_K1_U64 * k + c];
+        const uint32_t* fb = set + COUNTER_FB_WORD + 3u * k;
+        need = max(need, fb[0]);
+        pairs += fb[1];
+        tiles += fb[2];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) tot[c] += __shfl_down(tot[c], off);
+        need = max(need, (uint32_t)__shfl_down((int)need, off));
+        pairs += __shfl_down(pairs, off);
+        tiles += __shfl_down(tiles, off);
+    }
+    if (lane == 0) {
+        volatile unsigned long long* h64 = reinterpret_cast<volatile unsigned long long*>(host_sums);
+#pragma unroll
+        for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) h64[c] = tot[c];
+        volatile uint32_t* h32 = host_sums + 2u * COUNTER_K1_U64;
+        h32[0] = need;
+        h32[1] = pairs;
+        h32[2] = tiles;
+    }
+}
+
 // ---- 1a: histogram of the split digit per block + tile-count sums per (digit, block) ------------------------------------
+// (block `nblocks`, present when rb_set is given, carries the counter readback instead of a chunk of keys)
 __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ counts,
                                                           uint32_t n, uint32_t nblocks, const uint32_t* __restrict__ minmax,
-                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ csum) {
+                                                          uint32_t* __restrict__ hist, uint32_t* __restrict__ csum,
+                                                          const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host) {
     __shared__ uint32_t s_hist[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_csum[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
     const int tid = threadIdx.x, wave = tid >> 6;
+    if (blockIdx.x == nblocks) {   // (block-uniform: taken before the first barrier)
+        if (wave == 0) counter_sums_to_host(rb_set, rb_host, tid);
+        return;
+    }
     for (int i = tid; i < DS_WAVES * DS_RADIX; i += DS_WG) { (&s_hist[0][0])[i] = 0; (&s_csum[0][0])[i] = 0; }
     const DepthSplit sp = depth_split(minmax, s_red);   // (contains the barrier behind the clears)
     const uint32_t base = blockIdx.x * DS_TILE;
@@ -660,8 +703,10 @@ bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n +
 // keys: [n] depth keys (culled = 0xFFFFFFFF); minmax: K1's [COUNTER_SLOTS][2] (max key, max ~key over visible splats);
 // counts: [n] tiles hit per splat.  -> out_keys / out_vals: the stable argsort; cum: inclusive scan of counts[out_vals[i]]
 // over the visible prefix (entries behind it are not written).
+// rb_set / rb_host / rb_done (optional, all or none): the counter set whose sums the first kernel stores into the pinned host block
+// rb_host, and the event recorded right behind that kernel (counter_sums_to_host above).
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum) {
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done) {
     if (n == 0) return 0;
     const uint32_t nblocks = (n + DS_TILE - 1) / DS_TILE;
     // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables
@@ -671,8 +716,10 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
     if (!totals || !a_keys || !a_vals) return BH_ERR_OOM;
     uint32_t* hist = totals + 2 * DS_RADIX;
     uint32_t* csum = hist + (size_t)DS_RADIX * nblocks;
-    hipLaunchKernelGGL(dsort_hist_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, counts, n, nblocks, minmax, hist, csum);
+    hipLaunchKernelGGL(dsort_hist_kernel, dim3(nblocks + (rb_set ? 1u : 0u)), dim3(DS_WG), 0, ctx->stream, keys, counts, n, nblocks, minmax, hist, csum,
+                       rb_set, rb_host);
     BH_LAUNCH_CHECK(ctx, "dsort_hist_kernel");
+    if (rb_set) BH_HIP(ctx, hipEventRecord(rb_done, ctx->stream));
     hipLaunchKernelGGL(dsort_rowscan_kernel, dim3(DS_RADIX), dim3(DS_WG), 0, ctx->stream, hist, csum, nblocks, totals);
     BH_LAUNCH_CHECK(ctx, "dsort_rowscan_kernel");
     hipLaunchKernelGGL(dsort_split_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, n, nblocks, minmax, hist, totals, a_keys, a_vals, out_keys, out_vals);

@@ -211,6 +211,7 @@ BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float
 struct SliceArgs {
     uint32_t* done_bits = nullptr;          // [ceil(T/32)] bit per tile: its pixels are final
     uint32_t* unsat_count = nullptr;        // tiles PHASE 1 left unsaturated (the gate of everything the far slice launches)
+    uint32_t* gate_host = nullptr;          // pinned host word, zeroed by the host before the launch: a parked tile stores 1 (no copy launch for the host's decision)
     float* state = nullptr;                 // [H,W,4] raw rgb + signed T of those tiles
     const uint32_t* offsets_near = nullptr; // PHASE 2: the near slice's [T,2] table (shrunk ends: the tile's backward work so far)
     const uint32_t* cum = nullptr;          // cum_tiles_hit [Nv]: the exact list's slot ranges (feedback)
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         if (lane == 0) {
             if (BWD_INFO) tile_offsets[tile * 2 + 1] = last_useful;
             atomicAdd(sl.unsat_count, 1u);
+            if (sl.gate_host) *reinterpret_cast<volatile uint32_t*>(sl.gate_host) = 1u;
             if (sl.live_bands) {   // where the live tiles are: the far pass walks only splats whose box reaches these bands
                 const uint32_t ttx = tile % u.tile_bw, tty = tile / u.tile_bw;
                 atomicOr(&sl.live_bands[0], 1u << ((ttx * 32u) / u.tile_bw));
@@ -505,6 +507,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (slice) {
         sl.done_bits = slice->done_bits;
         sl.unsat_count = slice->unsat_count;
+        sl.gate_host = phase == 1 ? slice->gate_host : nullptr;
         sl.state = slice->state;
         sl.offsets_near = slice->offsets_near;
         sl.cum = slice->cum;
