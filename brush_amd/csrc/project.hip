@@ -163,7 +163,11 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
+#if defined(BH_K1_WALK_PROBE) && BH_K1_WALK_PROBE >= 2   // measurement-only (wrong results): the walk's skeleton without the ellipse test
+            if (keep(w, r, tx, ty) && (tx + ty) != 0xFFFFFFFFu) on_hit(r, tx, ty);
+#else
             if (keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
+#endif
         }
         before += (uint32_t)__popcll(marks);
     }
@@ -425,12 +429,30 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // unmarked tile holds everything there is, however its cut reads.
     const uint32_t tile_bw = u.tile_bw;
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
+#ifdef BH_K1_WALK_PROBE   // measurement-only (wrong results): 1 = hits are found but not counted, 2 = ... and not tested for, 3 = counted, no near test
+        if (BH_K1_WALK_PROBE != 3 && tile_bw != 0xFFFFFFFFu) return;
+#endif
         atomicAdd(&w.count[r], 1u);
+#if defined(BH_K1_WALK_PROBE) && BH_K1_WALK_PROBE == 3
+        if (tile_bw != 0xFFFFFFFFu) return;
+#endif
         if (zcut) {
             const uint32_t t = tx + ty * tile_bw;
+#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 1)
+            const uint32_t cut = __hip_atomic_load(&zcut[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             const uint32_t cut = zcut[t];
+#endif
+#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 4)
+            if (zcut_near(w.zkey[r], cut)) { if (tile_bw == 0xFFFFFFFFu) atomicAdd(&w.near[r], 1u); }
+#else
             if (zcut_near(w.zkey[r], cut)) atomicAdd(&w.near[r], 1u);
+#endif
+#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 2)
+            else if ((cut & 1u) == 0u && tile_bw == 0xFFFFFFFFu) zcut[t] = cut | 1u;
+#else
             else if ((cut & 1u) == 0u) zcut[t] = cut | 1u;
+#endif
         }
     }, KeepAllTiles{}, key);
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
