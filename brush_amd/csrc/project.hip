@@ -395,26 +395,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             visible = true;
         } while (false);
     }
-#ifdef BH_K1_NO_ROWS   // measurement-only probe (garbage image): the 36-byte projected rows are not written
-    if (visible && u.img_w == 0xFFFFFFFFu) {
-#else
-    if (visible) {  // project_visible.rs:56-87
-#endif
-        const Vec3A v = normalize(sub(mean, camera_pos(u)));
-        constexpr int C = (DEG + 1) * (DEG + 1);
-        const Vec3A raw = sh_coeffs_to_color_dc<DEG>(coeffs + (size_t)gid * C * 3, v, sh_dc);
-        const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
-        float* o = projected_by_gid + (size_t)gid * 9;
-        o[0] = mx;
-        o[1] = my;
-        o[2] = conic.c00;
-        o[3] = conic.c01;
-        o[4] = conic.c11;
-        o[5] = opac;
-        o[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
-        o[7] = clampf(is_finite_f32(cgc) ? cgc : 0.0f, -100.0f, 100.0f);
-        o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
-    }
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
@@ -466,6 +446,29 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 #else
     const bool listed = visible;
 #endif
+    // The splat's colour and its projected row (what K5 gathers by depth rank) — behind the walk since round 4: with per-tile cuts
+    // only the LISTED splats are ever gathered, a quarter of the visible ones, and the SH bands above DC (180 bytes per splat at
+    // degree 3) are only fetched for them.  Without cuts every visible splat is listed.
+#ifdef BH_K1_NO_ROWS   // measurement-only probe (garbage image): the 36-byte projected rows are not written
+    if (listed && u.img_w == 0xFFFFFFFFu) {
+#else
+    if (listed) {  // project_visible.rs:56-87
+#endif
+        const Vec3A v = normalize(sub(mean, camera_pos(u)));
+        constexpr int C = (DEG + 1) * (DEG + 1);
+        const Vec3A raw = sh_coeffs_to_color_dc<DEG>(coeffs + (size_t)gid * C * 3, v, sh_dc);
+        const float cr = raw.x + 0.5f, cgc = raw.y + 0.5f, cb = raw.z + 0.5f;
+        float* o = projected_by_gid + (size_t)gid * 9;
+        o[0] = mx;
+        o[1] = my;
+        o[2] = conic.c00;
+        o[3] = conic.c01;
+        o[4] = conic.c11;
+        o[5] = opac;
+        o[6] = clampf(is_finite_f32(cr) ? cr : 0.0f, -100.0f, 100.0f);
+        o[7] = clampf(is_finite_f32(cgc) ? cgc : 0.0f, -100.0f, 100.0f);
+        o[8] = clampf(is_finite_f32(cb) ? cb : 0.0f, -100.0f, 100.0f);
+    }
     if (gid < n) {
         depth_keys[gid] = listed ? key : 0xFFFFFFFFu;
         isect_counts[gid] = tiles_hit;
