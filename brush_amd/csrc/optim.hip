@@ -18,6 +18,16 @@ struct AdamArgs {
     uint32_t first;  // t == 1: initialise the moments instead of decaying them
 };
 
+#ifdef BH_UPDATE_WRITE_ALL   // A/B: every value is stored, changed or not (rounds 1-3)
+BH_DEV bool same_bits(float, float) { return false; }
+BH_DEV bool same_bits4(const float4&, const float4&) { return false; }
+#else
+BH_DEV bool same_bits(float a, float b) { return f2u(a) == f2u(b); }
+BH_DEV bool same_bits4(const float4& a, const float4& b) {
+    return ((f2u(a.x) ^ f2u(b.x)) | (f2u(a.y) ^ f2u(b.y)) | (f2u(a.z) ^ f2u(b.z)) | (f2u(a.w) ^ f2u(b.w))) == 0u;
+}
+#endif
+
 BH_DEV void adam_elem(float& p, float g, float& m1, float v, const AdamArgs& a, float step) {
     const float m1c = m1 / a.bc1;
     const float m2c = v / a.bc2;
@@ -195,7 +205,45 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
-    // ---- SH gradients -> LDS (coalesced), issued first so the loads overlap the work below
+    // ---- everything else the block reads, issued before the first value is consumed.  The sections below are separated by
+    // barriers (marks and noise travel through LDS, the SH rows need their second moment first): with each section fetching its
+    // own inputs a block was a chain of five dependent global round trips, and the "streaming" kernel ran at 3.4 TB/s.
+    // EARLY only for the short blocks of SH degree >= 1 (64 / 128 splats: 1-2 + 4-5 float4 pairs per thread): update at degree 3
+    // 266 -> 241 us.  At degree 0 (256 splats per block, 12 + 6 float4s per thread = 112 VGPRs, half the blocks per CU) the same
+    // change cost 9 us: there the sections' own loads stay where they were.
+    constexpr bool EARLY = ROWS != 256;
+    constexpr int T_IT = (ROWS * 10 / 4 + OPT_WG - 1) / OPT_WG;          // float4s of the block's transforms per thread
+    constexpr int S_IT = ROWS == 256 ? 3 : (ROWS == 128 ? 4 : 5);        // ... of its SH rows (launch_train_update's row choice)
+    const uint32_t t_count = nrows * 10u, t_vec_end = VEC ? (t_count & ~3u) : 0u;
+    const uint64_t t_base = row0 * 10u;
+    const uint32_t s_vec_end = VEC ? (sh_count & ~3u) : 0u;
+    const bool sh_early = EARLY && VEC && s_vec_end <= (uint32_t)S_IT * OPT_WG * 4u;   // block-uniform (false only under BH_UPDATE_ROWS)
+    float4 tg[T_IT], tm1[T_IT], tm2[T_IT], tp[T_IT], sm1[S_IT], sp[S_IT];
+    if (EARLY && VEC) {
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) {
+            const uint32_t e = (threadIdx.x + (uint32_t)k * OPT_WG) * 4u;
+            const uint64_t i = t_base + (e < t_vec_end ? e : 0u);   // (clamped: unconditional loads, masked at the use)
+            tg[k] = *reinterpret_cast<const float4*>(&g_t[i]);
+            tm1[k] = *reinterpret_cast<const float4*>(&m1_t[i]);
+            tm2[k] = *reinterpret_cast<const float4*>(&m2_t[i]);
+            tp[k] = *reinterpret_cast<const float4*>(&transforms[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < S_IT; ++k) {
+            const uint32_t e = (threadIdx.x + (uint32_t)k * OPT_WG) * 4u;
+            const uint64_t i = sh_base + ((sh_early && e < s_vec_end) ? e : 0u);
+            sm1[k] = *reinterpret_cast<const float4*>(&m1_sh[i]);
+            sp[k] = *reinterpret_cast<const float4*>(&sh[i]);
+        }
+    }
+    // this thread's splat (clamped for the threads behind the block's last row)
+    const uint64_t si = row0 + (threadIdx.x < nrows ? threadIdx.x : 0u);
+    float in_rw = refine_weight[si], in_rn = refine_weight_norm[si], in_vis = visible[si], in_vw = vis_weight[si];
+    float in_ms = max_screen_size[si], in_sr = screen_radius[si], in_go = g_o[si], in_m1o = m1_o[si], in_m2o = m2_o[si], in_op = opac[si];
+    float in_m2sh = m2_sh[si];
+    if (EARLY) asm volatile("" ::: "memory");   // (compiler-only: the loads above are issued HERE, not sunk to their uses behind the staging loop)
+    // ---- SH gradients -> LDS (coalesced), its loads queue behind the ones above
     {
         const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
         for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
@@ -217,28 +265,48 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             s_g[r * pitch + (e - r * row_len)] = (!masked || (mark_rows[r] >> 31) != 0u) ? g_sh[sh_base + e] * u.gscale : 0.0f;
         }
     }
+    // (one wait for all of it)
+    if (EARLY && VEC) {
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k)
+            asm volatile("" : "+v"(tg[k].x), "+v"(tg[k].y), "+v"(tg[k].z), "+v"(tg[k].w), "+v"(tm1[k].x), "+v"(tm1[k].y), "+v"(tm1[k].z), "+v"(tm1[k].w),
+                              "+v"(tm2[k].x), "+v"(tm2[k].y), "+v"(tm2[k].z), "+v"(tm2[k].w), "+v"(tp[k].x), "+v"(tp[k].y), "+v"(tp[k].z), "+v"(tp[k].w));
+#pragma unroll
+        for (int k = 0; k < S_IT; ++k)
+            asm volatile("" : "+v"(sm1[k].x), "+v"(sm1[k].y), "+v"(sm1[k].z), "+v"(sm1[k].w), "+v"(sp[k].x), "+v"(sp[k].y), "+v"(sp[k].z), "+v"(sp[k].w));
+    }
+    if (EARLY) asm volatile("" : "+v"(in_rw), "+v"(in_rn), "+v"(in_vis), "+v"(in_vw), "+v"(in_ms), "+v"(in_sr), "+v"(in_go), "+v"(in_m1o), "+v"(in_m2o), "+v"(in_op), "+v"(in_m2sh));
     // ---- statistics + opacity: one splat per thread
     if (threadIdx.x < nrows) {
         const uint64_t i = row0 + threadIdx.x;
-        const float rw_raw = refine_weight[i];
+        const float rw_raw = in_rw;
         const bool written = !masked || (f2u(rw_raw) >> 31) != 0u;
         if (masked) s_mask[threadIdx.x] = written ? 1.0f : 0.0f;
         // (masked: K18 stored the weight with the sign bit as the mark; an unmarked entry is the zero the forward left)
-        refine_weight_norm[i] = __builtin_fmaxf(masked ? __builtin_fabsf(rw_raw) : rw_raw, refine_weight_norm[i]);
-        const float v = u.vis_clamp ? __builtin_fminf(visible[i], 1.0f) : visible[i];
-        vis_weight[i] = vis_weight[i] + v;
-        max_screen_size[i] = __builtin_fmaxf(screen_radius[i], max_screen_size[i]);
-        const float g = written ? g_o[i] * u.gscale : 0.0f;
-        float mm1 = a.first ? g * a.f1 : m1_o[i] * a.beta1 + g * a.f1;
+        {
+            const float rn_old = in_rn, vw_old = in_vw, ms_old = in_ms;
+            const float rn = __builtin_fmaxf(masked ? __builtin_fabsf(rw_raw) : rw_raw, rn_old);
+            const float v = u.vis_clamp ? __builtin_fminf(in_vis, 1.0f) : in_vis;
+            const float vw = vw_old + v;
+            const float ms = __builtin_fmaxf(in_sr, ms_old);
+            if (!same_bits(rn, rn_old)) refine_weight_norm[i] = rn;
+            if (!same_bits(vw, vw_old)) vis_weight[i] = vw;
+            if (!same_bits(ms, ms_old)) max_screen_size[i] = ms;
+        }
+        const float g = written ? in_go * u.gscale : 0.0f;
+        const float m1_old = in_m1o, m2_old = in_m2o;
+        float mm1 = a.first ? g * a.f1 : m1_old * a.beta1 + g * a.f1;
         const float gsq = g * g;
-        const float mm2 = a.first ? gsq * a.f2 : m2_o[i] * a.beta2 + gsq * a.f2;
-        m1_o[i] = mm1;
-        m2_o[i] = mm2;
-        float p = opac[i];
+        const float mm2 = a.first ? gsq * a.f2 : m2_old * a.beta2 + gsq * a.f2;
+        const float p_old = in_op;
+        float p = p_old;
         adam_elem(p, g, mm1, mm2, a, u.lr_opac);
-        opac[i] = p;
+        // (stores of values that did not change are left out, here and below: see the note at the transforms)
+        if (a.first || !same_bits(mm1, m1_old)) m1_o[i] = mm1;
+        if (a.first || !same_bits(mm2, m2_old)) m2_o[i] = mm2;
+        if (!same_bits(p, p_old)) opac[i] = p;
         if (u.noise_on) {   // the gate reads the UPDATED opacity (train.rs:389)
-            const float w = mean_noise_gate(p, visible[i]);
+            const float w = mean_noise_gate(p, in_vis);
             float nz[3] = {0.0f, 0.0f, 0.0f};
             if (w != 0.0f) {
                 const float wm = w * u.noise_scale;
@@ -271,22 +339,30 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             if (u.noise_on && c < 3u) p = p + s_noise[r * 3u + c];
             o_p = p;
         };
-        const uint32_t vec_end = VEC ? (count & ~3u) : 0u;
-        for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+        const uint32_t vec_end = t_vec_end;
+#pragma unroll
+        for (int k = 0; k < T_IT; ++k) {
+            const uint32_t e = (threadIdx.x + (uint32_t)k * OPT_WG) * 4u;
+            if (e >= vec_end) break;
             const uint64_t i = base + e;
-            const float4 g4 = *reinterpret_cast<const float4*>(&g_t[i]);
-            float4 m14 = *reinterpret_cast<const float4*>(&m1_t[i]);
-            float4 m24 = *reinterpret_cast<const float4*>(&m2_t[i]);
-            float4 p4 = *reinterpret_cast<const float4*>(&transforms[i]);
+            const float4 g4 = EARLY ? tg[k] : *reinterpret_cast<const float4*>(&g_t[i]);
+            float4 m14 = EARLY ? tm1[k] : *reinterpret_cast<const float4*>(&m1_t[i]);
+            float4 m24 = EARLY ? tm2[k] : *reinterpret_cast<const float4*>(&m2_t[i]);
+            float4 p4 = EARLY ? tp[k] : *reinterpret_cast<const float4*>(&transforms[i]);
             const uint32_t ra = (e * 52429u) >> 19, rb = ((e + 3u) * 52429u) >> 19;   // the float4's first and last row
             const bool wa = !masked || s_mask[ra] != 0.0f, wb = !masked || s_mask[rb] != 0.0f;
+            const float4 m1_old = m14, m2_old = m24, p_old = p4;
             one(g4.x, wa, m14.x, m24.x, p4.x, e, m14.x, m24.x, p4.x);
             one(g4.y, (((e + 1u) * 52429u) >> 19) == ra ? wa : wb, m14.y, m24.y, p4.y, e + 1, m14.y, m24.y, p4.y);
             one(g4.z, (((e + 2u) * 52429u) >> 19) == ra ? wa : wb, m14.z, m24.z, p4.z, e + 2, m14.z, m24.z, p4.z);
             one(g4.w, wb, m14.w, m24.w, p4.w, e + 3, m14.w, m24.w, p4.w);
-            *reinterpret_cast<float4*>(&m1_t[i]) = m14;
-            *reinterpret_cast<float4*>(&m2_t[i]) = m24;
-            *reinterpret_cast<float4*>(&transforms[i]) = p4;
+            // A store whose four values are bit for bit what was loaded is left out.  That is the case for every splat that has
+            // never received a gradient (moments 0, gradient 0: the moments stay 0 and the parameter does not move) — nine tenths
+            // of the bench scene, where most splats lie behind saturated tiles in every view; a scene whose splats all reach a
+            // pixel now and then writes everything, as before.  The update is HBM-bound and 3 of its 7 streams are stores.
+            if (a.first || !same_bits4(m14, m1_old)) *reinterpret_cast<float4*>(&m1_t[i]) = m14;
+            if (a.first || !same_bits4(m24, m2_old)) *reinterpret_cast<float4*>(&m2_t[i]) = m24;
+            if (!same_bits4(p4, p_old)) *reinterpret_cast<float4*>(&transforms[i]) = p4;
         }
         for (uint32_t e = vec_end + threadIdx.x; e < count; e += OPT_WG) {
             const uint64_t i = base + e;
@@ -305,8 +381,9 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         for (uint32_t c = 0; c < row_len; ++c) acc += g[c] * g[c];
         const float row_gsq = acc / (float)row_len;
         const uint64_t r = row0 + threadIdx.x;
-        const float v = a.first ? row_gsq * a.f2 : m2_sh[r] * a.beta2 + row_gsq * a.f2;
-        m2_sh[r] = v;
+        const float v_old = in_m2sh;
+        const float v = a.first ? row_gsq * a.f2 : v_old * a.beta2 + row_gsq * a.f2;
+        if (a.first || !same_bits(v, v_old)) m2_sh[r] = v;
         s_v[threadIdx.x] = v;
     }
     __syncthreads();
@@ -321,17 +398,27 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             adam_elem(p, gi, mm1, s_v[r], a, u.tab_sh[c] * u.lr_sh);
             o_p = p;
         };
-        const uint32_t vec_end = VEC ? (sh_count & ~3u) : 0u;
-        for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+        const uint32_t vec_end = s_vec_end;
+        auto four = [&](float4 m14, float4 p4, uint32_t e) {
             const uint64_t i = sh_base + e;
-            float4 m14 = *reinterpret_cast<const float4*>(&m1_sh[i]);
-            float4 p4 = *reinterpret_cast<const float4*>(&sh[i]);
+            const float4 m1_old = m14, p_old = p4;
             one(m14.x, p4.x, e, m14.x, p4.x);
             one(m14.y, p4.y, e + 1, m14.y, p4.y);
             one(m14.z, p4.z, e + 2, m14.z, p4.z);
             one(m14.w, p4.w, e + 3, m14.w, p4.w);
-            *reinterpret_cast<float4*>(&m1_sh[i]) = m14;
-            *reinterpret_cast<float4*>(&sh[i]) = p4;
+            if (a.first || !same_bits4(m14, m1_old)) *reinterpret_cast<float4*>(&m1_sh[i]) = m14;
+            if (!same_bits4(p4, p_old)) *reinterpret_cast<float4*>(&sh[i]) = p4;
+        };
+        if (sh_early) {
+#pragma unroll
+            for (int k = 0; k < S_IT; ++k) {
+                const uint32_t e = (threadIdx.x + (uint32_t)k * OPT_WG) * 4u;
+                if (e >= vec_end) break;
+                four(sm1[k], sp[k], e);
+            }
+        } else {
+            for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u)
+                four(*reinterpret_cast<const float4*>(&m1_sh[sh_base + e]), *reinterpret_cast<const float4*>(&sh[sh_base + e]), e);
         }
         for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
             const uint64_t i = sh_base + e;
