@@ -176,7 +176,8 @@ struct UpdateArgs {
 // 256 rows, so it is aligned whenever the tensor is; a float4 may straddle two rows, rows/columns are resolved per
 // component).  The element arithmetic is identical either way.
 // ROWS: splats per block (multiple of 4, <= OPT_WG) — fewer for long SH rows keeps more blocks resident per CU.
-template <bool VEC, int ROWS>
+// S_IT: float4s of the block's SH rows per thread when the loads are issued up front (0: every section fetches its own inputs).
+template <bool VEC, int ROWS, int S_IT_>
 __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     float* __restrict__ transforms, float* __restrict__ m1_t, float* __restrict__ m2_t, const float* __restrict__ g_t,
     float* __restrict__ sh, float* __restrict__ m1_sh, float* __restrict__ m2_sh, const float* __restrict__ g_sh,
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     // EARLY only for the short blocks of SH degree >= 1 (64 / 128 splats: 1-2 + 4-5 float4 pairs per thread): update at degree 3
     // 266 -> 241 us.  At degree 0 (256 splats per block, 12 + 6 float4s per thread = 112 VGPRs, half the blocks per CU) the same
     // change cost 9 us: there the sections' own loads stay where they were.
-    constexpr bool EARLY = ROWS != 256;
+    constexpr bool EARLY = S_IT_ > 0;
     constexpr int T_IT = (ROWS * 10 / 4 + OPT_WG - 1) / OPT_WG;          // float4s of the block's transforms per thread
-    constexpr int S_IT = ROWS == 256 ? 3 : (ROWS == 128 ? 4 : 5);        // ... of its SH rows (launch_train_update's row choice)
+    constexpr int S_IT = S_IT_ > 0 ? S_IT_ : 1;                          // ... of its SH rows (launch_train_update's choice)
     const uint32_t t_count = nrows * 10u, t_vec_end = VEC ? (t_count & ~3u) : 0u;
     const uint64_t t_base = row0 * 10u;
     const uint32_t s_vec_end = VEC ? (sh_count & ~3u) : 0u;
@@ -463,13 +464,25 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
     bool vec = true;
     for (const void* q : vec_ptrs) vec = vec && ((uintptr_t)q & 15u) == 0;
-#define BH_LAUNCH_UPDATE(V, R)                                                                                                          \
-    hipLaunchKernelGGL((train_update_kernel<V, R>), dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,         \
+#define BH_LAUNCH_UPDATE(V, R, S)                                                                                                       \
+    hipLaunchKernelGGL((train_update_kernel<V, R, S>), dim3(nb), dim3(OPT_WG), lds, ctx->stream, st->transforms, st->m1_transforms,      \
                        st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, st->m2_sh, g_sh, st->raw_opacities, st->m1_opac, st->m2_opac, \
                        g_o, st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u)
-    if (rows == 256u) { if (vec) BH_LAUNCH_UPDATE(true, 256); else BH_LAUNCH_UPDATE(false, 256); }
-    else if (rows == 128u) { if (vec) BH_LAUNCH_UPDATE(true, 128); else BH_LAUNCH_UPDATE(false, 128); }
-    else { if (vec) BH_LAUNCH_UPDATE(true, 64); else BH_LAUNCH_UPDATE(false, 64); }
+    // float4s of a block's SH rows per thread: 1 (<= 1024 floats), 4 (128 x 27), 5 (64 x 75); 0 = no up-front loads
+    const uint32_t sh_f4 = (rows * u.sh_len / 4u + OPT_WG - 1) / OPT_WG;
+    const bool early = vec && rows != 256u && !ctx->knob_update_late;
+    if (rows == 256u) { if (vec) BH_LAUNCH_UPDATE(true, 256, 0); else BH_LAUNCH_UPDATE(false, 256, 0); }
+    else if (rows == 128u) {
+        if (!vec) BH_LAUNCH_UPDATE(false, 128, 0);
+        else if (!early) BH_LAUNCH_UPDATE(true, 128, 0);
+        else if (sh_f4 <= 1u) BH_LAUNCH_UPDATE(true, 128, 1);
+        else BH_LAUNCH_UPDATE(true, 128, 4);
+    } else {
+        if (!vec) BH_LAUNCH_UPDATE(false, 64, 0);
+        else if (!early) BH_LAUNCH_UPDATE(true, 64, 0);
+        else if (sh_f4 <= 1u) BH_LAUNCH_UPDATE(true, 64, 1);
+        else BH_LAUNCH_UPDATE(true, 64, 5);
+    }
 #undef BH_LAUNCH_UPDATE
     BH_LAUNCH_CHECK(ctx, "train_update_kernel");
     return 0;
