@@ -693,9 +693,11 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
     if (cum != nullptr) bk_scan_counts(out_vals + start, size, counts, tiles_before, cum + start, &L.keys[0], s_red);
 }
 
-// the fused path pays off while launches, not bytes, are the cost; beyond this the generic sort + scan run (6 M splats: 0.5 ms of an 8.7 ms step)
+// Up to the row scan's reach (4096 chunks of 4096 keys); beyond it the generic sort + scan run.  (Until round 4 the limit was 4 M:
+// "the fused path pays off while launches, not bytes, are the cost".  With per-tile cuts only the listed sixth of the 6 M / 4K
+// scene's splats is moved at all: depth order + scan 255 -> 97 us there; with complete lists 306 -> 302.)
 #ifndef BH_DSORT_MAX_N
-#define BH_DSORT_MAX_N (4u << 20)
+#define BH_DSORT_MAX_N (16u << 20)
 #endif
 constexpr uint32_t DSORT_MAX_N = BH_DSORT_MAX_N;
 bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n + DS_TILE - 1) / DS_TILE <= (uint32_t)DS_ROW_EPT * DS_WG; }
