@@ -283,6 +283,7 @@ struct bh_ctx {
     bool knob_zero_grads = false;     // BH_TRAIN_ZERO_GRADS: the single-GPU train step zero-fills its gradient span like the exchange path (A/B)
     uint32_t knob_fail_loss_at = 0;   // BH_TEST_FAIL_LOSS_AT: the k-th bh_train_step on this ctx returns BH_ERR_OOM between its forward and its loss (test hook)
     uint32_t train_steps_seen = 0;
+    uint32_t knob_loss_bands = 1;     // BH_LOSS_BANDS=0 (A/B): the fused loss's blocks take their tiles row-major instead of by XCD column bands
     bool knob_update_late = false;    // BH_UPDATE_LATE (A/B): the update kernel's sections fetch their own inputs at every SH degree
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort

@@ -18,8 +18,10 @@
 // ON and uses v_rcp_f32 in the SSIM quotient chain: the loss has no integer-valued
 // outputs to keep reproducible, and the results stay within the 2e-6 the parity tests
 // allow against the oracle (tests/test_gpu_loss_optim.py::test_fused_loss_matches_oracle_and_standalone).
-// (An XCD-banded tile order was measured neutral here — the 256 MB Infinity Cache already
-// absorbs the halo overlap — and is not used.)
+// Blocks take their tiles by XCD column bands (loss_tile below; round 4): the aprons of neighbouring tiles then come out of
+// the XCD's own L2 instead of over the fabric — FETCH_SIZE per launch 95 -> 43 MB (pass A), 333 -> 123 MB (pass B), the pair
+// 114 -> 108 us.  (Round 2 had measured a banded order "neutral" in time and left it out: the Infinity Cache served the
+// repeated fetches; what they cost is fabric bandwidth the step's other kernels do not need at that moment.)
 #include <cmath>
 
 #include "context.h"
@@ -65,8 +67,33 @@ struct FusedArgs {
     int sum_n;
     float* loss_out;   // device scalar
     float* loss_host;  // pinned host scalar or NULL: the train step's loss lands there without a copy launch
+    // block -> tile: gx x gy_blocks tiles of 16 x 32 pixels.  band_w != 0: a 1-D grid of 8 * band_w * gy_blocks blocks; block b
+    // belongs to XCD b & 7 (the dispatcher deals consecutive workgroups to the eight XCDs in turn) and takes the (b >> 3)-th
+    // tile, row-major, of column band b & 7 (band_w tile columns wide) — see loss_tile()
+    uint32_t gx, gy_blocks, band_w;
     Taps taps;
 };
+
+// Which 16 x 32 tile a block works on.  Row-major (band_w == 0), or by XCD column bands: a pass re-reads the 5-pixel apron of
+// everything it loads (2.13x), and with neighbouring tiles dealt to eight different XCDs — each with an L2 of its own — every
+// copy of an apron is fetched over the fabric: pass B's FETCH_SIZE was 341 MB per launch for 116 MB of planes, image and GT,
+// 5.6 TB/s of L2 misses, which is what the kernel's 61 us were made of.  Inside a band consecutive blocks of one XCD walk a
+// strip of band_w tiles row by row, so a tile's left / right / upper neighbours were loaded by the same L2 moments before.
+BH_DEV bool loss_tile(const FusedArgs& a, uint32_t& bx, uint32_t& by, uint32_t& linear) {
+    if (a.band_w == 0u) {
+        bx = blockIdx.x; by = blockIdx.y;
+        linear = by * a.gx + bx;
+        return true;
+    }
+    const uint32_t b = blockIdx.x, xcd = b & 7u, j = b >> 3;
+    const uint32_t x0 = xcd * a.band_w;
+    if (x0 >= a.gx) return false;
+    const uint32_t wb = min(a.band_w, a.gx - x0);
+    by = j / wb;
+    bx = x0 + (j - by * wb);
+    linear = b;
+    return by < a.gy_blocks;
+}
 
 BH_DEV float gt_ch(uint32_t val, uint32_t c) { return (float)((val >> (c * 8u)) & 0xffu) * INV_255; }
 
@@ -111,7 +138,9 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
     // exactly 40 KB = a quarter of the CU's LDS (conflict-free column reads AND four blocks per CU)
     __shared__ float s_h[(SR - 1) * HP + TW * 5];
     float* s_red = s_h;   // the four wave partials of the scalar loss reuse it after the last plane
-    const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
+    uint32_t bx, by, blin;
+    if (!loss_tile(a, bx, by, blin)) return;   // block-uniform
+    const int tx0 = (int)bx * TW, ty0 = (int)a.ty_base * LB + (int)by * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * TW + lx;
     const size_t plane = (size_t)a.h * a.w;
@@ -293,8 +322,8 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
     if ((rank & 63) == 0) s_red[rank >> 6] = acc;
     __syncthreads();
     if (rank < 2) {
-        const uint32_t tile_row = a.ty_base + 2u * blockIdx.y + (uint32_t)rank;
-        if (tile_row < gy) block_sums[(size_t)tile_row * gridDim.x + blockIdx.x] = s_red[2 * rank] + s_red[2 * rank + 1];
+        const uint32_t tile_row = a.ty_base + 2u * by + (uint32_t)rank;
+        if (tile_row < gy) block_sums[(size_t)tile_row * a.gx + bx] = s_red[2 * rank] + s_red[2 * rank + 1];
     }
 }
 
@@ -310,11 +339,10 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
     __shared__ float s_part[3][SR * SW];       // chain * (dmu1, dsigma1, dsigma12) of ONE colour plane
     __shared__ float s_h2[3][SR * H2P];
     // strip-wise loss: the launch covers pixel rows [row0, row1) (whole 16-row tile rows); blocks are 32 rows tall
-    const int tx0 = blockIdx.x * TW, ty0 = (int)a.ty_base * LB + blockIdx.y * TH;
     const int lx = threadIdx.x, ly = threadIdx.y;
     const int rank = ly * TW + lx;
     const size_t plane = (size_t)a.h * a.w;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {   // block-uniform
+    if (blockIdx.x == 0 && blockIdx.y == 0 && a.loss_out) {   // block-uniform (block 0 owns a tile in either mapping)
         __shared__ float s_w[4];
         float acc = 0.0f;
         for (int i = rank; i < a.sum_n; i += 256) acc += a.sum_src[i];
@@ -328,6 +356,9 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
             if (a.loss_host) a.loss_host[0] = total;
         }
     }
+    uint32_t bx, by, blin;
+    if (!loss_tile(a, bx, by, blin)) return;   // block-uniform
+    const int tx0 = (int)bx * TW, ty0 = (int)a.ty_base * LB + (int)by * TH;
     const int pxx = tx0 + lx;
     const int py[2] = {ty0 + 2 * ly, ty0 + 2 * ly + 1};
     // rows at or behind row_end belong to the next strip (the window ends on a 16-row boundary, blocks are 32 tall)
@@ -498,6 +529,7 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
     if (tile_y0 >= tile_y1) return set_error(ctx, BH_ERR_INVALID_ARG, "image loss: empty tile-row window");
     const uint32_t a0 = tile_y0 > 0 ? tile_y0 - 1 : 0, a1 = tile_y1 < gy ? tile_y1 + 1 : gy;  // pass A window
     const dim3 block(TW, 16);
+    const bool banded = ctx->knob_loss_bands != 0u && gx >= 16u;
     const size_t hw = (size_t)h * w;
     auto* partials = (float*)ensure(ctx, SLOT_LOSS_MAP, hw * 12 * sizeof(float));   // 9 floats per pixel used (the slot is shared with loss.hip's map)
     auto* block_sums = (float*)ensure(ctx, SLOT_MISC, (size_t)gx * gy * sizeof(float));
@@ -516,7 +548,10 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
         a.sum_src = nullptr; a.sum_n = 0; a.loss_out = nullptr; a.loss_host = nullptr;
         // (blocks are two tile rows tall: with an odd window the last block's lower half lies outside it — rows this rank may not
         //  have rendered — and its loss partial is not stored: the limit is the window's end a1, not the image's gy)
-        hipLaunchKernelGGL(loss_fused_forward_kernel, dim3(gx, (a1 - a0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a1, a);
+        a.gx = gx; a.gy_blocks = (a1 - a0 + 1) / 2;
+        a.band_w = banded ? (gx + 7u) / 8u : 0u;
+        const dim3 grid_a = banded ? dim3(8u * a.band_w * a.gy_blocks) : dim3(gx, a.gy_blocks);
+        hipLaunchKernelGGL(loss_fused_forward_kernel, grid_a, block, 0, ctx->stream, img_hwc4, gt, partials, block_sums, a1, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_forward_kernel");
     }
     {
@@ -528,7 +563,9 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
         a.sum_n = (int)((tile_y1 - tile_y0) * gx);
         a.loss_out = loss_out;
         a.loss_host = loss_host;
-        hipLaunchKernelGGL(loss_fused_backward_kernel, dim3(gx, (tile_y1 - tile_y0 + 1) / 2), block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
+        a.gy_blocks = (tile_y1 - tile_y0 + 1) / 2;
+        const dim3 grid_b = banded ? dim3(8u * a.band_w * a.gy_blocks) : dim3(gx, a.gy_blocks);
+        hipLaunchKernelGGL(loss_fused_backward_kernel, grid_b, block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
         BH_LAUNCH_CHECK(ctx, "loss_fused_backward_kernel");
     }
     return 0;
