@@ -65,7 +65,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "brush_amd/csrc"), "-I" + os.path.join(ROOT, "include"),
                                                                   os.path.join(ROOT, "brush_amd/csrc/rasterize.hip"), "-o", asm], stderr=subprocess.DEVNULL)
         text = open(asm).read().split("\n")
-    kernels = {"K16 rasterize_kernel<BWD_INFO=true, SMOOTH=false>": "_ZN2bh16rasterize_kernelILb1ELb0EEEv",
+    kernels = {"K16 rasterize_kernel<BWD_INFO=true, SMOOTH=false, PHASE=1>": "_ZN2bh16rasterize_kernelILb1ELb0ELi1EEEv",
                "K17 rasterize_backward_kernel<SMOOTH=false>": "_ZN2bh25rasterize_backward_kernelILb0EEEv"}
     for title, prefix in kernels.items():
         start = next(i for i, l in enumerate(text) if l.startswith(prefix) and ": ; @" in l)
