@@ -74,7 +74,9 @@ def main():
         vg = next((l.split()[-1] for l in text[end:end + 400] if "amdhsa_next_free_vgpr" in l), "?")
         print("=" * 100)
         print("%s   (%d lines of assembly, %s VGPRs)" % (title, len(body), vg))
-        inner = {k: v for k, v in loops(body).items() if k[1] == 2}
+        allloops = loops(body)
+        deepest = max(k[1] for k in allloops)   # the per-splat loops (K16: depth 2; K17: depth 3 since the two-segment loop of round 3)
+        inner = {k: v for k, v in allloops.items() if k[1] == deepest}
         for (lab, depth), ins in inner.items():
             hist = collections.Counter()
             ops = collections.Counter()
