@@ -361,6 +361,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     ctx->knob_update_late = getenv("BH_UPDATE_LATE") != nullptr;
+    ctx->knob_tile_sort_lsd = getenv("BH_TILE_SORT_LSD") != nullptr;
     if (const char* e = getenv("BH_LOSS_BANDS")) ctx->knob_loss_bands = (uint32_t)atoi(e);
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
     if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
@@ -846,6 +847,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     float* out_f32 = bwd_info ? (float*)out_img : nullptr;
     uint32_t* out_u8 = bwd_info ? nullptr : (uint32_t*)out_img;
 
+    bool offsets_done = false;   // the tile sort wrote the offsets table on its way
     if (nv > 0) {
         if (!fused_scan) {
             ProfScope ps(ctx, "PrefixSumGaussHits");
@@ -877,13 +879,19 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             {
                 ProfScope ps(ctx, "TileSort");
                 // (scratch sized for the whole list: the near list's length moves from frame to frame)
+                // host-known lengths: the sort that also writes the offsets table, four launches instead of seven (sort.hip)
+                if ((zcut_lists || !sliced) && tile_sort_supported(tile_bits, zcut_lists ? near_total : ni) && !ctx->knob_tile_sort_lsd) {
+                    BH_TRY(tile_sort_offsets(ctx, tile_ids, isect_gids, zcut_lists ? near_total : ni, tile_bits, num_tiles, tile_ids_sorted, isect_gids_sorted,
+                                             tile_offsets, ni));
+                    offsets_done = true;
+                } else
                 if (zcut_lists) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, near_total, nullptr, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
                 else if (sliced) BH_TRY(radix_argsort_dev(ctx, tile_ids, isect_gids, budget, slice_info + 1, nullptr, nullptr, tile_bits, tile_ids_sorted, isect_gids_sorted, ni));
                 else BH_TRY(radix_argsort(ctx, tile_ids, isect_gids, ni, tile_bits, tile_ids_sorted, isect_gids_sorted));
             }
         }
     }
-    {
+    if (!offsets_done) {
         ProfScope ps(ctx, "GetTileOffsets");   // K1 cleared the table (or a fill did, for n == 0)
         if (zcut_lists) BH_TRY(launch_tile_offsets(ctx, tile_ids_sorted, near_total, num_tiles, tile_offsets, /*pre_zeroed=*/true));
         else if (sliced) BH_TRY(launch_tile_offsets_dev(ctx, tile_ids_sorted, budget, slice_info + 1, nullptr, nullptr, num_tiles, tile_offsets));

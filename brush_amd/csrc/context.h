@@ -284,6 +284,7 @@ struct bh_ctx {
     uint32_t knob_fail_loss_at = 0;   // BH_TEST_FAIL_LOSS_AT: the k-th bh_train_step on this ctx returns BH_ERR_OOM between its forward and its loss (test hook)
     uint32_t train_steps_seen = 0;
     uint32_t knob_loss_bands = 1;     // BH_LOSS_BANDS=0 (A/B): the fused loss's blocks take their tiles row-major instead of by XCD column bands
+    bool knob_tile_sort_lsd = false;  // BH_TILE_SORT_LSD (A/B): the forward's tile sort as two LSD passes + the offsets kernel (rounds 1-4)
     bool knob_update_late = false;    // BH_UPDATE_LATE (A/B): the update kernel's sections fetch their own inputs at every SH degree
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
@@ -378,6 +379,11 @@ int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint3
 // (gate may be NULL); the result is written *out_base elements into out_keys / out_vals (out_base may be NULL).  Not in place.
 int radix_argsort_dev(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n_max, const uint32_t* n_dev, const uint32_t* gate,
                       const uint32_t* out_base, uint32_t bits, uint32_t* out_keys, uint32_t* out_vals, uint32_t alloc_n = 0);
+// sort.hip — the forward's tile sort AND its offsets table in four launches (high digit first, one block per bucket finishes);
+// bits in 9..16 and n <= 16 M (tile_sort_supported), the table zero on entry
+bool tile_sort_supported(uint32_t bits, uint32_t n);
+int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits, uint32_t num_tiles,
+                      uint32_t* out_keys, uint32_t* out_vals, uint32_t* tile_offsets, uint32_t alloc_n = 0);
 // depth_sort.hip — the forward's depth ordering: stable argsort of the depth keys + inclusive scan of the tile counts in that
 // order, four launches.  minmax: the second part of a counter set (K1).  cum == NULL: no scan.  rb_*: the first launch also adds
 // up counter set rb_set into the pinned host words rb_host (HOST_SUM_WORDS) and rb_done is recorded behind it.

@@ -361,6 +361,184 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The forward's tile sort + get_tile_offsets (render.rs:228-243, get_tile_offset.rs) in FOUR launches instead of seven.
+//
+// The (tile id, compact splat id) pairs arrive in depth order and leave grouped by tile, depth order kept.  As two LSD passes
+// plus the offsets kernel that is hist / row scan / scatter twice and one more launch: seven dependent launches of 5-18 us
+// for 20 MB.  Here the FIRST pass takes the HIGH digit (the three kernels above, stable): the pairs of one digit — a bucket of
+// 2^low_bits consecutive tiles — then sit together, still in depth order, and ONE block per bucket finishes the job without any
+// global table: it counts the bucket's pairs per tile and wave (a wave owns a contiguous part of the bucket), scans, writes the
+// tiles' [begin, end) rows of the offsets table — it knows them — and places every pair at
+//     bucket start + pairs of lower tiles + pairs of the same tile owned by earlier waves + rank inside the wave's part,
+// which is the stable order.  Ranking is the scatter kernel's (wave-wide digit matching, no LDS atomics).
+// ---------------------------------------------------------------------------
+constexpr int TB_WG = 1024;
+constexpr int TB_WAVES = TB_WG / 64;
+constexpr int TB_MAXBINS = 256;   // low_bits <= 8
+constexpr int TB_SLAB = 16;       // pairs per lane fetched ahead of the ranking steps
+
+__global__ __launch_bounds__(TB_WG) void tile_bucket_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                           const uint32_t* __restrict__ digit_totals, uint32_t low_bits, uint32_t num_tiles,
+                                                           uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals,
+                                                           uint32_t* __restrict__ tile_offsets) {
+    __shared__ uint32_t s_cnt[TB_WAVES][TB_MAXBINS];   // pairs per (wave, tile of the bucket) -> exclusive over the waves -> running
+    __shared__ uint32_t s_base[TB_MAXBINS];            // pairs of the bucket's lower tiles
+    __shared__ uint32_t s_red[TB_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t d = blockIdx.x;
+    // where the bucket starts: the pairs of all lower high digits (256 totals, left behind by the row scan)
+    {
+        uint32_t t = (tid < RADIX && (uint32_t)tid < d) ? digit_totals[tid] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) s_red[wave] = t;
+    }
+    for (int i = tid; i < TB_WAVES * TB_MAXBINS; i += TB_WG) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];   // (the totals live in the first four waves)
+    const uint32_t size = digit_totals[d];
+    if (size == 0u) return;   // block-uniform
+    const uint32_t bins = 1u << low_bits, low_mask = bins - 1u;
+    // the wave's contiguous part of the bucket, a multiple of 64 pairs except for the last one
+    const uint32_t per = ((size + TB_WAVES - 1u) / TB_WAVES + 63u) & ~63u;
+    const uint32_t lo = min(size, (uint32_t)wave * per), hi = min(size, lo + per);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto peers_of = [&](uint32_t b, bool valid) {
+        unsigned long long m = __ballot(valid);
+        for (uint32_t k = 0; k < low_bits; ++k) {
+            const unsigned long long bal = __ballot((b >> k) & 1u);
+            m &= ((b >> k) & 1u) ? bal : ~bal;
+        }
+        return m;
+    };
+    // ---- count: pairs per tile in this wave's part.  A slab of TB_SLAB x 64 pairs is fetched before the first one is looked at:
+    // a step is a chain of LDS round trips that cannot start before its key has arrived, so with a load per step the kernel was
+    // ten dependent global round trips per phase (31 us).  A typical part is ONE slab: its keys and values then stay in registers
+    // for the placement (one global round trip for the whole kernel); longer parts fetch their slabs again.
+    const bool one_slab = hi - lo <= 64u * TB_SLAB;   // wave-uniform
+    uint32_t kk[TB_SLAB], vv[TB_SLAB];
+    for (uint32_t s0 = lo; s0 < hi; s0 += 64u * TB_SLAB) {
+#pragma unroll
+        for (int k = 0; k < TB_SLAB; ++k) {
+            const uint32_t i = s0 + (uint32_t)k * 64u + (uint32_t)lane;
+            const uint32_t ic = start + (i < hi ? i : lo);   // (clamped, masked below)
+            kk[k] = keys[ic];
+            vv[k] = vals[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < TB_SLAB; ++k) {
+            const uint32_t i0 = s0 + (uint32_t)k * 64u;
+            if (i0 >= hi) break;   // wave-uniform
+            const bool valid = i0 + (uint32_t)lane < hi;
+            const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
+            const unsigned long long peers = peers_of(b, valid);
+            // (one wave runs in lock-step and its LDS operations retire in order: the leader of each group of equal tiles adds
+            //  the group's size to a counter only this wave touches)
+            if (valid && (peers & lt_mask) == 0ull) s_cnt[wave][b] += (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+    // ---- per tile: exclusive scan over the waves; exclusive scan of the tile totals over the bucket; the offsets table
+    uint32_t total = 0;
+    if ((uint32_t)tid < bins) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < TB_WAVES; ++w) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = run;
+            run += c;
+        }
+        total = run;
+    }
+    {
+        uint32_t incl = total;   // (threads >= bins contribute 0; bins <= 256 = the first four waves)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        __syncthreads();   // s_red was read above by every thread
+        if (lane == 63) s_red[wave] = incl;
+        __syncthreads();
+        uint32_t wofs = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wofs += (w < wave) ? s_red[w] : 0u;
+        if ((uint32_t)tid < bins) {
+            const uint32_t excl = incl - total + wofs;
+            s_base[tid] = excl;
+            const uint32_t tile = (d << low_bits) | (uint32_t)tid;
+            if (total != 0u && tile < num_tiles) {   // (an absent tile keeps the zeros the table was cleared to; sentinel ids have no row)
+                tile_offsets[tile * 2] = start + excl;
+                tile_offsets[tile * 2 + 1] = start + excl + total;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- place
+    for (uint32_t s0 = lo; s0 < hi; s0 += 64u * TB_SLAB) {
+        if (!one_slab) {
+#pragma unroll
+            for (int k = 0; k < TB_SLAB; ++k) {
+                const uint32_t i = s0 + (uint32_t)k * 64u + (uint32_t)lane;
+                const uint32_t ic = start + (i < hi ? i : lo);
+                kk[k] = keys[ic];
+                vv[k] = vals[ic];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TB_SLAB; ++k) {
+            const uint32_t i0 = s0 + (uint32_t)k * 64u;
+            if (i0 >= hi) break;   // wave-uniform
+            const bool valid = i0 + (uint32_t)lane < hi;
+            const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
+            const unsigned long long peers = peers_of(b, valid);
+            const uint32_t prior = s_cnt[wave][b];
+            if (valid) {
+                const uint32_t pos = start + s_base[b] + prior + (uint32_t)__popcll(peers & lt_mask);
+                out_keys[pos] = kk[k];
+                out_vals[pos] = vv[k];
+                if ((peers & lt_mask) == 0ull) s_cnt[wave][b] = prior + (uint32_t)__popcll(peers);
+            }
+        }
+    }
+}
+
+bool tile_sort_supported(uint32_t bits, uint32_t n) { return bits > 8u && bits <= 16u && n <= (16u << 20); }
+
+// keys = tile ids (< 2^bits, or the sentinel 0xFFFFFFFF), vals = compact splat ids, n pairs in depth order.  -> out_keys / out_vals
+// sorted by tile (stable) and tile_offsets[tile] = [begin, end) for every tile that has pairs (the table must be zero already).
+int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits, uint32_t num_tiles,
+                      uint32_t* out_keys, uint32_t* out_vals, uint32_t* tile_offsets, uint32_t alloc_n) {
+    if (!tile_sort_supported(bits, n)) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_sort_offsets: 9..16 key bits, at most 16 M pairs");
+    if (n == 0) return 0;
+    const uint32_t low_bits = bits - 8u, shift = low_bits, mask = 0xFFu;
+    uint32_t kpt = n <= SMALL_SORT_MAX ? 8u : 16u;
+    if (const uint32_t k = ctx->knob_sort_kpt) { if (k == 8 || k == 16) kpt = k; }
+    const uint32_t tile = SORT_WG * kpt;
+    const uint32_t nblocks = (n + tile - 1) / tile;
+    if (alloc_n < n) alloc_n = n;
+    const uint32_t alloc_blocks = (alloc_n + tile - 1) / tile;
+    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)RADIX * alloc_blocks + RADIX) * 4);
+    uint32_t* mid_k = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, (size_t)alloc_n * 4);
+    uint32_t* mid_v = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, (size_t)alloc_n * 4);
+    if (!totals || !mid_k || !mid_v) return BH_ERR_OOM;
+    uint32_t* hist = totals + RADIX;
+    const SortDyn none{};
+    const dim3 grid(nblocks), block(SORT_WG);
+    if (kpt == 8u) hipLaunchKernelGGL(radix_hist_kernel<8>, grid, block, 0, ctx->stream, keys, n, shift, mask, nblocks, hist, none);
+    else hipLaunchKernelGGL(radix_hist_kernel<16>, grid, block, 0, ctx->stream, keys, n, shift, mask, nblocks, hist, none);
+    BH_LAUNCH_CHECK(ctx, "radix_hist_kernel");
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX), dim3(SORT_WG), 0, ctx->stream, hist, nblocks, n, tile, totals, none);
+    BH_LAUNCH_CHECK(ctx, "radix_rowscan_kernel");
+    if (kpt == 8u) hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, ctx->stream, keys, vals, n, shift, mask, nblocks, hist, totals, mid_k, mid_v, none);
+    else hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, ctx->stream, keys, vals, n, shift, mask, nblocks, hist, totals, mid_k, mid_v, none);
+    BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
+    hipLaunchKernelGGL(tile_bucket_kernel, dim3(RADIX), dim3(TB_WG), 0, ctx->stream, mid_k, mid_v, totals, low_bits, num_tiles, out_keys, out_vals, tile_offsets);
+    BH_LAUNCH_CHECK(ctx, "tile_bucket_kernel");
+    return 0;
+}
+
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals) {
     return radix_argsort_impl(ctx, keys, vals, n, bits, out_keys, out_vals, SortDyn{});

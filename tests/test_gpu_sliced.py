@@ -483,7 +483,11 @@ def _grads_close(a, b, what):
     for k in ("v_transforms", "v_sh_coeffs", "v_raw_opacities", "v_refine_weight"):
         x, y = a[k].cpu().numpy().reshape(-1), b[k].cpu().numpy().reshape(-1)
         scale = max(float(np.abs(y).max()), 1e-20)
-        assert float(np.abs(x - y).max()) <= 5e-6 * scale, (what, k, float(np.abs(x - y).max()) / scale)   # the float atomics' order only
+        # the float atomics' order only.  (3e-5, not 5e-6: two FRESH contexts given the same call differ by up to 2.5e-6 of the
+        # largest gradient in one ill-conditioned element of op 110 — a sum of many pixel terms that nearly cancel — and a context
+        # with history by up to 7e-6 in the same element, both with complete lists; scripts/micro/grad_noise_probe.py measures
+        # 1e-7 .. 9e-7 for ordinary elements, with and without per-tile cuts.  A missing or doubled pair shows up at 1e-3 and more.)
+        assert float(np.abs(x - y).max()) <= 3e-5 * scale, (what, k, float(np.abs(x - y).max()) / scale)
 
 
 def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
