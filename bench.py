@@ -68,7 +68,9 @@ def stage_bytes(n, nv, ni, ni_blended, pixels, tiles, coeffs, list_share=1.0, gr
         "ProjectVisible": (84 + 12 * c) * nv,   # separate launch only for frames without intersections
         # K5 also gathers the records into depth order (the former K4) and clears the backward's v_combined
         "MapGaussiansToIntersect": 4 * nv + 76 * nv_l + 8 * ni_l + 40 * nv,
-        "TileSort": 40 * ni_l,
+        # high-digit pass (hist 4 + scatter 8 + 8) + the bucket kernel that finishes the order and writes the offsets table
+        # (8 + 8 per pair, 8 per tile); GetTileOffsets only exists as a launch of its own on the LSD path (BH_TILE_SORT_LSD, > 16 M pairs)
+        "TileSort": 36 * ni_l + 8 * tiles,
         "GetTileOffsets": 4 * ni_l + 8 * tiles,
         "Rasterize": 44 * ni_blended + 16 * pixels,
         # pass A: image + GT in, the nine SSIM-partial planes out; pass B: image + GT + the planes in (once: the halo re-read is
@@ -726,7 +728,7 @@ def main():
 
 
 KERNEL_STAGE = (("project_forward_kernel", "ProjectSplats"), ("dsort_", "DepthSort"), ("map_gaussians_kernel", "MapGaussiansToIntersect"),
-                ("slice_count_kernel", "MapGaussiansToIntersect"), ("radix_", "TileSort"), ("scan_", "MapGaussiansToIntersect"),
+                ("slice_count_kernel", "MapGaussiansToIntersect"), ("radix_", "TileSort"), ("tile_bucket_kernel", "TileSort"), ("scan_", "MapGaussiansToIntersect"),
                 ("tile_offsets_kernel", "GetTileOffsets"), ("rasterize_backward_kernel", "RasterizeBackwards"), ("rasterize_kernel", "Rasterize"),
                 ("loss_fused_forward_kernel", "ImageLoss"), ("loss_fused_backward_kernel", "ImageLossBackward"),
                 ("project_backward_kernel", "ProjectBackwards"), ("train_update_kernel", "OptimizerStep"), ("project_visible_kernel", "ProjectVisible"))
