@@ -206,12 +206,11 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
     const uint64_t sh_base = row0 * row_len;
-    // ---- everything else the block reads, issued before the first value is consumed.  The sections below are separated by
-    // barriers (marks and noise travel through LDS, the SH rows need their second moment first): with each section fetching its
-    // own inputs a block was a chain of five dependent global round trips, and the "streaming" kernel ran at 3.4 TB/s.
-    // EARLY only for the short blocks of SH degree >= 1 (64 / 128 splats: 1-2 + 4-5 float4 pairs per thread): update at degree 3
-    // 266 -> 241 us.  At degree 0 (256 splats per block, 12 + 6 float4s per thread = 112 VGPRs, half the blocks per CU) the same
-    // change cost 9 us: there the sections' own loads stay where they were.
+    // ---- the sections below are separated by barriers (marks and noise travel through LDS, the SH rows need their second moment
+    // first) and each fetches its own inputs: a block is a chain of dependent global round trips.  What shortened it (round 4):
+    // the per-splat section's eleven loads are unconditional and issued together, the transforms loop has a fixed trip count
+    // (unrolled: its loads leave together).  EARLY (S_IT_ > 0, BH_UPDATE_EARLY=1) goes further — every load of the block in front
+    // of the first barrier — and loses: see launch_train_update.
     constexpr bool EARLY = S_IT_ > 0;
     constexpr int T_IT = (ROWS * 10 / 4 + OPT_WG - 1) / OPT_WG;          // float4s of the block's transforms per thread
     constexpr int S_IT = S_IT_ > 0 ? S_IT_ : 1;                          // ... of its SH rows (launch_train_update's choice)
@@ -470,7 +469,10 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
                        g_o, st->refine_weight_norm, st->vis_weight, st->max_screen_size, refine_weight, visible, screen_radius, u)
     // float4s of a block's SH rows per thread: 1 (<= 1024 floats), 4 (128 x 27), 5 (64 x 75); 0 = no up-front loads
     const uint32_t sh_f4 = (rows * u.sh_len / 4u + OPT_WG - 1) / OPT_WG;
-    const bool early = vec && rows != 256u && !ctx->knob_update_late;
+    // (off by default: measured again with the store skipping and the fixed-trip loops in place, the sections' own loads win at
+    //  every degree — degree 3: 158 vs 209 us on the bench scene, 194 vs 233 us with every store forced — the 57 instead of 99
+    //  VGPRs are worth more than the shorter chain; BH_UPDATE_EARLY=1 selects the up-front loads)
+    const bool early = vec && rows != 256u && ctx->knob_update_early;
     if (rows == 256u) { if (vec) BH_LAUNCH_UPDATE(true, 256, 0); else BH_LAUNCH_UPDATE(false, 256, 0); }
     else if (rows == 128u) {
         if (!vec) BH_LAUNCH_UPDATE(false, 128, 0);
