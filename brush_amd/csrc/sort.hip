@@ -394,7 +394,7 @@ __global__ __launch_bounds__(TB_WG) void tile_bucket_kernel(const uint32_t* __re
         for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
         if (lane == 0) s_red[wave] = t;
     }
-    for (int i = tid; i < TB_WAVES * TB_MAXBINS; i += TB_WG) (&s_cnt[0][0])[i] = 0u;
+    for (int i = tid; i < TB_WAVES * TB_MAXBINS; i += TB_WG) (&s_cnt[0][0])[i] = 0u;   // (4 words per thread)
     __syncthreads();
     const uint32_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];   // (the totals live in the first four waves)
     const uint32_t size = digit_totals[d];
@@ -433,9 +433,9 @@ __global__ __launch_bounds__(TB_WG) void tile_bucket_kernel(const uint32_t* __re
             const bool valid = i0 + (uint32_t)lane < hi;
             const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
             const unsigned long long peers = peers_of(b, valid);
-            // (one wave runs in lock-step and its LDS operations retire in order: the leader of each group of equal tiles adds
-            //  the group's size to a counter only this wave touches)
-            if (valid && (peers & lt_mask) == 0ull) s_cnt[wave][b] += (uint32_t)__popcll(peers);
+            // (the leader of each group of equal tiles adds the group's size to a counter only this wave touches — an LDS atomic
+            //  WITHOUT return: nothing in the next step waits for it)
+            if (valid && (peers & lt_mask) == 0ull) atomicAdd(&s_cnt[wave][b], (uint32_t)__popcll(peers));
         }
     }
     __syncthreads();
@@ -493,12 +493,16 @@ __global__ __launch_bounds__(TB_WG) void tile_bucket_kernel(const uint32_t* __re
             const bool valid = i0 + (uint32_t)lane < hi;
             const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
             const unsigned long long peers = peers_of(b, valid);
-            const uint32_t prior = s_cnt[wave][b];
+            // the group's leader takes the running count with a RETURNING LDS atomic and hands it to its peers.  A wave's LDS
+            // operations execute in program order, so the steps stay in depth order — but no step's registers depend on the
+            // previous step's (a read followed by a write of read + n did: ten LDS round trips in a row per phase)
+            uint32_t prior = 0u;
+            if (valid && (peers & lt_mask) == 0ull) prior = atomicAdd(&s_cnt[wave][b], (uint32_t)__popcll(peers));
+            prior = (uint32_t)__shfl((int)prior, peers ? __ffsll((long long)peers) - 1 : 0);
             if (valid) {
                 const uint32_t pos = start + s_base[b] + prior + (uint32_t)__popcll(peers & lt_mask);
                 out_keys[pos] = kk[k];
                 out_vals[pos] = vv[k];
-                if ((peers & lt_mask) == 0ull) s_cnt[wave][b] = prior + (uint32_t)__popcll(peers);
             }
         }
     }
