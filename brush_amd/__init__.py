@@ -10,6 +10,7 @@ Names and argument meaning follow the reference (paths under
     render_splats     brush-render/src/gaussian_splats.rs:365-446 (forward / eval)
     render_splats_bwd brush-render/src/bwd/burn_glue.rs:223-311 (+ RenderBackwards::backward :121-182)
     radix_argsort     brush-sort/src/lib.rs:16
+    tile_sort_offsets render.rs:228-243 + get_tile_offset.rs:11-58 (the forward's tile sort and offsets table, one operator)
     prefix_sum        brush-prefix-sum/src/lib.rs:11
     image_loss        brush-loss/src/lib.rs:1075-1104
     splat_to_ply / load_splat_from_ply   brush-serde/src/export.rs:179-204, import.rs:166-330 (plain PLY)
@@ -21,7 +22,7 @@ computation runs in the hand-written HIP kernels. No CPU fallback exists.
 """
 from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
-    get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, render_splats,
+    get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, tile_sort_offsets, render_splats,
     render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
     splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader, set_list_slicing, last_list_counts, set_view_id,
 )

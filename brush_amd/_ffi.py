@@ -138,6 +138,7 @@ SYMBOLS = {
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
     "bh_last_render_out": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
     "bh_radix_argsort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bh_tile_sort_offsets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bh_prefix_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "bh_image_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_void_p]),
     "bh_image_loss_value_and_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(BhLossConfig), C.c_float, C.c_void_p, C.c_void_p]),

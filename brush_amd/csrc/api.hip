@@ -1239,6 +1239,23 @@ int bh_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, const
 
 }  // extern "C"
 
+extern "C" int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const uint32_t* compact_gids, uint32_t n, uint32_t num_tiles,
+                                    uint32_t* tile_ids_sorted, uint32_t* compact_gids_sorted, uint32_t* tile_offsets) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!tile_offsets || (n > 0 && (!tile_ids || !compact_gids || !tile_ids_sorted || !compact_gids_sorted)))
+        return set_error(ctx, BH_ERR_INVALID_ARG, "tile_sort_offsets: null argument");
+    if (num_tiles == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_sort_offsets: num_tiles == 0");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t bits = 0;
+    while (bits < 32 && (num_tiles >> bits) != 0) bits++;  // render.rs:228
+    BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, (size_t)num_tiles * 2 * 4, ctx->stream));
+    if (n == 0) return 0;
+    if (tile_sort_supported(bits, n) && !ctx->knob_tile_sort_lsd)
+        return tile_sort_offsets(ctx, tile_ids, compact_gids, n, bits, num_tiles, tile_ids_sorted, compact_gids_sorted, tile_offsets);
+    BH_TRY(radix_argsort(ctx, tile_ids, compact_gids, n, bits, tile_ids_sorted, compact_gids_sorted));
+    return launch_tile_offsets(ctx, tile_ids_sorted, n, num_tiles, tile_offsets, /*pre_zeroed=*/true);
+}
+
 extern "C" int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     const Buffer& s = ctx->slots[SLOT_GRADS];

@@ -545,6 +545,20 @@ def radix_argsort(keys, values=None, sorting_bits=32, ctx: Optional[Context] = N
     return ok, ov
 
 
+def tile_sort_offsets(tile_ids, compact_gids, num_tiles: int, ctx: Optional[Context] = None):
+    """The forward's tile sort + offsets table as one operator (render.rs:228-243 + get_tile_offset.rs:11-58): (tile id, compact
+    splat id) pairs in depth order -> (tile_ids_sorted, compact_gids_sorted, tile_offsets [num_tiles, 2]); stable."""
+    dev = tile_ids.device if isinstance(tile_ids, torch.Tensor) and tile_ids.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or get_context(dev)
+    k, v = _as_u32(tile_ids, dev), _as_u32(compact_gids, dev)
+    if k.dim() != 1 or v.shape != k.shape:
+        raise BrushHipError("tile_sort_offsets: tile ids and splat ids must be 1-D and of the same length")
+    ok, ov = torch.empty_like(k), torch.empty_like(k)
+    offs = torch.empty((int(num_tiles), 2), dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.bh_tile_sort_offsets(ctx._h, _ptr(k), _ptr(v), k.numel(), int(num_tiles), _ptr(ok), _ptr(ov), _ptr(offs)))
+    return ok, ov, offs
+
+
 def prefix_sum(x, ctx: Optional[Context] = None):
     """Inclusive u32 prefix sum (brush-prefix-sum/src/lib.rs:11)."""
     dev = x.device if isinstance(x, torch.Tensor) and x.is_cuda else torch.device("cuda", torch.cuda.current_device())

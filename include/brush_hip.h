@@ -242,6 +242,15 @@ int bh_radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, ui
                      uint32_t* out_keys, uint32_t* out_vals);
 /* Inclusive prefix sum (wrapping u32). in == out allowed. */
 int bh_prefix_sum(bh_ctx* ctx, const uint32_t* in, uint32_t n, uint32_t* out);
+/* The forward's tile sort and its offsets table as ONE operator — what render.rs:228-243 (radix_argsort of the tile ids, sorting
+ * bits = bits of num_tiles) followed by get_tile_offset.rs:11-58 produce: `n` (tile id, compact splat id) pairs in depth order ->
+ * the same pairs grouped by tile, depth order kept (stable), and tile_offsets[2 t .. 2 t + 1] = [begin, end) of tile t's run
+ * (0, 0 for a tile without pairs; the table is written entirely).  A tile id is < num_tiles or the reference's sentinel
+ * 0xFFFFFFFF (map_gaussians.rs:73-79): sentinel rows sort behind every tile and get no row.  All pointers device; inputs and outputs must not overlap.  bh_render_forward
+ * uses the same code: for 9..16 id bits and up to 16 M pairs that is four launches (high digit first, then one block per bucket
+ * of tiles finishes the order and writes the rows), otherwise the two LSD passes of bh_radix_argsort and an offsets kernel. */
+int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const uint32_t* compact_gids, uint32_t n, uint32_t num_tiles,
+                         uint32_t* tile_ids_sorted, uint32_t* compact_gids_sorted, uint32_t* tile_offsets /*[2 * num_tiles]*/);
 
 /* ---- image loss ------------------------------------------------------------ */
 typedef struct BhLossConfig {

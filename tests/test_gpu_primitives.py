@@ -135,3 +135,44 @@ def test_sort_argument_errors(dev):
         ba.radix_argsort(k, torch.zeros(9, dtype=torch.int32, device=dev), 32)
     with pytest.raises(ba.BrushHipError):
         ba.radix_argsort(k, None, 33)
+
+
+def _tile_sort_reference(keys, vals, num_tiles):
+    """numpy restatement of render.rs:228-243 + get_tile_offset.rs:11-58: stable sort by tile id, [begin, end) per tile (0, 0
+    for absent tiles); the reference's 0xFFFFFFFF sentinel rows sort last and get no row."""
+    idx = np.argsort(keys, kind="stable")
+    sk, sv = keys[idx], vals[idx]
+    offs = np.zeros((num_tiles, 2), np.uint32)
+    valid = sk[sk < num_tiles]
+    if valid.size:
+        tiles, first, counts = np.unique(valid, return_index=True, return_counts=True)
+        offs[tiles, 0] = first
+        offs[tiles, 1] = first + counts
+    return sk, sv, offs
+
+
+# (tiles, pairs): 9..16 id bits take the four-launch path (one bit .. eight low bits per bucket, buckets of one slab and of many,
+# empty buckets, a wave's last partial step), 130 tiles (8 bits) the two LSD passes + the offsets kernel
+@pytest.mark.parametrize("num_tiles,n", [(130, 5000), (256, 1), (256, 63), (300, 64), (300, 65), (1024, 40_000), (8160, 0), (8160, 3),
+                                          (8160, 300_000), (8160, 3_000_000), (32_640, 2_500_000), (65_535, 700_000)])
+@pytest.mark.parametrize("shape", ["uniform", "hot", "sentinels"])
+def test_tile_sort_offsets_matches_the_two_reference_steps(dev, num_tiles, n, shape):
+    """bh_tile_sort_offsets = radix_argsort on the tile ids + get_tile_offsets, bit for bit (order, stability, table), for uniform
+    tile ids, for lists in which a few tiles own most pairs (one bucket far longer than the others) and with sentinel rows."""
+    import brush_amd as ba
+    rng = np.random.default_rng(num_tiles * 7919 + n)
+    if shape == "hot":
+        hot = rng.integers(0, num_tiles, 5)
+        keys = np.where(rng.random(n) < 0.7, hot[rng.integers(0, 5, n)], rng.integers(0, num_tiles, n)).astype(np.uint32)
+    else:
+        keys = rng.integers(0, num_tiles, n).astype(np.uint32)
+    if shape == "sentinels" and n:
+        keys[rng.random(n) < 0.05] = 0xFFFFFFFF
+    vals = rng.integers(0, 2 ** 20, n).astype(np.uint32)   # (duplicates on purpose: stability shows in the order of equal tiles)
+    k = torch.from_numpy(keys.view(np.int32)).to(dev)
+    v = torch.from_numpy(vals.view(np.int32)).to(dev)
+    ok, ov, offs = ba.tile_sort_offsets(k, v, num_tiles)
+    rk, rv, roffs = _tile_sort_reference(keys, vals, num_tiles)
+    assert np.array_equal(util.u32(ok), rk)
+    assert np.array_equal(util.u32(ov), rv)
+    assert np.array_equal(util.u32(offs).reshape(-1, 2), roffs)
