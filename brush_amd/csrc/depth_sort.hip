@@ -27,10 +27,11 @@ namespace bh {
 constexpr int DS_WG = 256;
 constexpr int DS_WAVES = DS_WG / 64;
 #ifndef BH_DS_KPT
-#define BH_DS_KPT 16
+#define BH_DS_KPT 8   /* 16 until late in round 4: 2048-key chunks put twice the blocks on the chip for the histogram and the split
+                         (split 12.6 -> 9.8 us at 1 M splats, histogram + row scan +0.6); the fused path then reaches 8.4 M splats */
 #endif
 constexpr int DS_KPT = BH_DS_KPT;
-constexpr int DS_TILE = DS_WG * DS_KPT;   // 4096 keys per chunk
+constexpr int DS_TILE = DS_WG * DS_KPT;   // 2048 keys per chunk
 constexpr int DS_RADIX = 256;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
     if (cum != nullptr) bk_scan_counts(out_vals + start, size, counts, tiles_before, cum + start, &L.keys[0], s_red);
 }
 
-// Up to the row scan's reach (4096 chunks of 4096 keys); beyond it the generic sort + scan run.  (Until round 4 the limit was 4 M:
+// Up to the row scan's reach (4096 chunks of DS_TILE keys: 8.4 M splats); beyond it the generic sort + scan run.  (Until round 4 the limit was 4 M:
 // "the fused path pays off while launches, not bytes, are the cost".  With per-tile cuts only the listed sixth of the 6 M / 4K
 // scene's splats is moved at all: depth order + scan 255 -> 97 us there; with complete lists 306 -> 302.)
 #ifndef BH_DSORT_MAX_N
