@@ -10,6 +10,7 @@
 //   brush_hip::render_splats     brush-render/src/gaussian_splats.rs:365-446 -> (image, RenderAux)
 //   brush_hip::render_splats_bwd brush-render/src/bwd/burn_glue.rs:223-311   (+ RenderBackwards::backward :121-182)
 //   brush_hip::radix_argsort     brush-sort/src/lib.rs:16,  brush_hip::prefix_sum  brush-prefix-sum/src/lib.rs:11
+//   brush_hip::tile_sort_offsets render.rs:228-243 + kernels/get_tile_offset.rs:11-58
 //   brush_hip::SplatTrainer      brush-train/src/train.rs:140-893           (step, refine, set_view_cams)
 //   brush_hip::splat_to_ply / load_splat_from_ply   brush-serde/src/export.rs:179-204, import.rs:166-170
 //
@@ -293,6 +294,17 @@ inline void radix_argsort(const Context& ctx, const DeviceBuffer<uint32_t>& keys
     out_vals.resize(keys.size());
     ctx.check(bh_radix_argsort(ctx.get(), keys.data(), vals.data(), (uint32_t)keys.size(), bits, out_keys.data(), out_vals.data()));
     ctx.sync();  // the ctx owns a non-blocking stream: DeviceBuffer::download (default stream) must not overtake it
+}
+// the forward's tile sort and its offsets table as one operator (render.rs:228-243 + kernels/get_tile_offset.rs:11-58)
+inline void tile_sort_offsets(const Context& ctx, const DeviceBuffer<uint32_t>& tile_ids, const DeviceBuffer<uint32_t>& compact_gids, uint32_t num_tiles,
+                              DeviceBuffer<uint32_t>& tile_ids_sorted, DeviceBuffer<uint32_t>& compact_gids_sorted, DeviceBuffer<uint32_t>& tile_offsets) {
+    if (tile_ids.size() != compact_gids.size()) throw Error(BH_ERR_INVALID_ARG, "tile ids and splat ids must have the same number of elements");
+    tile_ids_sorted.resize(tile_ids.size());
+    compact_gids_sorted.resize(tile_ids.size());
+    tile_offsets.resize((size_t)num_tiles * 2);
+    ctx.check(bh_tile_sort_offsets(ctx.get(), tile_ids.data(), compact_gids.data(), (uint32_t)tile_ids.size(), num_tiles, tile_ids_sorted.data(),
+                                   compact_gids_sorted.data(), tile_offsets.data()));
+    ctx.sync();
 }
 inline void prefix_sum(const Context& ctx, const DeviceBuffer<uint32_t>& in, DeviceBuffer<uint32_t>& out) {
     out.resize(in.size());

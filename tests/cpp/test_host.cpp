@@ -161,6 +161,26 @@ static void test_primitives(const bh::Context& ctx) {
         std::vector<uint32_t> ref(n);
         std::partial_sum(small.begin(), small.end(), ref.begin());
         CHECK(dout.download() == ref, "prefix_sum n=%u", n);
+        // the forward's tile sort + offsets table as one operator (render.rs:228-243 + get_tile_offset.rs:11-58)
+        const uint32_t num_tiles = 8160;
+        std::vector<uint32_t> tiles(n);
+        for (uint32_t i = 0; i < n; ++i) tiles[i] = (uint32_t)(r.next() % num_tiles);
+        bh::DeviceBuffer<uint32_t> dt(tiles), dg(vals), st, sg, offs;
+        bh::tile_sort_offsets(ctx, dt, dg, num_tiles, st, sg, offs);
+        std::vector<uint32_t> tidx(n);
+        std::iota(tidx.begin(), tidx.end(), 0u);
+        std::stable_sort(tidx.begin(), tidx.end(), [&](uint32_t a, uint32_t b) { return tiles[a] < tiles[b]; });
+        std::vector<uint32_t> roffs((size_t)num_tiles * 2, 0u);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t t = tiles[tidx[i]];
+            if (i == 0 || tiles[tidx[i - 1]] != t) roffs[2 * t] = i;
+            roffs[2 * t + 1] = i + 1;
+        }
+        const auto gt = st.download();
+        const auto gg = sg.download();
+        bool tsame = offs.download() == roffs;
+        for (uint32_t i = 0; i < n; ++i) tsame = tsame && gg[i] == tidx[i] && gt[i] == tiles[tidx[i]];
+        CHECK(tsame, "tile_sort_offsets n=%u", n);
     }
     std::printf("ok primitives\n");
 }
