@@ -41,3 +41,31 @@ def test_gpus_2_on_a_box_without_two_devices_fails_loudly():
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "1"], {"BH_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_every_profiled_library_kernel_belongs_to_a_bench_stage():
+    """bench.py sums the child run's kernel times by stage through KERNEL_STAGE's name fragments.  A kernel that matches none of them
+    silently drops out of `stages` and `kernel_ms_per_step` (round 4: the new tile_bucket_kernel did, 25 us of the tile sort).  Every
+    `bh::` kernel in the committed traces of the latest round must match a fragment."""
+    import csv
+    import glob
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    block = re.search(r"KERNEL_STAGE = \((.*?)\)\)\n", src, re.S).group(0)
+    keys = re.findall(r'\("([A-Za-z_0-9<>]+)", "[A-Za-z]+"\)', block)
+    assert len(keys) >= 10
+    traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats*.csv")))
+    assert traces, "no committed kernel trace"
+    latest = max(int(re.search(r"/r(\d+)", t).group(1)) for t in traces)
+    unmatched = set()
+    for t in traces:
+        if int(re.search(r"/r(\d+)", t).group(1)) != latest:
+            continue
+        for row in csv.DictReader(open(t)):
+            name = row["Name"]
+            if not name.startswith(("void bh::", "bh::")):
+                continue
+            short = name.replace("void bh::", "").replace("bh::", "").split("(")[0]
+            if not any(k in short for k in keys):
+                unmatched.add(short)
+    assert not unmatched, unmatched
