@@ -133,7 +133,6 @@ SYMBOLS = {
     "bh_set_list_cut_threshold": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
-    "bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
     "bh_last_render_out": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
@@ -184,31 +183,47 @@ ABI_VERSION = 5   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were
 STRUCT_MIRRORS = (BhCamera, BhRenderOut, BhLossConfig, BhTrainConfig, BhTrainState, BhTrainBatch, BhTrainStats, BhRefineConfig, BhRefineStats, BhPlyInfo)
 
 _lib = None
+_lib_th = None
+# the test suite's fault-injection build (csrc/Makefile, -DBH_TEST_HOOKS): never loaded by product code
+TEST_HOOKS_LIB_PATH = os.path.join(_DIR, "libbrush_hip_testhooks.so")
+TEST_HOOK_SYMBOLS = {"bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32])}
 
 
 class BrushHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load libbrush_hip.so and bind every declared symbol. Raises if the library is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _bind(path, symbols):
+    if not os.path.exists(path):
         raise BrushHipError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in symbols.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     # ABI guard: the library fills these structs with ITS layout; a mirror of another revision would be overrun
     if lib.bh_abi_version() != ABI_VERSION:
-        raise BrushHipError("%s speaks ABI %d, this binding ABI %d" % (LIB_PATH, lib.bh_abi_version(), ABI_VERSION))
+        raise BrushHipError("%s speaks ABI %d, this binding ABI %d" % (path, lib.bh_abi_version(), ABI_VERSION))
     for i, mirror in enumerate(STRUCT_MIRRORS):
         if lib.bh_struct_size(i) != C.sizeof(mirror):
-            raise BrushHipError("%s: sizeof(%s) is %d in the library, %d in this binding" % (LIB_PATH, mirror.__name__, lib.bh_struct_size(i), C.sizeof(mirror)))
-    _lib = lib
+            raise BrushHipError("%s: sizeof(%s) is %d in the library, %d in this binding" % (path, mirror.__name__, lib.bh_struct_size(i), C.sizeof(mirror)))
     return lib
+
+
+def load():
+    """Load libbrush_hip.so and bind every declared symbol. Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(LIB_PATH, SYMBOLS)
+    return _lib
+
+
+def load_test_hooks():
+    """TESTS ONLY: the fault-injection build of the same sources (a second, independent copy of the library in the process);
+    pass it to Context(lib=...)."""
+    global _lib_th
+    if _lib_th is None:
+        _lib_th = _bind(TEST_HOOKS_LIB_PATH, dict(SYMBOLS, **TEST_HOOK_SYMBOLS))
+    return _lib_th

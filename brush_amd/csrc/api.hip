@@ -348,13 +348,15 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
     ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
     ctx->knob_zero_grads = getenv("BH_TRAIN_ZERO_GRADS") != nullptr;
+#ifdef BH_TEST_HOOKS   // libbrush_hip_testhooks.so only (csrc/Makefile): the shipping library neither reads these nor exports the hook below
     ctx->knob_break_allreduce = getenv("BH_BREAK_ALLREDUCE") != nullptr;
-    if (ctx->knob_break_allreduce)   // a test hook (bench.py's exchange self-check must catch it): never silent
+    if (ctx->knob_break_allreduce)   // (bench.py's exchange self-check must catch it): never silent
         fprintf(stderr, "brush_hip: BH_BREAK_ALLREDUCE is set - every all-reduce of this context's communicator is deliberately CORRUPTED (test hook)\n");
-    if (const char* e = getenv("BH_TEST_FAIL_LOSS_AT")) {   // test hook (tests/test_gpu_sliced.py): the k-th train step on this ctx fails between its forward and its loss
+    if (const char* e = getenv("BH_TEST_FAIL_LOSS_AT")) {   // (tests/test_gpu_sliced.py): the k-th train step on this ctx fails between its forward and its loss
         ctx->knob_fail_loss_at = (uint32_t)atoi(e);
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
+#endif
     if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
     ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
     ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
@@ -1256,6 +1258,7 @@ extern "C" int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const
     return launch_tile_offsets(ctx, tile_ids_sorted, n, num_tiles, tile_offsets, /*pre_zeroed=*/true);
 }
 
+#ifdef BH_TEST_HOOKS
 extern "C" int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     const Buffer& s = ctx->slots[SLOT_GRADS];
@@ -1264,11 +1267,37 @@ extern "C" int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern) {
     BH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.ptr), (int)pattern, s.cap / 4, ctx->stream));
     return 0;
 }
+#endif
 
 // ---- training step -------------------------------------------------------------
+static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
+                           bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats);
+
 extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
                              bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats) {
     if (!ctx) return BH_ERR_INVALID_ARG;
+    const int rc = train_step_impl(ctx, cfg, st, batch, hook, hook_user, grad_scale, stats);
+    if (rc != 0) {
+        // A step that fails behind its forward must not leave a deferred far-slice decision behind: the job holds the CALLER's
+        // parameter pointers (a per-tile-cut job replays the whole forward from them) and the caller is free to release or
+        // re-allocate them after a failed step (a refine changes n and every buffer).  Drop it; the frame it belonged to is
+        // incomplete, so nothing may be replayed from it either, and the view's next frame is rendered with complete lists.
+        if (ctx->far_job.pending) {
+            ctx->far_job.pending = false;
+            if (ctx->far_job.by_cut && ctx->far_job.view && ctx->far_job.view->exact_frames == 0u) ctx->far_job.view->exact_frames = 1u;
+        }
+        ctx->far_job.view = nullptr;
+        ctx->have_forward = false;
+        ctx->ext_visible = nullptr; ctx->ext_max_radius = nullptr; ctx->ext_visible_floats = 0;
+        ctx->ext_grad_begin = nullptr; ctx->ext_grad_floats = 0;
+        ctx->grad_rows_marked = false;
+        ctx->defer_far = false;
+    }
+    return rc;
+}
+
+static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* st, const BhTrainBatch* batch,
+                           bh_grad_hook hook, void* hook_user, float grad_scale, BhTrainStats* stats) {
     if (!cfg || !st || !batch || !stats) return set_error(ctx, BH_ERR_INVALID_ARG, "train_step: null argument");
     if (!st->transforms || !st->sh_coeffs || !st->raw_opacities || !st->m1_transforms || !st->m2_transforms || !st->m1_sh ||
         !st->m2_sh || !st->m1_opac || !st->m2_opac || !st->refine_weight_norm || !st->vis_weight || !st->max_screen_size ||
@@ -1383,8 +1412,10 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         }
         return launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host);
     };
+#ifdef BH_TEST_HOOKS
     if (ctx->knob_fail_loss_at && ++ctx->train_steps_seen == ctx->knob_fail_loss_at)   // (the forward is queued, a deferred far slice may be pending)
         return set_error(ctx, BH_ERR_OOM, "train_step: injected failure between the forward and the loss (BH_TEST_FAIL_LOSS_AT)");
+#endif
     // A view whose forecast keeps missing (two of its last eight cut frames) decides FIRST — the host waits for the near pass's blend,
     // ~15 us of bubble — instead of queueing loss kernels that a second attempt would make worthless (~120 us).  One isolated miss
     // does not switch: eight bubbles cost more than the one wasted loss they would insure against at a 3 % miss rate.

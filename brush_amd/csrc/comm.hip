@@ -66,9 +66,11 @@ static int rccl_check(bh_ctx* ctx, int rc, const char* what) {
     return set_error(ctx, BH_ERR_HIP, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(rc) : "RCCL error"));
 }
 
-// BH_BREAK_ALLREDUCE (developer knob, read once at bh_create): corrupt every all-reduce's first element — exists so that
+#ifdef BH_TEST_HOOKS
+// BH_BREAK_ALLREDUCE (test-hook build only, read once at bh_create): corrupt every all-reduce's first element — exists so that
 // bench.py's pre-timing self-check of the exchange path can be shown to catch a broken collective (tests/test_gpu_bench_selfcheck.py)
 __global__ void break_allreduce_kernel(float* buf) { buf[0] += 1.0f; }
+#endif
 
 int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op) {
     if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
@@ -77,7 +79,9 @@ int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op) {
     if (ctx->comm_world > 1)   // (one rank: nothing to exchange)
         rc = rccl_check(ctx, rccl().AllReduce(buf, buf, (size_t)count, RCCL_FLOAT32, max_op ? RCCL_MAX : RCCL_SUM, (RcclComm)ctx->comm, ctx->stream),
                         "ncclAllReduce");
+#ifdef BH_TEST_HOOKS
     if (rc == 0 && ctx->knob_break_allreduce) hipLaunchKernelGGL(break_allreduce_kernel, dim3(1), dim3(1), 0, ctx->stream, buf);
+#endif
     return rc;
 }
 

@@ -25,8 +25,9 @@ class Context:
     """One bh_ctx: a HIP stream + scratch arena. Single-threaded by contract
     (brush-async/src/lib.rs:1-17); make one per thread / per GPU."""
 
-    def __init__(self, device=None, use_torch_stream=True):
-        self.lib = _ffi.load()
+    def __init__(self, device=None, use_torch_stream=True, lib=None):
+        # lib: tests only — the fault-injection build (_ffi.load_test_hooks()); everything a Context does goes through self.lib
+        self.lib = lib if lib is not None else _ffi.load()
         if not torch.cuda.is_available():
             raise BrushHipError("no HIP device visible: brush_amd has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)

@@ -444,9 +444,13 @@ void bh_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg /*host*/, BhTrainState* state /*host*/,
                   const BhTrainBatch* batch /*host*/, bh_grad_hook hook, void* hook_user, float grad_scale,
                   BhTrainStats* stats /*host*/);
-/* Tests: overwrite that scratch buffer with a 32-bit pattern (e.g. a NaN) on the ctx stream — a step that then still
- * produces the zero-filling step's results has not read a row it did not write.  BH_ERR_STATE before the first step. */
+#ifdef BH_TEST_HOOKS
+/* NOT part of the shipping library: exported only by libbrush_hip_testhooks.so (built with -DBH_TEST_HOOKS, csrc/Makefile), which
+ * also reads the fault-injection variables BH_BREAK_ALLREDUCE and BH_TEST_FAIL_LOSS_AT.  Overwrites the step's gradient scratch
+ * with a 32-bit pattern (e.g. a NaN) on the ctx stream — a step that then still produces the zero-filling step's results has not
+ * read a row it did not write.  BH_ERR_STATE before the first step. */
 int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern);
+#endif
 
 /* ---- refine (densify / prune) ------------------------------------------------ */
 /* SplatTrainer::refine (brush-train/src/train.rs:431-893) in two calls, because the caller

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "brush_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef BH_TEST_HOOKS.*?#endif", "", src, flags=re.S)   # declared for the test-hook build only
     names = set(re.findall(r"\b(bh_[a-z_0-9]+)\s*\(", src))
     names.discard("bh_grad_hook")
     return names
@@ -26,6 +27,23 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.bh_version().startswith(b"brush_hip")
+
+
+def test_shipping_library_carries_no_test_hooks():
+    """fault injection (bh_debug_fill_train_scratch, BH_BREAK_ALLREDUCE, BH_TEST_FAIL_LOSS_AT) is compiled
+    only into libbrush_hip_testhooks.so (-DBH_TEST_HOOKS); the product neither exports the hook nor mentions the variables."""
+    import ctypes
+    import __graft_entry__ as g
+    g.build()
+    from brush_amd import _ffi
+    lib = _ffi.load()
+    with pytest.raises(AttributeError):
+        getattr(lib, "bh_debug_fill_train_scratch")
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"BH_BREAK_ALLREDUCE" not in blob and b"BH_TEST_FAIL_LOSS_AT" not in blob
+    th = ctypes.CDLL(_ffi.TEST_HOOKS_LIB_PATH)
+    assert th.bh_debug_fill_train_scratch is not None
+    assert b"BH_TEST_FAIL_LOSS_AT" in open(_ffi.TEST_HOOKS_LIB_PATH, "rb").read()
 
 
 def test_camera_setup_matches_oracle_host_math():

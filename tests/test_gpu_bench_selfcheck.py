@@ -37,7 +37,8 @@ def test_selfcheck_passes_and_is_recorded():
 
 
 def test_a_broken_allreduce_is_caught_and_the_run_falls_back():
-    line, err = _bench({"BH_BREAK_ALLREDUCE": "1"})
+    # fault injection lives in the -DBH_TEST_HOOKS build only; BRUSH_HIP_LIB points the bench's binding at it
+    line, err = _bench({"BH_BREAK_ALLREDUCE": "1", "BRUSH_HIP_LIB": os.path.join(ROOT, "brush_amd", "libbrush_hip_testhooks.so")})
     sc = line["exchange"]["selfcheck"]
     assert sc["native"].startswith("FAILED") and "all-reduce of" in sc["native"]
     assert sc["torch"] == "ok" and sc["timed_path"] == "torch" and line["exchange"]["comm"] == "torch"

@@ -36,7 +36,9 @@ def _run(ba, dev, zero_fill, sc, cams, gt, sh_degree, mip, min_scale_views, step
     else:
         os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
     try:
-        ctx = ba.Context(dev)   # the knob is read once, at bh_create
+        # the knob is read once, at bh_create.  The NaN fill is a test hook: only the -DBH_TEST_HOOKS build exports it
+        from brush_amd import _ffi
+        ctx = ba.Context(dev, lib=_ffi.load_test_hooks() if poison else None)
     finally:
         os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
     cfg = ba.TrainConfig()
@@ -115,7 +117,7 @@ def test_masked_and_exchange_steps_alternate(dev):
         if not alternate:
             os.environ["BH_TRAIN_ZERO_GRADS"] = "1"
         try:
-            ctx = ba.Context(dev)
+            ctx = ba.Context(dev, lib=_ffi.load_test_hooks() if alternate else None)   # (the NaN fill is a test hook)
         finally:
             os.environ.pop("BH_TRAIN_ZERO_GRADS", None)
         trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx, seed=99, sparse_exchange=False)

@@ -613,9 +613,10 @@ def test_a_step_that_fails_behind_its_near_slice_leaves_the_ctx_usable(dev):
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
     cam = util.hip_camera(ba, synth.default_camera_params(w, h))
     bg = (0.1, 0.2, 0.3)
+    from brush_amd import _ffi
     os.environ["BH_TEST_FAIL_LOSS_AT"] = "3"
     try:
-        A = ba.Context(dev)
+        A = ba.Context(dev, lib=_ffi.load_test_hooks())   # (fault injection exists in the -DBH_TEST_HOOKS build only)
     finally:
         del os.environ["BH_TEST_FAIL_LOSS_AT"]
     F = ba.Context(dev)
@@ -644,6 +645,65 @@ def test_a_step_that_fails_behind_its_near_slice_leaves_the_ctx_usable(dev):
         cfg = ba.TrainConfig()
         util.assert_adam_close(runs["A"][2][:, 3:7], runs["F"][2][:, 3:7], cfg.lr_rotation, 4, "rotation")
         util.assert_adam_close(runs["A"][3], runs["F"][3], cfg.lr_opac, 4, "opacity")
+    finally:
+        A.close()
+        F.close()
+
+
+def test_a_failed_step_drops_its_per_tile_cut_job_and_never_replays_freed_parameters(dev):
+    """a per-tile-cut frame whose far decision is still pending when bh_train_step fails keeps the CALLER's
+    parameter pointers in its job; collecting that job later (bh_sync, the next forward) replayed a whole forward from them — a
+    device use-after-free once the caller has released the tensors (a refine does).  The failing step must drop the job: nothing is
+    replayed (bh_far_slices_queued does not move), and the ctx then trains a DIFFERENT scene exactly like a fresh ctx."""
+    import os
+    import brush_amd as ba
+    from brush_amd import _ffi
+    n, w, h = 30000, 320, 208
+    sc, cp = _scene(n, w, h, 0x5B, scales=(0.03, 0.3), sh_degree=0)
+    cam = util.hip_camera(ba, cp)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+    bg = (0.1, 0.2, 0.3)
+    os.environ["BH_TEST_FAIL_LOSS_AT"] = "3"
+    try:
+        A = ba.Context(dev, lib=_ffi.load_test_hooks())
+    finally:
+        del os.environ["BH_TEST_FAIL_LOSS_AT"]
+    F = ba.Context(dev)
+    try:
+        tr = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=A)
+        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+        for _ in range(2):   # seed the view's table, then one cut frame
+            tr.step(ba.SceneBatch(gt, cam, view_id=5), spl, background=bg)
+        assert float(A.lib.bh_last_list_share(A._h)) < 1.0, "step 2 should have run with per-tile cut lists"
+        # step 3: every splat turns nearly transparent (the forecast WILL fail: live tiles behind cut lists) and the step fails behind
+        # its forward, with the decision pending
+        thin = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"] - 4.0, device=dev)
+        q0 = int(A.lib.bh_far_slices_queued(A._h))
+        with pytest.raises(ba.BrushHipError, match="injected failure"):
+            tr.step(ba.SceneBatch(gt, cam, view_id=5), thin, background=bg)
+        assert tr.step_count == 2
+        # the caller releases the parameters and poisons the memory they lived in (the caching allocator hands it out again)
+        thin.transforms.fill_(float("nan")); thin.sh_coeffs.fill_(float("nan")); thin.raw_opacities.fill_(float("nan"))
+        del thin
+        A.sync()
+        assert int(A.lib.bh_far_slices_queued(A._h)) == q0, "the dropped job must not be replayed"
+        # a different scene (other n) on the same ctx == a fresh ctx
+        sc2, _ = _scene(20000, w, h, 0x77, scales=(0.03, 0.3), sh_degree=0)
+        outs = {}
+        for key, ctx in (("A", A), ("F", F)):
+            s2 = ba.Splats(sc2["transforms"].copy(), sc2["sh"].copy(), sc2["raw_opac"].copy(), device=dev)
+            t2 = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx)
+            losses = []
+            for k in range(3):
+                t2.step(ba.SceneBatch(gt, cam, view_id=5), s2, background=bg)
+                losses.append(t2.stats(ctx).loss)
+            img, _ = ba.render_splats(s2, cam, (w, h), bg, ba.RasterPass.Backward, ctx=ctx, sliced=True)
+            outs[key] = (losses, s2.transforms.cpu().numpy(), s2.raw_opacities.cpu().numpy(), img)
+        assert all(np.isfinite(x) for x in outs["A"][0])
+        assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(outs["A"][0], outs["F"][0]))
+        cfg = ba.TrainConfig()
+        util.assert_adam_close(outs["A"][1][:, 3:7], outs["F"][1][:, 3:7], cfg.lr_rotation, 3, "rotation")
+        util.assert_adam_close(outs["A"][2], outs["F"][2], cfg.lr_opac, 3, "opacity")
     finally:
         A.close()
         F.close()
