@@ -155,6 +155,8 @@ def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args
     def run_path(use_native):
         ones = torch.ones(4096, device=dev)
         if use_native:
+            # every RCCL entry point the library binds (all-reduce SUM / MAX, all-gather, grouped send / recv), checked inside the library
+            ctx.comm_selftest()
             ctx.allreduce_sum(ones)
         else:
             dist.all_reduce(ones)
@@ -193,8 +195,8 @@ def exchange_selfcheck(ba, synth, torch, ctx, dev, pg, rank, world, native, args
     rec = {"world": world, "scene": "%d splats, %dx%d, 2 steps per path" % (n, w, h)}
     results = {}
     for name, use_native in (("native", True), ("torch", False)):
-        if use_native and (not native or tile_mode):
-            rec[name] = "not available" if not tile_mode else "not used (tile partition exchanges through the hooks)"
+        if use_native and not native:
+            rec[name] = "not available"
             continue
         try:
             results[name] = run_path(use_native)
@@ -312,7 +314,7 @@ def main():
     ctx = ba.get_context(dev)
     if args.near_share > 0:
         ba.set_list_slicing(args.near_share, ctx)
-    native = args.comm == "native" and not tile_mode and pg is not None
+    native = args.comm == "native" and pg is not None   # (tiles: the library also exchanges the strips' halos itself)
     if native:
         import threading
         import torch.distributed as dist

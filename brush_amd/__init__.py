@@ -9,6 +9,7 @@ Names and argument meaning follow the reference (paths under
     RasterPass        brush-render/src/gaussian_splats.rs:28-48
     render_splats     brush-render/src/gaussian_splats.rs:365-446 (forward / eval)
     render_splats_bwd brush-render/src/bwd/burn_glue.rs:223-311 (+ RenderBackwards::backward :121-182)
+    render_splats_diff / RenderNode   the same as an autodiff node: forward now, backward later from its SAVED state (burn_glue.rs:336-371)
     radix_argsort     brush-sort/src/lib.rs:16
     tile_sort_offsets render.rs:228-243 + get_tile_offset.rs:11-58 (the forward's tile sort and offsets table, one operator)
     prefix_sum        brush-prefix-sum/src/lib.rs:11
@@ -25,5 +26,6 @@ from .host import (  # noqa: F401
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, tile_sort_offsets, render_splats,
     render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
     splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader, set_list_slicing, last_list_counts, set_view_id,
+    render_splats_diff, RenderNode,
 )
 from ._ffi import BrushHipError  # noqa: F401

@@ -46,7 +46,12 @@ class BhRenderOut(C.Structure):
         ("global_from_compact_gid", C.c_void_p), ("cum_tiles_hit", C.c_void_p),
         ("intersect_counts", C.c_void_p), ("depths_sorted", C.c_void_p),
         ("tile_offsets_far", C.c_void_p), ("list_budget", C.c_uint32), ("num_listed_splats", C.c_uint32),
+        ("generation", C.c_uint64),
     ]
+
+
+class BhHaloOp(C.Structure):
+    _fields_ = [("send", C.c_int32), ("peer", C.c_int32), ("row_begin_px", C.c_uint32), ("rows", C.c_uint32)]
 
 
 class BhLossConfig(C.Structure):
@@ -134,6 +139,9 @@ SYMBOLS = {
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
+    "bh_render_backward_saved": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)] + [C.c_void_p] * 8),
+    "bh_render_retain": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
+    "bh_render_release": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
     "bh_last_v_combined": (C.c_void_p, [C.c_void_p]),
     "bh_last_render_out": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
     "bh_radix_argsort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -170,6 +178,10 @@ SYMBOLS = {
     "bh_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_allreduce_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bh_comm_rank": (C.c_int, [C.c_void_p]),
+    "bh_comm_selftest": (C.c_int, [C.c_void_p]),
+    "bh_strip_halo_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "bh_exchange_strip_halos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "bh_train_step": (C.c_int, [C.c_void_p, C.POINTER(BhTrainConfig), C.POINTER(BhTrainState), C.POINTER(BhTrainBatch), C.c_void_p, C.c_void_p, C.c_float, C.POINTER(BhTrainStats)]),
     "bh_sample_background": (None, [C.c_uint64, C.c_uint32, fp, C.c_float, fp]),
     "bh_normal_samples": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p]),
@@ -178,7 +190,7 @@ SYMBOLS = {
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
 }
 
-ABI_VERSION = 5   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
+ABI_VERSION = 6   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
 # bh_struct_size index -> mirror (the BH_STRUCT_* order of the header)
 STRUCT_MIRRORS = (BhCamera, BhRenderOut, BhLossConfig, BhTrainConfig, BhTrainState, BhTrainBatch, BhTrainStats, BhRefineConfig, BhRefineStats, BhPlyInfo)
 

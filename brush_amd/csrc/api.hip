@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -57,6 +58,17 @@ void* ensure(bh_ctx* ctx, Slot s, size_t bytes) {
         (void)hipFree(b.ptr);
         b.ptr = nullptr;
         b.cap = 0;
+    }
+    // a block handed back by bh_render_release (the smallest one that fits, at most 2x too large)
+    {
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); ++i)
+            if (ctx->pool[i].cap >= bytes && ctx->pool[i].cap <= 2 * bytes + 4096 && (best < 0 || ctx->pool[i].cap < ctx->pool[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) {
+            b = ctx->pool[(size_t)best];
+            ctx->pool.erase(ctx->pool.begin() + best);
+            return b.ptr;
+        }
     }
     size_t cap = bytes + bytes / 4;  // head-room so slowly growing scenes do not realloc every step
     cap = (cap + 255) & ~(size_t)255;
@@ -191,33 +203,63 @@ int enqueue_far_slice(bh_ctx* ctx, const FarJob& j) {
     return 0;
 }
 
-// The per-tile depth-cut table of view `id` for a (tile_bw x tile_bh) grid: created (all ZCUT_ALL = "list everything") on first
-// use, re-created when the grid changes, the least recently used one evicted beyond MAX_VIEW_STATES.
-static ViewState* view_state(bh_ctx* ctx, uint32_t id, uint32_t tile_bw, uint32_t tile_bh) {
-    auto it = ctx->views.find(id);
+// Which table a frame uses.  A caller that knows its views names them (bh_set_view_id / BhTrainBatch.view_id); one that does not
+// — the reference's SplatTrainer::step receives a SceneBatch without a view index (train.rs:176, brush-dataset/src/scene.rs:138-147)
+// — is keyed by the camera itself: a dataset's views are fixed cameras, and the same camera gives the same bits every time.
+// Bit 63 separates the two key spaces.
+static uint64_t view_key(const bh_ctx* ctx, const BhCamera& c) {
+    if (ctx->view_id != 0u || ctx->knob_no_view_hash) return (uint64_t)ctx->view_id;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    auto mix = [&](uint32_t w) {   // splitmix64 finaliser over a running sum: order-sensitive, cheap, well spread
+        h += (uint64_t)w + 0x9E3779B97F4A7C15ull;
+        uint64_t z = h;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h = z ^ (z >> 31);
+    };
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (int i = 0; i < 12; ++i) mix(bits(c.vm[i]));
+    mix(bits(c.fx)); mix(bits(c.fy)); mix(bits(c.cx)); mix(bits(c.cy));
+    mix(c.img_w); mix(c.img_h); mix(c.tile_row_begin); mix(c.tile_row_end); mix(c.model);
+    if (c.model != BH_CAMERA_PINHOLE) for (int i = 0; i < 8; ++i) mix(bits(c.dist[i]));
+    return h | (1ull << 63);
+}
+
+// The per-tile depth-cut table of view `key` for a (tile_bw x tile_bh) grid: created (all ZCUT_ALL = "list everything") on first
+// use, re-created when the grid changes; beyond MAX_VIEW_STATES tables (or VIEW_TABLE_BYTES of them) the least recently used view
+// gives its table up — to the new view when the grids match (no free, no host wait: the clears are ordered on the stream).
+static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32_t tile_bh) {
+    const size_t words = (size_t)tile_bw * tile_bh ? (size_t)tile_bw * tile_bh : 1;
+    auto it = ctx->views.find(key);
+    uint32_t* recycled = nullptr;
+    auto forget = [&](std::unordered_map<uint64_t, ViewState>::iterator v, bool keep_block) {
+        if (ctx->gate_view == &v->second) ctx->gate_view = nullptr;
+        if (ctx->far_job.view == &v->second) ctx->far_job.view = nullptr;
+        if (keep_block) recycled = v->second.zcut;
+        else {
+            (void)hipStreamSynchronize(ctx->stream);   // queued kernels may still use the block
+            (void)hipFree(v->second.zcut);
+        }
+        ctx->views.erase(v);
+    };
     if (it != ctx->views.end() && (it->second.tile_bw != tile_bw || it->second.tile_bh != tile_bh)) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(it->second.zcut);
-        ctx->views.erase(it);
+        forget(it, false);
         it = ctx->views.end();
     }
     if (it == ctx->views.end()) {
-        if (ctx->views.size() >= MAX_VIEW_STATES) {
+        const size_t max_views = std::min(MAX_VIEW_STATES, std::max<size_t>(8, VIEW_TABLE_BYTES / (2 * words * 4)));
+        while (ctx->views.size() >= max_views) {
             auto old = ctx->views.begin();
             for (auto k = ctx->views.begin(); k != ctx->views.end(); ++k)
                 if (k->second.last_used < old->second.last_used) old = k;
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(old->second.zcut);
-            if (ctx->gate_view == &old->second) ctx->gate_view = nullptr;
-            if (ctx->far_job.view == &old->second) ctx->far_job.view = nullptr;
-            ctx->views.erase(old);
+            forget(old, recycled == nullptr && old->second.tile_bw == tile_bw && old->second.tile_bh == tile_bh);
         }
         ViewState vs;
         vs.tile_bw = tile_bw;
         vs.tile_bh = tile_bh;
-        const size_t words = (size_t)tile_bw * tile_bh ? (size_t)tile_bw * tile_bh : 1;
         // [T] depth cuts (all "everything") | [T] per-tile work of the last frame (all zero)
-        if (hipMalloc((void**)&vs.zcut, 2 * words * 4) != hipSuccess) {
+        vs.zcut = recycled;
+        if (!vs.zcut && hipMalloc((void**)&vs.zcut, 2 * words * 4) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
@@ -227,7 +269,7 @@ static ViewState* view_state(bh_ctx* ctx, uint32_t id, uint32_t tile_bw, uint32_
             (void)hipFree(vs.zcut);
             return nullptr;
         }
-        it = ctx->views.emplace(id, vs).first;
+        it = ctx->views.emplace(key, vs).first;
     }
     it->second.last_used = ++ctx->view_clock;
     return &it->second;
@@ -359,6 +401,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
 #endif
     if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
     ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
+    ctx->knob_no_view_hash = getenv("BH_NO_VIEW_HASH") != nullptr;
     ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
@@ -389,6 +432,11 @@ void bh_destroy(bh_ctx* ctx) {
         if (b.ptr) (void)hipFree(b.ptr);
     for (auto& kv : ctx->views)
         if (kv.second.zcut) (void)hipFree(kv.second.zcut);
+    for (auto& rt : ctx->retained)
+        for (auto& b : rt.blocks)
+            if (b.ptr) (void)hipFree(b.ptr);
+    for (auto& b : ctx->pool)
+        if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
     if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
@@ -653,7 +701,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     ViewState* view = nullptr;
     bool cut_active = false;
     if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
-        view = view_state(ctx, ctx->view_id, u.tile_bw, u.tile_bh);
+        view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh);
         if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
         // (a frame with few pairs has nothing to save: the near count in K1 and an occasional far pass cost more than listing and
         //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
@@ -937,7 +985,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         j.out_f32 = out_f32; j.out_u8 = out_u8; j.visible = visible; j.lpt = ctx->lpt; j.class_width = class_width; j.rs = rs;
         j.by_cut = by_cut;
         j.view = by_cut ? view : nullptr;
-        j.view_shared = ctx->view_id == 0u;
+        j.view_shared = ctx->view_id == 0u && ctx->knob_no_view_hash;   // (one table shared by every frame without an id: the A/B knob only)
         if (by_cut) {   // what a second attempt with complete lists needs (finish_far_slice)
             j.cam = *cam;
             j.n = n; j.sh_degree = sh_degree; j.flags = flags; j.view_id = ctx->view_id;
@@ -988,6 +1036,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     r.depths_sorted = (float*)depths_sorted;
     r.tile_offsets_far = sliced ? tile_offsets_far : nullptr;
     r.list_budget = budget;   // (per-tile cuts: the pairs the near pass listed)
+    r.generation = ++ctx->generation;
     *out = r;
     ctx->last = r;
     ctx->last_listed_splats = nv;
@@ -1033,18 +1082,26 @@ float bh_last_list_share(bh_ctx* ctx) { return ctx ? ctx->last_slice_share : 0.0
 uint32_t bh_far_slices_queued(bh_ctx* ctx) { return ctx ? ctx->far_launches : 0u; }
 
 // ---- backward ------------------------------------------------------------------
-int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
-                       const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities,
-                       float* v_refine_weight) {
-    if (!ctx) return BH_ERR_INVALID_ARG;
-    if (!ctx->have_forward || !(ctx->flags & BH_FLAG_BWD_INFO))
-        return set_error(ctx, BH_ERR_STATE, "render_backward needs a preceding BH_FLAG_BWD_INFO forward on this context");
-    if (!v_output || !v_transforms || !v_sh_coeffs || !v_raw_opacities || !v_refine_weight)
-        return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward: null argument");
-    BH_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
-    const BhRenderOut& r = ctx->last;
-    const uint32_t n = ctx->n, nv = r.num_listed_splats, C = (ctx->sh_degree + 1) * (ctx->sh_degree + 1);
+}  // extern "C"
+
+namespace bh {
+
+static ForwardState latest_forward(const bh_ctx* ctx) {
+    ForwardState fs;
+    fs.out = ctx->last;
+    fs.uniforms = ctx->uniforms;
+    fs.n = ctx->n; fs.sh_degree = ctx->sh_degree; fs.flags = ctx->flags;
+    fs.bg[0] = ctx->bg[0]; fs.bg[1] = ctx->bg[1]; fs.bg[2] = ctx->bg[2];
+    fs.lpt = ctx->lpt;
+    return fs;
+}
+
+// The two backward kernels on the saved state `fs` (bwd/render_bwd.rs:21-171).  latest: `fs` is the ctx's most recent forward, whose
+// kernels may have cleared the accumulators on their way (GradSpan below); a retained older forward clears everything itself.
+static int backward_impl(bh_ctx* ctx, const ForwardState& fs, bool latest, const float* v_output, const float* transforms, const float* sh_coeffs,
+                         const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities, float* v_refine_weight) {
+    const BhRenderOut& r = fs.out;
+    const uint32_t n = fs.n, nv = r.num_listed_splats, C = (fs.sh_degree + 1) * (fs.sh_degree + 1);
     const size_t nvpad = nv ? nv : 1;
     auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4 + 16);   // + room to clear whole float4s
     if (!v_combined) return BH_ERR_OOM;
@@ -1053,7 +1110,8 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         // what the forward's kernels cleared on their way (K5: v_combined; K1: the train step's gradient span) is done
         const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
         // (grad_rows_marked: the single-GPU train step reads only the rows K18 writes and marks — its forward cleared the marks)
-        const bool vc_done = ctx->vcombined_prezeroed, span_done = one_span && (ctx->grads_prezeroed || ctx->grad_rows_marked);
+        const bool vc_done = latest && ctx->vcombined_prezeroed, span_done = latest && one_span && (ctx->grads_prezeroed || ctx->grad_rows_marked);
+        // either way the accumulator is dirty from here on: a backward of ANOTHER forward (a retained one) must not trust the flag
         ctx->vcombined_prezeroed = false;
         ctx->grads_prezeroed = false;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
@@ -1083,17 +1141,99 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
     {
         ProfScope ps(ctx, "RasterizeBackwards", /*dominant=*/true);
         if (r.num_intersections > 0)
-            BH_TRY(launch_rasterize_backward(ctx, ctx->uniforms, ctx->bg, ctx->flags & BH_FLAG_SMOOTH_CUTOFF,
-                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, ctx->lpt,
+            BH_TRY(launch_rasterize_backward(ctx, fs.uniforms, fs.bg, fs.flags & BH_FLAG_SMOOTH_CUTOFF,
+                                             r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, fs.lpt,
                                              r.tile_offsets_far));
     }
     {
         ProfScope ps(ctx, "ProjectBackwards");
-        BH_TRY(launch_project_backward(ctx, ctx->uniforms, nv, ctx->flags & BH_FLAG_MIP, ctx->sh_degree, transforms, sh_coeffs,
+        BH_TRY(launch_project_backward(ctx, fs.uniforms, nv, fs.flags & BH_FLAG_MIP, fs.sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
-                                       v_raw_opacities, v_refine_weight, ctx->grad_rows_marked));
+                                       v_raw_opacities, v_refine_weight, latest && ctx->grad_rows_marked));
     }
     return 0;
+}
+
+// the arena slots a BhRenderOut points into (everything a retained forward must keep alive)
+static const Slot kRetainSlots[RETAIN_SLOTS] = {SLOT_OUT_IMG, SLOT_VISIBLE, SLOT_MAX_RADIUS, SLOT_TILE_OFFSETS, SLOT_PROJECTED, SLOT_ISECT_GIDS_SORTED,
+                                                SLOT_TILE_IDS_SORTED, SLOT_GLOBAL_FROM_COMPACT, SLOT_CUM_TILES_HIT, SLOT_ISECT_COUNTS, SLOT_DEPTHS_SORTED,
+                                                SLOT_SLICE};
+
+}  // namespace bh
+
+extern "C" {
+
+int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
+                       const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities,
+                       float* v_refine_weight) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!ctx->have_forward || !(ctx->flags & BH_FLAG_BWD_INFO))
+        return set_error(ctx, BH_ERR_STATE, "render_backward needs a preceding BH_FLAG_BWD_INFO forward on this context");
+    if (!v_output || !v_transforms || !v_sh_coeffs || !v_raw_opacities || !v_refine_weight)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward: null argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    return backward_impl(ctx, latest_forward(ctx), /*latest=*/true, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
+                         v_refine_weight);
+}
+
+// SplatBwdOps::{rasterize_bwd, project_bwd} take the forward's saved tensors explicitly (bwd/burn_glue.rs:62-92, 336-371): so does this.
+int bh_render_backward_saved(bh_ctx* ctx, const BhRenderOut* saved, const float* v_output, const float* transforms, const float* sh_coeffs,
+                             const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities,
+                             float* v_refine_weight) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!saved || !v_output || !v_transforms || !v_sh_coeffs || !v_raw_opacities || !v_refine_weight)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward_saved: null argument");
+    if (!(saved->flags & BH_FLAG_BWD_INFO)) return set_error(ctx, BH_ERR_STATE, "render_backward_saved: the saved forward was not a BH_FLAG_BWD_INFO forward");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    for (const Retained& rt : ctx->retained)
+        if (rt.fs.out.generation == saved->generation && rt.fs.out.out_img == saved->out_img)
+            return backward_impl(ctx, rt.fs, /*latest=*/false, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
+                                 v_refine_weight);
+    if (ctx->have_forward && saved->generation == ctx->last.generation && saved->out_img == ctx->last.out_img)
+        return backward_impl(ctx, latest_forward(ctx), /*latest=*/true, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs,
+                             v_raw_opacities, v_refine_weight);
+    char msg[256];
+    snprintf(msg, sizeof msg, "render_backward_saved: forward #%llu is stale (the context's buffers now hold forward #%llu); call bh_render_retain "
+                              "on a forward that must outlive the next one", (unsigned long long)saved->generation, (unsigned long long)ctx->generation);
+    return set_error(ctx, BH_ERR_STATE, msg);
+}
+
+int bh_render_retain(bh_ctx* ctx, const BhRenderOut* out) {
+    if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    if (!ctx->have_forward || out->generation != ctx->last.generation || out->out_img != ctx->last.out_img || out->out_img_packed != ctx->last.out_img_packed)
+        return set_error(ctx, BH_ERR_STATE, "render_retain: only the context's most recent forward can be retained (and only once)");
+    Retained rt;
+    rt.fs = latest_forward(ctx);
+    for (int i = 0; i < RETAIN_SLOTS; ++i) {   // the blocks leave the arena: the next forward gets its own (from the pool, or hipMalloc)
+        rt.blocks[i] = ctx->slots[kRetainSlots[i]];
+        ctx->slots[kRetainSlots[i]] = Buffer{};
+    }
+    ctx->retained.push_back(rt);
+    ctx->have_forward = false;    // bh_render_backward ("the last forward") has nothing to refer to until the next forward
+    ctx->lpt = nullptr;
+    return 0;
+}
+
+int bh_render_release(bh_ctx* ctx, const BhRenderOut* out) {
+    if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    for (size_t k = 0; k < ctx->retained.size(); ++k) {
+        Retained& rt = ctx->retained[k];
+        if (rt.fs.out.generation != out->generation || rt.fs.out.out_img != out->out_img) continue;
+        // stream order protects the blocks: whoever gets them next is queued behind the kernels that still read them
+        for (int i = 0; i < RETAIN_SLOTS; ++i) {
+            if (!rt.blocks[i].ptr) continue;
+            Buffer& slot = ctx->slots[kRetainSlots[i]];
+            if (!slot.ptr) slot = rt.blocks[i];
+            else if (ctx->pool.size() < 64) ctx->pool.push_back(rt.blocks[i]);
+            else { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(rt.blocks[i].ptr); }
+        }
+        ctx->retained.erase(ctx->retained.begin() + (long)k);
+        return 0;
+    }
+    return set_error(ctx, BH_ERR_STATE, "render_release: this forward is not retained on this context");
 }
 
 int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out) {
@@ -1350,7 +1490,15 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     // (knob_force_exchange: a one-rank communicator still walks the whole exchange path — its kernels, readback and host logic —
     // with the collectives themselves degenerate: the one-GPU measurement of what the path costs per step)
     const bool exchanging = hook || (ctx->comm && (ctx->comm_world > 1 || ctx->knob_force_exchange));
-    const bool masked_grads = !exchanging && !batch->image_hook && !ctx->knob_zero_grads && n > 0;
+    // one frame split over the ranks by strips of tile rows: the caller's image hook moves the strips / halos, or — no hook, a
+    // communicator on the ctx, a proper tile-row window in the camera — the library exchanges the halos itself (comm.hip)
+    const ViewUniforms win_u = make_uniforms(batch->camera);
+    const bool window_partial = win_u.tile_y0 != 0u || win_u.tile_y1 != win_u.tile_bh;
+    const bool native_tiles = !batch->image_hook && window_partial && ctx->comm != nullptr && !hook;
+    if (native_tiles && !batch->strip_loss)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "train_step: a tile-row window without an image hook needs strip_loss = 1 (the library exchanges the strips' halos, not whole frames)");
+    const bool tile_mode = batch->image_hook != nullptr || native_tiles;
+    const bool masked_grads = !exchanging && !tile_mode && !ctx->knob_zero_grads && n > 0;
     if (masked_grads) {
         ctx->ext_grad_begin = exch + o_ref;
         ctx->ext_grad_floats = exch_count - o_ref;
@@ -1358,7 +1506,7 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     // depth-sliced lists: whether the far slice has to run is known once the near slice's blend has; a single-GPU step does not
     // wait for that — the loss kernels are queued behind the near slice first (below) and the host reads the answer while they run
     // (a tile-partitioned frame hands the image to its hook right after the forward: there the forward waits itself)
-    ctx->defer_far = !batch->image_hook;
+    ctx->defer_far = !tile_mode;
     const uint32_t caller_view = ctx->view_id;
     ctx->view_id = batch->view_id;
     const int frc = bh_render_forward(ctx, &batch->camera, n, st->sh_degree, r_transforms, st->sh_coeffs, r_raw_opac,
@@ -1376,11 +1524,12 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     if (masked_grads && !ctx->grads_prezeroed) BH_HIP(ctx, hipMemsetAsync(exch + o_ref, 0, (exch_count - o_ref) * sizeof(float), ctx->stream));
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
-    if (batch->image_hook) {
+    if (tile_mode) {
         ProfScope ps(ctx, "ImageExchange");
-        const ViewUniforms wu = make_uniforms(batch->camera);
+        const ViewUniforms& wu = win_u;
         const uint32_t r0 = wu.tile_y0 * TILE_WIDTH, r1 = wu.tile_y1 * TILE_WIDTH < H ? wu.tile_y1 * TILE_WIDTH : H;
-        if (batch->image_hook(batch->image_hook_user, ro.out_img, H, W, r0, r1) != 0) return set_error(ctx, BH_ERR_STATE, "image hook failed");
+        if (native_tiles) BH_TRY(comm_exchange_strip_halos(ctx, ro.out_img, H, W, r0, r1));
+        else if (batch->image_hook(batch->image_hook_user, ro.out_img, H, W, r0, r1) != 0) return set_error(ctx, BH_ERR_STATE, "image hook failed");
     }
 
     // ---- loss (train.rs:227-260)
@@ -1403,7 +1552,7 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
     auto queue_loss = [&]() -> int {
-        if (batch->image_hook && batch->strip_loss) {
+        if (tile_mode && batch->strip_loss) {
             // one frame over several ranks: the hook delivered only the 21-px halos; loss and dL/dimg for this rank's strip
             // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
             const ViewUniforms wu = make_uniforms(batch->camera);
@@ -1439,7 +1588,6 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     // ---- multi-GPU exchange, part 1 (mask-keyed mode, exchange.hip): the visible flags are final once the forward (incl. a far
     // slice, if it had to run) is, so they are summed, the union of contributing splats is listed and its size starts travelling
     // to the host NOW — the backward hides the collective's latency and the readback, and the host finds the count ready
-    const bool tile_mode = batch->image_hook != nullptr;
     // "sum `cnt` floats at `p` over the ranks, in place": the caller's hook, or the library's communicator
     auto sum_over_ranks = [&](float* p, uint64_t cnt) -> int {
         if (hook) return hook(hook_user, p, cnt) == 0 ? 0 : set_error(ctx, BH_ERR_STATE, "gradient hook failed");

@@ -8,27 +8,35 @@
 // RCCL is bound at run time (dlopen / dlsym), not at link time: a process that already carries an RCCL — a
 // PyTorch host does, in torch/lib — keeps using that one copy, and a single-GPU user never loads it at all.
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
+#include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "context.h"
 
 namespace bh {
 
-// the slice of rccl.h this file needs (ABI of RCCL 2.x / NCCL 2.x)
-typedef struct { char internal[128]; } RcclUniqueId;
-typedef void* RcclComm;
-enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT32 = 7, RCCL_UINT8 = 1 };
+// Types, enum values and signatures come from the toolchain's own <rccl/rccl.h> (compile time only: decltype of the declared
+// functions), so a mismatch between this file and the library's ABI is a compile error, not a silent wrong collective.  The
+// library itself is still resolved at run time.
 struct RcclApi {
     void* lib = nullptr;
-    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
-    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
-    int (*CommDestroy)(RcclComm) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
+static_assert(sizeof(ncclUniqueId) == 128, "bh_comm_unique_id hands out 128 bytes");
 
 static RcclApi& rccl() {
     static RcclApi api;
@@ -51,17 +59,21 @@ static RcclApi& rccl() {
         if (!p && api.error.empty()) api.error = std::string("RCCL symbol missing: ") + s;
         return p;
     };
-    api.GetUniqueId = (int (*)(RcclUniqueId*))sym("ncclGetUniqueId");
-    api.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))sym("ncclCommInitRank");
-    api.CommDestroy = (int (*)(RcclComm))sym("ncclCommDestroy");
-    api.AllReduce = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))sym("ncclAllReduce");
-    api.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))sym("ncclAllGather");
-    api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     return api;
 }
 
-static int rccl_check(bh_ctx* ctx, int rc, const char* what) {
-    if (rc == 0) return 0;
+static int rccl_check(bh_ctx* ctx, ncclResult_t rc, const char* what) {
+    if (rc == ncclSuccess) return 0;
     RcclApi& a = rccl();
     return set_error(ctx, BH_ERR_HIP, std::string(what) + ": " + (a.GetErrorString ? a.GetErrorString(rc) : "RCCL error"));
 }
@@ -75,14 +87,57 @@ __global__ void break_allreduce_kernel(float* buf) { buf[0] += 1.0f; }
 int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op) {
     if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
     if (count == 0) return 0;
-    int rc = 0;
-    if (ctx->comm_world > 1)   // (one rank: nothing to exchange)
-        rc = rccl_check(ctx, rccl().AllReduce(buf, buf, (size_t)count, RCCL_FLOAT32, max_op ? RCCL_MAX : RCCL_SUM, (RcclComm)ctx->comm, ctx->stream),
+    // (a one-rank communicator goes through RCCL like any other: the binding is the same code at every world size)
+    int rc = rccl_check(ctx, rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, max_op ? ncclMax : ncclSum, (ncclComm_t)ctx->comm, ctx->stream),
                         "ncclAllReduce");
 #ifdef BH_TEST_HOOKS
     if (rc == 0 && ctx->knob_break_allreduce) hipLaunchKernelGGL(break_allreduce_kernel, dim3(1), dim3(1), 0, ctx->stream, buf);
 #endif
     return rc;
+}
+
+// ---- one frame split into strips of tile rows: the 21-px halos of the strip-wise loss -----------------------------
+// Which rows go where: strips lie in rank order, rank r's directly above rank r + 1's; every strip is at least `halo` rows tall
+// (the caller's precondition, identical on all ranks).  Rank r then sends its first rows up and its last rows down, and receives
+// the rows just above / below its strip.  Pure host arithmetic, the same on both ends of every message.
+int strip_halo_plan(uint32_t h, uint32_t row_begin_px, uint32_t row_end_px, int rank, int world, uint32_t halo, BhHaloOp out[4]) {
+    int k = 0;
+    if (row_begin_px >= row_end_px || row_end_px > h) return -1;
+    if (rank > 0 && row_begin_px > 0) {
+        const uint32_t up = row_begin_px < halo ? row_begin_px : halo;                                    // rows [b - up, b) come from above
+        const uint32_t mine = (row_end_px - row_begin_px) < halo ? (row_end_px - row_begin_px) : halo;    // my first rows go up
+        out[k++] = BhHaloOp{/*send=*/1, rank - 1, row_begin_px, mine};
+        out[k++] = BhHaloOp{/*send=*/0, rank - 1, row_begin_px - up, up};
+    }
+    if (rank < world - 1 && row_end_px < h) {
+        const uint32_t down = (h - row_end_px) < halo ? (h - row_end_px) : halo;                          // rows [e, e + down) come from below
+        const uint32_t mine = (row_end_px - row_begin_px) < halo ? (row_end_px - row_begin_px) : halo;    // my last rows go down
+        out[k++] = BhHaloOp{/*send=*/1, rank + 1, row_end_px - mine, mine};
+        out[k++] = BhHaloOp{/*send=*/0, rank + 1, row_end_px, down};
+    }
+    return k;
+}
+
+int comm_exchange_strip_halos(bh_ctx* ctx, float* img, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px) {
+    if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
+    constexpr uint32_t HALO = 21;   // one 16-px tile row + the 5-px reach of the 11-tap SSIM window (loss_fused.hip)
+    if (ctx->comm_world > 1 && row_end_px - row_begin_px < HALO)
+        return set_error(ctx, BH_ERR_INVALID_ARG, "strip-wise loss: every rank's strip must be at least 21 pixel rows tall");
+    BhHaloOp ops[4];
+    const int k = strip_halo_plan(h, row_begin_px, row_end_px, ctx->comm_rank, ctx->comm_world, HALO, ops);
+    if (k < 0) return set_error(ctx, BH_ERR_INVALID_ARG, "strip halo exchange: bad strip");
+    if (k == 0) return 0;
+    RcclApi& a = rccl();
+    const size_t row = (size_t)w * 4;
+    BH_TRY(rccl_check(ctx, a.GroupStart(), "ncclGroupStart"));
+    int rc = 0;
+    for (int i = 0; i < k && rc == 0; ++i) {
+        float* p = img + (size_t)ops[i].row_begin_px * row;
+        rc = ops[i].send ? rccl_check(ctx, a.Send(p, ops[i].rows * row, ncclFloat32, ops[i].peer, (ncclComm_t)ctx->comm, ctx->stream), "ncclSend")
+                         : rccl_check(ctx, a.Recv(p, ops[i].rows * row, ncclFloat32, ops[i].peer, (ncclComm_t)ctx->comm, ctx->stream), "ncclRecv");
+    }
+    const int rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
 }
 
 }  // namespace bh
@@ -95,8 +150,8 @@ int bh_comm_unique_id(void* out_id) {
     if (!out_id) return BH_ERR_INVALID_ARG;
     RcclApi& a = rccl();
     if (!a.lib || !a.error.empty()) return BH_ERR_UNSUPPORTED;
-    RcclUniqueId id;
-    if (a.GetUniqueId(&id) != 0) return BH_ERR_HIP;
+    ncclUniqueId id;
+    if (a.GetUniqueId(&id) != ncclSuccess) return BH_ERR_HIP;
     std::memcpy(out_id, &id, sizeof id);
     return 0;
 }
@@ -108,9 +163,9 @@ int bh_comm_init(bh_ctx* ctx, int rank, int world, const void* unique_id) {
     RcclApi& a = rccl();
     if (!a.lib || !a.error.empty()) return set_error(ctx, BH_ERR_UNSUPPORTED, a.error.empty() ? "RCCL unavailable" : a.error);
     BH_HIP(ctx, hipSetDevice(ctx->device));
-    RcclUniqueId id;
+    ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
-    RcclComm comm = nullptr;
+    ncclComm_t comm = nullptr;
     BH_TRY(rccl_check(ctx, a.CommInitRank(&comm, world, id, rank), "ncclCommInitRank"));
     ctx->comm = comm;
     ctx->comm_rank = rank;
@@ -133,7 +188,7 @@ int bh_comm_destroy(bh_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); ctx->comm_stream = nullptr; }
     if (ctx->comm_ev) { (void)hipEventDestroy(ctx->comm_ev); ctx->comm_ev = nullptr; }
-    const int rc = rccl().CommDestroy((RcclComm)ctx->comm);
+    const ncclResult_t rc = rccl().CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_world = 1;
     ctx->comm_rank = 0;
@@ -162,7 +217,75 @@ int bh_allgather_bytes(bh_ctx* ctx, const void* send, void* recv, uint64_t bytes
     if (bytes_per_rank == 0) return 0;
     if (!send || !recv) return set_error(ctx, BH_ERR_INVALID_ARG, "allgather: null buffer");
     BH_HIP(ctx, hipSetDevice(ctx->device));
-    return rccl_check(ctx, rccl().AllGather(send, recv, (size_t)bytes_per_rank, RCCL_UINT8, (RcclComm)ctx->comm, ctx->stream), "ncclAllGather");
+    return rccl_check(ctx, rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream), "ncclAllGather");
+}
+
+int bh_comm_rank(bh_ctx* ctx) { return ctx && ctx->comm ? ctx->comm_rank : 0; }
+
+int bh_strip_halo_plan(uint32_t img_h, uint32_t row_begin_px, uint32_t row_end_px, int rank, int world, BhHaloOp* out /*[4]*/) {
+    if (!out || world < 1 || rank < 0 || rank >= world) return BH_ERR_INVALID_ARG;
+    const int k = strip_halo_plan(img_h, row_begin_px, row_end_px, rank, world, 21u, out);
+    return k < 0 ? BH_ERR_INVALID_ARG : k;
+}
+
+int bh_exchange_strip_halos(bh_ctx* ctx, float* img_hwc4, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!img_hwc4 || h == 0 || w == 0) return set_error(ctx, BH_ERR_INVALID_ARG, "exchange_strip_halos: bad argument");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    return comm_exchange_strip_halos(ctx, img_hwc4, h, w, row_begin_px, row_end_px);
+}
+
+// Every collective this file binds, run once on small rank-dependent patterns and checked on the host: out-of-place all-reduce
+// SUM and MAX, all-gather, and a grouped ring shift with send / recv.  What the first multi-GPU run of a build should call before
+// it trusts a gradient exchange; on one rank it still drives every entry point through RCCL with non-trivial data.
+int bh_comm_selftest(bh_ctx* ctx) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    RcclApi& a = rccl();
+    const int W = ctx->comm_world, R = ctx->comm_rank;
+    constexpr size_t N = 1027;   // (odd on purpose)
+    std::vector<float> host(N);
+    for (size_t i = 0; i < N; ++i) host[i] = (float)(R + 1) * (float)((i % 97) + 1) - ((i & 1) ? 3.0f * (float)R : 0.0f);
+    float* d = nullptr;   // [send N | sum N | max N | gather W*N | shifted N]
+    const size_t total = N * (4 + (size_t)W);
+    BH_HIP(ctx, hipMalloc((void**)&d, total * 4));
+    int rc = check_hip(ctx, hipMemsetAsync(d, 0xFF, total * 4, ctx->stream), "selftest memset");
+    if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(d, host.data(), N * 4, hipMemcpyHostToDevice, ctx->stream), "selftest upload");
+    float *sum = d + N, *mx = d + 2 * N, *gat = d + 3 * N, *shf = d + (3 + (size_t)W) * N;
+    if (rc == 0) rc = rccl_check(ctx, a.AllReduce(d, sum, N, ncclFloat32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream), "ncclAllReduce(sum)");
+    if (rc == 0) rc = rccl_check(ctx, a.AllReduce(d, mx, N, ncclFloat32, ncclMax, (ncclComm_t)ctx->comm, ctx->stream), "ncclAllReduce(max)");
+    if (rc == 0) rc = rccl_check(ctx, a.AllGather(d, gat, N * 4, ncclUint8, (ncclComm_t)ctx->comm, ctx->stream), "ncclAllGather");
+    if (rc == 0) {
+        rc = rccl_check(ctx, a.GroupStart(), "ncclGroupStart");
+        if (rc == 0) rc = rccl_check(ctx, a.Send(d, N, ncclFloat32, (R + 1) % W, (ncclComm_t)ctx->comm, ctx->stream), "ncclSend");
+        if (rc == 0) rc = rccl_check(ctx, a.Recv(shf, N, ncclFloat32, (R + W - 1) % W, (ncclComm_t)ctx->comm, ctx->stream), "ncclRecv");
+        const int rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
+        if (rc == 0) rc = rc2;
+    }
+    std::vector<float> got(total);
+    if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(got.data(), d, total * 4, hipMemcpyDeviceToHost, ctx->stream), "selftest download");
+    if (rc == 0) rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "selftest sync");
+    (void)hipFree(d);
+    if (rc != 0) return rc;
+    auto pattern = [&](int r, size_t i) { return (float)(r + 1) * (float)((i % 97) + 1) - ((i & 1) ? 3.0f * (float)r : 0.0f); };
+    for (size_t i = 0; i < N; ++i) {
+        double s = 0.0;
+        float m = pattern(0, i);
+        for (int r = 0; r < W; ++r) { s += pattern(r, i); m = pattern(r, i) > m ? pattern(r, i) : m; }
+        const char* what = nullptr;
+        if (std::fabs((double)got[N + i] - s) > 1e-3 * (1.0 + std::fabs(s))) what = "all-reduce SUM";
+        else if (got[2 * N + i] != m) what = "all-reduce MAX";
+        else if (got[(3 + (size_t)W) * N + i] != pattern((R + W - 1) % W, i)) what = "send / recv ring shift";
+        for (int r = 0; r < W && !what; ++r)
+            if (got[(3 + (size_t)r) * N + i] != pattern(r, i)) what = "all-gather";
+        if (what) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "comm_selftest: %s is wrong at element %zu on rank %d of %d", what, i, R, W);
+            return set_error(ctx, BH_ERR_HIP, msg);
+        }
+    }
+    return 0;
 }
 
 }  // extern "C"

@@ -136,6 +136,7 @@ struct ViewState {
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
 constexpr size_t MAX_VIEW_STATES = 4096;
+constexpr size_t VIEW_TABLE_BYTES = (size_t)256 << 20;   // ... and at most this much device memory in tables (8 B per tile and view: 64 KB at 1080p, 253 KB at 4K)
 
 // scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
 struct RasterSlice {
@@ -205,6 +206,21 @@ struct FarJob {
     size_t ext_grad_floats = 0;
 };
 
+// What a backward needs of the forward it belongs to (RenderBackwards' saved state, bwd/burn_glue.rs:336-371): the host side of it.
+struct ForwardState {
+    BhRenderOut out{};
+    ViewUniforms uniforms{};
+    uint32_t n = 0, sh_degree = 0, flags = 0;
+    float bg[3] = {0, 0, 0};
+    uint32_t* lpt = nullptr;   // longest-first tile order of the forward (rasterize.hip), or NULL
+};
+// A forward whose arena blocks were detached from the ctx (bh_render_retain): it stays replayable while later forwards run.
+constexpr int RETAIN_SLOTS = 12;
+struct Retained {
+    ForwardState fs;
+    Buffer blocks[RETAIN_SLOTS];
+};
+
 }  // namespace bh
 
 struct bh_ctx {
@@ -225,6 +241,9 @@ struct bh_ctx {
     uint32_t n = 0, sh_degree = 0, flags = 0;
     float bg[3] = {0, 0, 0};
     BhRenderOut last{};
+    uint64_t generation = 0;          // stamped into every BhRenderOut a forward of this ctx returns (bh_render_backward_saved checks it)
+    std::vector<bh::Retained> retained;   // forwards detached by bh_render_retain, until bh_render_release
+    std::vector<bh::Buffer> pool;     // blocks given back by bh_render_release: ensure() takes from here before it asks hipMalloc
     float* ext_visible = nullptr;     // train step: the forward writes visible / max_radius here (stats buffer)
     float* ext_max_radius = nullptr;
     size_t ext_visible_floats = 0;    // floats to clear at ext_visible (its section of the exchange buffer incl. padding)
@@ -262,12 +281,15 @@ struct bh_ctx {
     uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice / had to be run again with complete lists
     uint32_t last_listed_splats = 0;  // compact entries of the last forward (== num_visible unless per-tile cuts listed a subset)
     // per-tile depth cuts (automatic slicing): one table per view id (bh_set_view_id / BhTrainBatch.view_id; 0 = the ctx's own slot)
-    std::unordered_map<uint32_t, bh::ViewState> views;
+    // keyed by the caller's view id, or — id 0 — by a hash of the camera (api.hip view_key): an unmodified SplatTrainer::step
+    // (train.rs:176: a SceneBatch carries no view index, brush-dataset/src/scene.rs:138-147) gets the same tables
+    std::unordered_map<uint64_t, bh::ViewState> views;
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
     bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
+    bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
     bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
@@ -446,6 +468,7 @@ int launch_compute_min_scale(bh_ctx* ctx, const float* transforms, uint32_t n, c
 
 // comm.hip — in-place all-reduce of `count` floats over the ctx's RCCL communicator, on the ctx stream
 int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op);   // on ctx->stream
+int comm_exchange_strip_halos(bh_ctx* ctx, float* img, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px);
 
 // exchange.hip — compaction kernels of the mask-keyed gradient exchange
 int launch_union_index(bh_ctx* ctx, const float* visible_sum, uint32_t n, uint32_t* block_scratch /*[n/4096+2]*/, uint32_t* count_dev,

@@ -79,6 +79,13 @@ class Context:
     def comm_world(self):
         return int(self.lib.bh_comm_world(self._h))
 
+    def comm_rank(self):
+        return int(self.lib.bh_comm_rank(self._h))
+
+    def comm_selftest(self):
+        """bh_comm_selftest: every RCCL entry point the library binds, on rank-dependent patterns, checked on the host (collective)."""
+        self.check(self.lib.bh_comm_selftest(self._h))
+
     def allreduce_sum(self, t: torch.Tensor):
         """In place, asynchronous on the ctx stream; t: contiguous float32 device tensor."""
         self.check(self.lib.bh_allreduce_sum_f32(self._h, _ptr(t), t.numel()))
@@ -441,13 +448,60 @@ def render_splats_bwd(splats: Splats, camera, img_size, background, v_output, pa
     v_sh = torch.empty((n, c, 3), dtype=torch.float32, device=dev)
     v_op = torch.empty((n,), dtype=torch.float32, device=dev)
     v_rf = torch.empty((n,), dtype=torch.float32, device=dev)
-    ctx.check(ctx.lib.bh_render_backward(ctx._h, _ptr(v_output), _ptr(r_t), _ptr(splats.sh_coeffs), _ptr(r_o),
-                                         _ptr(v_t), _ptr(v_sh), _ptr(v_op), _ptr(v_rf)))
+    # the saved state goes in explicitly (SplatBwdOps::rasterize_bwd / project_bwd, bwd/burn_glue.rs:62-92)
+    ctx.check(ctx.lib.bh_render_backward_saved(ctx._h, C.byref(out), _ptr(v_output), _ptr(r_t), _ptr(splats.sh_coeffs), _ptr(r_o),
+                                               _ptr(v_t), _ptr(v_sh), _ptr(v_op), _ptr(v_rf)))
     if splats.min_scale is not None:  # chain through the fold (the autodiff of bwd/burn_glue.rs:260-270)
         ctx.check(ctx.lib.bh_fold_min_scale_backward(ctx._h, _ptr(splats.transforms), _ptr(splats.raw_opacities), _ptr(splats.min_scale), n,
                                                      _ptr(v_t), _ptr(v_op)))
     vc = _view(ctx.lib.bh_last_v_combined(ctx._h), (max(out.num_listed_splats, 1), 10), torch.float32, dev).clone()
     return dict(img=img, aux=aux, v_transforms=v_t, v_sh_coeffs=v_sh, v_raw_opacities=v_op, v_refine_weight=v_rf, v_combined=vc)
+
+
+class RenderNode:
+    """One differentiable render = the autodiff node `render_splats` registers in the reference (bwd/burn_glue.rs:223-311: the
+    forward's outputs + the state RenderBackwards saves, :336-371).  `backward(v_output)` may be called after OTHER renders have
+    run on the same ctx if the node was created with retain=True (bh_render_retain); without it a later forward makes the node
+    stale and backward raises BrushHipError (BH_ERR_STATE) instead of returning another frame's gradients."""
+
+    def __init__(self, ctx, splats, out, folded, img_size, retained):
+        self.ctx, self.splats, self.out, self._folded, self.img_size, self.retained = ctx, splats, out, folded, img_size, retained
+        w, h = img_size
+        self.img = _view(out.out_img, (h, w, 4), torch.float32, splats.device)   # aliases ctx memory: valid while the node is (retained nodes: until release)
+
+    def backward(self, v_output):
+        ctx, splats, dev = self.ctx, self.splats, self.splats.device
+        w, h = self.img_size
+        n, c = splats.num_splats(), splats.sh_coeffs.shape[1]
+        v_output = _f32c(v_output, dev).reshape(h, w, 4)
+        r_t, r_o = self._folded
+        v_t = torch.empty((n, 10), dtype=torch.float32, device=dev)
+        v_sh = torch.empty((n, c, 3), dtype=torch.float32, device=dev)
+        v_op = torch.empty((n,), dtype=torch.float32, device=dev)
+        v_rf = torch.empty((n,), dtype=torch.float32, device=dev)
+        ctx.check(ctx.lib.bh_render_backward_saved(ctx._h, C.byref(self.out), _ptr(v_output), _ptr(r_t), _ptr(splats.sh_coeffs), _ptr(r_o),
+                                                   _ptr(v_t), _ptr(v_sh), _ptr(v_op), _ptr(v_rf)))
+        if splats.min_scale is not None:
+            ctx.check(ctx.lib.bh_fold_min_scale_backward(ctx._h, _ptr(splats.transforms), _ptr(splats.raw_opacities), _ptr(splats.min_scale), n,
+                                                         _ptr(v_t), _ptr(v_op)))
+        return dict(v_transforms=v_t, v_sh_coeffs=v_sh, v_raw_opacities=v_op, v_refine_weight=v_rf)
+
+    def release(self):
+        if self.retained:
+            self.ctx.check(self.ctx.lib.bh_render_release(self.ctx._h, C.byref(self.out)))
+            self.retained = False
+
+
+def render_splats_diff(splats: Splats, camera, img_size, background=(0.0, 0.0, 0.0), pass_: RasterPass = RasterPass.Backward,
+                       ctx: Optional[Context] = None, retain=False, sliced=False) -> RenderNode:
+    """Forward of a differentiable render; gradients later through RenderNode.backward (bwd/burn_glue.rs:223-311)."""
+    assert pass_.bwd_info()
+    ctx = ctx or get_context(splats.device)
+    w, h = int(img_size[0]), int(img_size[1])
+    _, out, folded = _forward(ctx, splats, camera, (w, h), background, pass_, sliced)
+    if retain:
+        ctx.check(ctx.lib.bh_render_retain(ctx._h, C.byref(out)))
+    return RenderNode(ctx, splats, out, folded, (w, h), bool(retain))
 
 
 # ---------------------------------------------------------------------------
@@ -910,8 +964,9 @@ class SplatTrainer:
             raise ValueError("partition must be 'cameras' or 'tiles'")
         # native_comm: the ctx carries an RCCL communicator (Context.comm_init) and bh_train_step all-reduces the
         # exchange buffer itself — no torch.distributed, no callback (data parallel over cameras only)
-        if native_comm and (process_group is not None or partition != "cameras"):
-            raise ValueError("native_comm excludes process_group and supports partition='cameras' only")
+        # (partition "tiles": the library also moves the strips' 21-px halos itself — bh_exchange_strip_halos, strip-wise loss only)
+        if native_comm and process_group is not None:
+            raise ValueError("native_comm excludes process_group")
         self.native_comm = bool(native_comm)
         self.seed = None if seed is None else (int(seed) & 0xFFFFFFFFFFFFFFFF)
         # exchange only the gradient rows of splats some rank (view or strip) saw (BhTrainBatch.exchange_mode 1,
@@ -939,6 +994,7 @@ class SplatTrainer:
         # rank's share of the frame's loss (reduce_loss() sums the shares)
         self.strip_loss = True
         self._strip_loss_now = False
+        self.batch_patch = None   # optional callable(BhTrainBatch): edits the C struct right before bh_train_step
 
     MIN_SCALE_FACTOR = 0.1       # train.rs:44
     MIN_SCALE_FREEZE_FRAC = 0.9  # train.rs:37
@@ -1057,18 +1113,30 @@ class SplatTrainer:
         h, w = batch.img_size()
         b = _ffi.BhTrainBatch()
         b.camera = batch.camera if isinstance(batch.camera, _ffi.BhCamera) else batch.camera.uniforms((w, h))
-        tiles = self.pg is not None and self.partition == "tiles"
+        native_tiles = self.native_comm and self.partition == "tiles" and ctx.comm_world() > 1
+        tiles = (self.pg is not None and self.partition == "tiles") or native_tiles
         if tiles:
-            import torch.distributed as dist
-            rows = tile_rows_for_rank((h + 15) // 16, dist.get_rank(self.pg), dist.get_world_size(self.pg), self._row_weights)
+            if native_tiles:
+                t_rank, t_world = ctx.comm_rank(), ctx.comm_world()
+            else:
+                import torch.distributed as dist
+                t_rank, t_world = dist.get_rank(self.pg), dist.get_world_size(self.pg)
+            rows = tile_rows_for_rank((h + 15) // 16, t_rank, t_world, self._row_weights)
             cam = _ffi.BhCamera()
             C.memmove(C.byref(cam), C.byref(b.camera), C.sizeof(cam))
             cam.tile_row_begin, cam.tile_row_end = rows
             b.camera = cam
-            if self._img_hook is None:
-                self._img_hook = self._make_image_hook(dev)
-            b.image_hook = C.cast(self._img_hook, C.c_void_p)
-            self._strip_loss_now = bool(self.strip_loss) and strips_allow_halo_loss(strip_spans_px(h, dist.get_world_size(self.pg), self._row_weights))
+            halo_ok = strips_allow_halo_loss(strip_spans_px(h, t_world, self._row_weights))
+            if native_tiles:
+                # no hook: the library exchanges the halos over its own communicator (strip-wise loss is the only native mode)
+                if not halo_ok:
+                    raise BrushHipError("native tile partition needs every strip to be at least 21 pixel rows tall")
+                self._strip_loss_now = True
+            else:
+                if self._img_hook is None:
+                    self._img_hook = self._make_image_hook(dev)
+                b.image_hook = C.cast(self._img_hook, C.c_void_p)
+                self._strip_loss_now = bool(self.strip_loss) and halo_ok
             b.strip_loss = int(self._strip_loss_now)
         gt = _as_u32(batch.img_packed, dev)
         b.gt_packed = gt.data_ptr()
@@ -1086,11 +1154,13 @@ class SplatTrainer:
         b.view_id = int(getattr(batch, "view_id", 0)) & 0xFFFFFFFF
         hook, scale = None, 1.0
         if self.native_comm:
-            scale = 1.0 / ctx.comm_world()
+            scale = 1.0 if tiles else 1.0 / ctx.comm_world()
         if self.pg is not None:
             if self._hook is None:
                 self._hook = self._make_hook(dev)
             hook, scale = self._hook, (1.0 if tiles else 1.0 / self._world)
+        if self.batch_patch is not None:   # last word on the BhTrainBatch (callers that partition a frame themselves; tests)
+            self.batch_patch(b)
         ctx.check(ctx.lib.bh_train_step(ctx._h, C.byref(cfg), C.byref(st), C.byref(b), C.cast(hook, C.c_void_p) if hook else None, None,
                                         float(scale), C.byref(stats)))
         self.step_count = st.step_count
@@ -1106,13 +1176,20 @@ class SplatTrainer:
     def _measure_row_weights(self, ctx, tile_bh, tile_bw, dev):
         """Per tile row: intersections this frame actually blended (the lists' shrunk ends), summed over the ranks'
         strips -> the weights of the next cut.  One small readback + one [tile_bh] all-reduce every rebalance_every steps."""
-        import torch.distributed as dist
         out = _ffi.BhRenderOut()
         ctx.check(ctx.lib.bh_last_render_out(ctx._h, C.byref(out)))
         per_row = self._rows_blended(_view(out.tile_offsets, (tile_bh * tile_bw, 2), torch.int32, dev), tile_bh, tile_bw)
         if out.tile_offsets_far:   # depth-sliced lists: a tile's blended splats = its near segment + its far segment
             per_row = per_row + self._rows_blended(_view(out.tile_offsets_far, (tile_bh * tile_bw, 2), torch.int32, dev), tile_bh, tile_bw)
-        dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.native_comm:
+            per_row = per_row.contiguous()
+            if not ctx.uses_torch_stream:
+                torch.cuda.current_stream(dev).synchronize()
+            ctx.allreduce_sum(per_row)
+            ctx.sync()
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
         self._row_weights = [float(x) + 1.0 for x in per_row.tolist()]  # +1: empty rows still cost a launch slot
 
     @staticmethod
@@ -1123,9 +1200,10 @@ class SplatTrainer:
     def _warm_rebalance(self, tile_bh, tile_bw, dev):
         """The first use of each torch kernel above loads its code object (~200 ms in total on ROCm): pay that in the
         first step, not in the middle of training when the first re-cut happens."""
-        import torch.distributed as dist
         per_row = self._rows_blended(torch.zeros((tile_bh * tile_bw, 2), dtype=torch.int32, device=dev), tile_bh, tile_bw)
-        dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
+        if not self.native_comm:
+            import torch.distributed as dist
+            dist.all_reduce(per_row, op=dist.ReduceOp.SUM, group=self.pg)
         per_row.tolist()
 
     def _train_state(self, splats, s):
@@ -1210,6 +1288,14 @@ class SplatTrainer:
             import torch.distributed as dist
             t = torch.tensor([stats.loss], dtype=torch.float64, device=self.state["m2_o"].device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            return float(t.item())
+        if self.native_comm and self.partition == "tiles" and self._strip_loss_now:
+            ctx = self.ctx or get_context(self.state["m2_o"].device)
+            t = torch.tensor([stats.loss], dtype=torch.float32, device=self.state["m2_o"].device)
+            if not ctx.uses_torch_stream:
+                torch.cuda.current_stream(t.device).synchronize()
+            ctx.allreduce_sum(t)
+            ctx.sync()
             return float(t.item())
         return stats.loss
 

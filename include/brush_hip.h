@@ -143,6 +143,9 @@ typedef struct BhRenderOut {
      * compact ids inside compact_gid_from_isect.  == num_visible, except under BH_FLAG_SLICED_LISTS with per-tile cuts: then only
      * the splats that own a listed pair are sorted and numbered (a sub-sequence of the full depth order). */
     uint32_t num_listed_splats;
+    /* Which forward of its context this is (1, 2, ...): bh_render_backward_saved / bh_render_retain / bh_render_release identify
+     * the forward by it, and refuse (BH_ERR_STATE) a struct whose buffers a later forward has since taken over. */
+    uint64_t generation;
 } BhRenderOut;
 
 /* ---- ABI guard -------------------------------------------------------------- */
@@ -150,7 +153,7 @@ typedef struct BhRenderOut {
  * built against another revision would be overrun (BhRenderOut, BhTrainBatch and BhTrainConfig have grown).  A binding
  * checks once, at load time: bh_abi_version() == the BH_ABI_VERSION it was written against, and bh_struct_size(i) == the
  * size of its own mirror of struct i (brush_amd/_ffi.py and include/brush_hip.hpp do; INTEGRATION.md shows the Rust side). */
-#define BH_ABI_VERSION 5u
+#define BH_ABI_VERSION 6u
 enum {
     BH_STRUCT_CAMERA = 0, BH_STRUCT_RENDER_OUT, BH_STRUCT_LOSS_CONFIG, BH_STRUCT_TRAIN_CONFIG, BH_STRUCT_TRAIN_STATE,
     BH_STRUCT_TRAIN_BATCH, BH_STRUCT_TRAIN_STATS, BH_STRUCT_REFINE_CONFIG, BH_STRUCT_REFINE_STATS, BH_STRUCT_PLY_INFO,
@@ -191,8 +194,8 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
 
 /* BH_FLAG_SLICED_LISTS: how the near lists are cut.
  *   near_share <= 0 (the default): PER TILE, from the last frame of the same view on this ctx (bh_set_view_id).  Every blend
- *     launch records, per tile, the depth behind which the tile needed no splat (+ a quarter more of the depth order as a
- *     margin; "everything" for a tile that did not saturate); the view's next frame lists a (splat, tile) pair only if the
+ *     launch records, per tile, the depth behind which the tile needed no splat (+ a margin: 1.5x the tile's depth rank more of the depth
+ *     order; "everything" for a tile that did not saturate); the view's next frame lists a (splat, tile) pair only if the
  *     splat lies at or in front of the tile's cut — typically a tenth of the pairs, whatever the frame looks like (a blank
  *     background or thin regions keep their own short lists whole).  A tile that is still live behind a cut list is finished
  *     by the far pass (the pairs behind the cut, for those tiles only), which also corrects the table; a view's first frame,
@@ -203,9 +206,12 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
  * Note for bh_render_forward: a sliced frame makes the call wait for the near pass's blend (a 4-byte readback decides whether
  * the far pass is queued); bh_train_step hides that wait behind its loss kernels. */
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
-/* The view the following forwards on this ctx render (sticky; 0 = unknown, the default): selects the per-tile depth-cut table
- * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.  One
- * table is 4 bytes per tile; the 4096 most recently used views are kept. */
+/* The view the following forwards on this ctx render (sticky; 0 = not named, the default): selects the per-tile depth-cut table
+ * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.
+ * A frame without an id is keyed by its CAMERA (a hash of the BhCamera's view matrix, intrinsics, size, model and tile window): the
+ * views of a dataset are fixed cameras, so a caller that passes the reference's SceneBatch unchanged (no view index,
+ * brush-dataset/src/scene.rs:138-147) gets the same tables as one that numbers its views.  One table is 8 bytes per tile (cut +
+ * last work); the most recently used 4096 views / 256 MB of tables are kept. */
 int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
 /* Per-tile cuts pay when there are lists to shorten: a view whose last frame had fewer than min_pairs intersections keeps
  * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional far pass cost more than
@@ -224,13 +230,30 @@ uint32_t bh_far_slices_queued(bh_ctx* ctx);
  * Blocking (the counts live on the device: one 16-byte readback); BH_ERR_STATE without a forward. */
 int bh_last_list_counts(bh_ctx* ctx, uint32_t* near_pairs /*host*/, uint32_t* far_pairs /*host*/);
 
-/* Backward of the last BH_FLAG_BWD_INFO forward on this ctx.  v_output [H,W,4].
+/* Backward of the LAST BH_FLAG_BWD_INFO forward on this ctx (shorthand for bh_render_backward_saved with that forward's
+ * BhRenderOut; a caller that may have rendered something else in between uses the _saved form).  v_output [H,W,4].
  * All four outputs are dense and fully overwritten (zero where the splat got no
  * gradient).  v_refine_weight replaces the reference's "gradient of a dummy [1]
  * tensor" side channel (bwd/burn_glue.rs:165-180). */
 int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transforms, const float* sh_coeffs,
                        const float* raw_opacities, float* v_transforms /*[N,10]*/, float* v_sh_coeffs /*[N,C,3]*/,
                        float* v_raw_opacities /*[N]*/, float* v_refine_weight /*[N]*/);
+/* The same with the forward's saved state passed explicitly — the shape of SplatBwdOps::{rasterize_bwd, project_bwd}, which
+ * receive the tensors RenderBackwards saved (bwd/burn_glue.rs:62-92, 336-371, consumed at :121-182).  `saved` is the BhRenderOut a
+ * BH_FLAG_BWD_INFO forward on THIS ctx returned.  Valid: the ctx's most recent forward, or any forward that was retained
+ * (bh_render_retain) and not yet released.  Anything else — a forward whose buffers a later forward has overwritten, a struct of
+ * another ctx — fails with BH_ERR_STATE instead of computing the gradients of the wrong frame.  transforms / sh_coeffs /
+ * raw_opacities must be the tensors that forward rendered (the reference clones them into the saved state). */
+int bh_render_backward_saved(bh_ctx* ctx, const BhRenderOut* saved /*host*/, const float* v_output, const float* transforms,
+                             const float* sh_coeffs, const float* raw_opacities, float* v_transforms /*[N,10]*/,
+                             float* v_sh_coeffs /*[N,C,3]*/, float* v_raw_opacities /*[N]*/, float* v_refine_weight /*[N]*/);
+/* Keep a forward replayable while later forwards run on the same ctx (two render nodes in one autodiff graph; an eval render
+ * between a training forward and its backward): detaches the buffers `out` points into from the ctx's arena — they stay valid, and
+ * bh_render_backward_saved(out) keeps working, until bh_render_release(out).  Only the ctx's most recent forward can be retained.
+ * Costs no copy; the next forward takes fresh blocks (released ones are recycled, so a steady retain / release cycle allocates
+ * nothing).  After bh_train_step, `visible` / `max_radius` of its forward point into the step's own buffers and are not kept. */
+int bh_render_retain(bh_ctx* ctx, const BhRenderOut* out /*host*/);
+int bh_render_release(bh_ctx* ctx, const BhRenderOut* out /*host*/);
 /* The BhRenderOut of the last forward on this ctx (also the one inside bh_train_step); BH_ERR_STATE if there is none. */
 int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out /*host*/);
 /* [Nv,10] rasterize-backward accumulator of the last bh_render_backward (RasterizeGrads). */
@@ -381,8 +404,8 @@ typedef struct BhTrainBatch {
     int32_t strip_loss;
     /* Which view of the dataset this batch is (any stable non-zero number, e.g. its index + 1; 0 = unknown).  Only the TIME of a
      * step depends on it: the forward keeps, per view id, how deep every tile had to go the last time that view was rendered
-     * and lists only that much of every tile the next time (bh_set_view_id).  Without ids all frames share one table, which
-     * works for one repeated camera and turns itself off for alternating ones. */
+     * and lists only that much of every tile the next time (bh_set_view_id).  Optional: with 0 the table is keyed by the camera
+     * itself, which is the same thing for a dataset of fixed views. */
     uint32_t view_id;
 } BhTrainBatch;
 
@@ -426,6 +449,21 @@ int bh_comm_world(bh_ctx* ctx); /* 1 without a communicator */
 int bh_allreduce_sum_f32(bh_ctx* ctx, float* buf, uint64_t count);
 int bh_allreduce_max_f32(bh_ctx* ctx, float* buf, uint64_t count); /* e.g. RefineRecord maxima before refine */
 int bh_allgather_bytes(bh_ctx* ctx, const void* send, void* recv /*world * bytes_per_rank*/, uint64_t bytes_per_rank); /* e.g. image strips */
+int bh_comm_rank(bh_ctx* ctx);  /* 0 without a communicator */
+/* Every RCCL entry point the library binds (all-reduce SUM / MAX, all-gather, grouped send / recv) on small rank-dependent
+ * patterns, checked on the host; blocking, collective (every rank calls it).  Run it once after bh_comm_init before trusting an
+ * exchange: a build whose communicator has never met more than one rank finds out here, not in a gradient. */
+int bh_comm_selftest(bh_ctx* ctx);
+/* One frame split over the ranks by strips of tile rows, strip-wise loss: fetch the 21 pixel rows above and below
+ * this rank's strip [row_begin_px, row_end_px) of img [H,W,4] from the neighbouring ranks, and hand them this strip's first / last
+ * 21 rows (grouped ncclSend / ncclRecv on the ctx stream, in place).  Preconditions, identical on all ranks: strips lie in rank
+ * order (rank r directly above rank r + 1) and each is at least 21 rows tall.  bh_train_step calls this itself when the batch's
+ * camera has a tile-row window, strip_loss != 0, no image_hook is given and the ctx carries a communicator.
+ * bh_strip_halo_plan is the host arithmetic behind it (a caller with its own transport can reuse it): up to 4 operations, returns
+ * their number. */
+typedef struct BhHaloOp { int32_t send; int32_t peer; uint32_t row_begin_px, rows; } BhHaloOp;
+int bh_strip_halo_plan(uint32_t img_h, uint32_t row_begin_px, uint32_t row_end_px, int rank, int world, BhHaloOp* out /*host [4]*/);
+int bh_exchange_strip_halos(bh_ctx* ctx, float* img_hwc4, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px);
 
 /* The stochastic terms of step().  bh_sample_background: sample_background_color (train.rs:896-908) from the same
  * counter-based generator — base + U(-strength, strength)^3 clamped to [0,1], a pure function of (seed, step); host only.

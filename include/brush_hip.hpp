@@ -276,14 +276,61 @@ inline std::pair<RenderAux, SplatGrads> render_splats_bwd(const Context& ctx, co
     g.v_sh_coeffs.resize(splats.sh_coeffs.size());
     g.v_raw_opacities.resize(n);
     g.v_refine_weight.resize(n);
-    ctx.check(bh_render_backward(ctx.get(), v_output, f.t, splats.sh_coeffs.data(), f.o, g.v_transforms.data(), g.v_sh_coeffs.data(),
-                                 g.v_raw_opacities.data(), g.v_refine_weight.data()));
+    // the saved state goes in explicitly (SplatBwdOps::{rasterize_bwd, project_bwd}, bwd/burn_glue.rs:62-92)
+    ctx.check(bh_render_backward_saved(ctx.get(), &aux.raw, v_output, f.t, splats.sh_coeffs.data(), f.o, g.v_transforms.data(), g.v_sh_coeffs.data(),
+                                       g.v_raw_opacities.data(), g.v_refine_weight.data()));
     if (splats.min_scale)  // chain through the fold (the autodiff of bwd/burn_glue.rs:260-270)
         ctx.check(bh_fold_min_scale_backward(ctx.get(), splats.transforms.data(), splats.raw_opacities.data(), splats.min_scale->data(), n,
                                              g.v_transforms.data(), g.v_raw_opacities.data()));
     ctx.sync();
     return {std::move(aux), std::move(g)};
 }
+
+// One differentiable render as the autodiff node the reference registers (bwd/burn_glue.rs:223-311): the forward now, the backward
+// later from the node's SAVED state (:336-371).  retain = true keeps the node replayable while other renders run on the ctx
+// (bh_render_retain); without it a later forward makes the node stale and backward() throws (BH_ERR_STATE) instead of returning
+// another frame's gradients.
+class RenderNode {
+  public:
+    RenderNode(const Context& ctx, const Splats& splats, const Camera& camera, uint32_t img_w, uint32_t img_h, const float background[3],
+               bool retain = false, RasterPass pass = RasterPass::Backward)
+        : ctx_(ctx), splats_(splats), folded_(detail::fold(ctx, splats)) {
+        if (!bwd_info(pass)) throw Error(BH_ERR_INVALID_ARG, "RenderNode requires a Backward variant");
+        const BhCamera cam = camera.uniforms(img_w, img_h);
+        aux.img_w = img_w; aux.img_h = img_h; aux.num_splats = splats.num_splats();
+        ctx.check(bh_render_forward(ctx.get(), &cam, splats.num_splats(), splats.sh_degree(), folded_.t, splats.sh_coeffs.data(), folded_.o, background,
+                                    detail::flags_of(splats, pass), &aux.raw));
+        if (retain) {
+            ctx.check(bh_render_retain(ctx.get(), &aux.raw));
+            retained_ = true;
+        }
+    }
+    RenderNode(const RenderNode&) = delete;
+    RenderNode& operator=(const RenderNode&) = delete;
+    ~RenderNode() { if (retained_) (void)bh_render_release(ctx_.get(), &aux.raw); }
+    SplatGrads backward(const float* v_output) const {
+        const uint32_t n = splats_.num_splats();
+        SplatGrads g;
+        g.v_transforms.resize((size_t)n * 10);
+        g.v_sh_coeffs.resize(splats_.sh_coeffs.size());
+        g.v_raw_opacities.resize(n);
+        g.v_refine_weight.resize(n);
+        ctx_.check(bh_render_backward_saved(ctx_.get(), &aux.raw, v_output, folded_.t, splats_.sh_coeffs.data(), folded_.o, g.v_transforms.data(),
+                                            g.v_sh_coeffs.data(), g.v_raw_opacities.data(), g.v_refine_weight.data()));
+        if (splats_.min_scale)
+            ctx_.check(bh_fold_min_scale_backward(ctx_.get(), splats_.transforms.data(), splats_.raw_opacities.data(), splats_.min_scale->data(), n,
+                                                  g.v_transforms.data(), g.v_raw_opacities.data()));
+        ctx_.sync();
+        return g;
+    }
+    RenderAux aux;
+
+  private:
+    const Context& ctx_;
+    const Splats& splats_;
+    detail::Folded folded_;
+    bool retained_ = false;
+};
 
 // ---- primitives --------------------------------------------------------------------------------------------------
 inline void radix_argsort(const Context& ctx, const DeviceBuffer<uint32_t>& keys, const DeviceBuffer<uint32_t>& vals, uint32_t bits,

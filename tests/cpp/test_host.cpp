@@ -136,6 +136,57 @@ static void test_render_vs_oracle(const bh::Context& ctx, Oracle& bo, bh::Camera
     std::printf("ok render_vs_oracle[%s]  nv=%u isect=%u img_err=%.1e grad_err=%.1e\n", name, aux.num_visible(), aux.num_intersections(), dmax, e1);
 }
 
+// forward A, forward B, backward A.  With the saved state passed explicitly (bh_render_backward_saved) a
+// retained A still yields A's gradients (== the oracle's for A), and an A that was NOT retained fails loudly instead of returning
+// B's gradients (bwd/burn_glue.rs:62-92, 336-371: RenderBackwards owns its saved tensors).
+static void test_two_forwards_alive(const bh::Context& ctx, Oracle& bo) {
+    const uint32_t n = 4000, w = 144, h = 96, coeffs = 1;
+    const HostScene sc = make_scene(n, 0xABCD, coeffs);
+    bh::Splats splats = bh::Splats::from_host(sc.transforms, sc.sh, sc.raw_opac);
+    bh::Camera camA, camB;
+    camA.fov_x = camB.fov_x = 1.0471976; camA.fov_y = camB.fov_y = 2.0 * std::atan((double)h / w * std::tan(camA.fov_x / 2));
+    camB.position[0] = 1.5f;   // another view: other lists, other gradients
+    const float bg[3] = {0.2f, 0.1f, 0.0f};
+    std::vector<float> v_host((size_t)w * h * 4);
+    for (size_t i = 0; i < v_host.size(); ++i) v_host[i] = (float)((i * 2654435761u) >> 8 & 0xFFFF) / 65536.0f - 0.5f;
+    bh::DeviceBuffer<float> v_out(v_host);
+    auto oracle_grads = [&](const bh::Camera& cam, std::vector<float>& vt) {
+        BoCamera oc{};
+        bo.camera_setup_model(cam.position, cam.rotation, cam.fov_x, cam.fov_y, 0.5f, 0.5f, w, h, 0u, cam.dist, &oc);
+        void* r = bo.render_create();
+        CHECK(bo.render_forward(r, &oc, n, 0, sc.transforms.data(), sc.sh.data(), sc.raw_opac.data(), bg, 2) == 0, "oracle forward");
+        CHECK(bo.render_backward(r, v_host.data(), sc.transforms.data(), sc.sh.data(), sc.raw_opac.data()) == 0, "oracle backward");
+        uint64_t cnt = 0;
+        const float* p = bo.get_v_transforms(r, &cnt);
+        vt.assign(p, p + cnt);
+        bo.render_free(r);
+    };
+    std::vector<float> refA, refB;
+    oracle_grads(camA, refA);
+    oracle_grads(camB, refB);
+    CHECK(rel_linf(refA, refB.data(), refB.size()) > 1e-2f, "the two views must have different gradients for this test to mean anything");
+    {
+        bh::RenderNode A(ctx, splats, camA, w, h, bg, /*retain=*/true);
+        bh::RenderNode B(ctx, splats, camB, w, h, bg);
+        CHECK(B.aux.raw.generation == A.aux.raw.generation + 1, "forwards are numbered");
+        const float eA = rel_linf(A.backward(v_out.data()).v_transforms.download(), refA.data(), refA.size());
+        const float eB = rel_linf(B.backward(v_out.data()).v_transforms.download(), refB.data(), refB.size());
+        CHECK(eA <= 1e-4f && eB <= 1e-4f, "retained A after B: gradient rel. error %g (A) / %g (B)", eA, eB);
+        const float eA2 = rel_linf(A.backward(v_out.data()).v_transforms.download(), refA.data(), refA.size());
+        CHECK(eA2 <= 1e-4f, "a retained node can be replayed again: %g", eA2);
+    }
+    {
+        bh::RenderNode A(ctx, splats, camA, w, h, bg);   // not retained
+        bh::RenderNode B(ctx, splats, camB, w, h, bg);
+        bool threw = false;
+        try { (void)A.backward(v_out.data()); } catch (const bh::Error& e) { threw = e.code == BH_ERR_STATE; }
+        CHECK(threw, "backward of a forward that a later forward overwrote must fail with BH_ERR_STATE");
+        const float eB = rel_linf(B.backward(v_out.data()).v_transforms.download(), refB.data(), refB.size());
+        CHECK(eB <= 1e-4f, "... and the live forward is unharmed: %g", eB);
+    }
+    std::printf("ok two_forwards_alive\n");
+}
+
 static void test_primitives(const bh::Context& ctx) {
     for (uint32_t n : {1u, 1000u, 4097u, 300000u}) {
         Sm64 r{n};
@@ -269,6 +320,7 @@ int main(int argc, char** argv) {
         test_render_vs_oracle(ctx, bo, bh::CameraModel::Pinhole, "pinhole");
         test_render_vs_oracle(ctx, bo, bh::CameraModel::KannalaBrandt4, "kb4");
         test_render_vs_oracle(ctx, bo, bh::CameraModel::RadialTangential8, "rt8");
+        test_two_forwards_alive(ctx, bo);
         test_primitives(ctx);
         test_training_refine_ply(ctx);
         test_errors(ctx);

@@ -173,3 +173,54 @@ def test_sample_background_is_the_reference_law():
     assert abs(float(np.corrcoef(smp[:, 0], smp[:, 1])[0, 1])) < 0.06
     edge = np.stack([bg(11, k, (0.0, 1.0, 0.5), 0.1) for k in range(1, 201)])
     assert edge.min() >= 0.0 and edge.max() <= 1.0 and (edge[:, 0] == 0.0).any() and (edge[:, 1] == 1.0).any()
+
+
+def test_strip_halo_plan_moves_exactly_the_rows_the_strip_loss_reads():
+    """bh_strip_halo_plan (host arithmetic behind bh_exchange_strip_halos, the library-owned exchange of a frame split by strips of
+    tile rows): simulate `world` ranks on numpy images.  Every send has a matching receive of the same rows (the same
+    global pixel rows on both ends, else RCCL would hang or scramble), and afterwards every rank holds the true frame on its strip
+    +- 21 rows — what brush_amd/parallel.py:exchange_strip_halos delivers through torch.distributed."""
+    import ctypes
+    import numpy as np
+    import __graft_entry__ as g
+    g.build()
+    from brush_amd import _ffi
+    from brush_amd.parallel import strip_spans_px, strips_allow_halo_loss
+    lib = _ffi.load()
+    rng = np.random.default_rng(3)
+    for h, world, weights in ((1080, 8, None), (1080, 4, None), (2160, 8, None), (1080, 8, "random"), (400, 2, None), (208, 1, None), (1080, 3, "random")):
+        tile_bh = (h + 15) // 16
+        w8 = None if weights is None else list(rng.uniform(0.2, 3.0, tile_bh))
+        spans = strip_spans_px(h, world, w8)
+        if not strips_allow_halo_loss(spans):
+            continue
+        truth = np.arange(h, dtype=np.float32) + 1.0
+        imgs = []
+        for r, (b, e) in enumerate(spans):
+            im = np.full(h, -1.0, np.float32)
+            im[b:e] = truth[b:e]
+            imgs.append(im)
+        plans = []
+        for r, (b, e) in enumerate(spans):
+            ops = (_ffi.BhHaloOp * 4)()
+            k = lib.bh_strip_halo_plan(h, b, e, r, world, ops)
+            assert 0 <= k <= 4
+            plans.append([(ops[i].send, ops[i].peer, ops[i].row_begin_px, ops[i].rows) for i in range(k)])
+        staged = [im.copy() for im in imgs]
+        for r, plan in enumerate(plans):
+            for send, peer, row0, rows in plan:
+                if not send:
+                    continue
+                match = [(p0, pr) for (ps, pp, p0, pr) in plans[peer] if not ps and pp == r]
+                assert len(match) == 1, (h, world, r, peer)
+                assert match[0] == (row0, rows), "send and receive disagree on the rows: %r vs %r" % ((row0, rows), match[0])
+                assert spans[r][0] <= row0 and row0 + rows <= spans[r][1], "a rank may only send rows it rendered"
+                staged[peer][row0:row0 + rows] = imgs[r][row0:row0 + rows]
+        for r, plan in enumerate(plans):   # every receive has its send
+            for send, peer, row0, rows in plan:
+                if not send:
+                    assert (1, r, row0, rows) in plans[peer]
+        for r, (b, e) in enumerate(spans):
+            lo, hi = max(0, b - 21), min(h, e + 21)
+            assert np.array_equal(staged[r][lo:hi], truth[lo:hi]), (h, world, r)
+    assert lib.bh_strip_halo_plan(100, 50, 40, 0, 2, (_ffi.BhHaloOp * 4)()) < 0   # begin >= end

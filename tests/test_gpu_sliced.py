@@ -259,15 +259,22 @@ def test_train_step_sliced_equals_exact(dev, sh_degree):
     assert np.mean(res[True][5] != res[False][5]) <= 2e-3
 
 
-@pytest.mark.parametrize("with_ids", [True, False])
-def test_alternating_views_with_and_without_view_ids(dev, with_ids):
+@pytest.mark.parametrize("mode", ["ids", "camera_hash", "shared_table"])
+def test_alternating_views_with_and_without_view_ids(dev, mode):
     """a shallow and a deep view in turn.  With view ids every view has its own per-tile cuts: after each view's first frame the
-    near lists are a fraction of the pairs and no far pass runs.  Without ids the two views share one table: the deep view's
-    tiles are cut too early every time and the far pass finishes them (same image); a view that misses in six of eight cut frames
-    falls back to complete lists for a while."""
+    near lists are a fraction of the pairs and no far pass runs.  WITHOUT ids (the reference's SceneBatch carries none,
+    brush-dataset/src/scene.rs:138-147) the table is keyed by the camera itself: the same shares, frame for frame.  Only with the A/B
+    knob BH_NO_VIEW_HASH do the two views share one table (round 4's behaviour): the deep view's tiles are cut too early every time,
+    a second attempt finishes them (same image), and repeated misses put the table on hold."""
+    import os
     import brush_amd as ba
     n, w, h = 60000, 320, 208
-    ctx = ba.Context(dev)
+    if mode == "shared_table":
+        os.environ["BH_NO_VIEW_HASH"] = "1"
+    try:
+        ctx = ba.Context(dev)   # (knobs are read at bh_create)
+    finally:
+        os.environ.pop("BH_NO_VIEW_HASH", None)
     try:
         sc, cp = _scene(n, w, h, 0x59, scales=(0.03, 0.3))
         spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
@@ -281,18 +288,24 @@ def test_alternating_views_with_and_without_view_ids(dev, with_ids):
         queued, shares = [], []
         for i in range(16):
             name, cam = (("near", near_cam), ("far", far_cam))[i % 2]
-            ba.set_view_id(1 + i % 2 if with_ids else 0, ctx)
+            ba.set_view_id(1 + i % 2 if mode == "ids" else 0, ctx)
             img, aux = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
             assert torch.equal(img, ref[name][0]) and torch.equal(aux.visible, ref[name][1].visible), (i, name)
             queued.append(int(ctx.lib.bh_far_slices_queued(ctx._h)))
             shares.append(float(ctx.lib.bh_last_list_share(ctx._h)))
-        if with_ids:
+        if mode != "shared_table":
             assert shares[0] == 1.0 and shares[1] == 1.0 and max(shares[2:]) < 0.9, shares
             assert queued[-1] == 0, queued
+            _ALTERNATING_SHARES[mode] = shares
+            if len(_ALTERNATING_SHARES) == 2:   # keyed by id or by camera: the same tables, so the same near lists
+                assert _ALTERNATING_SHARES["ids"] == _ALTERNATING_SHARES["camera_hash"]
         else:
             assert queued[-1] >= 1, queued                    # the shared table mispredicts (the image is right all the same)
     finally:
         ctx.close()
+
+
+_ALTERNATING_SHARES = {}
 
 
 def test_blank_background_is_cut_like_any_other_frame(dev):
