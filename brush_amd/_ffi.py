@@ -178,6 +178,7 @@ SYMBOLS = {
     "bh_allreduce_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_allreduce_max_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bh_allgather_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "bh_forget_views": (C.c_int, [C.c_void_p]),
     "bh_comm_rank": (C.c_int, [C.c_void_p]),
     "bh_comm_selftest": (C.c_int, [C.c_void_p]),
     "bh_strip_halo_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),

@@ -228,7 +228,8 @@ static uint64_t view_key(const bh_ctx* ctx, const BhCamera& c) {
 // The per-tile depth-cut table of view `key` for a (tile_bw x tile_bh) grid: created (all ZCUT_ALL = "list everything") on first
 // use, re-created when the grid changes; beyond MAX_VIEW_STATES tables (or VIEW_TABLE_BYTES of them) the least recently used view
 // gives its table up — to the new view when the grids match (no free, no host wait: the clears are ordered on the stream).
-static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32_t tile_bh) {
+// touch = false: a second attempt at the frame that has just been counted (finish_far_slice): the view's gap and stamp stay
+static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32_t tile_bh, bool touch = true) {
     const size_t words = (size_t)tile_bw * tile_bh ? (size_t)tile_bw * tile_bh : 1;
     auto it = ctx->views.find(key);
     uint32_t* recycled = nullptr;
@@ -269,17 +270,34 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
             (void)hipFree(vs.zcut);
             return nullptr;
         }
-        it = ctx->views.emplace(key, vs).first;
+        vs.gap = (uint32_t)ctx->views.size() + 1u;   // (a new view of a dataset: it will come back after about as many frames as there are views)
+        vs.last_used = ++ctx->view_clock;
+        return &ctx->views.emplace(key, vs).first->second;
     }
-    it->second.last_used = ++ctx->view_clock;
+    if (touch) {
+        const uint64_t now = ++ctx->view_clock;
+        it->second.gap = (uint32_t)std::min<uint64_t>(now - it->second.last_used, 1u << 20);
+        it->second.last_used = now;
+    }
     return &it->second;
+}
+
+// margin (in % of a tile's depth rank) the blend kernel of this frame writes behind every tile's last useful splat
+static uint32_t cut_margin_pct(const bh_ctx* ctx, const ViewState* vs) {
+    const float gap = vs && vs->gap > 2u ? (float)vs->gap : 2.0f;
+    const float m = (float)ctx->knob_cut_margin_pct * ctx->margin_scale * std::cbrt(gap * 0.5f);
+    return m < 6400.0f ? (m > 10.0f ? (uint32_t)m : 10u) : 6400u;
 }
 
 // Outcome of a per-tile-cut frame of `vs`: did its far pass have to run (= the forecast failed for some tile)?  A miss now and
 // then is normal and cheap (the far pass lists a few pairs for a few tiles and corrects the table).  Six misses within the
 // view's last eight cut frames (alternating cameras sharing one table, a scene that changes faster than the margin) and the view's
 // next eight frames are rendered with complete lists, each of them re-seeding the table.
-static void view_outcome(ViewState* vs, bool missed, bool shared_table) {
+static void view_outcome(bh_ctx* ctx, ViewState* vs, bool missed, bool shared_table) {
+    if (!ctx->knob_fixed_margin) {
+        const float s = ctx->margin_scale * (missed ? 1.5f : 0.998f);
+        ctx->margin_scale = s < 0.5f ? 0.5f : (s > 16.0f ? 16.0f : s);
+    }
     if (!vs) return;
     vs->penalty = ((vs->penalty << 1) | (missed ? 1u : 0u)) & 0xFFu;   // (the history of the last eight cut frames, one bit each)
     // the table of view id 0 is shared by every frame that names no view: alternating cameras miss on every other frame there,
@@ -305,7 +323,7 @@ int finish_far_slice(bh_ctx* ctx, bool* launched) {
     const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
     if (ctx->far_job.by_cut) {
         FarJob& j = ctx->far_job;
-        view_outcome(j.view, unsat != 0u, j.view_shared);
+        view_outcome(ctx, j.view, unsat != 0u, j.view_shared);
         if (unsat == 0u) return 0;
         if (launched) *launched = true;
         ctx->far_launches++;
@@ -402,6 +420,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
     ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
     ctx->knob_no_view_hash = getenv("BH_NO_VIEW_HASH") != nullptr;
+    ctx->knob_fixed_margin = getenv("BH_CUT_MARGIN_FIXED") != nullptr;
     ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
@@ -701,7 +720,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     ViewState* view = nullptr;
     bool cut_active = false;
     if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
-        view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh);
+        view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh, /*touch=*/allow_cut);
         if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
         // (a frame with few pairs has nothing to save: the near count in K1 and an occasional far pass cost more than listing and
         //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
@@ -884,7 +903,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         rs.depth_keys_sorted = depths_sorted;
         rs.nv = nv;
         rs.cut_active = by_cut;
-        rs.margin_pct = ctx->knob_cut_margin_pct;
+        rs.margin_pct = ctx->knob_fixed_margin ? ctx->knob_cut_margin_pct : cut_margin_pct(ctx, view);
         rs.work = view->zcut + (size_t)num_tiles;
         rs.order = tile_order;
         rs.order_mode = ctx->knob_k16_order;
@@ -1075,6 +1094,22 @@ int bh_set_list_cut_threshold(bh_ctx* ctx, uint32_t min_pairs) {
 int bh_set_view_id(bh_ctx* ctx, uint32_t view_id) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     ctx->view_id = view_id;
+    return 0;
+}
+
+int bh_forget_views(bh_ctx* ctx) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    if (ctx->views.empty()) return 0;
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // queued kernels may still use the tables
+    deliver_pending_loss(ctx);
+    for (auto& kv : ctx->views)
+        if (kv.second.zcut) (void)hipFree(kv.second.zcut);
+    ctx->views.clear();
+    ctx->gate_view = nullptr;
+    ctx->far_job.view = nullptr;
+    ctx->margin_scale = 1.0f;
     return 0;
 }
 

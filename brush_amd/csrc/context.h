@@ -131,7 +131,9 @@ struct ViewState {
     bool seeded = false;            // a forward of this view has written the table
     uint32_t exact_frames = 0;      // frames to render with complete lists before the cut is trusted again (the forecast kept failing)
     uint32_t penalty = 0;           // one bit per recent cut frame: its far pass had to run (api.hip view_outcome)
-    uint64_t last_used = 0;         // LRU stamp
+    uint64_t last_used = 0;         // LRU stamp (the ctx's forward counter at the view's last frame)
+    uint32_t gap = 0;               // forwards between the view's last two frames (a new view: the number of views the ctx knows) —
+                                    // how stale the table will be when it is next read: the margin written into it grows with it
     uint32_t last_pairs = 0;        // num_intersections of the view's last frame
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
@@ -287,9 +289,15 @@ struct bh_ctx {
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
+    // The margin behind a tile's last useful splat adapts (api.hip cut_margin_pct): x (gap / 2)^(1/3) for a view that comes back
+    // after `gap` frames, x margin_scale — multiplied by 1.5 when a forecast fails, by 0.998 when one holds (about one second
+    // attempt in 200 cut frames at equilibrium), within [0.5, 16].  A scene that still moves fast (early training, many views between
+    // two visits) gets deep margins, a settled one tight ones.
+    float margin_scale = 1.0f;
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
     bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
     bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
+    bool knob_fixed_margin = false;       // BH_CUT_MARGIN_FIXED (A/B): the margin is BH_CUT_MARGIN_PCT for every frame (rounds 4's behaviour), not adaptive
     bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)

@@ -438,23 +438,21 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
         }
         // per-tile depth cut for this view's NEXT frame: a saturated tile needs the splats up to its last useful one — plus a margin
-        // of a quarter more of the depth order (parameters move between two visits of a view) — and nothing behind; a tile that
+        // of margin_pct % of its depth rank (parameters move between two visits of a view) — and nothing behind; a tile that
         // did not saturate needs everything there is.  forward-only passes keep no last_useful: `reached` (>= it) is used.
         if (sl.zcut) {
             uint32_t newcut = ZCUT_ALL;
             if (saturated && sl.nv) {
                 const uint32_t stop = BWD_INFO ? last_useful : reached;
+                // (the table is only kept in automatic mode, whose frames never run PHASE 2: a frame whose forecast failed is rendered
+                //  again with complete lists, api.hip finish_far_slice)
                 uint32_t g = 0xFFFFFFFFu;
                 if (stop > range_lo) g = isect_gids[stop - 1u];
-                else if (PHASE == 2) {   // (saturated by the near list's last splats, nothing blended here)
-                    const uint32_t n_lo = sl.offsets_near[tile * 2], n_hi = sl.offsets_near[tile * 2 + 1];
-                    if (n_hi > n_lo) g = isect_gids[n_hi - 1u];
-                }
                 if (g != 0xFFFFFFFFu) {
                     // (how deep a tile has to go is set by its SLOWEST pixel — an extreme value that jumps when a few small splats
-                    //  move, and the default step moves them on purpose: the margin is generous, the lists still a fraction)
-                    // (a tile the far pass had to finish has just shown that it is volatile: three times the margin)
-                    const unsigned long long mraw = (unsigned long long)g * sl.margin_pct / 100ull * (PHASE == 2 ? 3ull : 1ull);
+                    //  move, and the default step moves them on purpose: the margin is generous, the lists still a fraction.  The
+                    //  host scales it with how long the view will be away and with how forecasts have fared lately: api.hip cut_margin_pct)
+                    const unsigned long long mraw = (unsigned long long)g * sl.margin_pct / 100ull;
                     const uint32_t margin = mraw > 128ull ? (mraw < 0x7FFFFFFFull ? (uint32_t)mraw : 0x7FFFFFFFu) : 128u;
                     const uint32_t g2 = (unsigned long long)g + margin < sl.nv ? g + margin : sl.nv - 1u;
                     newcut = sl.depth_keys_sorted[g2] & ~1u;   // (bit 0 is the "incomplete" mark of the table's next frame: clear)

@@ -213,6 +213,9 @@ int bh_set_list_slicing(bh_ctx* ctx, float near_share);
  * brush-dataset/src/scene.rs:138-147) gets the same tables as one that numbers its views.  One table is 8 bytes per tile (cut +
  * last work); the most recently used 4096 views / 256 MB of tables are kept. */
 int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
+/* Drop every per-view table of this ctx (another scene or dataset was loaded: what the tables forecast no longer exists).  Only
+ * time depends on it — stale tables cost a few re-rendered frames until they have re-learnt — never results.  Blocking. */
+int bh_forget_views(bh_ctx* ctx);
 /* Per-tile cuts pay when there are lists to shorten: a view whose last frame had fewer than min_pairs intersections keeps
  * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional far pass cost more than
  * listing and sorting everything; 0 = always cut).  The environment variable BH_CUT_MIN_PAIRS sets the initial value of new

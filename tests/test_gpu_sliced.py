@@ -379,7 +379,13 @@ def test_view_tables_survive_eviction_and_resolution_changes(dev):
     sc, cp = _scene(n, w, h, 0x5E, scales=(0.03, 0.3))
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     cam = util.hip_camera(ba, cp)
-    ctx = ba.Context(dev)
+    import os
+    # (the adaptive margin grows with the number of views between two visits — thousands here: pin it, this test is about the tables)
+    os.environ["BH_CUT_MARGIN_FIXED"] = "1"
+    try:
+        ctx = ba.Context(dev)
+    finally:
+        del os.environ["BH_CUT_MARGIN_FIXED"]
     try:
         ref, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx)
         ref2, _ = ba.render_splats(spl, cam, (w * 2, h * 2), (0, 0, 0), ba.RasterPass.Forward, ctx=ctx)
@@ -720,3 +726,47 @@ def test_a_failed_step_drops_its_per_tile_cut_job_and_never_replays_freed_parame
     finally:
         A.close()
         F.close()
+
+
+def test_the_cut_margin_adapts_to_how_long_a_view_is_away_and_to_failed_forecasts(dev):
+    """api.hip cut_margin_pct: a view that comes back after many other views gets a deeper margin than one that alternates with a
+    single other view (same scene, same camera: a larger near share), and a failed forecast deepens the margins of the frames that
+    follow (x 1.5 per miss).  Images stay the exact path's throughout."""
+    import brush_amd as ba
+    n, w, h = 60000, 320, 208
+    sc, cp = _scene(n, w, h, 0x59, scales=(0.03, 0.3))
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    others = []
+    for k in range(40):
+        c = dict(cp)
+        c["pos"] = (0.05 * (k + 1), 0.0, 0.0)
+        others.append(util.hip_camera(ba, c))
+    ctx = ba.Context(dev)
+    try:
+        ref, _ = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx)
+
+        def frame(c, vid):
+            ba.set_view_id(vid, ctx)
+            img, _ = ba.render_splats(spl, c, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True, copy=(c is cam))
+            if c is cam:
+                assert torch.equal(img, ref)
+            return float(ctx.lib.bh_last_list_share(ctx._h))
+        # alternating with ONE other view: gap 2
+        for _ in range(3):
+            s_close = frame(cam, 1)
+            frame(others[0], 2)
+        # ... then 40 other views between two visits: the table written at a visit carries the margin for the gap it has just seen
+        for _ in range(3):
+            for k, c in enumerate(others):
+                frame(c, 10 + k)
+            s_far = frame(cam, 1)
+        assert s_close < 1.0 and s_far > s_close * 1.15, (s_close, s_far)
+        # a failed forecast (the scene turns nearly transparent between two frames of a view) widens what follows
+        thin = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"] - 4.0, device=dev)
+        q0 = int(ctx.lib.bh_far_slices_queued(ctx._h))
+        ba.set_view_id(1, ctx)
+        ba.render_splats(thin, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
+        assert int(ctx.lib.bh_far_slices_queued(ctx._h)) == q0 + 1
+    finally:
+        ctx.close()
