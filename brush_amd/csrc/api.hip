@@ -285,7 +285,7 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
 // margin (in % of a tile's depth rank) the blend kernel of this frame writes behind every tile's last useful splat
 static uint32_t cut_margin_pct(const bh_ctx* ctx, const ViewState* vs) {
     const float gap = vs && vs->gap > 2u ? (float)vs->gap : 2.0f;
-    const float m = (float)ctx->knob_cut_margin_pct * ctx->margin_scale * std::cbrt(gap * 0.5f);
+    const float m = (float)ctx->knob_cut_margin_pct * ctx->margin_scale * std::pow(gap * 0.5f, ctx->ctrl_gap_exp);
     return m < 6400.0f ? (m > 10.0f ? (uint32_t)m : 10u) : 6400u;
 }
 
@@ -295,8 +295,8 @@ static uint32_t cut_margin_pct(const bh_ctx* ctx, const ViewState* vs) {
 // next eight frames are rendered with complete lists, each of them re-seeding the table.
 static void view_outcome(bh_ctx* ctx, ViewState* vs, bool missed, bool shared_table) {
     if (!ctx->knob_fixed_margin) {
-        const float s = ctx->margin_scale * (missed ? 1.5f : 0.998f);
-        ctx->margin_scale = s < 0.5f ? 0.5f : (s > 16.0f ? 16.0f : s);
+        const float s = ctx->margin_scale * (missed ? ctx->ctrl_up : ctx->ctrl_down);
+        ctx->margin_scale = s < ctx->ctrl_floor ? ctx->ctrl_floor : (s > 16.0f ? 16.0f : s);
     }
     if (!vs) return;
     vs->penalty = ((vs->penalty << 1) | (missed ? 1u : 0u)) & 0xFFu;   // (the history of the last eight cut frames, one bit each)
@@ -421,6 +421,12 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
     ctx->knob_no_view_hash = getenv("BH_NO_VIEW_HASH") != nullptr;
     ctx->knob_fixed_margin = getenv("BH_CUT_MARGIN_FIXED") != nullptr;
+    if (const char* e = getenv("BH_CUT_CTRL")) {   // developer A/B of the margin controller: "up:down:floor:gap_exp"
+        float a = 0, b = 0, c = 0, d = 0;
+        if (sscanf(e, "%f:%f:%f:%f", &a, &b, &c, &d) == 4 && a >= 1.0f && b > 0.0f && b <= 1.0f && c > 0.0f && d >= 0.0f && d <= 1.0f) {
+            ctx->ctrl_up = a; ctx->ctrl_down = b; ctx->ctrl_floor = c; ctx->ctrl_gap_exp = d;
+        }
+    }
     ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
@@ -667,8 +673,7 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_
 int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_degree, const float* transforms, const float* sh_coeffs,
                             const float* raw_opacities, const float* background, uint32_t flags, BhRenderOut* out, bool allow_cut) {
     ctx->have_forward = false;
-    ctx->vcombined_prezeroed = false;   // set below only by the kernels of THIS forward
-    ctx->grads_prezeroed = false;
+    ctx->clears.begin_forward();   // (filled in below only by the kernels of THIS forward)
     const bool mip = flags & BH_FLAG_MIP, bwd_info = flags & BH_FLAG_BWD_INFO, smooth = flags & BH_FLAG_SMOOTH_CUTOFF;
     const ViewUniforms u = make_uniforms(*cam);
     if (u.tile_y0 >= u.tile_y1 || u.tile_y1 > u.tile_bh) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_row window must satisfy begin < end <= ceil(img_h / 16)");
@@ -766,12 +771,11 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 prep.order_tile_begin = u.tile_bw * u.tile_y0;
                 prep.order_mode = ctx->knob_k16_order;
             }
-            ctx->grads_prezeroed = false;
             if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
                 prep.span = reinterpret_cast<float4*>(ctx->ext_grad_begin);   // the train step's gradient span
                 prep.span_f4 = (uint32_t)(ctx->ext_grad_floats / 4);
-                ctx->grads_prezeroed = true;
+                ctx->clears.k1_cleared_span();
             }
             BH_TRY(launch_project_forward(ctx, u, n, mip, sh_degree, transforms, sh_coeffs, raw_opacities, depth_keys, isect_counts, max_radius,
                                           proj_by_gid, counters, prep, cut_active ? view->zcut : nullptr, near_counts));
@@ -931,15 +935,14 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 ProfScope ps(ctx, "MapGaussiansToIntersect");
                 // the backward's accumulator [nv,10] is cleared by K5 on its way (whole float4s: + 16 B of room)
                 float4* vc = nullptr;
-                ctx->vcombined_prezeroed = false;
                 if (bwd_info) {
                     vc = (float4*)ensure(ctx, SLOT_V_COMBINED, (size_t)nv * 10 * 4 + 16);
                     if (!vc) return BH_ERR_OOM;
-                    ctx->vcombined_prezeroed = true;
                 }
                 if (zcut_lists && near_total == 0u) {
-                    ctx->vcombined_prezeroed = false;   // no pair in front of any cut: nothing to emit (and K5 does not run to clear v_combined)
+                    // no pair in front of any cut: nothing to emit (and K5 does not run to clear v_combined)
                 } else {
+                    ctx->clears.k5_cleared_accum(vc != nullptr);
                     BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u,
                                                 (sliced && !by_cut) ? budget : 0xFFFFFFFFu, (sliced || zcut_lists) ? slice_info : nullptr, zcut_lists,
                                                 zcut_lists ? depths_sorted : nullptr));
@@ -1056,6 +1059,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     r.tile_offsets_far = sliced ? tile_offsets_far : nullptr;
     r.list_budget = budget;   // (per-tile cuts: the pairs the near pass listed)
     r.generation = ++ctx->generation;
+    ctx->clears.stamp(r.generation);
     *out = r;
     ctx->last = r;
     ctx->last_listed_splats = nv;
@@ -1140,15 +1144,20 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, bool latest, const
     const size_t nvpad = nv ? nv : 1;
     auto* v_combined = (float*)ensure(ctx, SLOT_V_COMBINED, nvpad * 10 * 4 + 16);   // + room to clear whole float4s
     if (!v_combined) return BH_ERR_OOM;
+    bool row_marks = false;
     {
         ProfScope ps(ctx, "ZeroGradBuffers");
         // what the forward's kernels cleared on their way (K5: v_combined; K1: the train step's gradient span) is done
         const bool one_span = n > 0 && ctx->ext_grad_begin == v_transforms && ctx->ext_grad_floats;
-        // (grad_rows_marked: the single-GPU train step reads only the rows K18 writes and marks — its forward cleared the marks)
-        const bool vc_done = latest && ctx->vcombined_prezeroed, span_done = latest && one_span && (ctx->grads_prezeroed || ctx->grad_rows_marked);
-        // either way the accumulator is dirty from here on: a backward of ANOTHER forward (a retained one) must not trust the flag
-        ctx->vcombined_prezeroed = false;
-        ctx->grads_prezeroed = false;
+        // Consumed here, whichever forward this backward belongs to: the accumulator and the span are dirty from now on, and a
+        // backward of ANOTHER forward (a retained one) finds nothing to trust (take_* check the generation).
+        const bool vc_done = ctx->clears.take_accum(r.generation);
+        const GradClears::Span span = ctx->clears.take_span(r.generation);
+        row_marks = span == GradClears::ROW_MARKS;
+        // (ROW_MARKS: the single-GPU train step reads only the rows K18 writes and marks — its forward cleared the marks)
+        if (row_marks && !one_span) return set_error(ctx, BH_ERR_STATE, "internal: row-marked gradients without the train step's gradient span");
+        const bool span_done = one_span && span != GradClears::NONE;
+        (void)latest;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
             // v_combined and the exchange buffer's gradient span cleared by ONE launch (hipMemsetAsync spends two or
             // three launches on them, each ~5 us of latency beyond the bytes)
@@ -1184,7 +1193,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, bool latest, const
         ProfScope ps(ctx, "ProjectBackwards");
         BH_TRY(launch_project_backward(ctx, fs.uniforms, nv, fs.flags & BH_FLAG_MIP, fs.sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
-                                       v_raw_opacities, v_refine_weight, latest && ctx->grad_rows_marked));
+                                       v_raw_opacities, v_refine_weight, row_marks));
     }
     return 0;
 }
@@ -1465,7 +1474,7 @@ extern "C" int bh_train_step(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState
         ctx->have_forward = false;
         ctx->ext_visible = nullptr; ctx->ext_max_radius = nullptr; ctx->ext_visible_floats = 0;
         ctx->ext_grad_begin = nullptr; ctx->ext_grad_floats = 0;
-        ctx->grad_rows_marked = false;
+        ctx->clears.begin_forward();
         ctx->defer_far = false;
     }
     return rc;
@@ -1553,10 +1562,6 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
     BH_TRY(frc);
-    // masked gradients rely on last step's row marks (sign bits of the refine-weight vector) being gone: K1 clears the vector on
-    // its way when the span is float4-addressable (always, with the pad4 layout and hipMalloc's alignment) - not an implicit
-    // invariant: if it could not, clear it here
-    if (masked_grads && !ctx->grads_prezeroed) BH_HIP(ctx, hipMemsetAsync(exch + o_ref, 0, (exch_count - o_ref) * sizeof(float), ctx->stream));
 
     // ---- tile-partitioned frame: fetch the other ranks' strips (not in the reference: SURVEY.md §8e)
     if (tile_mode) {
@@ -1663,11 +1668,17 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     float* g_op = exch + o_op;
     ctx->ext_grad_begin = g_tr;              // one zero-fill of the whole gradient span (padding included)
     ctx->ext_grad_floats = exch_count - o_tr;
-    ctx->grad_rows_marked = masked_grads;
+    // masked gradients rely on last step's row marks (sign bits of the refine-weight vector) being gone: K1 of the frame's (last)
+    // forward clears the vector on its way when the span is float4-addressable (always, with the pad4 layout and hipMalloc's
+    // alignment) - not an implicit invariant: if it could not, clear it here.  Decided HERE, behind every second attempt a failed
+    // forecast may have caused: the record describes the forward the backward is about to replay.
+    if (masked_grads) {
+        if (ctx->clears.span != GradClears::ZEROED) BH_HIP(ctx, hipMemsetAsync(exch + o_ref, 0, (exch_count - o_ref) * sizeof(float), ctx->stream));
+        ctx->clears.mark_rows();   // this step's backward runs K18 in marking mode and fills nothing
+    }
     const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
-    ctx->grad_rows_marked = false;
     BH_TRY(brc);
     if (st->min_scale && n > 0) {  // chain d/d(folded) -> d/d(raw) through the fold (autodiff of gaussian_splats.rs:86-111)
         ProfScope ps(ctx, "FoldMinScaleBackward");

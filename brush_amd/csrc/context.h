@@ -208,6 +208,32 @@ struct FarJob {
     size_t ext_grad_floats = 0;
 };
 
+// Clears done "on the way" by a forward's kernels, and how the train step wants its gradient span treated.
+//   span:  NONE        nobody cleared the span: the backward zero-fills every dense output it writes into
+//          ZEROED      K1 of forward `generation` cleared the WHOLE ext span it was given (exchange / multi-GPU step)
+//          ROW_MARKS   single-GPU train step: only the refine-weight vector is clear (K1 or a fill did it); K18 marks the rows it
+//                      writes in that vector's sign bits and the update kernel reads exactly those rows — the backward must NOT
+//                      fill the span and must run K18 in marking mode
+//   accum: K5 of forward `generation` cleared v_combined [num_listed_splats, 10]
+// Transitions: begin_forward() -> (k1_cleared_span | k5_cleared_accum)* -> stamp(generation) -> [mark_rows()] -> take_*() in the
+// backward of THAT generation (anything else finds NONE / false).  A backward always leaves the record empty: the accumulator
+// and the span are dirty afterwards.
+struct GradClears {
+    enum Span : uint8_t { NONE = 0, ZEROED, ROW_MARKS };
+    Span span = NONE;
+    bool accum = false;
+    uint64_t generation = 0;   // 0: not stamped yet (the forward is still being queued)
+    void begin_forward() { span = NONE; accum = false; generation = 0; }
+    void k1_cleared_span() { span = ZEROED; }
+    void k5_cleared_accum(bool yes) { accum = yes; }
+    void stamp(uint64_t gen) { generation = gen; }
+    // train step, single GPU: the refine-weight vector is clear (by K1: span == ZEROED for that sub-span, or by the caller's fill)
+    void mark_rows() { span = ROW_MARKS; }
+    bool valid_for(uint64_t gen) const { return generation != 0 && generation == gen; }
+    Span take_span(uint64_t gen) { const Span s = valid_for(gen) ? span : NONE; span = NONE; return s; }
+    bool take_accum(uint64_t gen) { const bool a = valid_for(gen) && accum; accum = false; return a; }
+};
+
 // What a backward needs of the forward it belongs to (RenderBackwards' saved state, bwd/burn_glue.rs:336-371): the host side of it.
 struct ForwardState {
     BhRenderOut out{};
@@ -251,12 +277,10 @@ struct bh_ctx {
     size_t ext_visible_floats = 0;    // floats to clear at ext_visible (its section of the exchange buffer incl. padding)
     float* ext_grad_begin = nullptr;  // train step: v_transforms .. end of the exchange buffer is one span to zero-fill
     size_t ext_grad_floats = 0;
-    // cleared on the way by the forward's kernels (K1: the gradient span, K5: v_combined) -> the backward skips its fills;
-    // each flag is consumed by the next bh_render_backward
-    bool grads_prezeroed = false, vcombined_prezeroed = false;
-    // single-GPU train step: of the gradient span only the refine-weight vector is zero-filled; K18 marks the splats whose rows it
-    // writes in that vector's sign bit, the update kernel reads exactly those rows
-    bool grad_rows_marked = false;
+    // What the forward's kernels cleared on their way, so that the backward can skip its fills (K1: the train step's gradient span;
+    // K5: the backward's accumulator v_combined).  ONE record with explicit transitions (bh::GradClears below) instead of loose
+    // flags: every fact is tied to the forward (generation) whose kernels established it and is consumed exactly once.
+    bh::GradClears clears;
     float* pending_loss_dst = nullptr; // where bh_sync delivers the last step's loss
     void* comm = nullptr;             // RCCL communicator (comm.hip), or NULL
     // the library communicator's side stream: the mask-keyed exchange sums the visible flags and lists their union there,
@@ -294,6 +318,7 @@ struct bh_ctx {
     // attempt in 200 cut frames at equilibrium), within [0.5, 16].  A scene that still moves fast (early training, many views between
     // two visits) gets deep margins, a settled one tight ones.
     float margin_scale = 1.0f;
+    float ctrl_up = 1.5f, ctrl_down = 0.998f, ctrl_floor = 0.5f, ctrl_gap_exp = 1.0f / 3.0f;   // BH_CUT_CTRL="up:down:floor:gap_exp" (A/B)
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
     bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
     bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
