@@ -163,6 +163,7 @@ struct UpdateArgs {
     float gscale;          // 1/world for data parallel over cameras, else 1
     uint32_t n, sh_len;    // splats, 3*C
     uint32_t vis_clamp;    // tile-partitioned frame: visible arrives summed over strips -> min(v, 1)
+    uint32_t dormant_skip; // 0 = BH_UPDATE_NO_DORMANT (A/B, tests): dormant splats are fetched and updated like everyone else
     uint32_t masked;       // the gradient tensors were not zero-filled: row i holds a gradient iff the sign bit of refine_weight[i] is set (K18's mark), else it is 0
     float tab_t[10];       // lr_mean x3, lr_rotation x4, lr_scale x3
     float tab_sh[75];      // 1 for the DC coefficient, 1/lr_coeffs_sh_scale for the rest
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     const uint32_t row_len = u.sh_len, pitch = row_len + 1;
     float* s_g = s_dyn;                       // [rows][row_len + 1]
     float* s_v = s_dyn + (uint32_t)ROWS * pitch;      // [rows]
-    float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written (only with u.masked)
-    float* s_noise = s_mask + (uint32_t)ROWS;         // [rows][3], only with noise_on
+    float* s_mask = s_v + (uint32_t)ROWS;             // [rows] 1 = the row's gradient was written, 2 = the splat is dormant (only with u.masked)
+    float* s_nz = s_mask + (uint32_t)ROWS;            // [rows] != 0: some moment of the splat is non-zero after this step (only with u.masked)
+    float* s_noise = s_nz + (uint32_t)ROWS;           // [rows][3], only with noise_on
     // masked (block-uniform): the gradient tensors were not zero-filled — row r of them counts iff K18 marked the splat: the sign
     // bit of its (non-negative) refine weight, a vector that WAS cleared.
     // No barrier stands in front of what the block fetches: the SH staging below reads the marks it needs straight from global
@@ -202,6 +204,18 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
     // marks come through LDS from the per-splat section (which reads the refine weight anyway), behind its barrier.  (Marks
     // staged through LDS up front, every gradient load predicated on them: +6 us at SH degree 0.)
     const bool masked = u.masked != 0u;
+    // DORMANT splats (single-GPU step).  Nine tenths of a scene like the bench's never receive a gradient: every Adam moment of such
+    // a splat is zero, its gradient row is not written this step either, the view did not reach it (no noise) — its update is
+    // exactly nothing, and fetching its 26 moments, 14 parameters and 14 gradient slots (240 B at SH degree 0, 1.6 KB at degree 3)
+    // only to find that out was most of this kernel's traffic.  The fact "all moments of this splat are zero" is kept where the
+    // caller's tensors already have a spare bit: the SIGN of the row-reduced SH second moment m2_sh[i] — a sum of squares,
+    // never negative — is set (the value is -0.0f) by the step that finds every new moment of the splat zero, and is cleared by the
+    // first step that writes a real second moment (any gradient).  -0.0 equals +0.0 in every comparison and in the arithmetic that
+    // reads it ((-0) b2 + g f2, sqrt, + eps), so the tensors stay what the reference's are; the mark travels with the caller's
+    // data through refine's row gathers and through checkpoints, and a tensor that was zero-filled or loaded from elsewhere simply
+    // carries no marks (every splat is processed until it is found dormant again).  A dormant splat costs its eleven per-splat
+    // words (44 B: statistics, marks, opacity moments) and nothing else.  Not on the first step (the moment tensors may hold anything).
+    const bool dorm_ok = masked && !a.first && u.dormant_skip != 0u;
     const uint32_t* mark_rows = reinterpret_cast<const uint32_t*>(refine_weight) + row0;
     const float rcp_len = 1.0f / (float)row_len;
     const uint32_t sh_count = nrows * row_len;
@@ -281,7 +295,8 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         const uint64_t i = row0 + threadIdx.x;
         const float rw_raw = in_rw;
         const bool written = !masked || (f2u(rw_raw) >> 31) != 0u;
-        if (masked) s_mask[threadIdx.x] = written ? 1.0f : 0.0f;
+        const bool dormant = dorm_ok && !written && f2u(in_m2sh) == 0x80000000u && in_vis == 0.0f;
+        if (masked) s_mask[threadIdx.x] = written ? 1.0f : (dormant ? 2.0f : 0.0f);
         // (masked: K18 stored the weight with the sign bit as the mark; an unmarked entry is the zero the forward left)
         {
             const float rn_old = in_rn, vw_old = in_vw, ms_old = in_ms;
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         if (a.first || !same_bits(mm1, m1_old)) m1_o[i] = mm1;
         if (a.first || !same_bits(mm2, m2_old)) m2_o[i] = mm2;
         if (!same_bits(p, p_old)) opac[i] = p;
+        if (masked) s_nz[threadIdx.x] = (mm1 != 0.0f || mm2 != 0.0f) ? 1.0f : 0.0f;
         if (u.noise_on) {   // the gate reads the UPDATED opacity (train.rs:389)
             const float w = mean_noise_gate(p, in_vis);
             float nz[3] = {0.0f, 0.0f, 0.0f};
@@ -345,17 +361,26 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             const uint32_t e = (threadIdx.x + (uint32_t)k * OPT_WG) * 4u;
             if (e >= vec_end) break;
             const uint64_t i = base + e;
+            const uint32_t ra = (e * 52429u) >> 19, rb = ((e + 3u) * 52429u) >> 19;   // the float4's first and last row
+            const float ka = masked ? s_mask[ra] : 1.0f, kb = masked ? s_mask[rb] : 1.0f;
+            if (ka == 2.0f && kb == 2.0f) continue;   // both rows dormant: nothing to fetch, nothing moves
             const float4 g4 = EARLY ? tg[k] : *reinterpret_cast<const float4*>(&g_t[i]);
             float4 m14 = EARLY ? tm1[k] : *reinterpret_cast<const float4*>(&m1_t[i]);
             float4 m24 = EARLY ? tm2[k] : *reinterpret_cast<const float4*>(&m2_t[i]);
             float4 p4 = EARLY ? tp[k] : *reinterpret_cast<const float4*>(&transforms[i]);
-            const uint32_t ra = (e * 52429u) >> 19, rb = ((e + 3u) * 52429u) >> 19;   // the float4's first and last row
-            const bool wa = !masked || s_mask[ra] != 0.0f, wb = !masked || s_mask[rb] != 0.0f;
+            const bool wa = ka == 1.0f, wb = kb == 1.0f;
             const float4 m1_old = m14, m2_old = m24, p_old = p4;
             one(g4.x, wa, m14.x, m24.x, p4.x, e, m14.x, m24.x, p4.x);
             one(g4.y, (((e + 1u) * 52429u) >> 19) == ra ? wa : wb, m14.y, m24.y, p4.y, e + 1, m14.y, m24.y, p4.y);
             one(g4.z, (((e + 2u) * 52429u) >> 19) == ra ? wa : wb, m14.z, m24.z, p4.z, e + 2, m14.z, m24.z, p4.z);
             one(g4.w, wb, m14.w, m24.w, p4.w, e + 3, m14.w, m24.w, p4.w);
+            if (masked) {   // which rows still carry a non-zero moment (the dormant mark is set from this at the end)
+                const uint32_t r1 = ((e + 1u) * 52429u) >> 19, r2 = ((e + 2u) * 52429u) >> 19;
+                if (m14.x != 0.0f || m24.x != 0.0f) s_nz[ra] = 1.0f;
+                if (m14.y != 0.0f || m24.y != 0.0f) s_nz[r1] = 1.0f;
+                if (m14.z != 0.0f || m24.z != 0.0f) s_nz[r2] = 1.0f;
+                if (m14.w != 0.0f || m24.w != 0.0f) s_nz[rb] = 1.0f;
+            }
             // A store whose four values are bit for bit what was loaded is left out.  That is the case for every splat that has
             // never received a gradient (moments 0, gradient 0: the moments stay 0 and the parameter does not move) — nine tenths
             // of the bench scene, where most splats lie behind saturated tiles in every view; a scene whose splats all reach a
@@ -367,10 +392,12 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         for (uint32_t e = vec_end + threadIdx.x; e < count; e += OPT_WG) {
             const uint64_t i = base + e;
             float o1, o2, op;
-            one(g_t[i], !masked || s_mask[(e * 52429u) >> 19] != 0.0f, m1_t[i], m2_t[i], transforms[i], e, o1, o2, op);
+            const uint32_t r = (e * 52429u) >> 19;
+            one(g_t[i], !masked || s_mask[r] == 1.0f, m1_t[i], m2_t[i], transforms[i], e, o1, o2, op);
             m1_t[i] = o1;
             m2_t[i] = o2;
             transforms[i] = op;
+            if (masked && (o1 != 0.0f || o2 != 0.0f)) s_nz[r] = 1.0f;
         }
     }
     // ---- SH: per-row second moment (adam_scaled.rs:99-104,152-165), row sums in index order
@@ -383,8 +410,11 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         const uint64_t r = row0 + threadIdx.x;
         const float v_old = in_m2sh;
         const float v = a.first ? row_gsq * a.f2 : v_old * a.beta2 + row_gsq * a.f2;
-        if (a.first || !same_bits(v, v_old)) m2_sh[r] = v;
+        const bool is_dormant = masked && s_mask[threadIdx.x] == 2.0f;
+        // (a dormant row keeps its -0.0: the recurrence would turn it into +0.0 and un-mark it every step)
+        if (!is_dormant && (a.first || !same_bits(v, v_old))) m2_sh[r] = v;
         s_v[threadIdx.x] = v;
+        if (masked && v != 0.0f) s_nz[threadIdx.x] = 1.0f;
     }
     __syncthreads();
     {
@@ -399,6 +429,7 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             o_p = p;
         };
         const uint32_t vec_end = s_vec_end;
+        auto row_of = [&](uint32_t e) { return (uint32_t)(((float)e + 0.5f) * rcp_len); };
         auto four = [&](float4 m14, float4 p4, uint32_t e) {
             const uint64_t i = sh_base + e;
             const float4 m1_old = m14, p_old = p4;
@@ -406,6 +437,12 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             one(m14.y, p4.y, e + 1, m14.y, p4.y);
             one(m14.z, p4.z, e + 2, m14.z, p4.z);
             one(m14.w, p4.w, e + 3, m14.w, p4.w);
+            if (masked) {
+                if (m14.x != 0.0f) s_nz[row_of(e)] = 1.0f;
+                if (m14.y != 0.0f) s_nz[row_of(e + 1u)] = 1.0f;
+                if (m14.z != 0.0f) s_nz[row_of(e + 2u)] = 1.0f;
+                if (m14.w != 0.0f) s_nz[row_of(e + 3u)] = 1.0f;
+            }
             if (a.first || !same_bits4(m14, m1_old)) *reinterpret_cast<float4*>(&m1_sh[i]) = m14;
             if (!same_bits4(p4, p_old)) *reinterpret_cast<float4*>(&sh[i]) = p4;
         };
@@ -417,8 +454,11 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
                 four(sm1[k], sp[k], e);
             }
         } else {
-            for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u)
+            for (uint32_t e = threadIdx.x * 4u; e < vec_end; e += OPT_WG * 4u) {
+                // (a float4 spans at most two rows for row_len >= 3: the first and the last component's)
+                if (masked && s_mask[row_of(e)] == 2.0f && s_mask[row_of(e + 3u)] == 2.0f) continue;   // dormant rows: nothing to fetch
                 four(*reinterpret_cast<const float4*>(&m1_sh[sh_base + e]), *reinterpret_cast<const float4*>(&sh[sh_base + e]), e);
+            }
         }
         for (uint32_t e = vec_end + threadIdx.x; e < sh_count; e += OPT_WG) {
             const uint64_t i = sh_base + e;
@@ -426,7 +466,13 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
             one(m1_sh[i], sh[i], e, o1, op);
             m1_sh[i] = o1;
             sh[i] = op;
+            if (masked && o1 != 0.0f) s_nz[row_of(e)] = 1.0f;
         }
+    }
+    // ---- a splat whose moments are ALL zero after this step is dormant from now on: the mark is the sign of its m2_sh (== -0.0f)
+    if (masked) {   // block-uniform
+        __syncthreads();
+        if (threadIdx.x < nrows && s_mask[threadIdx.x] != 2.0f && s_nz[threadIdx.x] == 0.0f) m2_sh[row0 + threadIdx.x] = -0.0f;
     }
 }
 
@@ -447,6 +493,7 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     u.lr_sh = lr_sh; u.lr_opac = lr_opac; u.gscale = gscale;
     u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
     u.masked = masked_rows ? 1u : 0u;
+    u.dormant_skip = ctx->knob_no_dormant ? 0u : 1u;
     u.noise_on = noise ? 1u : 0u;
     u.noise_step = noise ? noise->step : 0u;
     u.noise_scale = noise ? noise->scale : 0.0f;
@@ -458,7 +505,7 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     // SH degree 3: 0.368 ms @256, 0.300 @128, 0.290 @64, 0.327 @32; degree 0 is best at 256)
     uint32_t rows = u.sh_len <= 12 ? 256u : (u.sh_len <= 27 ? 128u : 64u);
     if (ctx->knob_update_rows) rows = ctx->knob_update_rows;  // developer knob BH_UPDATE_ROWS (read once at bh_create)
-    const size_t lds = ((size_t)rows * (u.sh_len + 1) + 2 * rows + (noise ? 3 * rows : 0)) * sizeof(float);
+    const size_t lds = ((size_t)rows * (u.sh_len + 1) + 3 * rows + (noise ? 3 * rows : 0)) * sizeof(float);
     const unsigned nb = (unsigned)(((uint64_t)n + rows - 1) / rows);
     const void* vec_ptrs[] = {st->transforms, st->m1_transforms, st->m2_transforms, g_t, st->sh_coeffs, st->m1_sh, g_sh};
     bool vec = true;

@@ -152,3 +152,48 @@ def test_masked_and_exchange_steps_alternate(dev):
         d_ab, d_bc = (a[k] - b[k]).abs(), (b[k] - c[k]).abs()
         assert float(d_ab.mean()) <= 2.0 * float(d_bc.mean()) + 1e-3 * lr[k], (k, float(d_ab.mean()), float(d_bc.mean()))
         assert float((d_ab > 0.5 * lr[k]).float().mean()) <= 2.0 * float((d_bc > 0.5 * lr[k]).float().mean()) + 1e-3, k
+
+
+@pytest.mark.parametrize("sh_degree", [0, 2])
+def test_dormant_splats_are_skipped_without_changing_a_bit(dev, sh_degree):
+    """The update kernel leaves out splats whose Adam moments are all zero and that neither received a gradient nor were reached
+    by the view (optim.hip: the mark is the sign of their m2_sh, -0.0).  On a ONE-tile image every splat has at most one (splat,
+    tile) pair, so the backward's float atomics add each gradient once into a zero: the step is deterministic, and a run with the
+    skip must equal a run without it (BH_UPDATE_NO_DORMANT) bit for bit — parameters, every moment (the sign of a zero m2_sh
+    aside), the refine statistics — while most splats are dormant (outside the tiny frustum or behind the saturated front)."""
+    import brush_amd as ba
+    n, w, h = 6000, 16, 16
+    sc = synth.make_scene(n, 0xD0A, sh_degree=sh_degree, log_scale_range=(math.log(0.05), math.log(0.4)),
+                          tan_half_fov=(math.tan(math.radians(50)), math.tan(math.radians(50))))
+    cams = _views(w, h, 3)
+    gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+    steps = 9
+    runs = {}
+    for key in ("skip", "full"):
+        if key == "full":
+            os.environ["BH_UPDATE_NO_DORMANT"] = "1"
+        try:
+            ctx = ba.Context(dev)
+        finally:
+            os.environ.pop("BH_UPDATE_NO_DORMANT", None)
+        try:
+            spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+            tr = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx, seed=77)   # the default stochastic step (device noise)
+            for s in range(steps):
+                tr.step(ba.SceneBatch(gt, util.hip_camera(ba, cams[s % len(cams)])), spl)
+            ctx.sync()
+            out = {"transforms": spl.transforms.clone(), "sh": spl.sh_coeffs.clone(), "opac": spl.raw_opacities.clone()}
+            out.update({k: v.clone() for k, v in tr.state.items()})
+            runs[key] = out
+        finally:
+            ctx.close()
+    a, b = runs["skip"], runs["full"]
+    for k in a:
+        if k == "m2_sh":
+            assert torch.equal(a[k], b[k]), k                                   # by value: -0.0 == +0.0
+        else:
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k   # bit for bit
+    marks = (a["m2_sh"].view(torch.int32) == -2147483648)
+    moments_zero = (a["m1_t"].abs().sum(1) == 0) & (a["m2_t"].abs().sum(1) == 0) & (a["m1_sh"].reshape(n, -1).abs().sum(1) == 0) & (a["m1_o"] == 0) & (a["m2_o"] == 0) & (a["m2_sh"] == 0)
+    assert torch.equal(marks, moments_zero), "the mark must say exactly: every moment of this splat is zero"
+    assert 0.25 < float(marks.float().mean()) < 1.0, float(marks.float().mean())         # many splats dormant, some trained
