@@ -479,6 +479,19 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             window_dt = [float(x) for x in tmax.tolist()]
         dt = sorted(window_dt)[len(window_dt) // 2]
+        # one more replica of the timed steps WITHOUT the two HIP events on the dominant kernel (each is a barrier packet: ~6 us of
+        # bubble in front of / behind that kernel): what a caller of bh_train_step gets; reported beside the contractual figure
+        dt_plain = None
+        if windows > 1:
+            start_replica()
+            gc.collect()
+            gc.disable()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trainer.step(next_batch(), splats)
+            barrier()
+            dt_plain = time.perf_counter() - t0
+            gc.enable()
         # one more replica, untimed: what the timed steps looked like at their first and last step (the work per frame moves while
         # the scene trains: the roofline's "bytes per launch" are the mean of the two), and — HIP events around every stage — the
         # per-stage table of exactly the timed steps
@@ -539,7 +552,7 @@ def main():
         return dict(scene=scene, cp=cp, w=w, h=h, n=n, coeffs=coeffs, dt=dt, window_dt=window_dt, stages=stages, stats=st, isect_blended=isect_blended,
                     nv=nv_mean, ni=ni_mean, per_view=per_view, nviews=nviews, loader=loader is not None, list_share=list_share,
                     near_share_min=min(shares) if shares else 1.0, near_share_max=max(shares) if shares else 1.0, far_slices_queued=far_queued,
-                    timed_steps=steps * max(1, windows), forward_only=fwd_only)
+                    timed_steps=steps * max(1, windows), forward_only=fwd_only, dt_plain=dt_plain)
 
     def blend_rooflines(m, steps):
         """HBM and VALU rooflines of the two blend kernels from one measurement."""
@@ -796,6 +809,9 @@ def main():
             "data": "synthetic" if not m["loader"] else "synthetic, a fresh host RGB8 image uploaded per step (PCIe-inclusive; not the headline)",
             "windows_ms_per_step": [round(x / steps * 1e3, 4) for x in m["window_dt"]],
             "windows_spread": round((max(m["window_dt"]) - min(m["window_dt"])) / max(dt, 1e-12), 4),
+            "windows_are": "replicas: every window times steps [warmup, warmup + steps) of the same training run from the same initial state (parameters, Adam "
+                           "moments, step counter, view cycle and the library's per-view tables reset before each): their spread is noise, not drift",
+            "ms_per_step_without_kernel_events": (round(m["dt_plain"] / steps * 1e3, 4) if m.get("dt_plain") else None),
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
                        "views": m["nviews"],
                        "view_cycle": ("step k trains view k %% %d; " % m["nviews"]) + ("two cameras 2 units apart in x as crates/brush-bench-test/src/benches.rs:198-220" if m["nviews"] == 2 else

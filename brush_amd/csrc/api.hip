@@ -21,10 +21,11 @@ int launch_image_loss_backward_strided(bh_ctx* ctx, const float* pred, uint32_t 
                                        const BhLossConfig& cfg, float* dl_dpred);
 
 int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
-                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host = nullptr);
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host = nullptr,
+                            uint32_t* started_host = nullptr, uint32_t started_tag = 0);
 int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
                                    bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
-                                   float* v_output, float* loss_host = nullptr);
+                                   float* v_output, float* loss_host = nullptr, uint32_t* started_host = nullptr, uint32_t started_tag = 0);
 
 // grid-stride clear of two float4 spans in one launch
 __global__ __launch_bounds__(256) void zero_two_kernel(float4* __restrict__ a, size_t na, float4* __restrict__ b, size_t nb) {
@@ -46,6 +47,24 @@ int check_hip(bh_ctx* ctx, hipError_t e, const char* what) {
     std::string m = std::string(what) + ": " + hipGetErrorString(e);
     (void)hipGetLastError();
     return set_error(ctx, e == hipErrorOutOfMemory ? BH_ERR_OOM : BH_ERR_HIP, m);
+}
+
+// Host wait for a tag word a kernel stores into pinned host memory (instead of an event behind the kernel: the barrier packet an
+// event costs is ~6 us of bubble in front of the NEXT kernel).  Spins; every 16 k polls it asks the stream whether it is still
+// alive, so a device fault ends in an error instead of a hang.
+static int wait_host_tag(bh_ctx* ctx, const volatile uint32_t* word, uint32_t want, const char* what) {
+    for (uint64_t it = 1;; ++it) {
+        if (*word == want) return 0;
+        if ((it & 0x3FFFull) == 0ull) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {   // everything queued has run: the tag must be there
+                if (*word == want) return 0;
+                return set_error(ctx, BH_ERR_STATE, std::string(what) + ": the kernel that signals the host never stored its tag");
+            }
+            if (q != hipErrorNotReady) return check_hip(ctx, q, what);
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 void* ensure(bh_ctx* ctx, Slot s, size_t bytes) {
@@ -319,7 +338,14 @@ int finish_far_slice(bh_ctx* ctx, bool* launched) {
     if (launched) *launched = false;
     if (!ctx->far_job.pending) return 0;
     ctx->far_job.pending = false;
-    BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
+    if (!ctx->far_job.gate_event_recorded && ctx->gate_signal_queued) {
+        // (bh_train_step: its loss kernel, queued behind the near blend, stores the job's tag when it starts)
+        BH_TRY(wait_host_tag(ctx, reinterpret_cast<const volatile uint32_t*>(ctx->host_counters) + HOST_GATE_TAG_WORD, ctx->far_job.gate_tag, "near-pass gate"));
+    } else {
+        if (!ctx->far_job.gate_event_recorded) BH_HIP(ctx, hipEventRecord(ctx->gate_ev, ctx->stream));   // (nobody queued a signal: an event behind whatever is queued now)
+        BH_HIP(ctx, hipEventSynchronize(ctx->gate_ev));
+    }
+    ctx->gate_signal_queued = false;
     const uint32_t unsat = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD];
     if (ctx->far_job.by_cut) {
         FarJob& j = ctx->far_job;
@@ -428,6 +454,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         }
     }
     ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
+    ctx->knob_event_waits = getenv("BH_EVENT_WAITS") != nullptr;
     if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     ctx->knob_update_early = getenv("BH_UPDATE_EARLY") != nullptr;
@@ -791,6 +818,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         // (the sort's first kernel adds the counter slots up and stores the sums into the pinned block itself; only the generic
         //  sort path still needs a copy launch between K1 and the sort)
         const bool sums_on_device = fused_scan && !ctx->knob_readback_copy;
+        // ... and the host does not wait for an event behind that kernel either: it polls a tag word the kernel stores behind the sums
+        const bool poll_tag = sums_on_device && !ctx->knob_event_waits;
         if (!sums_on_device) {
             BH_HIP(ctx, hipMemcpyAsync(hslots, counters, counter_read_bytes, hipMemcpyDeviceToHost, ctx->stream));
             BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
@@ -805,13 +834,15 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 cum_early = (uint32_t*)ensure(ctx, SLOT_CUM_TILES_HIT, npad * 4);
                 if (!cum_early) return BH_ERR_OOM;
                 // (per-tile cuts: the scan of the NEAR counts = the slot ranges of the near pass's list)
+                if (poll_tag && ++ctx->readback_tag == 0u) ctx->readback_tag = 1u;
                 BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early,
-                                       sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev));
+                                       sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev, poll_tag ? ctx->readback_tag : 0u));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
         }
-        BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+        if (poll_tag) BH_TRY(wait_host_tag(ctx, reinterpret_cast<const volatile uint32_t*>(hslots) + HOST_SUM_WORDS - 1u, ctx->readback_tag, "count readback"));
+        else BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
         if (ctx->gate_learn) {   // the previous sliced frame queued its far slice unasked: did it need it?
             ctx->gate_learn = false;
             ctx->far_direct = reinterpret_cast<const volatile uint32_t*>(ctx->host_counters)[HOST_GATE_WORD] != 0u;
@@ -1024,7 +1055,13 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             BH_TRY(enqueue_far_slice(ctx, j));
             ctx->gate_learn = true;
         } else {
-            BH_HIP(ctx, hipEventRecord(ctx->gate_ev, ctx->stream));
+            // bh_train_step (defer_far) queues its loss kernels next and lets the first of them signal "the blend is done" through a
+            // tag word: no event behind the blend (finish_far_slice records one late if nobody queued the signal)
+            if (++ctx->gate_tag == 0u) ctx->gate_tag = 1u;
+            j.gate_tag = ctx->gate_tag;
+            ctx->gate_signal_queued = false;
+            j.gate_event_recorded = !(ctx->defer_far && !ctx->knob_event_waits && !ctx->knob_readback_copy);
+            if (j.gate_event_recorded) BH_HIP(ctx, hipEventRecord(ctx->gate_ev, ctx->stream));
             j.pending = true;
             if (!ctx->defer_far) {
                 bool again = false;
@@ -1593,14 +1630,23 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     const float dl_alpha = alpha_match ? cfg->match_alpha_weight / (float)hw : 0.0f;
     // fused forward + backward of the loss on the rasterizer's [H,W,4] image (loss_fused.hip)
     auto queue_loss = [&]() -> int {
+        // a deferred far-slice decision without an event behind the blend: this loss kernel tells the host when it starts
+        uint32_t* started_host = nullptr;
+        uint32_t started_tag = 0u;
+        if (ctx->far_job.pending && !ctx->far_job.gate_event_recorded && !ctx->gate_signal_queued) {
+            started_host = ctx->host_counters + HOST_GATE_TAG_WORD;
+            started_tag = ctx->far_job.gate_tag;
+            ctx->gate_signal_queued = true;
+        }
         if (tile_mode && batch->strip_loss) {
             // one frame over several ranks: the hook delivered only the 21-px halos; loss and dL/dimg for this rank's strip
             // (stats->loss is the strip's share of the mean: the ranks' shares add up to the frame's loss)
             const ViewUniforms wu = make_uniforms(batch->camera);
             return launch_image_loss_fused_window(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, wu.tile_y0, wu.tile_y1,
-                                                  loss_dev, v_output, loss_host);
+                                                  loss_dev, v_output, loss_host, started_host, started_tag);
         }
-        return launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host);
+        return launch_image_loss_fused(ctx, ro.out_img, batch->gt_packed, H, W, lc, alpha_match, dl_rgb, dl_alpha, loss_dev, v_output, loss_host, started_host,
+                                       started_tag);
     };
 #ifdef BH_TEST_HOOKS
     if (ctx->knob_fail_loss_at && ++ctx->train_steps_seen == ctx->knob_fail_loss_at)   // (the forward is queued, a deferred far slice may be pending)

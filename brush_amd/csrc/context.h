@@ -94,11 +94,12 @@ constexpr uint32_t SLICE_CTRL_WORDS = 8;
 constexpr uint32_t FAR_GROUP_BLOCKS = 64;   // far slice: count-kernel blocks per group total (<= the projection workgroup size)
 constexpr size_t COUNTER_READ_BYTES = COUNTER_SLOTS * 8 * COUNTER_K1_U64 + COUNTER_SLOTS * 12;
 // ... or, when the depth sort's first kernel adds the slots up on the device: [COUNTER_K1_U64] u64 totals | [3] u32 feedback
-constexpr uint32_t HOST_SUM_WORDS = 2 * COUNTER_K1_U64 + 3;
+constexpr uint32_t HOST_SUM_WORDS = 2 * COUNTER_K1_U64 + 3 + 1;   // (+ the tag word the host polls)
 // pinned host block: [16] u32 scalars (refine control block / bounds picks / exchange rows) | the counter slots + feedback | the
 // loss word.  The loss has a word of its own BEHIND everything the refine / bounds / exchange readbacks overwrite.
 constexpr size_t HOST_LOSS_WORD = 16 + COUNTER_READ_BYTES / 4;
 constexpr size_t HOST_GATE_WORD = HOST_LOSS_WORD + 16;   // depth-sliced forward: tiles the near slice left unsaturated
+constexpr size_t HOST_GATE_TAG_WORD = HOST_GATE_WORD + 1;   // ... and the tag the kernel queued BEHIND the near blend stores when it starts (= the blend has finished)
 constexpr size_t HOST_COUNTERS_BYTES = 64 + COUNTER_READ_BYTES + 64 + 64;
 
 struct Profiler {
@@ -193,6 +194,11 @@ struct FarJob {
     // per-tile cut lists: only the splats with a pair in front of some cut were sorted and listed, so there is no far pass — if a
     // tile is still live behind a cut list the forecast has failed and the whole forward is run again with complete lists
     // (api.hip finish_far_slice).  Its arguments, and the train step's redirections that were in force:
+    // how the host learns that the near blend has finished: an event behind it (recorded when the job is created, or late, by
+    // finish_far_slice), or — bh_train_step — the tag word its loss kernel stores when it starts (no event: a barrier packet
+    // costs ~6 us of bubble in front of the next kernel)
+    bool gate_event_recorded = false;
+    uint32_t gate_tag = 0;
     bool by_cut = false;
     ViewState* view = nullptr;      // whose prediction failed
     bool view_shared = false;       // ... and whether that is the table of view id 0 (shared by all frames without an id)
@@ -303,6 +309,9 @@ struct bh_ctx {
     // bh_render_forward waits for it, bh_train_step queues the loss kernels first and waits behind them (far_job.pending).
     bool far_direct = false;
     bool defer_far = false;           // set by bh_train_step around its forward: return with far_job.pending instead of waiting
+    uint32_t readback_tag = 0;        // tag of the last count readback the host polled for (depth_sort.hip counter_sums_to_host)
+    uint32_t gate_tag = 0;            // tag of the last deferred far-slice decision
+    bool gate_signal_queued = false;  // a kernel that stores far_job.gate_tag when it starts is queued behind the near blend
     bool gate_learn = false;          // a gate word copied out by a far_direct frame has not been looked at yet
     uint32_t far_launches = 0;        // diagnostics: sliced forwards that queued a far slice / had to be run again with complete lists
     uint32_t last_listed_splats = 0;  // compact entries of the last forward (== num_visible unless per-tile cuts listed a subset)
@@ -320,6 +329,7 @@ struct bh_ctx {
     float margin_scale = 1.0f;
     float ctrl_up = 1.5f, ctrl_down = 0.998f, ctrl_floor = 0.5f, ctrl_gap_exp = 1.0f / 3.0f;   // BH_CUT_CTRL="up:down:floor:gap_exp" (A/B)
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
+    bool knob_event_waits = false;        // BH_EVENT_WAITS (A/B): the host's two mid-step waits use events behind the kernels, as before round 5, instead of polled tag words
     bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
     bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
     bool knob_fixed_margin = false;       // BH_CUT_MARGIN_FIXED (A/B): the margin is BH_CUT_MARGIN_PCT for every frame (rounds 4's behaviour), not adaptive
@@ -445,7 +455,8 @@ int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, u
 // up counter set rb_set into the pinned host words rb_host (HOST_SUM_WORDS) and rb_done is recorded behind it.
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr);
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr,
+                    uint32_t rb_tag = 0);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 // gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);

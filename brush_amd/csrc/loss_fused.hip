@@ -67,6 +67,10 @@ struct FusedArgs {
     int sum_n;
     float* loss_out;   // device scalar
     float* loss_host;  // pinned host scalar or NULL: the train step's loss lands there without a copy launch
+    // pass A, optional: a pinned host word that receives `started_tag` as soon as the kernel starts — i.e. when everything queued
+    // in front of it on the stream (the forward's blend) has finished: the host's "near pass is done" signal without an event
+    uint32_t* started_host;
+    uint32_t started_tag;
     // block -> tile: gx x gy_blocks tiles of 16 x 32 pixels.  band_w != 0: a 1-D grid of 8 * band_w * gy_blocks blocks; block b
     // belongs to XCD b & 7 (the dispatcher deals consecutive workgroups to the eight XCDs in turn) and takes the (b >> 3)-th
     // tile, row-major, of column band b & 7 (band_w tile columns wide) — see loss_tile()
@@ -138,6 +142,8 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
     // exactly 40 KB = a quarter of the CU's LDS (conflict-free column reads AND four blocks per CU)
     __shared__ float s_h[(SR - 1) * HP + TW * 5];
     float* s_red = s_h;   // the four wave partials of the scalar loss reuse it after the last plane
+    if (a.started_host && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0)
+        *reinterpret_cast<volatile uint32_t*>(a.started_host) = a.started_tag;
     uint32_t bx, by, blin;
     if (!loss_tile(a, bx, by, blin)) return;   // block-uniform
     const int tx0 = (int)bx * TW, ty0 = (int)a.ty_base * LB + (int)by * TH;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
 // strip's pixels.  Image-border zero padding is unchanged.
 int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
                                    bool alpha_match, float dl_rgb, float dl_alpha, uint32_t tile_y0, uint32_t tile_y1, float* loss_out,
-                                   float* v_output, float* loss_host) {
+                                   float* v_output, float* loss_host, uint32_t* started_host, uint32_t started_tag) {
     const uint32_t gx = (w + LB - 1) / LB, gy = (h + LB - 1) / LB;
     if (tile_y1 > gy) tile_y1 = gy;
     if (tile_y0 >= tile_y1) return set_error(ctx, BH_ERR_INVALID_ARG, "image loss: empty tile-row window");
@@ -546,6 +552,7 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
         a.ty_base = a0;
         a.row_end = h;
         a.sum_src = nullptr; a.sum_n = 0; a.loss_out = nullptr; a.loss_host = nullptr;
+        a.started_host = started_host; a.started_tag = started_tag;
         // (blocks are two tile rows tall: with an odd window the last block's lower half lies outside it — rows this rank may not
         //  have rendered — and its loss partial is not stored: the limit is the window's end a1, not the image's gy)
         a.gx = gx; a.gy_blocks = (a1 - a0 + 1) / 2;
@@ -563,6 +570,7 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
         a.sum_n = (int)((tile_y1 - tile_y0) * gx);
         a.loss_out = loss_out;
         a.loss_host = loss_host;
+        a.started_host = nullptr; a.started_tag = 0;
         a.gy_blocks = (tile_y1 - tile_y0 + 1) / 2;
         const dim3 grid_b = banded ? dim3(8u * a.band_w * a.gy_blocks) : dim3(gx, a.gy_blocks);
         hipLaunchKernelGGL(loss_fused_backward_kernel, grid_b, block, 0, ctx->stream, img_hwc4, gt, partials, v_output, a);
@@ -572,8 +580,10 @@ int launch_image_loss_fused_window(bh_ctx* ctx, const float* img_hwc4, const uin
 }
 
 int launch_image_loss_fused(bh_ctx* ctx, const float* img_hwc4, const uint32_t* gt, uint32_t h, uint32_t w, const BhLossConfig& cfg,
-                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host) {
-    return launch_image_loss_fused_window(ctx, img_hwc4, gt, h, w, cfg, alpha_match, dl_rgb, dl_alpha, 0, (h + LB - 1) / LB, loss_out, v_output, loss_host);
+                            bool alpha_match, float dl_rgb, float dl_alpha, float* loss_out, float* v_output, float* loss_host, uint32_t* started_host,
+                            uint32_t started_tag) {
+    return launch_image_loss_fused_window(ctx, img_hwc4, gt, h, w, cfg, alpha_match, dl_rgb, dl_alpha, 0, (h + LB - 1) / LB, loss_out, v_output, loss_host,
+                                          started_host, started_tag);
 }
 
 }  // namespace bh
