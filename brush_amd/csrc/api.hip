@@ -308,10 +308,10 @@ static uint32_t cut_margin_pct(const bh_ctx* ctx, const ViewState* vs) {
     return m < 6400.0f ? (m > 10.0f ? (uint32_t)m : 10u) : 6400u;
 }
 
-// Outcome of a per-tile-cut frame of `vs`: did its far pass have to run (= the forecast failed for some tile)?  A miss now and
-// then is normal and cheap (the far pass lists a few pairs for a few tiles and corrects the table).  Six misses within the
-// view's last eight cut frames (alternating cameras sharing one table, a scene that changes faster than the margin) and the view's
-// next eight frames are rendered with complete lists, each of them re-seeding the table.
+// Outcome of a per-tile-cut frame of `vs`: did the forecast fail for some tile (the frame was then rendered a second time with
+// complete lists, which re-seeds the table)?  Every outcome moves the ctx's margin factor (x ctrl_up on a miss, x ctrl_down on a
+// hit: about one miss in 200 cut frames at equilibrium).  Six misses within the view's last eight cut frames (a scene that
+// changes faster than any margin) and the view's next eight frames are rendered with complete lists from the start.
 static void view_outcome(bh_ctx* ctx, ViewState* vs, bool missed, bool shared_table) {
     if (!ctx->knob_fixed_margin) {
         const float s = ctx->margin_scale * (missed ? ctx->ctrl_up : ctx->ctrl_down);
@@ -319,8 +319,8 @@ static void view_outcome(bh_ctx* ctx, ViewState* vs, bool missed, bool shared_ta
     }
     if (!vs) return;
     vs->penalty = ((vs->penalty << 1) | (missed ? 1u : 0u)) & 0xFFu;   // (the history of the last eight cut frames, one bit each)
-    // the table of view id 0 is shared by every frame that names no view: alternating cameras miss on every other frame there,
-    // each miss a far pass over MANY tiles — three misses are enough, and the table stays untrusted for longer
+    // (BH_NO_VIEW_HASH only: the table of view id 0 shared by every frame that names no view — alternating cameras miss on every
+    //  other frame there: three misses are enough, and the table stays untrusted for longer)
     if (__builtin_popcount(vs->penalty) >= (shared_table ? 3 : 6)) {
         vs->exact_frames = shared_table ? 32u : 8u;
         vs->penalty = 0u;
@@ -748,14 +748,15 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     // front of the tile's cut: K1 counts those hits beside the exact ones (same walk), the scan runs over the near counts, K5 /
     // tile sort / offsets handle ~a tenth of the pairs — per tile, so a frame with thin or empty regions (whose tiles keep
     // "everything", i.e. their own short lists) is cut as deep as a frame that saturates everywhere.  Correctness does not rest
-    // on the forecast: a tile that is still live behind an incomplete list is parked, and the far pass lists the pairs BEHIND the
-    // cut for exactly those tiles (same machinery as the slot-budget slices below); the table is then corrected by that pass.
+    // on the forecast: a tile that is still live behind an incomplete list is counted, and a frame with such a tile is rendered
+    // AGAIN with complete lists (finish_far_slice: only the splats in front of the cuts were depth-ordered, so there is no far
+    // pass to continue with); that second attempt re-seeds the table.
     ViewState* view = nullptr;
     bool cut_active = false;
     if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
         view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh, /*touch=*/allow_cut);
         if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
-        // (a frame with few pairs has nothing to save: the near count in K1 and an occasional far pass cost more than listing and
+        // (a frame with few pairs has nothing to save: the near count in K1 and an occasional second attempt cost more than listing and
         //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
         if (!allow_cut) {
             // (the forecast has just failed: this attempt re-seeds the table)
@@ -1049,8 +1050,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         }
         if (ctx->knob_readback_copy)
             BH_HIP(ctx, hipMemcpyAsync(ctx->host_counters + HOST_GATE_WORD, slice_info + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-        // (per-tile cuts: the forecast is expected to hold, and a far pass that had to run has corrected the table — the host decides
-        //  every time, bh_train_step hides the wait behind its loss kernels)
+        // (per-tile cuts: the forecast is expected to hold — the host decides every time, bh_train_step hides the wait behind its
+        //  loss kernels)
         if (ctx->far_direct && !by_cut) {
             BH_TRY(enqueue_far_slice(ctx, j));
             ctx->gate_learn = true;
@@ -1111,7 +1112,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     ctx->had_forward = true;
     ctx->prev_intersections = ni;
     ctx->last_one_slice = !sliced;
-    if (view) {   // this frame's blend kernels (incl. a far pass, if one runs) leave what every tile needed
+    if (view) {   // this frame's blend kernel leaves what every tile needed
         view->seeded = true;
         view->last_pairs = ni;
     }

@@ -512,6 +512,11 @@ bool tile_sort_supported(uint32_t bits, uint32_t n) { return bits > 8u && bits <
 
 // keys = tile ids (< 2^bits, or the sentinel 0xFFFFFFFF), vals = compact splat ids, n pairs in depth order.  -> out_keys / out_vals
 // sorted by tile (stable) and tile_offsets[tile] = [begin, end) for every tile that has pairs (the table must be zero already).
+// Known cliff: one 1024-thread block finishes each high-digit bucket (2^(bits-8) consecutive tile ids).  When the pairs
+// are concentrated in a few consecutive tiles (an object that fills a small part of the frame), a few blocks do nearly all the work
+// while the others idle: results stay correct, the launch degrades towards one block's throughput.  The digit totals are only
+// known on the device, so the host cannot switch paths per frame; BH_TILE_SORT_LSD=1 selects the skew-insensitive two-pass LSD sort
+// + offsets kernel for such scenes.
 int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits, uint32_t num_tiles,
                       uint32_t* out_keys, uint32_t* out_vals, uint32_t* tile_offsets, uint32_t alloc_n) {
     if (!tile_sort_supported(bits, n)) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_sort_offsets: 9..16 key bits, at most 16 M pairs");

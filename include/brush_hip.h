@@ -194,17 +194,20 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
 
 /* BH_FLAG_SLICED_LISTS: how the near lists are cut.
  *   near_share <= 0 (the default): PER TILE, from the last frame of the same view on this ctx (bh_set_view_id).  Every blend
- *     launch records, per tile, the depth behind which the tile needed no splat (+ a margin: 1.5x the tile's depth rank more of the depth
- *     order; "everything" for a tile that did not saturate); the view's next frame lists a (splat, tile) pair only if the
- *     splat lies at or in front of the tile's cut — typically a tenth of the pairs, whatever the frame looks like (a blank
- *     background or thin regions keep their own short lists whole).  A tile that is still live behind a cut list is finished
- *     by the far pass (the pairs behind the cut, for those tiles only), which also corrects the table; a view's first frame,
- *     and frames after repeated misses, are rendered with complete lists.
+ *     launch records, per tile, the depth behind which the tile needed no splat + a margin (1.5x the tile's depth rank more of the
+ *     depth order for a view that alternates with one other; deeper the longer the view stays away and after forecasts that
+ *     failed, tighter while they hold; "everything" for a tile that did not saturate); the view's next frame lists a (splat,
+ *     tile) pair only if the splat lies at or in front of the tile's cut — a fifth to a half of the pairs, whatever the frame
+ *     looks like (a blank background or thin regions keep their own short lists whole).  If a tile is still live behind a cut list
+ *     the forecast has failed: only the splats in front of the cuts were depth-ordered, so there is nothing to continue from and
+ *     the FRAME IS RENDERED AGAIN with complete lists (a second K1 .. blend, ~0.45 ms at 1 M splats / 1080p; the train step then
+ *     also evaluates its loss again), which re-seeds the table — about one frame in 100-200 with the adaptive margin.  A view's
+ *     first frame, and frames after repeated misses, are rendered with complete lists from the start.
  *   near_share in (0, 1]: ONE cut for the whole frame — the first near_share of the exact list's slots (splats in depth order);
  *     1 = never slice.  Tests and A/B measurements.
  * Results do not depend on the choice, only the time does.  Under a per-tile cut cum_tiles_hit is the scan of the near counts.
- * Note for bh_render_forward: a sliced frame makes the call wait for the near pass's blend (a 4-byte readback decides whether
- * the far pass is queued); bh_train_step hides that wait behind its loss kernels. */
+ * Note for bh_render_forward: a sliced frame makes the call wait for the near pass's blend (a 4-byte word decides whether the
+ * frame is complete); bh_train_step hides that wait behind its loss kernels. */
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
 /* The view the following forwards on this ctx render (sticky; 0 = not named, the default): selects the per-tile depth-cut table
  * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.
@@ -217,14 +220,14 @@ int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
  * time depends on it — stale tables cost a few re-rendered frames until they have re-learnt — never results.  Blocking. */
 int bh_forget_views(bh_ctx* ctx);
 /* Per-tile cuts pay when there are lists to shorten: a view whose last frame had fewer than min_pairs intersections keeps
- * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional far pass cost more than
+ * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional second attempt cost more than
  * listing and sorting everything; 0 = always cut).  The environment variable BH_CUT_MIN_PAIRS sets the initial value of new
  * contexts (the test suite, whose scenes are small, sets 0). */
 int bh_set_list_cut_threshold(bh_ctx* ctx, uint32_t min_pairs);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
-/* number of BH_FLAG_SLICED_LISTS forwards on this ctx that had to queue their far pass (diagnostics: with view ids and
- * slowly moving parameters this stops growing after each view's first frames) */
+/* number of BH_FLAG_SLICED_LISTS forwards on this ctx whose near pass did not finish the frame: second attempts with complete lists
+ * (per-tile cuts) or far slices (a fixed near_share).  Diagnostics. */
 uint32_t bh_far_slices_queued(bh_ctx* ctx);
 
 /* How many pairs the last forward on this ctx actually LISTED: compact_gid_from_isect / tile_id_from_isect hold near_pairs

@@ -5,10 +5,11 @@ TAG=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-pmc"
-# the kernel trace over a run long enough for the clocks to settle: with 13 steps the profiled process reads ~10 % slower
-# than an unprofiled one, with 200 the trace's averages and the bench's own events agree to 0.3 %
-LONG="python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-pmc"
+# Every pass profiles THE DRIVER'S COMMAND (--steps 20 --warmup 5) without its side measurements: the windows of bench.py are replicas
+# of the same 20 steps of the same training run, so the kernels of every pass are the kernels of the headline (VERDICT r4 weak #5/#6:
+# a 200-step trace of a scene that trains while it is timed was a different workload from the 20 steps the driver times).
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-pmc --no-stages"
+LONG="$CMD"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $LONG > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace exit $?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/bench_fetch.json 2> $OUT/fetch.err
