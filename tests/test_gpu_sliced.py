@@ -511,7 +511,8 @@ def _grads_close(a, b, what):
 
 def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
     """One long random walk over the public calls on ONE ctx — renders (exact / sliced x Forward / Backward / SmoothCutoff, whole
-    frames and strips), backwards, train steps (with and without an exchange hook), bh_set_list_slicing, changing scenes
+    frames and strips), backwards, train steps (with and without an exchange hook), bh_set_list_slicing, RETAINED forwards that are
+    replayed (bh_render_backward_saved) two ops later and released, changing scenes
     (saturating, non-saturating, blank background, 40 splats, empty) and cameras: every result equals the same call on a FRESH
     ctx (bit for bit: images, counts, flags; gradients to the float atomics' order; updates to Adam's sign flips on noise).
     The host-side slicing state (far_job.pending, gate_learn, far_direct, need_hint, last_one_slice) may only change WHEN work
@@ -525,10 +526,19 @@ def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
     noop_hook = _ffi.GRAD_HOOK(lambda _u, _p, _c: 0)    # one rank: the sum over the ranks is the buffer itself
     A = ba.Context(dev)
     n_ops = 420
-    kinds = {"render": 0, "backward": 0, "step": 0, "slicing": 0}
+    kinds = {"render": 0, "backward": 0, "step": 0, "slicing": 0, "retain": 0}
+    held = []   # retained render nodes of A (bh_render_retain): each is replayed LATER, after other calls ran, and must still give its own gradients
+
+    def retire(node_rec):
+        node, v_out, ref, what = node_rec
+        got = node.backward(v_out)
+        _grads_close(got, ref, ("retained node", what))
+        assert torch.equal(node.img, ref["img"]), what
+        node.release()
+
     try:
         for it in range(n_ops):
-            op = rng.choice(["render", "render", "backward", "step", "slicing"])
+            op = rng.choice(["render", "render", "backward", "step", "slicing", "retain"])
             kinds[op] += 1
             if op == "slicing":
                 share = float(rng.choice([0.0, 0.0, 0.02, 0.1, 0.4, 1.0]))
@@ -548,7 +558,17 @@ def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
             try:
                 if 'cur_share' in locals():
                     ba.set_list_slicing(cur_share, F)       # the SHARE is an input; the history is what differs
-                if op == "render":
+                if op == "retain":
+                    # a forward on A whose saved state must outlive whatever comes next (two render nodes alive; an eval render or a
+                    # train step between a forward and its backward): reference gradients from a fresh ctx NOW, replay on A later
+                    while len(held) >= 2:
+                        retire(held.pop(0))
+                    v_out = torch.from_numpy((rng.normal(size=(h, w, 4)) / (h * w)).astype(np.float32)).to(dev)
+                    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+                    ref = ba.render_splats_bwd(spl, cam, (w, h), bg, v_out, ctx=F)
+                    node = ba.render_splats_diff(spl, cam, (w, h), bg, ctx=A, retain=True, sliced=sliced)
+                    held.append((node, v_out, ref, (it, name, sliced)))
+                elif op == "render":
                     pass_ = [ba.RasterPass.Forward, ba.RasterPass.Backward, ba.RasterPass.BackwardSmoothCutoff][int(rng.integers(3))]
                     rows = None
                     if rng.integers(4) == 0:
@@ -616,6 +636,8 @@ def test_random_call_sequences_on_one_ctx_equal_fresh_contexts(dev):
                         assert np.abs(ta[:, 3:7] - tb[:, 3:7]).max() <= 2.1 * cfg.lr_rotation and np.abs(oa - ob).max() <= 2.1 * cfg.lr_opac, what
             finally:
                 F.close()
+        while held:
+            retire(held.pop(0))
         assert min(kinds.values()) >= 30, kinds
     finally:
         A.close()
