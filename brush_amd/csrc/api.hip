@@ -1174,9 +1174,10 @@ static ForwardState latest_forward(const bh_ctx* ctx) {
     return fs;
 }
 
-// The two backward kernels on the saved state `fs` (bwd/render_bwd.rs:21-171).  latest: `fs` is the ctx's most recent forward, whose
-// kernels may have cleared the accumulators on their way (GradSpan below); a retained older forward clears everything itself.
-static int backward_impl(bh_ctx* ctx, const ForwardState& fs, bool latest, const float* v_output, const float* transforms, const float* sh_coeffs,
+// The two backward kernels on the saved state `fs` (bwd/render_bwd.rs:21-171).  What the forward's kernels cleared on their way is
+// recorded in ctx->clears under that forward's generation: a backward of any other forward (a retained, older one) finds nothing
+// there and clears everything itself.
+static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_output, const float* transforms, const float* sh_coeffs,
                          const float* raw_opacities, float* v_transforms, float* v_sh_coeffs, float* v_raw_opacities, float* v_refine_weight) {
     const BhRenderOut& r = fs.out;
     const uint32_t n = fs.n, nv = r.num_listed_splats, C = (fs.sh_degree + 1) * (fs.sh_degree + 1);
@@ -1196,7 +1197,6 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, bool latest, const
         // (ROW_MARKS: the single-GPU train step reads only the rows K18 writes and marks — its forward cleared the marks)
         if (row_marks && !one_span) return set_error(ctx, BH_ERR_STATE, "internal: row-marked gradients without the train step's gradient span");
         const bool span_done = one_span && span != GradClears::NONE;
-        (void)latest;
         if (one_span && (ctx->ext_grad_floats & 3u) == 0 && (reinterpret_cast<uintptr_t>(v_transforms) & 15u) == 0) {
             // v_combined and the exchange buffer's gradient span cleared by ONE launch (hipMemsetAsync spends two or
             // three launches on them, each ~5 us of latency beyond the bytes)
@@ -1256,7 +1256,7 @@ int bh_render_backward(bh_ctx* ctx, const float* v_output, const float* transfor
         return set_error(ctx, BH_ERR_INVALID_ARG, "render_backward: null argument");
     BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
-    return backward_impl(ctx, latest_forward(ctx), /*latest=*/true, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
+    return backward_impl(ctx, latest_forward(ctx), v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
                          v_refine_weight);
 }
 
@@ -1272,10 +1272,10 @@ int bh_render_backward_saved(bh_ctx* ctx, const BhRenderOut* saved, const float*
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     for (const Retained& rt : ctx->retained)
         if (rt.fs.out.generation == saved->generation && rt.fs.out.out_img == saved->out_img)
-            return backward_impl(ctx, rt.fs, /*latest=*/false, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
+            return backward_impl(ctx, rt.fs, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs, v_raw_opacities,
                                  v_refine_weight);
     if (ctx->have_forward && saved->generation == ctx->last.generation && saved->out_img == ctx->last.out_img)
-        return backward_impl(ctx, latest_forward(ctx), /*latest=*/true, v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs,
+        return backward_impl(ctx, latest_forward(ctx), v_output, transforms, sh_coeffs, raw_opacities, v_transforms, v_sh_coeffs,
                              v_raw_opacities, v_refine_weight);
     char msg[256];
     snprintf(msg, sizeof msg, "render_backward_saved: forward #%llu is stale (the context's buffers now hold forward #%llu); call bh_render_retain "

@@ -359,7 +359,11 @@ typedef struct BhTrainState {
     float* sh_coeffs;     /* [N,C,3] */
     float* raw_opacities; /* [N] */
     float* m1_transforms; float* m2_transforms; /* [N,10] each */
-    float* m1_sh; float* m2_sh;                 /* [N,C,3], [N] (reduced) */
+    float* m1_sh; float* m2_sh;                 /* [N,C,3], [N] (reduced).  A ZERO entry of m2_sh may carry a negative sign (-0.0f): the
+                                                   library's mark "every Adam moment of this splat is zero" (bh_train_step then skips the
+                                                   splat while it receives no gradient and is not reached by the view).  -0.0 compares equal
+                                                   to 0.0 and behaves like it in the recurrence; zero-filling or overwriting the tensor simply
+                                                   removes the marks.  Copy the moment tensors together (checkpoints, refine does). */
     float* m1_opac; float* m2_opac;             /* [N] each */
     float* refine_weight_norm; float* vis_weight; float* max_screen_size; /* [N] each */
     uint32_t step_count; /* number of steps already taken (host; incremented by the call) */
