@@ -258,6 +258,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         local_tile = tile_of_block(blockIdx.x, u.num_tiles);
     }
     if (local_tile >= u.num_tiles) return;
+#if defined(BH_K16_PROBE) && BH_K16_PROBE == 3   // measurement-only: the launch floor (every wave returns at once)
+    if (u.num_tiles != 0xFFFFFFFFu) return;
+#endif
     const uint32_t tile = u.tile_begin + local_tile;
 #ifdef BH_K16_TRACE
     const unsigned long long trace_t0 = wall_clock64();
@@ -285,7 +288,11 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         }
     }
     const uint32_t range_lo = tile_offsets[tile * 2];
+#if defined(BH_K16_PROBE) && (BH_K16_PROBE == 1 || BH_K16_PROBE == 4 || BH_K16_PROBE == 5)   // measurement-only (wrong results): no batches at all — the tile's prologue + epilogue
+    const uint32_t range_hi = range_lo + (tile_offsets[tile * 2 + 1] == 0xFFFFFFFFu ? 1u : 0u);
+#else
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
+#endif
     uint32_t last_useful = range_lo;
     uint32_t reached = range_lo;        // one past the last splat the loop looked at (forward-only passes keep no last_useful)
     uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
@@ -302,7 +309,12 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
         reached = batch_start + cnt;
-        for (uint32_t t = 0; t < cnt; ++t) {
+#if defined(BH_K16_PROBE) && BH_K16_PROBE == 2   // measurement-only (wrong results): batches are staged (loads, LDS, barriers) but not blended
+        const uint32_t cnt_blend = s_splat[0] == 123.456f ? cnt : 0u;
+#else
+        const uint32_t cnt_blend = cnt;
+#endif
+        for (uint32_t t = 0; t < cnt_blend; ++t) {
             const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut
@@ -386,6 +398,9 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         return;
     }
 
+#if defined(BH_K16_PROBE) && BH_K16_PROBE == 4   // measurement-only: probe 1 without the image stores
+    if (tr[0] != 123.456f) goto after_image;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
@@ -407,6 +422,12 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
         }
     }
+#if defined(BH_K16_PROBE) && BH_K16_PROBE == 4
+after_image:
+#endif
+#if defined(BH_K16_PROBE) && BH_K16_PROBE == 5   // measurement-only: probe 1 without the tile's bookkeeping (cut, work, list end, work class)
+    if (tr[0] != 123.456f) return;
+#endif
 #ifdef BH_K16_TRACE
     if (lane == 0 && blockIdx.x < 65536u) {
         uint32_t hwid;

@@ -30,7 +30,7 @@ case "$verb" in
   build-one)
     NAME=$1; UNIT=$2; EXTRA=$3; mkdir -p $OUT; cd $ROOT/brush_amd/csrc; make -s -j8 >/dev/null
     /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $UNIT.hip -o $OUT/${UNIT}_$NAME.o
-    OBJS=$(ls *.o | grep -v "^$UNIT.o$")
+    OBJS=$(ls *.o | grep -v "^$UNIT.o$" | grep -v "\.th\.o$")   # (the test-hook objects belong to the other library)
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS $OUT/${UNIT}_$NAME.o -ldl -o $OUT/libbrush_hip_$NAME.so
     rm -f $OUT/${UNIT}_$NAME.o; echo built $OUT/libbrush_hip_$NAME.so ;;
   stages)
