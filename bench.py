@@ -812,6 +812,10 @@ def main():
             "windows_are": "replicas: every window times steps [warmup, warmup + steps) of the same training run from the same initial state (parameters, Adam "
                            "moments, step counter, view cycle and the library's per-view tables reset before each): their spread is noise, not drift",
             "ms_per_step_without_kernel_events": (round(m["dt_plain"] / steps * 1e3, 4) if m.get("dt_plain") else None),
+            "timed_phase": "steps %d..%d of a training run from the untrained synthetic scene (the heaviest phase: the blended pairs per frame fall as the scene "
+                           "trains, see config.per_view[].intersections_blended_first_last_timed_step).  Rounds 1-4 timed consecutive windows of a scene that "
+                           "kept training (round 4: ~60 steps, 7.5 %% monotone drift between its windows): their views/s are not comparable with this line"
+                           % (args.warmup, args.warmup + steps - 1),
             "config": {"workload": "%s: %d splats, %dx%d, SH degree %d, one view per rank per step (BASELINE.json configs[2])" % (args.workload, n, w, h, args.sh_degree),
                        "views": m["nviews"],
                        "view_cycle": ("step k trains view k %% %d; " % m["nviews"]) + ("two cameras 2 units apart in x as crates/brush-bench-test/src/benches.rs:198-220" if m["nviews"] == 2 else
