@@ -74,6 +74,12 @@ def main():
           "cut frames %d mean share %.3f | complete-list frames %d" % (
               args.tag, args.views, args.steps, args.refine_every, not args.no_noise, args.exact, os.environ.get("BH_CUT_MARGIN_PCT", "150"), dt / args.steps * 1e3, len(miss), len(miss_first),
               len(first_after_refine), len(cutf), (sum(r[2] for r in cutf) / max(1, len(cutf))), len(log) - len(cutf)))
+    seg = max(200, args.steps // 6)
+    for a in range(0, args.steps, seg):
+        part = [r for r in log if a < r[0] <= a + seg]
+        cut = [r for r in part if r[2] < 1.0]
+        print("   steps %5d-%5d: second attempts %3d, frames with complete lists %3d, mean share of the cut frames %.3f" % (
+            a + 1, a + len(part), sum(1 for r in part if r[3]), len(part) - len(cut), sum(r[2] for r in cut) / max(1, len(cut))))
     gaps = {}
     for r in log:
         if r[5] > 0:
