@@ -459,6 +459,7 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
     if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
     ctx->knob_update_early = getenv("BH_UPDATE_EARLY") != nullptr;
     ctx->knob_no_dormant = getenv("BH_UPDATE_NO_DORMANT") != nullptr;
+    if (const char* e = getenv("BH_K5_EXACT_SPW")) ctx->knob_k5_exact_spw = (uint32_t)atoi(e);
     ctx->knob_tile_sort_lsd = getenv("BH_TILE_SORT_LSD") != nullptr;
     if (const char* e = getenv("BH_LOSS_BANDS")) ctx->knob_loss_bands = (uint32_t)atoi(e);
     if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }

@@ -350,6 +350,7 @@ struct bh_ctx {
     uint32_t train_steps_seen = 0;
     uint32_t knob_loss_bands = 1;     // BH_LOSS_BANDS=0 (A/B): the fused loss's blocks take their tiles row-major instead of by XCD column bands
     bool knob_tile_sort_lsd = false;  // BH_TILE_SORT_LSD (A/B): the forward's tile sort as two LSD passes + the offsets kernel (rounds 1-4)
+    uint32_t knob_k5_exact_spw = 32;  // BH_K5_EXACT_SPW = 16 | 32 | 64 (A/B): splats per wave of K5 for complete lists
     bool knob_no_dormant = false;     // BH_UPDATE_NO_DORMANT (A/B, tests): the update kernel fetches and updates dormant splats like everyone else
     bool knob_update_early = false;   // BH_UPDATE_EARLY (A/B): the update kernel's blocks of SH degree >= 1 issue all their loads up front
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel

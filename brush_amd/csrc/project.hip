@@ -822,6 +822,17 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                            projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, zcut, depth_keys_sorted);
+    } else if (ctx->knob_k5_exact_spw != 64u) {
+        // complete lists: 32 splats per wave (the wave's flat candidate list is half as long: 50.9 -> 46.9 us at 1 M splats / 9.8 M pairs;
+        // 16: 49.5).  BH_K5_EXACT_SPW = 16 | 64 selects the others (A/B).
+        const uint32_t spw = ctx->knob_k5_exact_spw == 16u ? 16u : 32u;
+        const dim3 gridn((nv + PROJ_WAVES * spw - 1) / (PROJ_WAVES * spw));
+        if (spw == 16u)
+            hipLaunchKernelGGL((map_gaussians_kernel<false, 16>), gridn, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
+        else
+            hipLaunchKernelGGL((map_gaussians_kernel<false, 32>), gridn, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
+                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
     } else {
         hipLaunchKernelGGL((map_gaussians_kernel<false, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                            projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
