@@ -862,6 +862,14 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if pg is not None:
         import torch.distributed as dist
+        # the library's communicator goes first, while RCCL is certainly still alive (left to the interpreter's teardown it was
+        # destroyed after torch's process group, in whatever order the garbage collector chose: a crash at exit now and then)
+        try:
+            torch.cuda.synchronize(dev)
+            ctx.comm_destroy()
+        except Exception as e:
+            print("bench.py: bh_comm_destroy: %s" % (e,), file=sys.stderr)
+        dist.barrier()
         dist.destroy_process_group()
 
 

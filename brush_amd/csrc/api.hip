@@ -754,12 +754,20 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     // pass to continue with); that second attempt re-seeds the table.
     ViewState* view = nullptr;
     bool cut_active = false;
-    if (want_sliced && !(ctx->slice_fraction > 0.0f) && n > 0) {
+    const bool auto_cuts = want_sliced && !(ctx->slice_fraction > 0.0f);
+    // A frame with COMPLETE lists (no BH_FLAG_SLICED_LISTS: the reference's exact aux tensors, eval renders, exact_lists steps) takes
+    // the view's table too — not to cut anything, but for the forward blend's tile order: its tiles start in descending order of the
+    // work they had at the same camera's last frame (K16 193 -> ~150 us at 1 M splats / 1080p), and it refreshes the table.
+    const bool order_only = !want_sliced && ctx->knob_k16_order != 0u && n >= 8u * 256u;
+    if (n > 0 && (auto_cuts || order_only)) {
         view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh, /*touch=*/allow_cut);
-        if (!view) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
+        if (!view && auto_cuts) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
+        if (!view) (void)hipGetLastError();   // (ordering is optional: carry on in index order)
         // (a frame with few pairs has nothing to save: the near count in K1 and an occasional second attempt cost more than listing and
         //  sorting them all — 100 k splats at 512 x 512 trained 4 % slower with cuts; the view's last frame tells)
-        if (!allow_cut) {
+        if (!auto_cuts || !view) {
+            // (complete lists by request)
+        } else if (!allow_cut) {
             // (the forecast has just failed: this attempt re-seeds the table)
         } else if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) cut_active = true;
         else if (view->exact_frames) view->exact_frames--;
