@@ -22,6 +22,16 @@ def _scene(n, w, h, seed, opacity=(0.05, 0.95), scales=(0.02, 0.2), sh_degree=0)
     return sc, synth.default_camera_params(w, h)
 
 
+def _reference_render(ba, ctx, *args, **kw):
+    """A complete-list render that must not seed the per-view table of the camera under test (since round 5 complete-list frames
+    take part in the per-view state: the forward blend's tile order): it runs under a view id of its own."""
+    ba.set_view_id(0xEEEE, ctx)
+    try:
+        return ba.render_splats(*args, ctx=ctx, **kw)
+    finally:
+        ba.set_view_id(0, ctx)
+
+
 def _blended_lists(aux):
     """per tile: the splats (GLOBAL ids) the blend kernels consumed, front to back — compact ids are translated, because a frame
     with per-tile cuts numbers only the splats that own a listed pair (a sub-sequence of the full depth order)"""
@@ -211,7 +221,7 @@ def test_automatic_cuts_follow_the_views_previous_frame(dev):
         sc, _ = _scene(n, w, h, 0x56, scales=(0.03, 0.3))
         spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
         lib = ctx.lib
-        img_e, aux_e = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx)
+        img_e, aux_e = _reference_render(ba, ctx, spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward)
         img0, aux0 = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx, sliced=True)
         assert lib.bh_last_list_share(ctx._h) == 1.0 and aux0.tile_offsets_far is None        # no history: complete lists
         assert torch.equal(aux0.compact_gid_from_isect, aux_e.compact_gid_from_isect)
@@ -299,7 +309,7 @@ def test_alternating_views_with_and_without_view_ids(dev, mode):
         far_cam = util.hip_camera(ba, far)
         ref = {}
         for name, cam in (("near", near_cam), ("far", far_cam)):
-            ref[name] = ba.render_splats(spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx)
+            ref[name] = _reference_render(ba, ctx, spl, cam, (w, h), (0, 0, 0), ba.RasterPass.Backward)
         queued, shares = [], []
         for i in range(16):
             name, cam = (("near", near_cam), ("far", far_cam))[i % 2]
@@ -334,7 +344,7 @@ def test_blank_background_is_cut_like_any_other_frame(dev):
                               tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w), spread=0.45)
         spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
         cam = util.hip_camera(ba, synth.default_camera_params(w, h))
-        ref, aux_e = ba.render_splats(spl, cam, (w, h), (0.2, 0.2, 0.2), ba.RasterPass.Backward, ctx=ctx)
+        ref, aux_e = _reference_render(ba, ctx, spl, cam, (w, h), (0.2, 0.2, 0.2), ba.RasterPass.Backward)
         assert float(ref[..., 3].min()) == 0.0                        # blank border: those tiles never saturate
         shares = []
         for _ in range(6):
