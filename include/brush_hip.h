@@ -210,7 +210,9 @@ int bh_render_forward(bh_ctx* ctx, const BhCamera* cam /*host*/, uint32_t n, uin
  * frame is complete); bh_train_step hides that wait behind its loss kernels. */
 int bh_set_list_slicing(bh_ctx* ctx, float near_share);
 /* The view the following forwards on this ctx render (sticky; 0 = not named, the default): selects the per-tile depth-cut table
- * BH_FLAG_SLICED_LISTS forwards read and refresh.  bh_train_step sets it from BhTrainBatch.view_id for its own forward.
+ * BH_FLAG_SLICED_LISTS forwards read and refresh (forwards with complete lists refresh it too and take their blend's tile order
+ * from it: tiles start in descending order of the work they had at the same view's last frame).  bh_train_step sets it from
+ * BhTrainBatch.view_id for its own forward.
  * A frame without an id is keyed by its CAMERA (a hash of the BhCamera's view matrix, intrinsics, size, model and tile window): the
  * views of a dataset are fixed cameras, so a caller that passes the reference's SceneBatch unchanged (no view index,
  * brush-dataset/src/scene.rs:138-147) gets the same tables as one that numbers its views.  One table is 8 bytes per tile (cut +
