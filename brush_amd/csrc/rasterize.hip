@@ -628,6 +628,10 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                float* __restrict__ v_combined, const uint32_t* __restrict__ lpt,
                                                                const uint32_t* __restrict__ tile_offsets_far) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
+#ifdef BH_BWD_LDS_PAD   // measurement-only: cap the occupancy through the block's LDS footprint (bytes)
+    __shared__ float s_pad[BH_BWD_LDS_PAD / 4];
+    if (u.num_tiles == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1.0f;
+#endif
     uint32_t local_tile;
     if (lpt) {
         // block j of XCD x takes the j-th tile of band x in descending work-class order (wave-uniform scalar code)
