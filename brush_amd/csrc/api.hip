@@ -1241,7 +1241,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_out
         ProfScope ps(ctx, "ProjectBackwards");
         BH_TRY(launch_project_backward(ctx, fs.uniforms, nv, fs.flags & BH_FLAG_MIP, fs.sh_degree, transforms, sh_coeffs,
                                        raw_opacities, r.global_from_compact_gid, v_combined, v_transforms, v_sh_coeffs,
-                                       v_raw_opacities, v_refine_weight, row_marks));
+                                       v_raw_opacities, v_refine_weight, row_marks, r.projected));
     }
     return 0;
 }

@@ -257,6 +257,12 @@ struct Retained {
 
 }  // namespace bh
 
+// 1 (default): the blend backward accumulates RAW per-splat sums into v_combined and the projection backward maps them to the
+// reference's RasterizeGrads row (and stores it back) — rasterize.hip / project.hip.  0: the maps run in the blend backward (A/B).
+#ifndef BH_RAW_SUMS
+#define BH_RAW_SUMS 1
+#endif
+
 struct bh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -437,8 +443,8 @@ int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, co
                              uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids);
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
-                            const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine, bool mark_written = false);
+                            float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
+                            float* v_refine, bool mark_written = false, const float* projected = nullptr);
 // sort.hip
 int radix_argsort(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits,
                   uint32_t* out_keys, uint32_t* out_vals);

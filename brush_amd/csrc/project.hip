@@ -925,17 +925,42 @@ template <bool MIP, int DEG, bool PINHOLE>
 __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
     ViewUniforms u, uint32_t nv, const float* __restrict__ transforms, const float* __restrict__ sh_coeffs,
     const float* __restrict__ raw_opac, const uint32_t* __restrict__ global_from_compact_gid,
-    const float* __restrict__ v_combined, float* __restrict__ v_transforms, float* __restrict__ v_coeffs,
-    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const bool mark_written) {
+    float* __restrict__ v_combined, float* __restrict__ v_transforms, float* __restrict__ v_coeffs,
+    float* __restrict__ v_raw_opac, float* __restrict__ v_refine_weight, const bool mark_written, const float* __restrict__ projected) {
     const uint32_t cg = blockIdx.x * PROJ_WG + threadIdx.x;
     if (cg >= nv) return;
     uint32_t gid = global_from_compact_gid[cg];
-    const float* rg = v_combined + (size_t)cg * 10;
+    float* rg = v_combined + (size_t)cg * 10;
     float g[10];
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 10; ++k) g[k] = rg[k];
     asm volatile("" : "+v"(gid));   // (the splat id travels with the accumulator row, not behind the test on it)
+#if BH_RAW_SUMS
+    // The blend backward left RAW sums (rasterize.hip): P Q = sums of v_sigma (pixel - mean), R2 R3 R4 = its second moments, the
+    // three colour sums, Vs = sum of v_sigma, the refine weight.  Their per-splat linear maps (rasterize_backwards.rs:318-381:
+    // v_xy = -conic (P, Q), v_conic = (R2/2, R3, R4/2), the colour clamp's gates, v_alpha0 = -Vs / alpha0) commute with the sum
+    // over tiles and are applied here, once per splat; the row is stored back, so v_combined IS RasterizeGrads afterwards.
+    {
+        bool raw_any = false;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) raw_any = raw_any || (g[k] != 0.0f);
+        if (!raw_any) return;   // (nothing reached this splat: the row is zero and stays zero)
+        const float* pr = projected + (size_t)cg * 9;
+        const float c00 = pr[2], c01 = pr[3], c11 = pr[4], a0 = pr[5], cr = pr[6], cg_ = pr[7], cb = pr[8];
+        const float P = g[0], Q = g[1];
+        g[0] = -__builtin_fmaf(c00, P, c01 * Q);
+        g[1] = -__builtin_fmaf(c11, Q, c01 * P);
+        g[2] = 0.5f * g[2];
+        g[4] = 0.5f * g[4];
+        g[5] = cr >= 0.0f ? g[5] : 0.0f;    // rasterize.rs:147-149: a colour channel clamped at 0 passes no gradient
+        g[6] = cg_ >= 0.0f ? g[6] : 0.0f;
+        g[7] = cb >= 0.0f ? g[7] : 0.0f;
+        g[8] = -g[8] / a0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) rg[k] = g[k];
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 10; ++k) any = any || (g[k] != 0.0f);
     constexpr int C = (DEG + 1) * (DEG + 1);
@@ -1001,14 +1026,14 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 
 template <bool MIP, bool PINHOLE>
 static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32_t deg, const float* t, const float* sh,
-                         const float* ro, const uint32_t* gid, const float* vc, float* vt, float* vsh, float* vro, float* vr, bool rm) {
+                         const float* ro, const uint32_t* gid, float* vc, float* vt, float* vsh, float* vro, float* vr, bool rm, const float* pj) {
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     switch (deg) {
-        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
-        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
-        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
-        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
-        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm); break;
+        case 0: hipLaunchKernelGGL((project_backward_kernel<MIP, 0, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm, pj); break;
+        case 1: hipLaunchKernelGGL((project_backward_kernel<MIP, 1, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm, pj); break;
+        case 2: hipLaunchKernelGGL((project_backward_kernel<MIP, 2, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm, pj); break;
+        case 3: hipLaunchKernelGGL((project_backward_kernel<MIP, 3, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm, pj); break;
+        case 4: hipLaunchKernelGGL((project_backward_kernel<MIP, 4, PINHOLE>), grid, block, 0, ctx->stream, u, nv, t, sh, ro, gid, vc, vt, vsh, vro, vr, rm, pj); break;
         default: return set_error(ctx, BH_ERR_INVALID_ARG, "sh_degree must be 0..4");
     }
     BH_LAUNCH_CHECK(ctx, "project_backward_kernel");
@@ -1017,14 +1042,17 @@ static int launch_pb_deg(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, uint32
 
 int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, bool mip, uint32_t sh_degree,
                             const float* transforms, const float* sh, const float* raw_opac, const uint32_t* gid,
-                            const float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
-                            float* v_refine, bool row_mask) {
+                            float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
+                            float* v_refine, bool row_mask, const float* projected) {
     if (nv == 0) return 0;
+#if BH_RAW_SUMS
+    if (!projected) return set_error(ctx, BH_ERR_INVALID_ARG, "project_backward: the projected rows are needed to map the raw gradient sums");
+#endif
     if (u.model == CAM_PINHOLE)
-        return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask)
-                   : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask);
-    return mip ? launch_pb_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask)
-               : launch_pb_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask);
+        return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected)
+                   : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected);
+    return mip ? launch_pb_deg<true, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected)
+               : launch_pb_deg<false, false>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected);
 }
 
 }  // namespace bh

@@ -793,6 +793,13 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 }
             }
             if (__ballot(any) != 0ull) {
+#if BH_RAW_SUMS
+                // The ten RAW sums leave as they are: the per-splat linear maps that turn them into the reference's ten gradients
+                // (conic / 1/2 factors, colour gates, -1/alpha0: ~20 issue slots incl. a quarter-rate rcp) commute with the sum over
+                // tiles, so K18 applies them ONCE per splat to the accumulated row instead of this kernel once per (splat, tile).
+                const float h0 = swap32_add(aP, aQ), h1 = swap32_add(aR2, aR3), h2 = swap32_add(aR4, aCr);
+                const float h3 = swap32_add(aCg, aCb), h4 = swap32_add(aVs, aRf);
+#else
                 const float g0 = -__builtin_fmaf(c00, aP, c01 * aQ), g1 = -__builtin_fmaf(c11, aQ, c01 * aP);
                 const float g2 = 0.5f * aR2, g4 = 0.5f * aR4;
                 const uint32_t gate = f2u(s_splat[t * SPLAT_STRIDE + 10]);
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 const float g8 = -aVs * __builtin_amdgcn_rcpf(color_a);
                 const float h0 = swap32_add(g0, g1), h1 = swap32_add(g2, aR3), h2 = swap32_add(g4, g5);
                 const float h3 = swap32_add(g6, g7), h4 = swap32_add(g8, aRf);
+#endif
                 const float k0 = row_allreduce(swap16_add(h0, h1));
                 const float k1 = row_allreduce(swap16_add(h2, h3));
                 const float k2 = row_allreduce(swap16_add(h4, 0.0f));
