@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     // minus what has been replayed) and only ever uses it inside a dot product with the pixel's v_rgb, so the state kept here
     // is that dot product: S = remaining . v_rgb (one register and one fma per update instead of three).  T = 0: finished.
     float sS[4], sw[4];
-    float vox[4], voy[4], voz[4], inv_fa[4];
+    float vox[4], voy[4], voz[4], w2q[4], h2q[4];   // w2q / h2q: (W / A)^2, (H / A)^2 of the pixel — the refine weight's 1 / max(A, 1e-5) folded into its norm
     // (the eight pixel loads side by side, from clamped — always valid — addresses, masked afterwards: under `if (inside)` they
     //  were four dependent global round trips at the head of every tile)
     float4 o4[4], vo4[4];
@@ -696,14 +696,15 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
             sS[q] = __builtin_fmaf(o.z - t_final * u.bg_b, vo.z, __builtin_fmaf(o.y - t_final * u.bg_g, vo.y, (o.x - t_final * u.bg_r) * vo.x)) - v_o_w;
             sw[q] = 1.0f;
             vox[q] = vo.x; voy[q] = vo.y; voz[q] = vo.z;
-            inv_fa[q] = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
+            const float inv_fa = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
+            w2q[q] = (img_w_f * inv_fa) * (img_w_f * inv_fa);
+            h2q[q] = (img_h_f * inv_fa) * (img_h_f * inv_fa);
         } else {
             sS[q] = sw[q] = 0.0f;
             vox[q] = voy[q] = voz[q] = 0.0f;
-            inv_fa[q] = 1.0f;
+            w2q[q] = h2q[q] = 0.0f;
         }
     }
-    const float w2 = img_w_f * img_w_f, h2 = img_h_f * img_h_f;   // in VGPRs: an SGPR operand halves a VALU op's issue rate
 
     // The ten per-lane partial sums of the splat in flight, RAW: aP aQ = sums of v_sigma (pixel - mean), aR2 aR3 aR4 = its second
     // moments, aCr aCg aCb = rgb, aVs = sum of v_sigma, aRf = refine; the per-splat linear maps that turn them into the
@@ -783,8 +784,9 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                         aVs += v_sigma;
                         // refine weight: |(v_xy.x W, v_xy.y H)| / max(A, 1e-5), v_xy = -v_sigma conic (pixel - mean)   (…:340-349)
                         const float ex = e_x[k] + e_y[m], ey = b_x[k] + c_y[m];
-                        const float n2 = __builtin_fmaf(h2 * ey, ey, w2 * (ex * ex));
-                        aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2) * inv_fa[q], aRf);
+                        // (|(W vx, H vy)| / A = sqrt((W/A)^2 vx^2 + (H/A)^2 vy^2): the per-pixel 1/A lives in w2q / h2q)
+                        const float n2 = __builtin_fmaf(h2q[q] * ey, ey, w2q[q] * (ex * ex));
+                        aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2), aRf);
                         // --- state update ---------------------------------------------------------
                         sS[q] = __builtin_fmaf(-vis, cv, sS[q]);
                         sw[q] = next_t;
