@@ -8,7 +8,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+check_only = "--check" in sys.argv[1:]   # exit 1 if DESIGN.md does not carry exactly the figures of the committed profiles
+tag = args_[0] if args_ else "r5"
 
 
 def load(name):
@@ -93,8 +95,15 @@ head = "\n\n".join(h)
 
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
+before = s
 s = re.sub(r"<!-- figures:begin -->.*?<!-- figures:end -->", lambda m: "<!-- figures:begin -->\n" + fig + "\n<!-- figures:end -->", s, flags=re.S)
 s = re.sub(r"<!-- headline:begin -->.*?<!-- headline:end -->", lambda m: "<!-- headline:begin -->\n" + head + "\n<!-- headline:end -->", s, flags=re.S)
+if check_only:
+    if s != before:
+        print("DESIGN.md does not match profiles/%s_*.json: run `python scripts/design_figures.py %s`" % (tag, tag))
+        sys.exit(1)
+    print("DESIGN.md carries the figures of profiles/%s_*.json" % tag)
+    sys.exit(0)
 open(p, "w").write(s)
 print(fig)
 print()
