@@ -503,7 +503,10 @@ const char* bh_last_error(bh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int bh_sync(bh_ctx* ctx) {
     if (!ctx) return BH_ERR_INVALID_ARG;
-    if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    if (ctx->far_job.pending) {   // (a deferred decision may queue kernels: on the ctx's device)
+        BH_HIP(ctx, hipSetDevice(ctx->device));
+        BH_TRY(finish_far_slice(ctx, nullptr));
+    }
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     deliver_pending_loss(ctx);  // the last train step's loss, staged through pinned memory
     return 0;
@@ -1294,6 +1297,7 @@ int bh_render_backward_saved(bh_ctx* ctx, const BhRenderOut* saved, const float*
 
 int bh_render_retain(bh_ctx* ctx, const BhRenderOut* out) {
     if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     if (!ctx->have_forward || out->generation != ctx->last.generation || out->out_img != ctx->last.out_img || out->out_img_packed != ctx->last.out_img_packed)
         return set_error(ctx, BH_ERR_STATE, "render_retain: only the context's most recent forward can be retained (and only once)");
@@ -1311,6 +1315,7 @@ int bh_render_retain(bh_ctx* ctx, const BhRenderOut* out) {
 
 int bh_render_release(bh_ctx* ctx, const BhRenderOut* out) {
     if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
     for (size_t k = 0; k < ctx->retained.size(); ++k) {
         Retained& rt = ctx->retained[k];
         if (rt.fs.out.generation != out->generation || rt.fs.out.out_img != out->out_img) continue;
@@ -1331,6 +1336,7 @@ int bh_render_release(bh_ctx* ctx, const BhRenderOut* out) {
 int bh_last_render_out(bh_ctx* ctx, BhRenderOut* out) {
     if (!ctx || !out) return BH_ERR_INVALID_ARG;
     if (!ctx->have_forward) return set_error(ctx, BH_ERR_STATE, "no forward render on this context yet");
+    BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     *out = ctx->last;
     return 0;
