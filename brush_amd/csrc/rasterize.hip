@@ -245,17 +245,26 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
                                                       float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
+#ifdef BH_K16_HALF   // measurement-only (the per-tile bookkeeping is the upper half's alone): two waves per tile, 16 x 8 pixels each
+    constexpr int NQ = 2;
+    const uint32_t half = (blockIdx.x >> 3) & 1u;
+    const uint32_t bidx = (blockIdx.x & 7u) | ((blockIdx.x >> 4) << 3);   // (blocks b and b + 8: the two halves of a tile, on the same XCD)
+#else
+    constexpr int NQ = 4;
+    const uint32_t half = 0u;
+    const uint32_t bidx = blockIdx.x;
+#endif
     uint32_t local_tile;
     if (sl.order) {
         const uint32_t per = (u.num_tiles + 7u) / 8u;
-        uint32_t j = blockIdx.x >> 3;
+        uint32_t j = bidx >> 3;
         if (sl.order_mode == 2u) {   // dealt: consecutive blocks of a band take every seg-th rank (the grid covers 8 * seg ranks per band)
             const uint32_t seg = (per + 7u) / 8u;
             j = (j & 7u) * seg + (j >> 3);
         }
-        local_tile = j < per ? sl.order[(blockIdx.x & 7u) * per + j] : 0xFFFFFFFFu;
+        local_tile = j < per ? sl.order[(bidx & 7u) * per + j] : 0xFFFFFFFFu;
     } else {
-        local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+        local_tile = tile_of_block(bidx, u.num_tiles);
     }
     if (local_tile >= u.num_tiles) return;
 #if defined(BH_K16_PROBE) && BH_K16_PROBE == 3   // measurement-only: the launch floor (every wave returns at once)
@@ -271,13 +280,19 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     }
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
-    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
+    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + 8u * half + (lane >> 3);
     const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
     const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
     // transmittance; a finished pixel keeps its final T with the sign flipped
-    float tr[4], pr[4], pg[4], pb[4];
+    float tr[NQ], pr[NQ], pg[NQ], pb[NQ];
+    auto any_live = [&]() {
+        bool l = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) l = l || tr[q] > 0.0f;
+        return l;
+    };
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
         const bool inside = px < u.img_w && py < u.img_h;
         tr[q] = inside ? 1.0f : -1.0f;
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     // (A per-batch variant without the v_min of the 0.999 clamp — the backward's trick — was measured here: the second copy of
     //  the loop costs 16 VGPRs, 8 -> 7 waves per SIMD, 160 -> 170 us.)
     for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
-        const bool live = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+        const bool live = any_live();
         if (__ballot(live) == 0ull) break;
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
         __syncthreads();  // previous batch fully consumed (single wave: cheap)
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
             bool any = false;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int k = q & 1, m = q >> 1;
                 const float half_qv = __builtin_fmaf(c_y[m], dy[m], a_xx[k]);   // (the staged diagonal is halved)
                 const float sigma = __builtin_fmaf(b_x[k], dy[m], half_qv);
@@ -363,7 +378,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             // every pixel of the tile saturated: the rest of the batch (32 splats on average, ~45 VALU ops each just
             // to fail the quadrant tests) cannot contribute.  Checked every 8th splat; the batch loop's own test ends the tile.
             if ((t & 7u) == 7u) {
-                const bool still = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+                const bool still = any_live();
                 if (__ballot(still) == 0ull) { reached = batch_start + t + 1; break; }
             }
         }
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             if ((contrib_mask >> lane) & 1ull) visible[global_from_compact[cg]] = 1.0f;
         }
     }
-    const bool live_end = tr[0] > 0.0f || tr[1] > 0.0f || tr[2] > 0.0f || tr[3] > 0.0f;
+    const bool live_end = any_live();
     const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
 
     // (per-tile depth cuts: a tile whose near list was NOT cut holds everything there is — unsaturated or not, it is final)
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     if (PHASE == 1 && !saturated && !near_complete) {
         // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
             if (px < u.img_w && py < u.img_h)
                 *reinterpret_cast<float4*>(&sl.state[((size_t)px + (size_t)py * u.img_w) * 4]) = make_float4(pr[q], pg[q], pb[q], tr[q]);
@@ -402,7 +417,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
     if (tr[0] != 123.456f) goto after_image;
 #endif
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
         if (px < u.img_w && py < u.img_h) {
             const float tf = __builtin_fabsf(tr[q]);
@@ -438,7 +453,7 @@ after_image:
         tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = ((unsigned long long)xcc << 32) | hwid; tr[3] = ((unsigned long long)tile << 32) | (last_useful - range_lo);
     }
 #endif
-    if (lane == 0) {
+    if (lane == 0 && half == 0u) {
         if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
         uint32_t work = (BWD_INFO ? last_useful : reached) - range_lo;
         uint32_t listed = range_hi - range_lo;
@@ -453,7 +468,7 @@ after_image:
             tile_offsets[tile * 2 + 1] = last_useful;
             if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
                 const uint32_t cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
-                const uint32_t list = (blockIdx.x & 7u) * LPT_CLASSES + cls;
+                const uint32_t list = (bidx & 7u) * LPT_CLASSES + cls;
                 const uint32_t pos = atomicAdd(&lpt[list], 1u);
                 lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
             }
@@ -548,6 +563,9 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;
     uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     if (sl.order && sl.order_mode == 2u) nblocks = (((u.num_tiles + 7u) / 8u + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
+#ifdef BH_K16_HALF
+    nblocks *= 2u;
+#endif
     const dim3 grid(nblocks);
     if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
