@@ -13,6 +13,12 @@
 //   brush_hip::tile_sort_offsets render.rs:228-243 + kernels/get_tile_offset.rs:11-58
 //   brush_hip::SplatTrainer      brush-train/src/train.rs:140-893           (step, refine, set_view_cams)
 //   brush_hip::splat_to_ply / load_splat_from_ply   brush-serde/src/export.rs:179-204, import.rs:166-170
+//   brush_hip::image_loss / image_loss_backward      brush-loss/src/lib.rs:718-733, 1075-1104 (LossOps; [H,W,C] in, [H,W,C] out)
+//   brush_hip::image_loss_value_and_grad             the composition SplatTrainer::step makes of it (train.rs:227-260)
+//   brush_hip::adam_step / gather_stats              brush-train/src/adam_scaled.rs:75-147, stats.rs:40-50
+//   brush_hip::BatchUploader / SceneLoader           brush-dataset/src/scene.rs:97-136, scene_loader.rs:59-174
+//   brush_hip::sample_background / normal_samples    train.rs:896-908, 389-416 (the library's counter-based generator)
+//   Context::comm_* / allreduce_* / exchange_strip_halos   not in the reference: RCCL behind the C ABI
 //
 // Errors are exceptions (brush_hip::Error carrying bh_last_error) where the reference panics.  Device memory is
 // owned by DeviceBuffer<T> (hipMalloc/hipFree); nothing here computes — every operation is one C-ABI call.
@@ -20,8 +26,13 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <functional>
+#include <numeric>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -113,6 +124,65 @@ class Context {
     bh_ctx* get() const { return h_; }
     void check(int rc) const { if (rc != 0) throw Error(rc, bh_last_error(h_)); }
     void sync() const { check(bh_sync(h_)); }
+
+    // ---- per-tile list controls (include/brush_hip.h "depth-sliced lists"): only the TIME of a render depends on them
+    void set_list_slicing(float near_share) const { check(bh_set_list_slicing(h_, near_share)); }       // <= 0: automatic (per-tile cuts)
+    void set_list_cut_threshold(uint32_t min_pairs) const { check(bh_set_list_cut_threshold(h_, min_pairs)); }
+    void set_view_id(uint32_t view_id) const { check(bh_set_view_id(h_, view_id)); }                     // sticky; 0 = keyed by the camera
+    void forget_views() const { check(bh_forget_views(h_)); }                                            // after loading another scene
+    float last_list_share() const { return bh_last_list_share(h_); }
+    uint32_t far_slices_queued() const { return bh_far_slices_queued(h_); }
+    std::pair<uint32_t, uint32_t> last_list_counts() const {   // (near pairs, far pairs) of the last forward
+        uint32_t a = 0, b = 0;
+        check(bh_last_list_counts(h_, &a, &b));
+        return {a, b};
+    }
+    BhRenderOut last_render_out() const {
+        BhRenderOut o{};
+        check(bh_last_render_out(h_, &o));
+        return o;
+    }
+
+    // ---- per-stage profile (HIP events around every pipeline stage; 2 = only the dominant kernel)
+    void profile(int level = 1) const { check(bh_profile_enable(h_, level)); }
+    struct StageTime { std::string name; float ms; uint32_t calls; };
+    std::vector<StageTime> profile_fetch() const {
+        const char* names[64]; float ms[64]; uint32_t calls[64];
+        const int n = bh_profile_fetch(h_, names, ms, calls, 64);
+        if (n < 0) check(n);
+        std::vector<StageTime> out;
+        for (int i = 0; i < n; ++i) out.push_back({names[i], ms[i], calls[i]});
+        return out;
+    }
+
+    // ---- the library's communicator (RCCL, resolved at first use; SURVEY §8e — not in the reference, which is single-GPU).
+    // Rank 0 calls comm_unique_id() and hands the 128 bytes to every rank by its own means; every rank calls comm_init.  With a
+    // communicator of world > 1 and no hook, SplatTrainer::step sums its gradients (and, for a tile-row window, exchanges the strips'
+    // halos) through it.
+    static std::array<uint8_t, 128> comm_unique_id() {
+        std::array<uint8_t, 128> id{};
+        const int rc = bh_comm_unique_id(id.data());
+        if (rc != 0) throw Error(rc, "bh_comm_unique_id failed (is librccl.so loadable?)");
+        return id;
+    }
+    void comm_init(int rank, int world, const std::array<uint8_t, 128>& id) const { check(bh_comm_init(h_, rank, world, id.data())); }
+    void comm_destroy() const { check(bh_comm_destroy(h_)); }
+    int comm_world() const { return bh_comm_world(h_); }
+    int comm_rank() const { return bh_comm_rank(h_); }
+    void comm_selftest() const { check(bh_comm_selftest(h_)); }   // collective: every rank calls it once after comm_init
+    void allreduce_sum(float* dev, uint64_t count) const { check(bh_allreduce_sum_f32(h_, dev, count)); }
+    void allreduce_max(float* dev, uint64_t count) const { check(bh_allreduce_max_f32(h_, dev, count)); }   // RefineRecord maxima before refine
+    void allgather_bytes(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) const { check(bh_allgather_bytes(h_, send_dev, recv_dev, bytes_per_rank)); }
+    // one frame split into strips of tile rows: fetch the 21 pixel rows above and below this rank's strip from its neighbours
+    void exchange_strip_halos(float* img_hwc4, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px) const {
+        check(bh_exchange_strip_halos(h_, img_hwc4, h, w, row_begin_px, row_end_px));
+    }
+    static std::vector<BhHaloOp> strip_halo_plan(uint32_t img_h, uint32_t row_begin_px, uint32_t row_end_px, int rank, int world) {
+        BhHaloOp ops[4];
+        const int n = bh_strip_halo_plan(img_h, row_begin_px, row_end_px, rank, world, ops);
+        if (n < 0) throw Error(n, "strip_halo_plan: bad strip");
+        return std::vector<BhHaloOp>(ops, ops + n);
+    }
 
   private:
     bh_ctx* h_;
@@ -359,6 +429,82 @@ inline void prefix_sum(const Context& ctx, const DeviceBuffer<uint32_t>& in, Dev
     ctx.sync();
 }
 
+// ---- image loss (brush-loss) ---------------------------------------------------------------------------------------
+struct LossConfig {  // image_loss's arguments (brush-loss/src/lib.rs:1075-1104)
+    float l1_weight = 0.8f, ssim_weight = -0.2f;
+    std::optional<std::array<float, 3>> composite_bg;  // Some(bg): the GT is composited over bg first (gt + (1 - gt.a) * bg)
+    bool mask = false;                                  // loss *= gt.a
+    BhLossConfig c() const {
+        BhLossConfig k{};
+        k.l1_weight = l1_weight; k.ssim_weight = ssim_weight;
+        if (composite_bg) { k.bg[0] = (*composite_bg)[0]; k.bg[1] = (*composite_bg)[1]; k.bg[2] = (*composite_bg)[2]; }
+        k.composite_bg = composite_bg ? 1 : 0;
+        k.mask = mask ? 1 : 0;
+        return k;
+    }
+};
+// LossOps::image_loss_forward (lib.rs:718-725): pred [C,H,W] (C = 3, or 4 with the alpha-match plane), gt [H,W] rgba8 -> loss map [C,H,W]
+inline DeviceBuffer<float> image_loss(const Context& ctx, const float* pred_chw, const uint32_t* gt_packed, uint32_t channels, uint32_t h, uint32_t w,
+                                      const LossConfig& cfg = {}) {
+    if (channels != 3 && channels != 4) throw Error(BH_ERR_INVALID_ARG, "image_loss: 3 or 4 channels");
+    DeviceBuffer<float> out((size_t)channels * h * w);
+    const BhLossConfig k = cfg.c();
+    ctx.check(bh_image_loss_forward(ctx.get(), pred_chw, gt_packed, channels, h, w, &k, out.data()));
+    ctx.sync();
+    return out;
+}
+// LossOps::image_loss_backward (lib.rs:726-733): dL/d(loss map) [C,H,W] -> dL/d(pred) [C,H,W]
+inline DeviceBuffer<float> image_loss_backward(const Context& ctx, const float* pred_chw, const uint32_t* gt_packed, const float* dl_dmap, uint32_t channels,
+                                               uint32_t h, uint32_t w, const LossConfig& cfg = {}) {
+    if (channels != 3 && channels != 4) throw Error(BH_ERR_INVALID_ARG, "image_loss_backward: 3 or 4 channels");
+    DeviceBuffer<float> out((size_t)channels * h * w);
+    const BhLossConfig k = cfg.c();
+    ctx.check(bh_image_loss_backward(ctx.get(), pred_chw, gt_packed, dl_dmap, channels, h, w, &k, out.data()));
+    ctx.sync();
+    return out;
+}
+// What SplatTrainer::step composes from image_loss + mean (+ the alpha term) + autodiff (train.rs:227-260), fused: the rasterizer's
+// [H,W,4] image in, (loss, dloss/dimg [H,W,4]) out.
+inline std::pair<float, DeviceBuffer<float>> image_loss_value_and_grad(const Context& ctx, const float* img_hwc4, const uint32_t* gt_packed, uint32_t h, uint32_t w,
+                                                                       const LossConfig& cfg = {}, float alpha_weight = 0.0f) {
+    DeviceBuffer<float> v_out((size_t)h * w * 4), loss(1);
+    const BhLossConfig k = cfg.c();
+    ctx.check(bh_image_loss_value_and_grad(ctx.get(), img_hwc4, gt_packed, h, w, &k, alpha_weight, loss.data(), v_out.data()));
+    ctx.sync();
+    return {loss.download()[0], std::move(v_out)};
+}
+
+// ---- optimizer / statistics (brush-train) -------------------------------------------------------------------------
+// AdamScaled::step on one [rows, row_len] parameter, in place (adam_scaled.rs:75-147).  t = state.time AFTER this step (1 on the
+// first call); col_scale: per-column learning-rate scale or null; reduce_m2: one second moment per row (m2 has `rows` entries).
+inline void adam_step(const Context& ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len, float lr, uint32_t t,
+                      const float* col_scale = nullptr, bool reduce_m2 = false, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-15f) {
+    ctx.check(bh_adam_step(ctx.get(), param, grad, m1, m2, rows, row_len, col_scale, lr, t, reduce_m2 ? 1 : 0, beta1, beta2, eps));
+}
+// RefineRecord::gather_stats (stats.rs:40-50): running maxima of the refine weight and the screen radius, running sum of visibility
+inline void gather_stats(const Context& ctx, float* refine_weight_norm, float* vis_weight, float* max_screen_size, const float* refine_weight, const float* visible,
+                         const float* screen_radius, uint64_t n) {
+    ctx.check(bh_gather_stats(ctx.get(), refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, n));
+}
+
+// ---- the stochastic terms of step() (train.rs:389-416, 896-908) as pure functions of (seed, step) -------------------------
+inline std::array<float, 3> sample_background(uint64_t seed, uint32_t step, const float base[3], float strength) {
+    std::array<float, 3> out{};
+    bh_sample_background(seed, step, base, strength, out.data());
+    return out;
+}
+inline DeviceBuffer<float> normal_samples(const Context& ctx, uint64_t seed, uint32_t step, uint64_t n) {   // [n,3] N(0,1): what a device_noise step draws
+    DeviceBuffer<float> out((size_t)n * 3);
+    ctx.check(bh_normal_samples(ctx.get(), seed, step, n, out.data()));
+    ctx.sync();
+    return out;
+}
+inline std::array<uint32_t, 4> philox4x32_10(const std::array<uint32_t, 4>& ctr, const std::array<uint32_t, 2>& key) {   // Random123's generator, host
+    std::array<uint32_t, 4> out{};
+    bh_philox4x32_10(ctr.data(), key.data(), out.data());
+    return out;
+}
+
 // ---- PLY (brush-serde) -------------------------------------------------------------------------------------------
 inline std::vector<uint8_t> splat_to_ply(const Context& ctx, const Splats& s, const float* up_axis = nullptr) {
     uint64_t need = 0;
@@ -418,6 +564,139 @@ struct SceneBatch {  // brush-dataset/src/scene.rs:139-147
 };
 
 struct TrainStepStats { uint32_t num_visible, num_intersections; double lr_mean; float loss; };
+
+// ---- host image -> packed device batch (brush-dataset) ---------------------------------------------------------------
+// view_to_packed_data (scene.rs:97-136) on the device behind a ring of pinned staging slots and a copy stream: the decoded RGB8 / RGBA8
+// bytes cross PCIe unpacked, widening (a = 255), the byte-space premultiply of AlphaMode::Transparent and the packing run in a kernel
+// on the copy stream while the previous batch trains.  Life of a slot: map -> (decode into the pinned bytes) -> commit -> acquire
+// (the ctx stream waits for the upload on the device: no host block) -> queue the train step -> release.
+class BatchUploader {
+  public:
+    BatchUploader(const Context& ctx, uint64_t max_pixels, uint32_t slots = 3) : slots_(slots) {
+        up_ = bh_uploader_create(ctx.get(), max_pixels, slots);
+        if (!up_) throw Error(BH_ERR_INVALID_ARG, "bh_uploader_create failed (max_pixels > 0, 2 <= slots <= 16, enough pinned memory)");
+    }
+    BatchUploader(const BatchUploader&) = delete;
+    BatchUploader& operator=(const BatchUploader&) = delete;
+    ~BatchUploader() { bh_uploader_destroy(up_); }
+    uint32_t slots() const { return slots_; }
+    // the next slot's pinned buffer to decode straight into (blocks only when the ring wraps onto a slot whose step is still running)
+    std::pair<int, uint8_t*> map(uint64_t bytes) {
+        void* p = nullptr;
+        const int slot = check(bh_uploader_begin(up_, bytes, &p));
+        return {slot, (uint8_t*)p};
+    }
+    void commit(int slot, uint32_t w, uint32_t h, uint32_t channels, bool premultiply) { check(bh_uploader_commit(up_, slot, w, h, channels, premultiply ? 1 : 0)); }
+    // map + memcpy + commit for pixels that already live elsewhere: tightly packed [H,W,3|4] bytes; returns the slot
+    int submit(const uint8_t* pixels, uint32_t w, uint32_t h, uint32_t channels, bool premultiply = true) {
+        if (channels != 3 && channels != 4) throw Error(BH_ERR_INVALID_ARG, "image must be [H,W,3] or [H,W,4] uint8");
+        return check(bh_uploader_submit(up_, pixels, w, h, channels, (premultiply && channels == 4) ? 1 : 0));
+    }
+    struct Packed { const uint32_t* img; uint32_t w, h; bool has_alpha; };   // device [H,W] rgba8, aliasing the slot
+    Packed acquire(int slot) {
+        Packed r{};
+        int ha = 0;
+        check(bh_uploader_acquire(up_, slot, &r.img, &r.w, &r.h, &ha));
+        r.has_alpha = ha != 0;
+        return r;
+    }
+    void release(int slot) { check(bh_uploader_release(up_, slot)); }   // once the step that reads the slot is queued
+
+  private:
+    int check(int rc) const {
+        if (rc < 0) throw Error(rc, std::string("uploader: ") + bh_uploader_last_error(up_));
+        return rc;
+    }
+    bh_uploader* up_ = nullptr;
+    uint32_t slots_;
+};
+
+// SceneLoader (scene_loader.rs:59-174): an endless shuffled stream of SceneBatch over a list of views, the upload of the NEXT views
+// in flight while the current one trains.  Every epoch is a seeded Fisher-Yates permutation (SplitMix64) of this rank's views — the
+// reference's order comes from rand::StdRng inside racing loader tasks and is not reproducible, so only "every view once per epoch"
+// is kept.  rank / world shard the view list for data-parallel training (view i belongs to rank i % world).  No loader thread here:
+// next_batch() submits the views that follow before it hands the current one out (the copies and the packing kernel run on the
+// uploader's stream; what the host does per view is one memcpy into pinned memory, or the caller's decode straight into it).
+struct LoaderView {
+    uint32_t w = 0, h = 0, channels = 3;
+    std::function<void(uint8_t* dst)> decode;   // writes w * h * channels tightly packed bytes
+    Camera camera;
+    bool alpha_is_mask = false;
+};
+
+class SceneLoader {
+  public:
+    SceneLoader(const Context& ctx, std::vector<LoaderView> views, uint64_t seed = 0, uint32_t slots = 3, uint32_t rank = 0, uint32_t world = 1)
+        : seed_(seed) {
+        for (size_t i = 0; i < views.size(); ++i)
+            if (world == 0 || i % world == rank) { views_.push_back(std::move(views[i])); ids_.push_back((uint32_t)i + 1u); }
+        if (views_.empty()) throw Error(BH_ERR_INVALID_ARG, "Need at least one view in dataset");  // scene_loader.rs:130
+        uint64_t mp = 0;
+        for (const LoaderView& v : views_) mp = std::max<uint64_t>(mp, (uint64_t)v.w * v.h);
+        up_.emplace(ctx, mp, slots);
+        depth_ = slots > 1 ? slots - 1 : 1;   // slots in flight = submitted + the one being trained on
+    }
+    // the view order of `epoch` (deterministic in seed, epoch and the shard)
+    std::vector<uint32_t> epoch_order(uint64_t epoch) const {
+        std::vector<uint32_t> order(views_.size());
+        std::iota(order.begin(), order.end(), 0u);
+        uint64_t st = seed_ ^ (0xD1B54A32D192ED03ull * (epoch + 1));
+        for (size_t i = order.size(); i-- > 1;) {
+            st += 0x9E3779B97F4A7C15ull;
+            uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            std::swap(order[i], order[(size_t)(z % (i + 1))]);
+        }
+        return order;
+    }
+    // -> the next batch (its img_packed aliases an uploader slot that stays valid until the NEXT next_batch call).  Call after queuing
+    // the train step of the previous batch: that is what releases its slot.
+    SceneBatch next_batch() {
+        if (held_ >= 0) { up_->release(held_); held_ = -1; }
+        // slots - 1 views submitted ahead: the slot mapped here was released one call ago, i.e. behind a step that has finished by
+        // the time the NEXT step is running — map() does not wait for the GPU in steady state
+        while (inflight_.size() < depth_) submit_next();
+        const InFlight f = inflight_.front();
+        inflight_.erase(inflight_.begin());
+        const BatchUploader::Packed p = up_->acquire(f.slot);
+        held_ = f.slot;
+        const LoaderView& v = views_[f.idx];
+        SceneBatch b;
+        b.img_packed = p.img; b.img_w = p.w; b.img_h = p.h;
+        b.has_alpha = p.has_alpha; b.alpha_is_mask = v.alpha_is_mask;
+        b.camera = v.camera;
+        b.view_id = ids_[f.idx];
+        last_index_ = f.idx;
+        return b;
+    }
+    uint32_t last_view_index() const { return last_index_; }   // index (within this rank's shard) of the batch just handed out
+    size_t num_views() const { return views_.size(); }
+
+  private:
+    struct InFlight { int slot; uint32_t idx; };
+    void submit_next() {
+        if (cursor_ >= order_.size()) { order_ = epoch_order(epoch_++); cursor_ = 0; }
+        const uint32_t idx = order_[cursor_++];
+        const LoaderView& v = views_[idx];
+        auto [slot, dst] = up_->map((uint64_t)v.w * v.h * v.channels);
+        v.decode(dst);
+        up_->commit(slot, v.w, v.h, v.channels, v.channels == 4 && !v.alpha_is_mask);
+        inflight_.push_back({slot, idx});
+    }
+    std::vector<LoaderView> views_;
+    std::vector<uint32_t> ids_;
+    std::optional<BatchUploader> up_;
+    uint64_t seed_;
+    uint64_t epoch_ = 0;
+    std::vector<uint32_t> order_;
+    size_t cursor_ = 0;
+    std::vector<InFlight> inflight_;
+    size_t depth_ = 2;
+    int held_ = -1;
+    uint32_t last_index_ = 0;
+};
 
 class SplatTrainer {
   public:

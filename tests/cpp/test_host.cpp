@@ -5,6 +5,9 @@
 //   * radix_argsort / prefix_sum vs std::stable_sort / std::partial_sum on SplitMix64 inputs
 //     (brush-sort/src/lib.rs:154-339, brush-prefix-sum/src/lib.rs:105-196)
 //   * SplatTrainer::step x N + refine + PLY export / import round trip (tests/integration.rs:186-235, export.rs:305-349)
+//   * image_loss / image_loss_backward / the fused value-and-gradient, adam_step, gather_stats vs the oracle (brush-loss, adam_scaled.rs, stats.rs)
+//   * SceneLoader + BatchUploader (every view once per epoch, packed bytes exact, 15 steps through the ring), list controls, stage
+//     profile, the counter-based generator, the strip-halo plan and a one-rank RCCL self-test
 //   * error behaviour: what the reference asserts, this host throws.
 // Build + run: tests/test_gpu_cpp_host.py.
 #include <dlfcn.h>
@@ -76,6 +79,10 @@ struct Oracle {
     const uint32_t* (*get_cgfi)(void*, uint64_t*);
     const float* (*get_v_transforms)(void*, uint64_t*);
     const float* (*get_v_raw_opac)(void*, uint64_t*);
+    void (*image_loss_forward)(const float*, const uint32_t*, uint32_t, uint32_t, uint32_t, float, float, const float*, int, int, float*);
+    void (*image_loss_backward)(const float*, const uint32_t*, const float*, uint32_t, uint32_t, uint32_t, float, float, const float*, int, int, float*);
+    void (*adam_step)(float*, const float*, float*, float*, uint64_t, uint32_t, const float*, float, uint32_t, int, float, float, float);
+    void (*gather_stats)(float*, float*, float*, const float*, const float*, const float*, uint64_t);
     bool load(const char* path) {
         lib = dlopen(path, RTLD_NOW);
         if (!lib) { std::printf("cannot load oracle %s: %s\n", path, dlerror()); return false; }
@@ -84,6 +91,8 @@ struct Oracle {
         SYM(render_forward, "bo_render_forward") SYM(render_backward, "bo_render_backward") SYM(num_visible, "bo_num_visible")
         SYM(num_intersections, "bo_num_intersections") SYM(get_out_img, "bo_get_out_img") SYM(get_cgfi, "bo_get_compact_gid_from_isect")
         SYM(get_v_transforms, "bo_get_v_transforms") SYM(get_v_raw_opac, "bo_get_v_raw_opac")
+        SYM(image_loss_forward, "bo_image_loss_forward") SYM(image_loss_backward, "bo_image_loss_backward") SYM(adam_step, "bo_adam_step")
+        SYM(gather_stats, "bo_gather_stats")
 #undef SYM
         return true;
     }
@@ -294,6 +303,194 @@ static void test_training_refine_ply(const bh::Context& ctx) {
     std::printf("ok training_refine_ply  loss %.4f -> %.4f, %u splats after refine, ply %zu bytes\n", first, last, rs.total_splats, ply.size());
 }
 
+// LossOps / AdamScaled / RefineRecord through the header vs the oracle (brush-loss/src/lib.rs:718-733, adam_scaled.rs:75-147, stats.rs:40-50)
+static void test_loss_optimizer(const bh::Context& ctx, Oracle& bo) {
+    const uint32_t h = 40, w = 56;
+    Sm64 r{0x10555};
+    for (uint32_t ch : {3u, 4u}) {
+        std::vector<float> pred((size_t)ch * h * w), dl((size_t)ch * h * w);
+        std::vector<uint32_t> gt((size_t)h * w);
+        for (float& v : pred) v = r.uni(-0.1f, 1.1f);
+        for (float& v : dl) v = r.uni(-1.0f, 1.0f);
+        for (uint32_t& v : gt) v = (uint32_t)r.next();
+        bh::LossConfig cfg;
+        if (ch == 4) { cfg.composite_bg = std::array<float, 3>{0.2f, 0.4f, 0.6f}; }
+        const float* bgp = cfg.composite_bg ? cfg.composite_bg->data() : nullptr;
+        bh::DeviceBuffer<float> dpred(pred), ddl(dl);
+        bh::DeviceBuffer<uint32_t> dgt(gt);
+        const auto lm = bh::image_loss(ctx, dpred.data(), dgt.data(), ch, h, w, cfg).download();
+        std::vector<float> ref(lm.size()), refg(lm.size());
+        bo.image_loss_forward(pred.data(), gt.data(), ch, h, w, cfg.l1_weight, cfg.ssim_weight, bgp, cfg.composite_bg ? 1 : 0, 0, ref.data());
+        float d = 0;
+        for (size_t i = 0; i < lm.size(); ++i) d = std::max(d, std::fabs(lm[i] - ref[i]));
+        CHECK(d <= 2e-6f, "image_loss [%u ch]: loss map max |d| = %g", ch, d);
+        const auto g = bh::image_loss_backward(ctx, dpred.data(), dgt.data(), ddl.data(), ch, h, w, cfg).download();
+        bo.image_loss_backward(pred.data(), gt.data(), dl.data(), ch, h, w, cfg.l1_weight, cfg.ssim_weight, bgp, cfg.composite_bg ? 1 : 0, 0, refg.data());
+        float dg = 0, gm = 1.0f;
+        for (size_t i = 0; i < g.size(); ++i) { dg = std::max(dg, std::fabs(g[i] - refg[i])); gm = std::max(gm, std::fabs(refg[i])); }
+        CHECK(dg <= 2e-6f * gm, "image_loss_backward [%u ch]: max |d| %g (max |g| %g)", ch, dg, gm);
+    }
+    {   // the fused value-and-gradient == mean(loss map) and its gradient (train.rs:227-260)
+        std::vector<float> img((size_t)h * w * 4), chw((size_t)3 * h * w);
+        std::vector<uint32_t> gt((size_t)h * w);
+        for (float& v : img) v = r.uni(0.0f, 1.0f);
+        for (uint32_t& v : gt) v = (uint32_t)r.next() | 0xFF000000u;
+        for (uint32_t c = 0; c < 3; ++c)
+            for (size_t p = 0; p < (size_t)h * w; ++p) chw[c * h * w + p] = img[p * 4 + c];
+        bh::DeviceBuffer<float> dimg(img);
+        bh::DeviceBuffer<uint32_t> dgt(gt);
+        auto [loss, v_out] = bh::image_loss_value_and_grad(ctx, dimg.data(), dgt.data(), h, w);
+        std::vector<float> ref(chw.size()), dl(chw.size(), 1.0f / (float)chw.size()), refg(chw.size());
+        bo.image_loss_forward(chw.data(), gt.data(), 3, h, w, 0.8f, -0.2f, nullptr, 0, 0, ref.data());
+        bo.image_loss_backward(chw.data(), gt.data(), dl.data(), 3, h, w, 0.8f, -0.2f, nullptr, 0, 0, refg.data());
+        double mean = 0;
+        for (float v : ref) mean += v;
+        mean /= (double)ref.size();
+        CHECK(std::fabs(loss - mean) <= 2e-6 * std::max(1.0, std::fabs(mean)), "fused loss %g vs mean of the loss map %g", loss, mean);
+        const auto v = v_out.download();
+        double dmax = 0, gmax = 0;
+        for (uint32_t c = 0; c < 3; ++c)
+            for (size_t p = 0; p < (size_t)h * w; ++p) {
+                dmax = std::max(dmax, (double)std::fabs(v[p * 4 + c] - refg[c * h * w + p]));
+                gmax = std::max(gmax, (double)std::fabs(refg[c * h * w + p]));
+            }
+        bool alpha_zero = true;
+        for (size_t p = 0; p < (size_t)h * w; ++p) alpha_zero = alpha_zero && v[p * 4 + 3] == 0.0f;
+        CHECK(dmax <= 2e-6 * gmax && alpha_zero, "fused dloss/dimg: max |d| %g of %g", dmax, gmax);
+    }
+    {   // AdamScaled: three steps, bit for bit (column scale on; and the row-reduced second moment of the SH parameters)
+        for (int reduce = 0; reduce < 2; ++reduce) {
+            const uint64_t rows = 777; const uint32_t len = reduce ? 12 : 10;
+            std::vector<float> p(rows * len), g(rows * len), m1(rows * len, 0.0f), m2(reduce ? rows : rows * len, 0.0f), cs(len);
+            for (float& v : p) v = r.uni(-1.0f, 1.0f);
+            for (uint32_t k = 0; k < len; ++k) cs[k] = k < 3 ? 1.0f : 0.1f;
+            bh::DeviceBuffer<float> dp(p), dm1(m1), dm2(m2), dcs(cs), dg(g.size());
+            for (uint32_t t = 1; t <= 3; ++t) {
+                for (float& v : g) v = r.uni(-1e-3f, 1e-3f);
+                dg.upload(g);
+                bh::adam_step(ctx, dp.data(), dg.data(), dm1.data(), dm2.data(), rows, len, 2e-3f, t, dcs.data(), reduce != 0);
+                bo.adam_step(p.data(), g.data(), m1.data(), m2.data(), rows, len, cs.data(), 2e-3f, t, reduce, 0.9f, 0.999f, 1e-15f);
+            }
+            ctx.sync();
+            CHECK(dp.download() == p && dm1.download() == m1 && dm2.download() == m2, "adam_step (reduce_m2 = %d) is bit-exact after three steps", reduce);
+        }
+    }
+    {   // RefineRecord::gather_stats
+        const uint64_t n = 5000;
+        std::vector<float> a(n), b(n), c(n), rw(n), vis(n), rad(n);
+        for (uint64_t i = 0; i < n; ++i) { a[i] = r.unit(); b[i] = (float)(r.next() % 5); c[i] = r.uni(0, 50); rw[i] = r.unit(); vis[i] = (float)(r.next() & 1); rad[i] = r.uni(0, 60); }
+        bh::DeviceBuffer<float> da(a), db(b), dc(c), drw(rw), dvis(vis), drad(rad);
+        bh::gather_stats(ctx, da.data(), db.data(), dc.data(), drw.data(), dvis.data(), drad.data(), n);
+        ctx.sync();
+        bo.gather_stats(a.data(), b.data(), c.data(), rw.data(), vis.data(), rad.data(), n);
+        CHECK(da.download() == a && db.download() == b && dc.download() == c, "gather_stats is exact");
+    }
+    std::printf("ok loss_optimizer\n");
+}
+
+// BatchUploader / SceneLoader (scene.rs:97-136, scene_loader.rs:59-174), the list controls, the profile, the generator, the communicator
+static void test_loader_controls_comm(const bh::Context& ctx) {
+    const uint32_t w = 64, h = 48, nviews = 5;
+    auto pixel = [](uint32_t v, uint32_t x, uint32_t y, uint32_t c) { return (uint8_t)((x * 3 + y * 5 + v * 37 + c * 91) & 255u); };
+    std::vector<bh::LoaderView> views;
+    for (uint32_t v = 0; v < nviews; ++v) {
+        bh::LoaderView lv;
+        lv.w = w; lv.h = h; lv.channels = v == 3 ? 4 : 3;   // view 3 carries an alpha channel: premultiplied on the device
+        const uint32_t ch = lv.channels;
+        lv.decode = [=](uint8_t* dst) {
+            for (uint32_t y = 0; y < h; ++y)
+                for (uint32_t x = 0; x < w; ++x)
+                    for (uint32_t c = 0; c < ch; ++c) dst[((size_t)y * w + x) * ch + c] = pixel(v, x, y, c);
+        };
+        lv.camera.fov_x = 1.0471976; lv.camera.fov_y = 2.0 * std::atan(0.75 * std::tan(1.0471976 / 2));
+        lv.camera.position[0] = 0.05f * (float)v;
+        views.push_back(lv);
+    }
+    bh::SceneLoader loader(ctx, views, /*seed=*/7);
+    CHECK(loader.epoch_order(0) == loader.epoch_order(0) && loader.epoch_order(0) != loader.epoch_order(1), "epoch orders are seeded permutations");
+    const HostScene sc = make_scene(3000, 0xFEED, 1);
+    bh::Splats splats = bh::Splats::from_host(sc.transforms, sc.sh, sc.raw_opac);
+    bh::TrainConfig cfg;
+    cfg.total_train_iters = 1000;
+    bh::SplatTrainer trainer(ctx, cfg, 3.0f);
+    trainer.set_seed(0xB5EED);
+    ctx.set_list_cut_threshold(0);   // (a small scene: let the per-tile cuts engage at all)
+    ctx.profile(1);
+    bool pixels_ok = true, finite = true;
+    for (uint32_t epoch = 0; epoch < 3; ++epoch) {
+        std::vector<int> seen(nviews, 0);
+        for (uint32_t k = 0; k < nviews; ++k) {
+            const bh::SceneBatch b = loader.next_batch();
+            CHECK(b.view_id >= 1 && b.view_id <= nviews && b.img_w == w && b.img_h == h, "batch of view %u", b.view_id);
+            const uint32_t v = b.view_id - 1;
+            seen[v]++;
+            CHECK(b.has_alpha == (v == 3), "has_alpha follows the channel count");
+            const bh::TrainStepStats st = trainer.step(b, splats);   // queued on the ctx stream behind the upload
+            finite = finite && std::isfinite(st.loss);
+            if (epoch == 0) {   // the packed image: widened (a = 255) or byte-space premultiplied ((c * a + 127) / 255)
+                const auto got = bh::download(b.img_packed, (size_t)w * h);
+                for (uint32_t y = 0; y < h && pixels_ok; ++y)
+                    for (uint32_t x = 0; x < w; ++x) {
+                        uint32_t c[4] = {pixel(v, x, y, 0), pixel(v, x, y, 1), pixel(v, x, y, 2), v == 3 ? pixel(v, x, y, 3) : 255u};
+                        if (v == 3) for (int k2 = 0; k2 < 3; ++k2) c[k2] = (c[k2] * c[3] + 127u) / 255u;
+                        if (got[(size_t)y * w + x] != (c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24))) { pixels_ok = false; break; }
+                    }
+            }
+        }
+        bool once = true;
+        for (int c : seen) once = once && c == 1;
+        CHECK(once, "epoch %u visits every view exactly once", epoch);
+    }
+    CHECK(pixels_ok, "uploaded batches equal view_to_packed_data of the host bytes");
+    CHECK(finite && trainer.step_count() == 3 * nviews, "15 steps through the loader");
+    const auto stages = ctx.profile_fetch();
+    bool has_blend = false, has_update = false;
+    for (const auto& st : stages) { has_blend = has_blend || st.name == "Rasterize"; has_update = has_update || st.name == "OptimizerStep"; }
+    CHECK(has_blend && has_update && !stages.empty(), "the stage profile names the pipeline's stages (%zu of them)", stages.size());
+    ctx.profile(0);
+    const BhRenderOut lo = ctx.last_render_out();
+    const auto counts = ctx.last_list_counts();
+    CHECK(lo.generation >= 15 && lo.num_intersections > 0 && counts.first > 0 && counts.first <= lo.num_intersections, "last_render_out / last_list_counts");
+    CHECK(ctx.last_list_share() > 0.0f && ctx.last_list_share() <= 1.0f, "last_list_share %g", ctx.last_list_share());
+    ctx.forget_views();
+    ctx.set_view_id(3); ctx.set_view_id(0);
+    ctx.set_list_slicing(0.0f);
+    // the generator
+    const float base[3] = {0.2f, 0.5f, 0.8f};
+    const auto bg1 = bh::sample_background(0xB5EED, 7, base, 0.1f), bg2 = bh::sample_background(0xB5EED, 7, base, 0.1f), bg3 = bh::sample_background(0xB5EED, 8, base, 0.1f);
+    CHECK(bg1 == bg2 && bg1 != bg3 && bg1[0] >= 0.1f && bg1[0] <= 0.3f, "sample_background is a function of (seed, step)");
+    const auto ns = bh::normal_samples(ctx, 0xB5EED, 3, 20000).download();
+    double m = 0, v2 = 0;
+    for (float x : ns) { m += x; v2 += (double)x * x; }
+    m /= (double)ns.size(); v2 = v2 / (double)ns.size() - m * m;
+    CHECK(std::fabs(m) < 0.02 && std::fabs(v2 - 1.0) < 0.03, "normal_samples: mean %g variance %g", m, v2);
+    const auto kat = bh::philox4x32_10({0u, 0u, 0u, 0u}, {0u, 0u});
+    CHECK(kat[0] == 0x6627e8d5u && kat[1] == 0xe169c58du && kat[2] == 0xbc57ac4cu && kat[3] == 0x9b00dbd8u, "Philox-4x32-10 known answer (Random123)");
+    // the communicator: the strip plan is host arithmetic; a one-rank RCCL group exercises the binding when RCCL is loadable
+    CHECK(ctx.comm_world() == 1 && ctx.comm_rank() == 0, "no communicator: world 1, rank 0");
+    const auto plan = bh::Context::strip_halo_plan(1080, 360, 720, 1, 3);
+    int sends = 0, recvs = 0;
+    for (const BhHaloOp& op : plan) { (op.send ? sends : recvs)++; CHECK(op.rows == 21 && (op.peer == 0 || op.peer == 2), "halo op: 21 rows to / from a neighbour"); }
+    CHECK(plan.size() == 4 && sends == 2 && recvs == 2, "a middle strip sends and receives two halos");
+    try {
+        const auto id = bh::Context::comm_unique_id();
+        ctx.comm_init(0, 1, id);
+        ctx.comm_selftest();
+        std::vector<float> x(1000);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = (float)i * 0.5f;
+        bh::DeviceBuffer<float> dx(x);
+        ctx.allreduce_sum(dx.data(), x.size());
+        ctx.allreduce_max(dx.data(), x.size());
+        ctx.sync();
+        CHECK(dx.download() == x && ctx.comm_world() == 1, "one-rank RCCL all-reduce is the identity");
+        ctx.comm_destroy();
+        std::printf("   (RCCL bound and self-tested on one rank)\n");
+    } catch (const bh::Error& e) {
+        std::printf("   (communicator part skipped: %s)\n", e.what());
+    }
+    std::printf("ok loader_controls_comm\n");
+}
+
 static void test_errors(const bh::Context& ctx) {
     const HostScene sc = make_scene(10, 1, 1);
     bh::Splats splats = bh::Splats::from_host(sc.transforms, sc.sh, sc.raw_opac);
@@ -323,6 +520,8 @@ int main(int argc, char** argv) {
         test_two_forwards_alive(ctx, bo);
         test_primitives(ctx);
         test_training_refine_ply(ctx);
+        test_loss_optimizer(ctx, bo);
+        test_loader_controls_comm(ctx);
         test_errors(ctx);
     } catch (const std::exception& e) {
         std::printf("EXCEPTION %s\n", e.what());

@@ -29,5 +29,5 @@ def test_cpp_host_program_passes_on_the_gpu(oracle_lib):
     print(p.stdout[-3000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "all C++ host checks passed" in p.stdout
-    for name in ("render_vs_oracle[pinhole]", "render_vs_oracle[kb4]", "render_vs_oracle[rt8]", "primitives", "training_refine_ply", "errors"):
+    for name in ("render_vs_oracle[pinhole]", "render_vs_oracle[kb4]", "render_vs_oracle[rt8]", "primitives", "training_refine_ply", "loss_optimizer", "loader_controls_comm", "errors"):
         assert "ok " + name in p.stdout, name
