@@ -24,7 +24,7 @@ computation runs in the hand-written HIP kernels. No CPU fallback exists.
 from .host import (  # noqa: F401
     Camera, Context, RasterPass, RenderAux, SplatTrainer, Splats, TrainConfig, SceneBatch,
     get_context, image_loss, image_loss_backward, image_loss_value_and_grad, prefix_sum, radix_argsort, tile_sort_offsets, render_splats,
-    render_splats_bwd, adam_step, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
+    render_splats_bwd, adam_step, gather_stats, RefineStats, splat_bounds, bounds_median_size, fov_to_focal, focal_to_fov,
     splat_to_ply, load_splat_from_ply, ply_parse_header, ParseMetadata, BatchUploader, SceneLoader, set_list_slicing, last_list_counts, set_view_id,
     render_splats_diff, RenderNode,
 )

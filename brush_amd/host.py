@@ -93,6 +93,38 @@ class Context:
     def allreduce_max(self, t: torch.Tensor):
         self.check(self.lib.bh_allreduce_max_f32(self._h, _ptr(t), t.numel()))
 
+    def allgather_bytes(self, send: torch.Tensor, recv: torch.Tensor):
+        """bh_allgather_bytes: every rank's `send` (contiguous, any dtype) lands in `recv` (world x the same bytes) in rank order."""
+        nbytes = send.numel() * send.element_size()
+        if recv.numel() * recv.element_size() != nbytes * self.comm_world():
+            raise ValueError("recv must hold world x the bytes of send")
+        self.check(self.lib.bh_allgather_bytes(self._h, _ptr(send), _ptr(recv), nbytes))
+
+    def exchange_strip_halos(self, img_hwc4: torch.Tensor, row_begin_px: int, row_end_px: int):
+        """bh_exchange_strip_halos: one frame split into strips of tile rows — fetch the 21 pixel rows above and below this rank's strip
+        [row_begin_px, row_end_px) of the [H,W,4] f32 image from the neighbouring ranks, in place on the ctx stream."""
+        h, w, c = img_hwc4.shape
+        if c != 4:
+            raise ValueError("img must be [H,W,4]")
+        self.check(self.lib.bh_exchange_strip_halos(self._h, _ptr(img_hwc4), h, w, int(row_begin_px), int(row_end_px)))
+
+    @staticmethod
+    def strip_halo_plan(img_h, row_begin_px, row_end_px, rank, world):
+        """The host arithmetic behind exchange_strip_halos (bh_strip_halo_plan): [(send, peer, first row, rows)], at most four."""
+        ops = (_ffi.BhHaloOp * 4)()
+        k = _ffi.load().bh_strip_halo_plan(int(img_h), int(row_begin_px), int(row_end_px), int(rank), int(world), ops)
+        if k < 0:
+            raise BrushHipError("strip_halo_plan: bad strip (%d)" % k)
+        return [(bool(ops[i].send), int(ops[i].peer), int(ops[i].row_begin_px), int(ops[i].rows)) for i in range(k)]
+
+    def set_list_cut_threshold(self, min_pairs: int):
+        """bh_set_list_cut_threshold: frames with fewer intersections than this keep complete lists (default 1.5 M)."""
+        self.check(self.lib.bh_set_list_cut_threshold(self._h, int(min_pairs)))
+
+    def forget_views(self):
+        """bh_forget_views: drop the per-view tile tables (after loading another scene)."""
+        self.check(self.lib.bh_forget_views(self._h))
+
     def profile(self, on=True):
         """True/1: HIP events around every stage; 2: only around the dominant kernel; False/0: off."""
         self.check(self.lib.bh_profile_enable(self._h, int(on)))
@@ -678,6 +710,15 @@ def image_loss_value_and_grad(img_hwc4, gt_packed, l1_weight=0.8, ssim_weight=-0
     cfg = _loss_cfg(l1_weight, ssim_weight, composite_bg, mask)
     ctx.check(ctx.lib.bh_image_loss_value_and_grad(ctx._h, _ptr(img), _ptr(gt), h, w, C.byref(cfg), float(alpha_weight), _ptr(loss), _ptr(v_out)))
     return loss, v_out
+
+
+def gather_stats(refine_weight_norm, vis_weight, max_screen_size, refine_weight, visible, screen_radius, ctx: Optional[Context] = None):
+    """RefineRecord::gather_stats (brush-train/src/stats.rs:40-50), in place on the three running [N] tensors: maxima of the refine
+    weight and the screen radius, sum of the visibility flags."""
+    ctx = ctx or get_context(refine_weight.device)
+    n = refine_weight.numel()
+    ctx.check(ctx.lib.bh_gather_stats(ctx._h, _ptr(refine_weight_norm), _ptr(vis_weight), _ptr(max_screen_size), _ptr(refine_weight), _ptr(visible),
+                                      _ptr(screen_radius), n))
 
 
 def adam_step(param, grad, m1, m2, lr, t, col_scale=None, reduce_m2=False, beta1=0.9, beta2=0.999, eps=1e-15, ctx: Optional[Context] = None):

@@ -224,6 +224,11 @@ def test_strip_halo_plan_moves_exactly_the_rows_the_strip_loss_reads():
             lo, hi = max(0, b - 21), min(h, e + 21)
             assert np.array_equal(staged[r][lo:hi], truth[lo:hi]), (h, world, r)
     assert lib.bh_strip_halo_plan(100, 50, 40, 0, 2, (_ffi.BhHaloOp * 4)()) < 0   # begin >= end
+    # the Python mirror's wrapper says the same
+    from brush_amd.host import Context
+    assert Context.strip_halo_plan(1080, 360, 720, 1, 3) == [(True, 0, 360, 21), (False, 0, 339, 21), (True, 2, 699, 21), (False, 2, 720, 21)]
+    with pytest.raises(_ffi.BrushHipError):
+        Context.strip_halo_plan(100, 50, 40, 0, 2)
 
 
 def test_design_md_carries_the_figures_of_the_committed_bench_line():

@@ -104,3 +104,18 @@ def test_gather_stats(dev, oracle_lib):
     oracle_lib.lib().bo_gather_stats(*[oracle_lib._fp(x) for x in a], n)
     for x, y in zip(t[:3], a[:3]):
         assert np.array_equal(x.cpu().numpy(), y)
+
+
+def test_gather_stats_is_the_running_max_sum_max(dev):
+    """RefineRecord::gather_stats (brush-train/src/stats.rs:40-50) through the Python mirror: exact (max / add / max per splat)."""
+    import brush_amd as ba
+    rng = np.random.default_rng(11)
+    n = 100003
+    a, b, c = rng.random(n, dtype=np.float32), rng.integers(0, 5, n).astype(np.float32), rng.uniform(0, 50, n).astype(np.float32)
+    rw, vis, rad = rng.random(n, dtype=np.float32), rng.integers(0, 2, n).astype(np.float32), rng.uniform(0, 60, n).astype(np.float32)
+    ta, tb, tc = (torch.from_numpy(x.copy()).to(dev) for x in (a, b, c))
+    for _ in range(2):
+        ba.gather_stats(ta, tb, tc, torch.from_numpy(rw).to(dev), torch.from_numpy(vis).to(dev), torch.from_numpy(rad).to(dev))
+        a, b, c = np.maximum(a, rw), b + vis, np.maximum(c, rad)
+    ba.get_context(dev).sync()
+    assert np.array_equal(ta.cpu().numpy(), a) and np.array_equal(tb.cpu().numpy(), b) and np.array_equal(tc.cpu().numpy(), c)
