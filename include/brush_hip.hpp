@@ -477,6 +477,7 @@ inline std::pair<float, DeviceBuffer<float>> image_loss_value_and_grad(const Con
 // ---- optimizer / statistics (brush-train) -------------------------------------------------------------------------
 // AdamScaled::step on one [rows, row_len] parameter, in place (adam_scaled.rs:75-147).  t = state.time AFTER this step (1 on the
 // first call); col_scale: per-column learning-rate scale or null; reduce_m2: one second moment per row (m2 has `rows` entries).
+// Queued on the ctx stream like every call that returns no host value: Context::sync() before touching the buffers from elsewhere.
 inline void adam_step(const Context& ctx, float* param, const float* grad, float* m1, float* m2, uint64_t rows, uint32_t row_len, float lr, uint32_t t,
                       const float* col_scale = nullptr, bool reduce_m2 = false, float beta1 = 0.9f, float beta2 = 0.999f, float eps = 1e-15f) {
     ctx.check(bh_adam_step(ctx.get(), param, grad, m1, m2, rows, row_len, col_scale, lr, t, reduce_m2 ? 1 : 0, beta1, beta2, eps));
@@ -631,6 +632,9 @@ class SceneLoader {
         for (size_t i = 0; i < views.size(); ++i)
             if (world == 0 || i % world == rank) { views_.push_back(std::move(views[i])); ids_.push_back((uint32_t)i + 1u); }
         if (views_.empty()) throw Error(BH_ERR_INVALID_ARG, "Need at least one view in dataset");  // scene_loader.rs:130
+        for (const LoaderView& v : views_)
+            if (!v.decode || v.w == 0 || v.h == 0 || (v.channels != 3 && v.channels != 4))
+                throw Error(BH_ERR_INVALID_ARG, "LoaderView: needs a decode function, a size and 3 or 4 channels");
         uint64_t mp = 0;
         for (const LoaderView& v : views_) mp = std::max<uint64_t>(mp, (uint64_t)v.w * v.h);
         up_.emplace(ctx, mp, slots);
