@@ -65,7 +65,7 @@ class BhTrainConfig(C.Structure):
         ("lr_coeffs_dc", C.c_double), ("lr_coeffs_sh_scale", C.c_float), ("lr_opac", C.c_double),
         ("lr_scale", C.c_double), ("lr_rotation", C.c_double), ("ssim_weight", C.c_float),
         ("match_alpha_weight", C.c_float), ("mean_noise_weight", C.c_float), ("background", C.c_float * 3),
-        ("median_scene_scale", C.c_float), ("render_mip", C.c_int32), ("exact_lists", C.c_int32),
+        ("median_scene_scale", C.c_float), ("render_mip", C.c_int32), ("exact_lists", C.c_int32), ("growth_stop_iter", C.c_uint32),
     ]
 
 
@@ -128,6 +128,10 @@ SYMBOLS = {
     "bh_abi_version": (C.c_uint32, []),
     "bh_struct_size": (C.c_uint32, [C.c_uint32]),
     "bh_last_list_counts": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "bh_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "bh_option_count": (C.c_int, []),
+    "bh_option_name": (C.c_char_p, [C.c_int]),
+    "bh_option_help": (C.c_char_p, [C.c_int]),
     "bh_camera_setup": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(BhCamera)]),
     "bh_camera_setup_model": (C.c_int, [fp, fp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(BhCamera)]),
     "bh_fov_to_focal": (C.c_double, [C.c_double, C.c_uint32, C.c_uint32, fp]),
@@ -138,6 +142,7 @@ SYMBOLS = {
     "bh_set_list_cut_threshold": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bh_last_list_share": (C.c_float, [C.c_void_p]),
     "bh_far_slices_queued": (C.c_uint32, [C.c_void_p]),
+    "bh_view_table_count": (C.c_uint32, [C.c_void_p]),
     "bh_render_backward": (C.c_int, [C.c_void_p] * 9),
     "bh_render_backward_saved": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)] + [C.c_void_p] * 8),
     "bh_render_retain": (C.c_int, [C.c_void_p, C.POINTER(BhRenderOut)]),
@@ -191,7 +196,7 @@ SYMBOLS = {
     "bh_profile_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), fp, u32p, C.c_int]),
 }
 
-ABI_VERSION = 6   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
+ABI_VERSION = 7   # the BH_ABI_VERSION of include/brush_hip.h these mirrors were written against
 # bh_struct_size index -> mirror (the BH_STRUCT_* order of the header)
 STRUCT_MIRRORS = (BhCamera, BhRenderOut, BhLossConfig, BhTrainConfig, BhTrainState, BhTrainBatch, BhTrainStats, BhRefineConfig, BhRefineStats, BhPlyInfo)
 

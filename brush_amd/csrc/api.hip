@@ -248,13 +248,16 @@ static uint64_t view_key(const bh_ctx* ctx, const BhCamera& c) {
 // use, re-created when the grid changes; beyond MAX_VIEW_STATES tables (or VIEW_TABLE_BYTES of them) the least recently used view
 // gives its table up — to the new view when the grids match (no free, no host wait: the clears are ordered on the stream).
 // touch = false: a second attempt at the frame that has just been counted (finish_far_slice): the view's gap and stamp stay
-static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32_t tile_bh, bool touch = true) {
+// casual = a forward-only frame keyed by its camera hash (viewer / eval renders): never more than CASUAL_VIEW_STATES such tables,
+// and none at all for a camera met for the first time (returns nullptr: the frame runs in index order, nothing is allocated).
+static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32_t tile_bh, bool touch = true, bool casual = false) {
     const size_t words = (size_t)tile_bw * tile_bh ? (size_t)tile_bw * tile_bh : 1;
     auto it = ctx->views.find(key);
     uint32_t* recycled = nullptr;
     auto forget = [&](std::unordered_map<uint64_t, ViewState>::iterator v, bool keep_block) {
         if (ctx->gate_view == &v->second) ctx->gate_view = nullptr;
         if (ctx->far_job.view == &v->second) ctx->far_job.view = nullptr;
+        if (v->second.casual && ctx->casual_views) ctx->casual_views--;
         if (keep_block) recycled = v->second.zcut;
         else {
             (void)hipStreamSynchronize(ctx->stream);   // queued kernels may still use the block
@@ -267,6 +270,21 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
         it = ctx->views.end();
     }
     if (it == ctx->views.end()) {
+        if (casual) {
+            bool seen = false;
+            for (uint64_t k : ctx->seen_keys) seen = seen || k == key;
+            if (!seen) {   // first meeting: remember the camera, allocate nothing
+                ctx->seen_keys[ctx->seen_pos++ % SEEN_KEYS] = key;
+                return nullptr;
+            }
+            while (ctx->casual_views >= CASUAL_VIEW_STATES) {   // the least recently used casual table makes room (its block is reused when the grids match)
+                auto old = ctx->views.end();
+                for (auto k = ctx->views.begin(); k != ctx->views.end(); ++k)
+                    if (k->second.casual && (old == ctx->views.end() || k->second.last_used < old->second.last_used)) old = k;
+                if (old == ctx->views.end()) { ctx->casual_views = 0; break; }
+                forget(old, recycled == nullptr && old->second.tile_bw == tile_bw && old->second.tile_bh == tile_bh);
+            }
+        }
         const size_t max_views = std::min(MAX_VIEW_STATES, std::max<size_t>(8, VIEW_TABLE_BYTES / (2 * words * 4)));
         while (ctx->views.size() >= max_views) {
             auto old = ctx->views.begin();
@@ -277,6 +295,7 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
         ViewState vs;
         vs.tile_bw = tile_bw;
         vs.tile_bh = tile_bh;
+        vs.casual = casual;
         // [T] depth cuts (all "everything") | [T] per-tile work of the last frame (all zero)
         vs.zcut = recycled;
         if (!vs.zcut && hipMalloc((void**)&vs.zcut, 2 * words * 4) != hipSuccess) {
@@ -291,7 +310,12 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
         }
         vs.gap = (uint32_t)ctx->views.size() + 1u;   // (a new view of a dataset: it will come back after about as many frames as there are views)
         vs.last_used = ++ctx->view_clock;
+        if (casual) ctx->casual_views++;
         return &ctx->views.emplace(key, vs).first->second;
+    }
+    if (it->second.casual && !casual) {   // a training frame adopts the table: it now counts as a dataset view
+        it->second.casual = false;
+        if (ctx->casual_views) ctx->casual_views--;
     }
     if (touch) {
         const uint64_t now = ++ctx->view_clock;
@@ -422,18 +446,14 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         }
         ctx->owns_stream = true;
     }
-    if (hipHostMalloc((void**)&ctx->host_counters, bh::HOST_COUNTERS_BYTES, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&ctx->host_counters, bh::HOST_COUNTERS_BYTES, hipHostMallocCoherent)   /* (polled by the host while kernels store into it: never the non-coherent flavour HIP_HOST_COHERENT=0 would make of the default) */ != hipSuccess) {
         (void)hipGetLastError();
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return nullptr;
     }
     std::memset(ctx->host_counters, 0, bh::HOST_COUNTERS_BYTES);
-    // developer knobs: read here once, never on the per-step path
-    ctx->knob_no_lpt = getenv("BH_NO_LPT") != nullptr;
-    ctx->knob_generic_depth_sort = getenv("BH_GENERIC_DEPTH_SORT") != nullptr;
-    ctx->knob_force_exchange = getenv("BH_FORCE_PG") != nullptr;
-    ctx->knob_zero_grads = getenv("BH_TRAIN_ZERO_GRADS") != nullptr;
+    // No environment variable configures the shipping library: every tuning / A-B knob is a documented bh_set_option key.
 #ifdef BH_TEST_HOOKS   // libbrush_hip_testhooks.so only (csrc/Makefile): the shipping library neither reads these nor exports the hook below
     ctx->knob_break_allreduce = getenv("BH_BREAK_ALLREDUCE") != nullptr;
     if (ctx->knob_break_allreduce)   // (bench.py's exchange self-check must catch it): never silent
@@ -443,27 +463,6 @@ bh_ctx* bh_create(int device, void* stream, int own_stream) {
         if (ctx->knob_fail_loss_at) fprintf(stderr, "brush_hip: BH_TEST_FAIL_LOSS_AT=%u - that train step of this context will FAIL on purpose (test hook)\n", ctx->knob_fail_loss_at);
     }
 #endif
-    if (const char* e = getenv("BH_CUT_MIN_PAIRS")) ctx->cut_min_pairs = (uint32_t)strtoul(e, nullptr, 10);   // (the test suite sets 0: its scenes are small)
-    ctx->knob_cut_sort_all = getenv("BH_CUT_SORT_ALL") != nullptr;
-    ctx->knob_no_view_hash = getenv("BH_NO_VIEW_HASH") != nullptr;
-    ctx->knob_fixed_margin = getenv("BH_CUT_MARGIN_FIXED") != nullptr;
-    if (const char* e = getenv("BH_CUT_CTRL")) {   // developer A/B of the margin controller: "up:down:floor:gap_exp"
-        float a = 0, b = 0, c = 0, d = 0;
-        if (sscanf(e, "%f:%f:%f:%f", &a, &b, &c, &d) == 4 && a >= 1.0f && b > 0.0f && b <= 1.0f && c > 0.0f && d >= 0.0f && d <= 1.0f) {
-            ctx->ctrl_up = a; ctx->ctrl_down = b; ctx->ctrl_floor = c; ctx->ctrl_gap_exp = d;
-        }
-    }
-    ctx->knob_readback_copy = getenv("BH_READBACK_COPY") != nullptr;
-    ctx->knob_event_waits = getenv("BH_EVENT_WAITS") != nullptr;
-    if (const char* e = getenv("BH_K16_ORDER")) { const int m = atoi(e); if (m >= 0 && m <= 2) ctx->knob_k16_order = (uint32_t)m; }
-    if (const char* e = getenv("BH_CUT_MARGIN_PCT")) { const int m = atoi(e); if (m >= 0 && m <= 10000) ctx->knob_cut_margin_pct = (uint32_t)m; }
-    ctx->knob_update_early = getenv("BH_UPDATE_EARLY") != nullptr;
-    ctx->knob_no_dormant = getenv("BH_UPDATE_NO_DORMANT") != nullptr;
-    if (const char* e = getenv("BH_K5_EXACT_SPW")) ctx->knob_k5_exact_spw = (uint32_t)atoi(e);
-    ctx->knob_tile_sort_lsd = getenv("BH_TILE_SORT_LSD") != nullptr;
-    if (const char* e = getenv("BH_LOSS_BANDS")) ctx->knob_loss_bands = (uint32_t)atoi(e);
-    if (const char* e = getenv("BH_UPDATE_ROWS")) { const int r = atoi(e); if (r == 64 || r == 128 || r == 256) ctx->knob_update_rows = (uint32_t)r; }
-    if (const char* e = getenv("BH_SORT_KPT")) { const int k = atoi(e); if (k == 4 || k == 8 || k == 16) ctx->knob_sort_kpt = (uint32_t)k; }
     if (hipEventCreateWithFlags(&ctx->readback_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->gate_ev, hipEventDisableTiming) != hipSuccess) {
         if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
@@ -530,6 +529,108 @@ int bh_profile_fetch(bh_ctx* ctx, const char** names, float* ms, uint32_t* calls
     }
     p.count = 0;
     return n;
+}
+
+// ---- options ---------------------------------------------------------------------
+// One documented setter for everything earlier revisions read from BH_* environment variables at bh_create (include/brush_hip.h
+// lists the keys).  Options select between paths that give the SAME results (A/B measurements, tests of the alternative paths);
+// they are host fields read when the next call is queued.
+namespace {
+struct OptionKey { const char* name; const char* help; };
+const OptionKey kOptionKeys[] = {
+    {"cut_min_pairs", "u32: a view whose last frame had fewer pairs keeps complete lists (= bh_set_list_cut_threshold)"},
+    {"cut_margin_pct", "0..10000: base margin behind a tile's last useful splat, % of its depth rank (default 150)"},
+    {"cut_margin_fixed", "0|1: the margin is cut_margin_pct for every frame instead of adaptive"},
+    {"cut_ctrl", "up:down:floor:gap_exp — the margin controller's constants (default 1.5:0.998:0.5:0.3333)"},
+    {"cut_sort_all", "0|1: with per-tile cuts, still depth-sort every visible splat"},
+    {"auto_exact_share", "0..1: a view whose last cut frame listed more than this share of its pairs renders complete lists (default 0.9; 0 = never)"},
+    {"no_view_hash", "0|1: frames without a view id share ONE table instead of being keyed by their camera"},
+    {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
+    {"k5_exact_spw", "16|32|64: splats per wave of the list builder for complete lists"},
+    {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
+    {"generic_depth_sort", "0|1: depth order by the generic radix sort + scan instead of the fused split sort"},
+    {"tile_sort", "auto|bucket|lsd: the forward's tile sort (auto: bucket sort unless the view's pairs are concentrated in few tiles)"},
+    {"event_waits", "0|1: the host's mid-step waits use events behind the kernels instead of polled tag words"},
+    {"readback_copy", "0|1: counts and gate word reach the host through copy launches"},
+    {"force_exchange", "0|1: a one-rank communicator still walks the whole gradient-exchange path (overhead measurement)"},
+    {"zero_grads", "0|1: the single-GPU train step zero-fills its gradient span like the exchange path"},
+    {"loss_bands", "0|1: the fused loss's blocks take their tiles by XCD column bands (1) or row-major (0)"},
+    {"update_rows", "0|64|128|256: splats per block of the update kernel (0 = default)"},
+    {"update_early", "0|1: the update kernel's blocks issue all their loads up front"},
+    {"no_dormant", "0|1: the update kernel fetches and updates dormant splats like everyone else"},
+    {"sort_kpt", "0|4|8|16: keys per thread of the generic radix sort (0 = default)"},
+    {"grad_allreduce", "ring|direct: the dense gradient block's collective — ncclAllReduce, or reduce-scatter + all-gather over grouped send/recv"},
+};
+bool parse_u32(const char* v, uint32_t lo, uint32_t hi, uint32_t* out) {
+    if (!v || !*v) return false;
+    char* end = nullptr;
+    const unsigned long long x = strtoull(v, &end, 10);
+    if (*end != '\0' || x < lo || x > hi) return false;
+    *out = (uint32_t)x;
+    return true;
+}
+bool parse_flag(const char* v, bool* out) {
+    uint32_t x = 0;
+    if (!parse_u32(v, 0, 1, &x)) return false;
+    *out = x != 0;
+    return true;
+}
+}  // namespace
+
+extern "C" int bh_option_count(void) { return (int)(sizeof(kOptionKeys) / sizeof(kOptionKeys[0])); }
+extern "C" const char* bh_option_name(int i) { return i >= 0 && i < bh_option_count() ? kOptionKeys[i].name : nullptr; }
+extern "C" const char* bh_option_help(int i) { return i >= 0 && i < bh_option_count() ? kOptionKeys[i].help : nullptr; }
+
+extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
+    if (!ctx) return BH_ERR_INVALID_ARG;
+    if (!key || !value) return set_error(ctx, BH_ERR_INVALID_ARG, "set_option: null key or value");
+    const std::string k(key);
+    bool ok = false;
+    uint32_t u = 0;
+    if (k == "cut_min_pairs") { if ((ok = parse_u32(value, 0, 0xFFFFFFFFu, &u))) ctx->cut_min_pairs = u; }
+    else if (k == "cut_margin_pct") { if ((ok = parse_u32(value, 0, 10000, &u))) ctx->knob_cut_margin_pct = u; }
+    else if (k == "cut_margin_fixed") ok = parse_flag(value, &ctx->knob_fixed_margin);
+    else if (k == "cut_ctrl") {
+        float a = 0, b = 0, c = 0, d = 0;
+        if (sscanf(value, "%f:%f:%f:%f", &a, &b, &c, &d) == 4 && a >= 1.0f && b > 0.0f && b <= 1.0f && c > 0.0f && d >= 0.0f && d <= 1.0f) {
+            ctx->ctrl_up = a; ctx->ctrl_down = b; ctx->ctrl_floor = c; ctx->ctrl_gap_exp = d;
+            ok = true;
+        }
+    }
+    else if (k == "cut_sort_all") ok = parse_flag(value, &ctx->knob_cut_sort_all);
+    else if (k == "auto_exact_share") {
+        char* end = nullptr;
+        const float f = strtof(value, &end);
+        if (end != value && *end == '\0' && f >= 0.0f && f <= 1.0f) { ctx->auto_exact_share = f; ok = true; }
+    }
+    else if (k == "no_view_hash") ok = parse_flag(value, &ctx->knob_no_view_hash);
+    else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
+    else if (k == "k5_exact_spw") { if ((ok = parse_u32(value, 16, 64, &u) && (u == 16 || u == 32 || u == 64))) ctx->knob_k5_exact_spw = u; }
+    else if (k == "no_lpt") ok = parse_flag(value, &ctx->knob_no_lpt);
+    else if (k == "generic_depth_sort") ok = parse_flag(value, &ctx->knob_generic_depth_sort);
+    else if (k == "tile_sort") {
+        const std::string v(value);
+        if (v == "auto") { ctx->knob_tile_sort = 0; ok = true; }
+        else if (v == "bucket") { ctx->knob_tile_sort = 1; ok = true; }
+        else if (v == "lsd") { ctx->knob_tile_sort = 2; ok = true; }
+    }
+    else if (k == "event_waits") ok = parse_flag(value, &ctx->knob_event_waits);
+    else if (k == "readback_copy") ok = parse_flag(value, &ctx->knob_readback_copy);
+    else if (k == "force_exchange") ok = parse_flag(value, &ctx->knob_force_exchange);
+    else if (k == "zero_grads") ok = parse_flag(value, &ctx->knob_zero_grads);
+    else if (k == "loss_bands") { if ((ok = parse_u32(value, 0, 1, &u))) ctx->knob_loss_bands = u; }
+    else if (k == "update_rows") { if ((ok = parse_u32(value, 0, 256, &u) && (u == 0 || u == 64 || u == 128 || u == 256))) ctx->knob_update_rows = u; }
+    else if (k == "update_early") ok = parse_flag(value, &ctx->knob_update_early);
+    else if (k == "no_dormant") ok = parse_flag(value, &ctx->knob_no_dormant);
+    else if (k == "sort_kpt") { if ((ok = parse_u32(value, 0, 16, &u) && (u == 0 || u == 4 || u == 8 || u == 16))) ctx->knob_sort_kpt = u; }
+    else if (k == "grad_allreduce") {
+        const std::string v(value);
+        if (v == "ring") { ctx->knob_direct_allreduce = false; ok = true; }
+        else if (v == "direct") { ctx->knob_direct_allreduce = true; ok = true; }
+    }
+    else return set_error(ctx, BH_ERR_INVALID_ARG, "set_option: unknown key '" + k + "' (bh_option_name lists the keys)");
+    if (!ok) return set_error(ctx, BH_ERR_INVALID_ARG, "set_option: bad value '" + std::string(value) + "' for '" + k + "'");
+    return 0;
 }
 
 // ---- lens laws in f64 (brush-render/src/camera.rs:85-198) ------------------------------------
@@ -763,7 +864,10 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     // work they had at the same camera's last frame (K16 193 -> ~150 us at 1 M splats / 1080p), and it refreshes the table.
     const bool order_only = !want_sliced && ctx->knob_k16_order != 0u && n >= 8u * 256u;
     if (n > 0 && (auto_cuts || order_only)) {
-        view = view_state(ctx, view_key(ctx, *cam), u.tile_bw, u.tile_bh, /*touch=*/allow_cut);
+        const uint64_t vkey = view_key(ctx, *cam);
+        // (a forward-only frame without a view id — a viewer's moving camera, an eval render — must not mint a table per frame)
+        const bool casual = order_only && !bwd_info && (vkey >> 63) != 0ull;
+        view = view_state(ctx, vkey, u.tile_bw, u.tile_bh, /*touch=*/allow_cut, casual);
         if (!view && auto_cuts) return set_error(ctx, BH_ERR_OOM, "hipMalloc for the per-view tile table failed");
         if (!view) (void)hipGetLastError();   // (ordering is optional: carry on in index order)
         // (a frame with few pairs has nothing to save: the near count in K1 and an occasional second attempt cost more than listing and
@@ -997,7 +1101,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 ProfScope ps(ctx, "TileSort");
                 // (scratch sized for the whole list: the near list's length moves from frame to frame)
                 // host-known lengths: the sort that also writes the offsets table, four launches instead of seven (sort.hip)
-                if ((zcut_lists || !sliced) && tile_sort_supported(tile_bits, zcut_lists ? near_total : ni) && !ctx->knob_tile_sort_lsd) {
+                if ((zcut_lists || !sliced) && tile_sort_supported(tile_bits, zcut_lists ? near_total : ni) && !(ctx->knob_tile_sort == 2u)) {
                     BH_TRY(tile_sort_offsets(ctx, tile_ids, isect_gids, zcut_lists ? near_total : ni, tile_bits, num_tiles, tile_ids_sorted, isect_gids_sorted,
                                              tile_offsets, ni));
                     offsets_done = true;
@@ -1162,6 +1266,8 @@ int bh_forget_views(bh_ctx* ctx) {
     for (auto& kv : ctx->views)
         if (kv.second.zcut) (void)hipFree(kv.second.zcut);
     ctx->views.clear();
+    ctx->casual_views = 0;
+    for (uint64_t& k : ctx->seen_keys) k = 0ull;
     ctx->gate_view = nullptr;
     ctx->far_job.view = nullptr;
     ctx->margin_scale = 1.0f;
@@ -1170,6 +1276,7 @@ int bh_forget_views(bh_ctx* ctx) {
 
 float bh_last_list_share(bh_ctx* ctx) { return ctx ? ctx->last_slice_share : 0.0f; }
 uint32_t bh_far_slices_queued(bh_ctx* ctx) { return ctx ? ctx->far_launches : 0u; }
+uint32_t bh_view_table_count(bh_ctx* ctx) { return ctx ? (uint32_t)ctx->views.size() : 0u; }
 
 // ---- backward ------------------------------------------------------------------
 }  // extern "C"
@@ -1238,7 +1345,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_out
         if (r.num_intersections > 0)
             BH_TRY(launch_rasterize_backward(ctx, fs.uniforms, fs.bg, fs.flags & BH_FLAG_SMOOTH_CUTOFF,
                                              r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, fs.lpt,
-                                             r.tile_offsets_far));
+                                             r.tile_offsets_far, /*want_refine=*/!ctx->bwd_skip_refine));
     }
     {
         ProfScope ps(ctx, "ProjectBackwards");
@@ -1490,7 +1597,7 @@ extern "C" int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const
     while (bits < 32 && (num_tiles >> bits) != 0) bits++;  // render.rs:228
     BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, (size_t)num_tiles * 2 * 4, ctx->stream));
     if (n == 0) return 0;
-    if (tile_sort_supported(bits, n) && !ctx->knob_tile_sort_lsd)
+    if (tile_sort_supported(bits, n) && !(ctx->knob_tile_sort == 2u))
         return tile_sort_offsets(ctx, tile_ids, compact_gids, n, bits, num_tiles, tile_ids_sorted, compact_gids_sorted, tile_offsets);
     BH_TRY(radix_argsort(ctx, tile_ids, compact_gids, n, bits, tile_ids_sorted, compact_gids_sorted));
     return launch_tile_offsets(ctx, tile_ids_sorted, n, num_tiles, tile_offsets, /*pre_zeroed=*/true);
@@ -1739,7 +1846,11 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
         if (ctx->clears.span != GradClears::ZEROED) BH_HIP(ctx, hipMemsetAsync(exch + o_ref, 0, (exch_count - o_ref) * sizeof(float), ctx->stream));
         ctx->clears.mark_rows();   // this step's backward runs K18 in marking mode and fills nothing
     }
+    // the refine weight's one consumer stops reading it at growth_stop_iter (train.rs:589-614): from then on the blend backward
+    // runs without it (refine_weight_norm stays as refine() zeroed it)
+    ctx->bwd_skip_refine = cfg->growth_stop_iter != 0u && step >= cfg->growth_stop_iter;
     const int brc = bh_render_backward(ctx, v_output, r_transforms, st->sh_coeffs, r_raw_opac, g_tr, g_sh, g_op, s_refine);
+    ctx->bwd_skip_refine = false;
     ctx->ext_grad_begin = nullptr;
     ctx->ext_grad_floats = 0;
     BH_TRY(brc);

@@ -136,9 +136,17 @@ struct ViewState {
     uint32_t gap = 0;               // forwards between the view's last two frames (a new view: the number of views the ctx knows) —
                                     // how stale the table will be when it is next read: the margin written into it grows with it
     uint32_t last_pairs = 0;        // num_intersections of the view's last frame
+    float last_share = 0.0f;        // share of its pairs the view's last CUT frame listed (0: none yet)
+    uint32_t complete_frames = 0;   // frames to render with complete lists because cutting saved (almost) nothing last time; then one probe frame
+    bool casual = false;            // created by a forward-only frame keyed by its camera (a viewer / eval render): these compete for CASUAL_VIEW_STATES tables only
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
 constexpr size_t MAX_VIEW_STATES = 4096;
+// Forward-only frames that name no view (a viewer's free camera, an eval render, a pose-optimised camera: a new hash every frame) get
+// a table only when the same camera is seen a SECOND time, and at most this many of them are kept: such frames cut nothing, the table
+// only orders their blend's tiles.
+constexpr size_t CASUAL_VIEW_STATES = 32;
+constexpr size_t SEEN_KEYS = 64;   // ring of camera hashes met once
 constexpr size_t VIEW_TABLE_BYTES = (size_t)256 << 20;   // ... and at most this much device memory in tables (8 B per tile and view: 64 KB at 1080p, 253 KB at 4K)
 
 // scratch of a depth-sliced forward (rasterize.hip SliceArgs); feedback alone may be set for the exact path (phase 0)
@@ -257,11 +265,8 @@ struct Retained {
 
 }  // namespace bh
 
-// 1 (default): the blend backward accumulates RAW per-splat sums into v_combined and the projection backward maps them to the
-// reference's RasterizeGrads row (and stores it back) — rasterize.hip / project.hip.  0: the maps run in the blend backward (A/B).
-#ifndef BH_RAW_SUMS
-#define BH_RAW_SUMS 1
-#endif
+// The blend backward accumulates RAW per-splat sums into v_combined and the projection backward maps them to the reference's
+// RasterizeGrads row (and stores it back) — rasterize.hip / project.hip.
 
 struct bh_ctx {
     int device = 0;
@@ -314,6 +319,7 @@ struct bh_ctx {
     // (device-gated, no host wait; the gate word is copied out to keep learning); otherwise the host reads the gate word —
     // bh_render_forward waits for it, bh_train_step queues the loss kernels first and waits behind them (far_job.pending).
     bool far_direct = false;
+    bool bwd_skip_refine = false;     // set by bh_train_step around its backward: step >= BhTrainConfig.growth_stop_iter, nobody reads the refine weight
     bool defer_far = false;           // set by bh_train_step around its forward: return with far_job.pending instead of waiting
     uint32_t readback_tag = 0;        // tag of the last count readback the host polled for (depth_sort.hip counter_sums_to_host)
     uint32_t gate_tag = 0;            // tag of the last deferred far-slice decision
@@ -325,6 +331,9 @@ struct bh_ctx {
     // keyed by the caller's view id, or — id 0 — by a hash of the camera (api.hip view_key): an unmodified SplatTrainer::step
     // (train.rs:176: a SceneBatch carries no view index, brush-dataset/src/scene.rs:138-147) gets the same tables
     std::unordered_map<uint64_t, bh::ViewState> views;
+    uint64_t seen_keys[bh::SEEN_KEYS] = {};   // camera hashes of forward-only frames that found no table (api.hip casual_view)
+    uint32_t seen_pos = 0;
+    uint32_t casual_views = 0;                // tables whose ViewState::casual is set
     uint32_t view_id = 0;
     uint64_t view_clock = 0;
     bh::ViewState* gate_view = nullptr;   // the view whose far pass was queued unasked (gate_learn): penalised if it was needed
@@ -346,7 +355,7 @@ struct bh_ctx {
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
-    // developer knobs (A/B measurements), read from the environment ONCE at bh_create
+    // developer knobs (A/B measurements): bh_set_option
     bool knob_no_lpt = false;         // BH_NO_LPT: backward tiles in index order
     bool knob_force_exchange = false;       // BH_FORCE_PG: run the gradient-exchange path with a one-rank communicator too (overhead measurement)
     bool knob_break_allreduce = false;      // BH_BREAK_ALLREDUCE: corrupt the library's all-reduce (the bench self-check must notice)
@@ -355,7 +364,9 @@ struct bh_ctx {
     uint32_t knob_fail_loss_at = 0;   // BH_TEST_FAIL_LOSS_AT: the k-th bh_train_step on this ctx returns BH_ERR_OOM between its forward and its loss (test hook)
     uint32_t train_steps_seen = 0;
     uint32_t knob_loss_bands = 1;     // BH_LOSS_BANDS=0 (A/B): the fused loss's blocks take their tiles row-major instead of by XCD column bands
-    bool knob_tile_sort_lsd = false;  // BH_TILE_SORT_LSD (A/B): the forward's tile sort as two LSD passes + the offsets kernel (rounds 1-4)
+    uint32_t knob_tile_sort = 0;      // option tile_sort: 0 auto (bucket sort unless the view's pairs sit in few tiles), 1 bucket, 2 two LSD passes + the offsets kernel
+    float auto_exact_share = 0.9f;    // option auto_exact_share: a view whose last cut frame listed more than this share renders complete lists
+    bool knob_direct_allreduce = false;   // option grad_allreduce=direct: reduce-scatter + all-gather over grouped send / recv (comm.hip)
     uint32_t knob_k5_exact_spw = 32;  // BH_K5_EXACT_SPW = 16 | 32 | 64 (A/B): splats per wave of K5 for complete lists
     bool knob_no_dormant = false;     // BH_UPDATE_NO_DORMANT (A/B, tests): the update kernel fetches and updates dormant splats like everyone else
     bool knob_update_early = false;   // BH_UPDATE_EARLY (A/B): the update kernel's blocks of SH degree >= 1 issue all their loads up front
@@ -483,7 +494,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
                               const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
-                              const uint32_t* tile_offsets_far = nullptr);
+                              const uint32_t* tile_offsets_far = nullptr, bool want_refine = true);
 // loss.hip
 int launch_image_loss_forward(bh_ctx* ctx, const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h,
                               uint32_t w, const BhLossConfig& cfg, float* loss_map);

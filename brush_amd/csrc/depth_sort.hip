@@ -26,10 +26,8 @@ namespace bh {
 
 constexpr int DS_WG = 256;
 constexpr int DS_WAVES = DS_WG / 64;
-#ifndef BH_DS_KPT
 #define BH_DS_KPT 8   /* 16 until late in round 4: 2048-key chunks put twice the blocks on the chip for the histogram and the split
                          (split 12.6 -> 9.8 us at 1 M splats, histogram + row scan +0.6); the fused path then reaches 8.4 M splats */
-#endif
 constexpr int DS_KPT = BH_DS_KPT;
 constexpr int DS_TILE = DS_WG * DS_KPT;   // 2048 keys per chunk
 constexpr int DS_RADIX = 256;
@@ -393,10 +391,8 @@ __global__ __launch_bounds__(DS_WG) void dsort_split_kernel(const uint32_t* __re
 }
 
 // ---- 2: one block per bucket: sort on the low bits, then the scan of the tile counts --------------------------------------------
-#ifndef BH_BK_WG
 #define BH_BK_WG 1024   /* 16 waves: four per SIMD, the only block on its CU (LDS).  512 (rounds 2-3): 39.5 us, 1024: 34.0 us — the
                            kernel is one latency chain per bucket, the largest bucket sets its length, more waves shorten every link */
-#endif
 constexpr int BK_WG = BH_BK_WG;
 constexpr int BK_WAVES = BK_WG / 64;
 constexpr int BK_KPT = DS_TILE / BK_WG;        // scan / chunk granularity: 4096 elements, 8 per thread
@@ -459,12 +455,6 @@ BH_DEV void bk_scan_counts(const uint32_t* vals, uint32_t size, const uint32_t* 
     }
 }
 
-#ifdef DS_DEBUG
-__device__ unsigned long long g_ds_dbg[256 * 8];
-#define DS_MARK(i) do { if (threadIdx.x == 0) g_ds_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define DS_MARK(i)
-#endif
 __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restrict__ a_keys, uint32_t* __restrict__ a_vals /*the split's output (scratch)*/,
                                                             uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals,
                                                             const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ digit_totals,
@@ -475,7 +465,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
     __shared__ uint32_t s_red[2 * BK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    DS_MARK(0);
     // the split parameters (as depth_split, for this block shape)
     DepthSplit sp;
     uint32_t gt_pre, ct_pre;
@@ -512,7 +501,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         __syncthreads();
     }
     if (size == 0u) return;
-    DS_MARK(1);
     const uint32_t bits = sp.sub_bits;   // the keys of a bucket span less than 2^bits (0: one distinct key — nothing to sort)
     if (size <= (uint32_t)FAST_CAP) {
         // ---- resident path (the usual case): the whole bucket lives in LDS and is sorted there by stable counting passes on
@@ -538,7 +526,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
 #pragma unroll
         for (int w = 0; w < BK_WAVES; ++w) lo = min(lo, s_red[w]);
         __syncthreads();
-        DS_MARK(2);
         const uint32_t passes = (bits + 8u) / 9u;              // 0 for bits == 0
         const uint32_t base_w = passes ? bits / passes : 0u, wide = passes ? bits % passes : 0u;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -601,7 +588,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             __syncthreads();
             cur ^= 1u;
         }
-        DS_MARK(3);
         const uint32_t* fk = s_dyn + cur * (2 * FAST_CAP); const uint32_t* fv = fk + FAST_CAP;
         uint32_t* spare = s_dyn + (cur ^ 1u) * (2 * FAST_CAP);   // the other buffer: 2 * FAST_CAP words
         // on the way out: the tile count of every splat, all gathers in flight at once
@@ -611,7 +597,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             out_vals[start + i] = v;
             if (cum != nullptr) { const uint32_t e = i; spare[e + e / BK_KPT] = counts[v]; }
         }
-        DS_MARK(4);
         if (cum == nullptr) return;
         __syncthreads();
         // inclusive scan of the tile counts in sorted order (render.rs:185-187): thread t owns 8 consecutive elements of each 4096-run
@@ -640,10 +625,6 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             __syncthreads();
             for (uint32_t i = tid; i < size; i += BK_WG) cum[start + i] = spare[i + i / BK_KPT];
         }
-        DS_MARK(5);
-#ifdef DS_DEBUG
-        if (threadIdx.x == 0) g_ds_dbg[blockIdx.x * 8 + 6] = size;
-#endif
         return;
     }
     // ---- chunked path: a bucket of any size (depth distributions that defeat the range split), through global scratch:
@@ -703,9 +684,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
 // Up to the row scan's reach (4096 chunks of DS_TILE keys: 8.4 M splats); beyond it the generic sort + scan run.  (Until round 4 the limit was 4 M:
 // "the fused path pays off while launches, not bytes, are the cost".  With per-tile cuts only the listed sixth of the 6 M / 4K
 // scene's splats is moved at all: depth order + scan 255 -> 97 us there; with complete lists 306 -> 302.)
-#ifndef BH_DSORT_MAX_N
 #define BH_DSORT_MAX_N (16u << 20)
-#endif
 constexpr uint32_t DSORT_MAX_N = BH_DSORT_MAX_N;
 bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n + DS_TILE - 1) / DS_TILE <= (uint32_t)DS_ROW_EPT * DS_WG; }
 
@@ -746,8 +725,3 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
 
 }  // namespace bh
 
-#ifdef DS_DEBUG
-extern "C" int bh_debug_dsort_clocks(unsigned long long* out /*host [256*8]*/) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bh::g_ds_dbg), sizeof(unsigned long long) * 256 * 8);
-}
-#endif

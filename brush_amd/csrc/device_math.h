@@ -312,20 +312,8 @@ BH_DEV bool will_primitive_contribute(uint32_t tx, uint32_t ty, float mx, float 
         const float dyf = y_above ? height : -height;
         const float diff_x = mx - corner_x;
         const float diff_y = my - corner_y;
-#ifdef BH_WALK_FASTDIV_PROBE   // measurement-only: what a hoisted reciprocal + BH_WALK_FASTDIV_PROBE correction steps would cost
-        auto qdiv = [](float a, float d) {
-            const float r = __builtin_amdgcn_rcpf(d);
-            float q = a * r;
-#pragma unroll
-            for (int it = 0; it < BH_WALK_FASTDIV_PROBE; ++it) q = __builtin_fmaf(__builtin_fmaf(-q, d, a), r, q);
-            return q;
-        };
-        const float tx_raw = qdiv(dxf * conic.c00 * diff_x + dxf * conic.c01 * diff_y, dxf * conic.c00 * dxf);
-        const float ty_raw = qdiv(dyf * conic.c01 * diff_x + dyf * conic.c11 * diff_y, dyf * conic.c11 * dyf);
-#else
         const float tx_raw = (dxf * conic.c00 * diff_x + dxf * conic.c01 * diff_y) / (dxf * conic.c00 * dxf);
         const float ty_raw = (dyf * conic.c01 * diff_x + dyf * conic.c11 * diff_y) / (dyf * conic.c11 * dyf);
-#endif
         const float t_x = in_y_range ? 0.0f : clampf(tx_raw, 0.0f, 1.0f);
         const float t_y = in_x_range ? 0.0f : clampf(ty_raw, 0.0f, 1.0f);
         const float max_x = corner_x + t_x * dxf;

@@ -114,16 +114,12 @@ namespace {
 constexpr int TW = 16, TH = 32;
 constexpr int SW = TW + 2 * HALO;   // 26
 constexpr int SR = TH + 2 * HALO;   // 42
-#ifndef BH_LOSS_HP
 /* 88, not TW * 5 = 80: a thread's rows are 2 * 88 = 176 floats = 48 banks apart, the four ly of a wave sit 0 / 48 / 32 / 16 banks
    apart and lx * 5 covers every residue mod 16 once — the column pass's 60 reads per plane are conflict-free (80: the rows of ly and
    ly + 2 share their banks).  Only with the block still at 40 KB = four per CU (s_h's last row unpadded, s_red inside it): 68.2 ->
    63.5 us; at 41.0 KB (three blocks per CU) the same pitch cost +5 us. */
 #define BH_LOSS_HP 88
-#endif
-#ifndef BH_LOSS_H2P
 #define BH_LOSS_H2P 24   /* 2 rows apart = 48 floats = 16 banks: the two output rows of a 32-lane half never share a bank (65.0 vs 66.2 us) */
-#endif
 constexpr int HP = BH_LOSS_HP;      // row pitch (floats) of pass A's horizontally blurred moments
 constexpr int H2P = BH_LOSS_H2P;    // ... of pass B's
 }  // namespace
@@ -216,11 +212,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
         __syncthreads();   // the tile is loaded (c == 0) / the previous plane's column pass is done with s_h
         // horizontal blur of (x, x^2, y, y^2, xy): 42 rows x 8 column PAIRS — an item loads the 12 pixels its two adjacent
         // outputs share once and squares each of them once
-#ifdef BH_LOSSA_PROBE   // measurement-only (wrong results): 1 = no row pass, 2 = no column pass + SSIM, 3 = neither (tile load only)
-        const int probe_rows = (BH_LOSSA_PROBE == 1 || BH_LOSSA_PROBE == 3) ? (a.h == 0xFFFFFFFFu ? SR * (TW / 2) : 0) : SR * (TW / 2);
-#else
         const int probe_rows = SR * (TW / 2);
-#endif
         for (int i = rank; i < probe_rows; i += 256) {
             const int r = i / (TW / 2), pair = i - r * (TW / 2);
             const float2* row = &s_tile[c][r * SW + 2 * pair];   // row[k] = pixel at tile column 2*pair - HALO + k
@@ -255,9 +247,6 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
             }
         }
         __syncthreads();
-#if defined(BH_LOSSA_PROBE) && (BH_LOSSA_PROBE == 2 || BH_LOSSA_PROBE == 3)
-        if (a.h != 0xFFFFFFFFu) { acc_rgb += s_h[rank]; continue; }
-#endif
         // vertical blur: rows 2 ly .. 2 ly + 11 of s_h serve both outputs (output o: rows o .. o + 10, centre o + 5)
         float v[12][5];
 #pragma unroll
@@ -336,9 +325,7 @@ __global__ __launch_bounds__(256) void loss_fused_forward_kernel(const float* __
 // ---------------------------------------------------------------------------
 // pass B
 // ---------------------------------------------------------------------------
-#ifndef BH_LOSSB_WAVES
 #define BH_LOSSB_WAVES 1
-#endif
 __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kernel(const float* __restrict__ img, const uint32_t* __restrict__ gt,
                                                                  const float* __restrict__ partials /*[3][3][H][W]*/,
                                                                  float* __restrict__ v_output /*[H,W,4]*/, FusedArgs a) {
@@ -382,11 +369,7 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
     }
     float out[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // block-uniform: rows of the partial planes can be fetched as aligned float4s
-#ifdef BH_LOSSB_NARROW   // A/B: the 4-byte loads of round 2
-    const bool wide_rows = false;
-#else
     const bool wide_rows = (a.w & 3u) == 0u && (plane & 3u) == 0u && (reinterpret_cast<uintptr_t>(partials) & 15u) == 0;
-#endif
     // A tile row is 26 floats from column tx0 - 5: fetched as the 8 aligned float4s from tx0 - 8 (128 contiguous bytes; W % 4 == 0,
     // so a float4 lies entirely inside or outside the image) — 3 x 336 16-byte loads per colour instead of 3 x 1092 4-byte ones,
     // four per thread, and they are issued one colour AHEAD into registers: a block is a chain of nine barrier-separated phases
@@ -403,11 +386,7 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
                 const int j = i / (SR * 8), rem = i - j * (SR * 8);
                 const int r = rem >> 3, k = rem & 7;
                 const int y = ty0 + r - HALO, x = tx0 - 8 + 4 * k;
-#if defined(BH_LOSSB_PROBE) && BH_LOSSB_PROBE == 4
-                const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w && a.h == 0xFFFFFFFFu;
-#else
                 const bool in = y >= 0 && x >= 0 && y < (int)a.h && x < (int)a.w;
-#endif
                 if (in) dst[t] = *reinterpret_cast<const float4*>(&pc[(size_t)j * plane + (size_t)y * a.w + (size_t)x]);
             }
         }
@@ -433,19 +412,11 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
     if (wide_rows) fetch_rows(0, pre);
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-#if defined(BH_LOSSB_PROBE) && BH_LOSSB_PROBE == 5   // no colour loop at all: the kernel's prologue + epilogue
-        if (a.h != 0xFFFFFFFFu) { out[0][c] = pv[0].x; out[1][c] = pv[1].y; continue; }
-#endif
         __syncthreads();   // the previous plane's column pass is done with the buffers
-#ifdef BH_LOSSB_NO_PREFETCH
-        if (wide_rows && c > 0) fetch_rows(c, pre);
-#endif
         const float* pc = partials + (size_t)(c * 3) * plane;
         if (wide_rows) {
             stash_rows(pre);
-#ifndef BH_LOSSB_NO_PREFETCH
             if (c < 2) fetch_rows(c + 1, pre);   // in flight while this plane goes through the two blur passes
-#endif
         } else {
             for (int i = rank; i < SR * SW; i += 256) {
                 const int r = i / SW, q = i - r * SW;
@@ -458,11 +429,7 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
             }
         }
         __syncthreads();
-#ifdef BH_LOSSB_PROBE   // measurement-only (wrong results): 1 = no row pass, 2 = no column pass, 3 = neither, 4 = zeros instead of the partial planes
-        const int probe_items = (BH_LOSSB_PROBE == 1 || BH_LOSSB_PROBE == 3) ? (a.h == 0xFFFFFFFFu ? 3 * SR * TW : 0) : 3 * SR * TW;
-#else
         const int probe_items = 3 * SR * TW;
-#endif
         for (int i = rank; i < probe_items; i += 256) {
             const int j = i / (SR * TW), rem = i - j * (SR * TW);
             const int r = rem / TW, col = (rem - r * TW) + HALO;
@@ -474,9 +441,6 @@ __global__ __launch_bounds__(256, BH_LOSSB_WAVES) void loss_fused_backward_kerne
             s_h2[j][r * H2P + (col - HALO)] = acc;
         }
         __syncthreads();
-#if defined(BH_LOSSB_PROBE) && (BH_LOSSB_PROBE == 2 || BH_LOSSB_PROBE == 3)
-        if (a.h != 0xFFFFFFFFu) { out[0][c] = s_h2[0][rank] + s_part[0][rank]; continue; }
-#endif
         float v[3][12];
 #pragma unroll
         for (int j = 0; j < 3; ++j)

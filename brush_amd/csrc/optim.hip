@@ -18,15 +18,10 @@ struct AdamArgs {
     uint32_t first;  // t == 1: initialise the moments instead of decaying them
 };
 
-#ifdef BH_UPDATE_WRITE_ALL   // A/B: every value is stored, changed or not (rounds 1-3)
-BH_DEV bool same_bits(float, float) { return false; }
-BH_DEV bool same_bits4(const float4&, const float4&) { return false; }
-#else
 BH_DEV bool same_bits(float a, float b) { return f2u(a) == f2u(b); }
 BH_DEV bool same_bits4(const float4& a, const float4& b) {
     return ((f2u(a.x) ^ f2u(b.x)) | (f2u(a.y) ^ f2u(b.y)) | (f2u(a.z) ^ f2u(b.z)) | (f2u(a.w) ^ f2u(b.w))) == 0u;
 }
-#endif
 
 BH_DEV void adam_elem(float& p, float g, float& m1, float v, const AdamArgs& a, float step) {
     const float m1c = m1 / a.bc1;

@@ -61,14 +61,10 @@ struct WalkLds {
 // classic condition) — walk_magic returns m when every index of the box satisfies that (any box of a 4K frame does by orders
 // of magnitude), else 0 and walk_row divides.  (Before: a float quotient + two exec-masked corrections, ~15 VALU ops and three
 // SALU exec swaps per candidate.)
-#ifdef BH_WALK_FLOAT_ROW   // A/B: the float quotient of rounds 1-3
-BH_DEV uint32_t walk_magic(uint32_t, uint32_t) { return 0u; }
-#else
 BH_DEV uint32_t walk_magic(uint32_t bw, uint32_t nb) {
     if (bw < 2u || (unsigned long long)nb * bw >= (1ull << 32)) return 0u;
     return 0xFFFFFFFFu / bw + 1u;
 }
-#endif
 BH_DEV uint32_t walk_row(uint32_t i, uint32_t bw, uint32_t magic) {
     if (magic) return __umulhi(i, magic);
     if (bw < 2u) return i;
@@ -163,11 +159,7 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
-#if defined(BH_K1_WALK_PROBE) && BH_K1_WALK_PROBE >= 2   // measurement-only (wrong results): the walk's skeleton without the ellipse test
-            if (keep(w, r, tx, ty) && (tx + ty) != 0xFFFFFFFFu) on_hit(r, tx, ty);
-#else
             if (keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
-#endif
         }
         before += (uint32_t)__popcll(marks);
     }
@@ -354,12 +346,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
                       "+v"(raw_opac), "+v"(sh_dc[0]), "+v"(sh_dc[1]), "+v"(sh_dc[2]));
     if (gid < n) {
         do {
-#ifdef BH_K1_NO_MATH   // measurement-only probe (wrong results: nothing is visible): the loads and the per-splat stores alone
-            float acc = raw_opac;
-            for (int k = 0; k < 10; ++k) acc += tr[k];
-            for (int k = 0; k < 3; ++k) acc += sh_dc[k];
-            if (acc != 12345.678f) break;
-#endif
             mean = v3(tr[0], tr[1], tr[2]);
             const Vec3A mean_c = world_to_cam(mean, u);
             if (!(finite3(mean_c) && mean_c.z <= 1.0e10f)) break;
@@ -398,9 +384,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // helpers.rs:204-223 count_contributing_tiles, load-balanced over the wave
     const uint32_t nb = visible ? (bb.max_y - bb.min_y) * (bb.max_x - bb.min_x) : 0u;
     WalkLds& w = s_walk[wave];
-#ifdef BH_K1_NO_WALK   // measurement-only probe (wrong results: no splat hits a tile)
-    const uint32_t tiles_hit = nb == 0xFFFFFFFFu ? w.count[0] : 0u;
-#else
     // per-tile depth cuts (zcut != NULL, wave-uniform): a hit also counts for the NEAR list if the splat is at or in front of its
     // tile's cut - K5 lists exactly those pairs (same keys, same table, same test).  A hit BEHIND the cut sets bit 0 of the tile's
     // entry — the bit is not part of the cut, and the other 31 bits do not change while K1 runs, so every writer stores the SAME
@@ -409,51 +392,24 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // unmarked tile holds everything there is, however its cut reads.
     const uint32_t tile_bw = u.tile_bw;
     const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
-#ifdef BH_K1_WALK_PROBE   // measurement-only (wrong results): 1 = hits are found but not counted, 2 = ... and not tested for, 3 = counted, no near test
-        if (BH_K1_WALK_PROBE != 3 && tile_bw != 0xFFFFFFFFu) return;
-#endif
         atomicAdd(&w.count[r], 1u);
-#if defined(BH_K1_WALK_PROBE) && BH_K1_WALK_PROBE == 3
-        if (tile_bw != 0xFFFFFFFFu) return;
-#endif
         if (zcut) {
             const uint32_t t = tx + ty * tile_bw;
-#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 1)
-            const uint32_t cut = __hip_atomic_load(&zcut[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
             const uint32_t cut = zcut[t];
-#endif
-#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 4)
-            if (zcut_near(w.zkey[r], cut)) { if (tile_bw == 0xFFFFFFFFu) atomicAdd(&w.near[r], 1u); }
-#else
             if (zcut_near(w.zkey[r], cut)) atomicAdd(&w.near[r], 1u);
-#endif
-#if defined(BH_K1_NEAR_PROBE) && (BH_K1_NEAR_PROBE & 2)
-            else if ((cut & 1u) == 0u && tile_bw == 0xFFFFFFFFu) zcut[t] = cut | 1u;
-#else
             else if ((cut & 1u) == 0u) zcut[t] = cut | 1u;
-#endif
         }
     }, KeepAllTiles{}, key);
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
     const uint32_t near_hit = (nb && zcut) ? w.near[wrank] : 0u;
-#endif
     // per-tile cuts: a visible splat without a single pair in front of a cut takes no part in this frame's lists — it gets the
     // culled key, so the depth sort (whose stable order IS the compaction) numbers and orders only the splats that own a near
     // pair: a quarter of the visible ones at the bench workload.  It still counts as visible (the reference's num_visible).
-#ifndef BH_K1_NO_WALK
     const bool listed = visible && (!zcut || near_hit > 0u || prep.list_all_visible);
-#else
-    const bool listed = visible;
-#endif
     // The splat's colour and its projected row (what K5 gathers by depth rank) — behind the walk since round 4: with per-tile cuts
     // only the LISTED splats are ever gathered, a quarter of the visible ones, and the SH bands above DC (180 bytes per splat at
     // degree 3) are only fetched for them.  Without cuts every visible splat is listed.
-#ifdef BH_K1_NO_ROWS   // measurement-only probe (garbage image): the 36-byte projected rows are not written
-    if (listed && u.img_w == 0xFFFFFFFFu) {
-#else
     if (listed) {  // project_visible.rs:56-87
-#endif
         const Vec3A v = normalize(sub(mean, camera_pos(u)));
         constexpr int C = (DEG + 1) * (DEG + 1);
         const Vec3A raw = sh_coeffs_to_color_dc<DEG>(coeffs + (size_t)gid * C * 3, v, sh_dc);
@@ -473,9 +429,7 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         depth_keys[gid] = listed ? key : 0xFFFFFFFFu;
         isect_counts[gid] = tiles_hit;
         max_radius[gid] = radius;
-#ifndef BH_K1_NO_WALK
         if (zcut) near_counts[gid] = near_hit;
-#endif
     }
     // block totals -> two global atomics per block (the reference does two per splat), spread over COUNTER_SLOTS
     // (visible, hits) pairs that the host adds up: 7814 atomics on ONE pair of addresses serialise at ~7 ns each on
@@ -486,13 +440,11 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wave_hits += __shfl_down(wave_hits, off);
     uint32_t wave_near = 0;
-#ifndef BH_K1_NO_WALK
     if (zcut) {   // wave-uniform
         wave_near = near_hit;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wave_near += __shfl_down(wave_near, off);
     }
-#endif
     // range of the visible depth keys, for the depth sort's split (depth_sort.hip): maxima of key and of ~key
     uint32_t kmax = listed ? key : 0u, nmax = listed ? ~key : 0u;
 #pragma unroll
@@ -731,9 +683,6 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const uint32_t wave_total = __shfl(end, last_lane) - wave_base;
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
-#ifdef BH_K5_NO_WALK   // measurement-only probe (empty image): no candidate is visited, every slot leaves as a sentinel pair
-    nb = nb == 0xFFFFFFFFu ? 1u : 0u;
-#endif
     if (FAR) {
         (void)flat_tile_walk_emit(w, lane, nb, xy_x, xy_y, conic, pt, bb, wave_base, wave_total, tile_bw, cg0, tile_id_from_isect, compact_gid_from_isect, KeepLiveTiles{done_bits, tile_bw});
     } else {
@@ -815,9 +764,7 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
     const uint32_t* nul = nullptr;
     if (slice_info) {   // the near slice of a sliced frame: few, large splats (see SPW)
-#ifndef BH_K5_SPW
 #define BH_K5_SPW 16
-#endif
         constexpr int SPW = BH_K5_SPW;
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
@@ -936,7 +883,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) g[k] = rg[k];
     asm volatile("" : "+v"(gid));   // (the splat id travels with the accumulator row, not behind the test on it)
-#if BH_RAW_SUMS
     // The blend backward left RAW sums (rasterize.hip): P Q = sums of v_sigma (pixel - mean), R2 R3 R4 = its second moments, the
     // three colour sums, Vs = sum of v_sigma, the refine weight.  Their per-splat linear maps (rasterize_backwards.rs:318-381:
     // v_xy = -conic (P, Q), v_conic = (R2/2, R3, R4/2), the colour clamp's gates, v_alpha0 = -Vs / alpha0) commute with the sum
@@ -960,7 +906,6 @@ __global__ __launch_bounds__(PROJ_WG) void project_backward_kernel(
 #pragma unroll
         for (int k = 0; k < 10; ++k) rg[k] = g[k];
     }
-#endif
 #pragma unroll
     for (int k = 0; k < 10; ++k) any = any || (g[k] != 0.0f);
     constexpr int C = (DEG + 1) * (DEG + 1);
@@ -1045,9 +990,7 @@ int launch_project_backward(bh_ctx* ctx, const ViewUniforms& u, uint32_t nv, boo
                             float* v_combined, float* v_transforms, float* v_sh, float* v_raw_opac,
                             float* v_refine, bool row_mask, const float* projected) {
     if (nv == 0) return 0;
-#if BH_RAW_SUMS
     if (!projected) return set_error(ctx, BH_ERR_INVALID_ARG, "project_backward: the projected rows are needed to map the raw gradient sums");
-#endif
     if (u.model == CAM_PINHOLE)
         return mip ? launch_pb_deg<true, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected)
                    : launch_pb_deg<false, true>(ctx, u, nv, sh_degree, transforms, sh, raw_opac, gid, v_combined, v_transforms, v_sh, v_raw_opac, v_refine, row_mask, projected);

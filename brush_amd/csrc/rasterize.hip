@@ -140,9 +140,6 @@ constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend 
 // exponent spliced in by adding k << 23 to the bit pattern.  The CPU checker used by the tests
 // restates the same sequence, so images stay bit-identical to it.
 BH_DEV float exp_blend(float x) {
-#ifdef BH_HW_EXP  // measurement-only variant (not the shipped numerical spec)
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-#endif
     const float s = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f);
     const float nkf = 12582912.0f - s;                               // -rint(x log2e), exact (as a subtraction: both fmas keep
     const float f = __builtin_fmaf(x, 1.44269504088896341f, nkf);    //  their constant as a literal, no SGPR operand)
@@ -197,11 +194,6 @@ BH_DEV uint32_t stage_batch(const uint32_t* __restrict__ isect_gids, const float
 // ---------------------------------------------------------------------------
 // K16: rasterize (kernels/rasterize.rs:27-190)
 // ---------------------------------------------------------------------------
-#ifdef BH_FWD_WAVES  // measurement-only: cap the forward's occupancy (waves per SIMD)
-#define BH_FWD_ATTR __attribute__((amdgpu_waves_per_eu(BH_FWD_WAVES, BH_FWD_WAVES)))
-#else
-#define BH_FWD_ATTR
-#endif
 // Depth-sliced lists (BH_FLAG_SLICED_LISTS; api.hip has the whole story).  The per-tile lists are built for a NEAR slice of the
 // depth order first; PHASE 1 blends it and a tile whose 256 pixels all saturated is final (bit set in done_bits) — at the
 // bench workload that is every tile after a fifth of the pairs.  A tile with live pixels left parks its raw (rgb, T) state and
@@ -235,25 +227,15 @@ struct SliceArgs {
     uint32_t* work = nullptr;
 };
 
-#ifdef BH_K16_TRACE   // measurement-only: per-tile (start, end, hw id, blended) of the last launch
-__device__ unsigned long long g_k16_trace[65536 * 4];
-#endif
 template <bool BWD_INFO, bool SMOOTH, int PHASE>
-__global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+__global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
                                                       const uint32_t* __restrict__ global_from_compact,
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
                                                       float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-#ifdef BH_K16_HALF   // measurement-only (the per-tile bookkeeping is the upper half's alone): two waves per tile, 16 x 8 pixels each
-    constexpr int NQ = 2;
-    const uint32_t half = (blockIdx.x >> 3) & 1u;
-    const uint32_t bidx = (blockIdx.x & 7u) | ((blockIdx.x >> 4) << 3);   // (blocks b and b + 8: the two halves of a tile, on the same XCD)
-#else
     constexpr int NQ = 4;
-    const uint32_t half = 0u;
     const uint32_t bidx = blockIdx.x;
-#endif
     uint32_t local_tile;
     if (sl.order) {
         const uint32_t per = (u.num_tiles + 7u) / 8u;
@@ -267,20 +249,14 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         local_tile = tile_of_block(bidx, u.num_tiles);
     }
     if (local_tile >= u.num_tiles) return;
-#if defined(BH_K16_PROBE) && BH_K16_PROBE == 3   // measurement-only: the launch floor (every wave returns at once)
-    if (u.num_tiles != 0xFFFFFFFFu) return;
-#endif
     const uint32_t tile = u.tile_begin + local_tile;
-#ifdef BH_K16_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-#endif
     if (PHASE == 2) {
         if (*sl.unsat_count == 0u) return;                                     // the near slice finished the frame
         if ((sl.done_bits[tile >> 5] >> (tile & 31u)) & 1u) return;            // ... or this tile
     }
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
-    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + 8u * half + (lane >> 3);
+    const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
     const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
     const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
     // transmittance; a finished pixel keeps its final T with the sign flipped
@@ -303,11 +279,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         }
     }
     const uint32_t range_lo = tile_offsets[tile * 2];
-#if defined(BH_K16_PROBE) && (BH_K16_PROBE == 1 || BH_K16_PROBE == 4 || BH_K16_PROBE == 5)   // measurement-only (wrong results): no batches at all — the tile's prologue + epilogue
-    const uint32_t range_hi = range_lo + (tile_offsets[tile * 2 + 1] == 0xFFFFFFFFu ? 1u : 0u);
-#else
     const uint32_t range_hi = tile_offsets[tile * 2 + 1];
-#endif
     uint32_t last_useful = range_lo;
     uint32_t reached = range_lo;        // one past the last splat the loop looked at (forward-only passes keep no last_useful)
     uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
@@ -324,12 +296,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
         reached = batch_start + cnt;
-#if defined(BH_K16_PROBE) && BH_K16_PROBE == 2   // measurement-only (wrong results): batches are staged (loads, LDS, barriers) but not blended
-        const uint32_t cnt_blend = s_splat[0] == 123.456f ? cnt : 0u;
-#else
-        const uint32_t cnt_blend = cnt;
-#endif
-        for (uint32_t t = 0; t < cnt_blend; ++t) {
+        for (uint32_t t = 0; t < cnt; ++t) {
             const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut
@@ -403,7 +370,13 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         if (lane == 0) {
             if (BWD_INFO) tile_offsets[tile * 2 + 1] = last_useful;
             atomicAdd(sl.unsat_count, 1u);
-            if (sl.gate_host) *reinterpret_cast<volatile uint32_t*>(sl.gate_host) = 1u;
+            if (sl.gate_host) {
+                // system-scope release: the host learns that the blend is done from a tag ANOTHER kernel stores (the loss kernel
+                // queued behind this one), possibly from another XCD — this word has to be visible to the host before that tag can be
+                // (parked tiles are rare: the fence costs nothing)
+                *reinterpret_cast<volatile uint32_t*>(sl.gate_host) = 1u;
+                __threadfence_system();
+            }
             if (sl.live_bands) {   // where the live tiles are: the far pass walks only splats whose box reaches these bands
                 const uint32_t ttx = tile % u.tile_bw, tty = tile / u.tile_bw;
                 atomicOr(&sl.live_bands[0], 1u << ((ttx * 32u) / u.tile_bw));
@@ -413,9 +386,6 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
         return;
     }
 
-#if defined(BH_K16_PROBE) && BH_K16_PROBE == 4   // measurement-only: probe 1 without the image stores
-    if (tr[0] != 123.456f) goto after_image;
-#endif
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
@@ -437,23 +407,7 @@ __global__ __launch_bounds__(64) BH_FWD_ATTR void rasterize_kernel(RasterUniform
             }
         }
     }
-#if defined(BH_K16_PROBE) && BH_K16_PROBE == 4
-after_image:
-#endif
-#if defined(BH_K16_PROBE) && BH_K16_PROBE == 5   // measurement-only: probe 1 without the tile's bookkeeping (cut, work, list end, work class)
-    if (tr[0] != 123.456f) return;
-#endif
-#ifdef BH_K16_TRACE
-    if (lane == 0 && blockIdx.x < 65536u) {
-        uint32_t hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* tr = &g_k16_trace[(size_t)blockIdx.x * 4];
-        tr[0] = trace_t0; tr[1] = wall_clock64(); tr[2] = ((unsigned long long)xcc << 32) | hwid; tr[3] = ((unsigned long long)tile << 32) | (last_useful - range_lo);
-    }
-#endif
-    if (lane == 0 && half == 0u) {
+    if (lane == 0) {
         if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
         uint32_t work = (BWD_INFO ? last_useful : reached) - range_lo;
         uint32_t listed = range_hi - range_lo;
@@ -563,9 +517,6 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;
     uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     if (sl.order && sl.order_mode == 2u) nblocks = (((u.num_tiles + 7u) / 8u + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
-#ifdef BH_K16_HALF
-    nblocks *= 2u;
-#endif
     const dim3 grid(nblocks);
     if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
@@ -627,18 +578,17 @@ BH_DEV float row_allreduce(float x) {
 // within an ulp of a threshold takes the other branch, and at 1 M splats / 1080p the conic gradient of one splat came out
 // 2.2e-4 * max|g| off the CPU checker (far pixels carry dx^2), beyond the 1e-4 the gradients are specified to.
 BH_DEV float blend_exp_bwd(float x) {
-#ifdef BH_BWD_HW_EXP
-    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-#else
     return exp_blend(x);
-#endif
 }
 
-#ifndef BH_BWD_WAVES
-#define BH_BWD_WAVES 3
-#endif
-template <bool SMOOTH>
-__global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+constexpr int BWD_WAVES = 3;   // waves per SIMD the backward is compiled for (four cost nothing and bought nothing: profiles/EXPERIMENTS.md)
+// REFINE = false: the refine weight (…:340-349: a per-pixel norm — two fmas, a quarter-rate v_sqrt, an fma per contributing
+// pixel-quadrant, a third of the gradient block — and the two per-pixel registers its 1/A factors live in) is left out: its one
+// consumer, refine()'s growth selection, stops reading it at growth_stop_iter (train.rs:589-614), i.e. for the second half of a
+// default training run.  bh_train_step selects it from BhTrainConfig.growth_stop_iter; bh_render_backward* always compute it.
+// The nine other sums are bit-identical either way (same instructions in the same order).
+template <bool SMOOTH, bool REFINE>
+__global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                                const uint32_t* __restrict__ tile_offsets,
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
@@ -646,10 +596,6 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                                                                float* __restrict__ v_combined, const uint32_t* __restrict__ lpt,
                                                                const uint32_t* __restrict__ tile_offsets_far) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-#ifdef BH_BWD_LDS_PAD   // measurement-only: cap the occupancy through the block's LDS footprint (bytes)
-    __shared__ float s_pad[BH_BWD_LDS_PAD / 4];
-    if (u.num_tiles == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1.0f;
-#endif
     uint32_t local_tile;
     if (lpt) {
         // block j of XCD x takes the j-th tile of band x in descending work-class order (wave-uniform scalar code)
@@ -714,9 +660,13 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
             sS[q] = __builtin_fmaf(o.z - t_final * u.bg_b, vo.z, __builtin_fmaf(o.y - t_final * u.bg_g, vo.y, (o.x - t_final * u.bg_r) * vo.x)) - v_o_w;
             sw[q] = 1.0f;
             vox[q] = vo.x; voy[q] = vo.y; voz[q] = vo.z;
-            const float inv_fa = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
-            w2q[q] = (img_w_f * inv_fa) * (img_w_f * inv_fa);
-            h2q[q] = (img_h_f * inv_fa) * (img_h_f * inv_fa);
+            if (REFINE) {
+                const float inv_fa = 1.0f / __builtin_fmaxf(o.w, 1.0e-5f);
+                w2q[q] = (img_w_f * inv_fa) * (img_w_f * inv_fa);
+                h2q[q] = (img_h_f * inv_fa) * (img_h_f * inv_fa);
+            } else {
+                w2q[q] = h2q[q] = 0.0f;
+            }
         } else {
             sS[q] = sw[q] = 0.0f;
             vox[q] = voy[q] = voz[q] = 0.0f;
@@ -801,10 +751,12 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                         aR4 = __builtin_fmaf(uy, dyp[m], aR4);
                         aVs += v_sigma;
                         // refine weight: |(v_xy.x W, v_xy.y H)| / max(A, 1e-5), v_xy = -v_sigma conic (pixel - mean)   (…:340-349)
-                        const float ex = e_x[k] + e_y[m], ey = b_x[k] + c_y[m];
-                        // (|(W vx, H vy)| / A = sqrt((W/A)^2 vx^2 + (H/A)^2 vy^2): the per-pixel 1/A lives in w2q / h2q)
-                        const float n2 = __builtin_fmaf(h2q[q] * ey, ey, w2q[q] * (ex * ex));
-                        aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2), aRf);
+                        if (REFINE) {
+                            const float ex = e_x[k] + e_y[m], ey = b_x[k] + c_y[m];
+                            // (|(W vx, H vy)| / A = sqrt((W/A)^2 vx^2 + (H/A)^2 vy^2): the per-pixel 1/A lives in w2q / h2q)
+                            const float n2 = __builtin_fmaf(h2q[q] * ey, ey, w2q[q] * (ex * ex));
+                            aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2), aRf);
+                        }
                         // --- state update ---------------------------------------------------------
                         sS[q] = __builtin_fmaf(-vis, cv, sS[q]);
                         sw[q] = next_t;
@@ -813,21 +765,11 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 }
             }
             if (__ballot(any) != 0ull) {
-#if BH_RAW_SUMS
                 // The ten RAW sums leave as they are: the per-splat linear maps that turn them into the reference's ten gradients
                 // (conic / 1/2 factors, colour gates, -1/alpha0: ~20 issue slots incl. a quarter-rate rcp) commute with the sum over
                 // tiles, so K18 applies them ONCE per splat to the accumulated row instead of this kernel once per (splat, tile).
                 const float h0 = swap32_add(aP, aQ), h1 = swap32_add(aR2, aR3), h2 = swap32_add(aR4, aCr);
-                const float h3 = swap32_add(aCg, aCb), h4 = swap32_add(aVs, aRf);
-#else
-                const float g0 = -__builtin_fmaf(c00, aP, c01 * aQ), g1 = -__builtin_fmaf(c11, aQ, c01 * aP);
-                const float g2 = 0.5f * aR2, g4 = 0.5f * aR4;
-                const uint32_t gate = f2u(s_splat[t * SPLAT_STRIDE + 10]);
-                const float g5 = (gate & 1u) ? aCr : 0.0f, g6 = (gate & 2u) ? aCg : 0.0f, g7 = (gate & 4u) ? aCb : 0.0f;
-                const float g8 = -aVs * __builtin_amdgcn_rcpf(color_a);
-                const float h0 = swap32_add(g0, g1), h1 = swap32_add(g2, aR3), h2 = swap32_add(g4, g5);
-                const float h3 = swap32_add(g6, g7), h4 = swap32_add(g8, aRf);
-#endif
+                const float h3 = swap32_add(aCg, aCb), h4 = swap32_add(aVs, REFINE ? aRf : 0.0f);
                 const float k0 = row_allreduce(swap16_add(h0, h1));
                 const float k1 = row_allreduce(swap16_add(h2, h3));
                 const float k2 = row_allreduce(swap16_add(h4, 0.0f));
@@ -835,11 +777,7 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
                 const int comp = ri * 4 + (((rrow & 1) << 1) | (rrow >> 1));
                 const float mine = ri == 0 ? k0 : (ri == 1 ? k1 : k2);
                 const uint32_t cg = f2u(s_splat[t * SPLAT_STRIDE + 11]);
-#ifdef BH_NO_ATOMIC  // measurement-only variant
-                if (ri < 3 && comp < 10 && mine == 123.456f) v_combined[(size_t)cg * 10 + comp] = mine;
-#else
                 if (ri < 3 && comp < 10) unsafeAtomicAdd(&v_combined[(size_t)cg * 10 + comp], mine);
-#endif
                 aP = aQ = aR2 = aR3 = aR4 = aCr = aCg = aCb = aVs = aRf = 0.0f;
             }
         }
@@ -860,10 +798,21 @@ __global__ __launch_bounds__(64, BH_BWD_WAVES) void rasterize_backward_kernel(Ra
     }
 }
 
+template <bool SMOOTH, bool REFINE>
+static void launch_rasterize_backward_t(hipStream_t stream, dim3 grid, hipEvent_t ea, hipEvent_t eb, const RasterUniforms& u, const uint32_t* isect_gids,
+                                        const uint32_t* tile_offsets, const float* projected, const float* out_img, const float* v_output, float* v_combined,
+                                        const uint32_t* lpt, const uint32_t* tile_offsets_far) {
+    const dim3 block(64);
+    if (ea)   // profiling level 2 (bench.py's timed region): the launch carries its own start / stop events (context.h)
+        hipExtLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE>), grid, block, 0, stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+    else
+        hipLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+}
+
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
                               const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
-                              const uint32_t* tile_offsets_far) {
+                              const uint32_t* tile_offsets_far, bool want_refine) {
     RasterUniforms u;
     u.rcp_class_width = 1.0f;
     u.tile_bw = vu.tile_bw;
@@ -873,26 +822,16 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
     const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
-    const dim3 grid(nblocks), block(64);
-    // profiling level 2 (bench.py's timed region): the launch carries its own start / stop events (context.h)
+    const dim3 grid(nblocks);
     hipEvent_t ea = ctx->prof.ext_a, eb = ctx->prof.ext_b;
     ctx->prof.ext_a = ctx->prof.ext_b = nullptr;
-    if (ea && smooth)
-        hipExtLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else if (ea)
-        hipExtLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else if (smooth)
-        hipLaunchKernelGGL(rasterize_backward_kernel<true>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else
-        hipLaunchKernelGGL(rasterize_backward_kernel<false>, grid, block, 0, ctx->stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+    if (smooth && want_refine) launch_rasterize_backward_t<true, true>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+    else if (smooth) launch_rasterize_backward_t<true, false>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+    else if (want_refine) launch_rasterize_backward_t<false, true>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+    else launch_rasterize_backward_t<false, false>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
     BH_LAUNCH_CHECK(ctx, "rasterize_backward_kernel");
     return 0;
 }
 
 }  // namespace bh
 
-#ifdef BH_K16_TRACE
-extern "C" int bh_debug_k16_trace(unsigned long long* host_out, unsigned long long count) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(bh::g_k16_trace), count * 8, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -373,9 +373,7 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
 //     bucket start + pairs of lower tiles + pairs of the same tile owned by earlier waves + rank inside the wave's part,
 // which is the stable order.  Ranking is the scatter kernel's (wave-wide digit matching, no LDS atomics).
 // ---------------------------------------------------------------------------
-#ifndef BH_TB_WG
 #define BH_TB_WG 1024
-#endif
 constexpr int TB_WG = BH_TB_WG;   // 256 / 512 / 1024 (the first four waves hold the digit totals and the bins)
 constexpr int TB_WAVES = TB_WG / 64;
 constexpr int TB_MAXBINS = 256;   // low_bits <= 8

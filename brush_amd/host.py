@@ -7,6 +7,7 @@ as device memory.
 import ctypes as C
 import enum
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -21,11 +22,38 @@ from .parallel import (allreduce_exchange, allreduce_refine_maxima, allgather_st
 # ---------------------------------------------------------------------------
 # context
 # ---------------------------------------------------------------------------
+# The library reads no environment variable (bh_set_option is its one configuration entry point).  THIS harness — the test suite,
+# bench.py, scripts/ab.sh — still lets a developer pick an A/B path from the shell: BH_OPTIONS="key=value,key=value", and the
+# variable names earlier rounds' scripts use, translated here into options of every Context this process creates.
+_LEGACY_ENV_OPTIONS = (   # (environment variable, option key, value or None = the variable's own value)
+    ("BH_NO_LPT", "no_lpt", "1"), ("BH_GENERIC_DEPTH_SORT", "generic_depth_sort", "1"), ("BH_FORCE_PG", "force_exchange", "1"),
+    ("BH_TRAIN_ZERO_GRADS", "zero_grads", "1"), ("BH_CUT_MIN_PAIRS", "cut_min_pairs", None), ("BH_CUT_SORT_ALL", "cut_sort_all", "1"),
+    ("BH_NO_VIEW_HASH", "no_view_hash", "1"), ("BH_CUT_MARGIN_FIXED", "cut_margin_fixed", "1"), ("BH_CUT_CTRL", "cut_ctrl", None),
+    ("BH_READBACK_COPY", "readback_copy", "1"), ("BH_EVENT_WAITS", "event_waits", "1"), ("BH_K16_ORDER", "k16_order", None),
+    ("BH_CUT_MARGIN_PCT", "cut_margin_pct", None), ("BH_UPDATE_EARLY", "update_early", "1"), ("BH_UPDATE_NO_DORMANT", "no_dormant", "1"),
+    ("BH_K5_EXACT_SPW", "k5_exact_spw", None), ("BH_TILE_SORT_LSD", "tile_sort", "lsd"), ("BH_LOSS_BANDS", "loss_bands", None),
+    ("BH_UPDATE_ROWS", "update_rows", None), ("BH_SORT_KPT", "sort_kpt", None),
+)
+
+
+def options_from_environment(env=None):
+    """[(key, value)] a developer asked for through the shell (see above); applied by Context.__init__."""
+    env = os.environ if env is None else env
+    out = []
+    for var, key, val in _LEGACY_ENV_OPTIONS:
+        if var in env:
+            out.append((key, env[var] if val is None else val))
+    for item in filter(None, (x.strip() for x in env.get("BH_OPTIONS", "").split(","))):
+        k, _, v = item.partition("=")
+        out.append((k.strip(), v.strip()))
+    return out
+
+
 class Context:
     """One bh_ctx: a HIP stream + scratch arena. Single-threaded by contract
     (brush-async/src/lib.rs:1-17); make one per thread / per GPU."""
 
-    def __init__(self, device=None, use_torch_stream=True, lib=None):
+    def __init__(self, device=None, use_torch_stream=True, lib=None, options=None):
         # lib: tests only — the fault-injection build (_ffi.load_test_hooks()); everything a Context does goes through self.lib
         self.lib = lib if lib is not None else _ffi.load()
         if not torch.cuda.is_available():
@@ -41,6 +69,16 @@ class Context:
         if not self._h:
             raise BrushHipError("bh_create failed on %s" % self.device)
         self._h = C.c_void_p(self._h)
+        for k, v in options_from_environment() + list((options or {}).items()):
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        """bh_set_option: select one of the library's alternative paths (same results; A/B measurements and their tests)."""
+        self.check(self.lib.bh_set_option(self._h, str(key).encode(), str(value).encode()))
+
+    def options(self):
+        """{key: help} of every option this build knows (bh_option_name / bh_option_help)."""
+        return {self.lib.bh_option_name(i).decode(): self.lib.bh_option_help(i).decode() for i in range(self.lib.bh_option_count())}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -120,6 +158,10 @@ class Context:
     def set_list_cut_threshold(self, min_pairs: int):
         """bh_set_list_cut_threshold: frames with fewer intersections than this keep complete lists (default 1.5 M)."""
         self.check(self.lib.bh_set_list_cut_threshold(self._h, int(min_pairs)))
+
+    def view_table_count(self):
+        """bh_view_table_count: per-view tables the ctx holds (diagnostics)."""
+        return int(self.lib.bh_view_table_count(self._h))
 
     def forget_views(self):
         """bh_forget_views: drop the per-view tile tables (after loading another scene)."""
@@ -1141,6 +1183,7 @@ class SplatTrainer:
         cfg.median_scene_scale = self.median_scene_scale
         cfg.render_mip = 1 if (c.render_mip or splats.render_mip) else 0
         cfg.exact_lists = 1 if getattr(c, "exact_lists", False) else 0
+        cfg.growth_stop_iter = int(c.growth_stop_iter)   # from that step on nobody reads the refine weight (train.rs:589-614): the step stops computing it
         s = self.state
         st = _ffi.BhTrainState()
         st.n, st.sh_degree = splats.num_splats(), splats.sh_degree()

@@ -153,7 +153,7 @@ typedef struct BhRenderOut {
  * built against another revision would be overrun (BhRenderOut, BhTrainBatch and BhTrainConfig have grown).  A binding
  * checks once, at load time: bh_abi_version() == the BH_ABI_VERSION it was written against, and bh_struct_size(i) == the
  * size of its own mirror of struct i (brush_amd/_ffi.py and include/brush_hip.hpp do; INTEGRATION.md shows the Rust side). */
-#define BH_ABI_VERSION 6u
+#define BH_ABI_VERSION 7u
 enum {
     BH_STRUCT_CAMERA = 0, BH_STRUCT_RENDER_OUT, BH_STRUCT_LOSS_CONFIG, BH_STRUCT_TRAIN_CONFIG, BH_STRUCT_TRAIN_STATE,
     BH_STRUCT_TRAIN_BATCH, BH_STRUCT_TRAIN_STATS, BH_STRUCT_REFINE_CONFIG, BH_STRUCT_REFINE_STATS, BH_STRUCT_PLY_INFO,
@@ -171,6 +171,20 @@ void bh_destroy(bh_ctx* ctx);
 const char* bh_last_error(bh_ctx* ctx); /* host string, valid until the next call */
 int bh_sync(bh_ctx* ctx);
 const char* bh_version(void);
+
+/* ---- options ----------------------------------------------------------------- */
+/* The library reads NO environment variable.  Everything earlier revisions took from BH_* variables at bh_create is one key of
+ * this setter (value as text; BH_ERR_INVALID_ARG for an unknown key or a value out of range).  Options choose between paths that
+ * produce the SAME results — A/B measurements and the tests of the alternative paths — never between results:
+ *   cut_min_pairs u32 | cut_margin_pct 0..10000 | cut_margin_fixed 0|1 | cut_ctrl up:down:floor:gap_exp | cut_sort_all 0|1 |
+ *   auto_exact_share 0..1 | no_view_hash 0|1 | k16_order 0|1|2 | k5_exact_spw 16|32|64 | no_lpt 0|1 | generic_depth_sort 0|1 |
+ *   tile_sort auto|bucket|lsd | event_waits 0|1 | readback_copy 0|1 | force_exchange 0|1 | zero_grads 0|1 | loss_bands 0|1 |
+ *   update_rows 0|64|128|256 | update_early 0|1 | no_dormant 0|1 | sort_kpt 0|4|8|16 | grad_allreduce ring|direct
+ * bh_option_count / bh_option_name / bh_option_help enumerate them with one line of documentation each (host strings). */
+int bh_set_option(bh_ctx* ctx, const char* key /*host*/, const char* value /*host*/);
+int bh_option_count(void);
+const char* bh_option_name(int index);
+const char* bh_option_help(int index);
 
 /* ---- camera (host only) --------------------------------------------------- */
 /* pos[3], rot_xyzw[4] (glam order), fov in radians (f64 like camera.rs), centre in uv. */
@@ -223,14 +237,17 @@ int bh_set_view_id(bh_ctx* ctx, uint32_t view_id);
 int bh_forget_views(bh_ctx* ctx);
 /* Per-tile cuts pay when there are lists to shorten: a view whose last frame had fewer than min_pairs intersections keeps
  * complete lists (default 1 500 000: below that the near count in the projection kernel and an occasional second attempt cost more than
- * listing and sorting everything; 0 = always cut).  The environment variable BH_CUT_MIN_PAIRS sets the initial value of new
- * contexts (the test suite, whose scenes are small, sets 0). */
+ * listing and sorting everything; 0 = always cut; the test suite, whose scenes are small, sets 0).  Same as option "cut_min_pairs". */
 int bh_set_list_cut_threshold(bh_ctx* ctx, uint32_t min_pairs);
 /* share the last BH_FLAG_SLICED_LISTS forward on this ctx used (1 = it ran as one slice) */
 float bh_last_list_share(bh_ctx* ctx);
 /* number of BH_FLAG_SLICED_LISTS forwards on this ctx whose near pass did not finish the frame: second attempts with complete lists
  * (per-tile cuts) or far slices (a fixed near_share).  Diagnostics. */
 uint32_t bh_far_slices_queued(bh_ctx* ctx);
+/* per-view tables this ctx holds right now (8 bytes per tile each).  Training frames and frames that name their view always get one;
+ * a forward-only frame keyed by its camera (a viewer's free camera, an eval render) gets one only from its camera's SECOND frame on,
+ * and at most 32 such tables exist at a time: a moving camera allocates nothing.  Diagnostics. */
+uint32_t bh_view_table_count(bh_ctx* ctx);
 
 /* How many pairs the last forward on this ctx actually LISTED: compact_gid_from_isect / tile_id_from_isect hold near_pairs
  * entries sorted by tile, then far_pairs entries sorted by tile; everything behind near_pairs + far_pairs is undefined.
@@ -351,6 +368,12 @@ typedef struct BhTrainConfig {
     float median_scene_scale;     /* bounds.median_size() */
     int32_t render_mip;
     int32_t exact_lists;          /* 0 (default): the step's forward runs with BH_FLAG_SLICED_LISTS; 1: the reference's full lists */
+    /* TrainConfig::growth_stop_iter (config.rs:72, 15000).  The refine weight a step accumulates into RefineRecord::refine_weight_norm
+     * is read by ONE consumer, refine()'s growth selection, and only while iter < growth_stop_iter (train.rs:589-614).  From step
+     * number growth_stop_iter on, bh_train_step therefore runs its blend backward WITHOUT the refine weight's per-pixel norm (a
+     * third of that kernel's gradient block): refine_weight_norm then stays as refine() zeroed it; every gradient, vis_weight and
+     * max_screen_size are computed as before.  0 = always compute it (what the reference's step does). */
+    uint32_t growth_stop_iter;
 } BhTrainConfig;
 
 /* Parameters + optimizer state of one model replica, all device memory owned

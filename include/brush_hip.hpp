@@ -130,8 +130,16 @@ class Context {
     void set_list_cut_threshold(uint32_t min_pairs) const { check(bh_set_list_cut_threshold(h_, min_pairs)); }
     void set_view_id(uint32_t view_id) const { check(bh_set_view_id(h_, view_id)); }                     // sticky; 0 = keyed by the camera
     void forget_views() const { check(bh_forget_views(h_)); }                                            // after loading another scene
+    // bh_set_option: select one of the library's alternative paths (same results; the keys: bh_option_name / include/brush_hip.h)
+    void set_option(const std::string& key, const std::string& value) const { check(bh_set_option(h_, key.c_str(), value.c_str())); }
+    static std::vector<std::pair<std::string, std::string>> options() {   // (key, one line of documentation)
+        std::vector<std::pair<std::string, std::string>> out;
+        for (int i = 0; i < bh_option_count(); ++i) out.emplace_back(bh_option_name(i), bh_option_help(i));
+        return out;
+    }
     float last_list_share() const { return bh_last_list_share(h_); }
     uint32_t far_slices_queued() const { return bh_far_slices_queued(h_); }
+    uint32_t view_table_count() const { return bh_view_table_count(h_); }
     std::pair<uint32_t, uint32_t> last_list_counts() const {   // (near pairs, far pairs) of the last forward
         uint32_t a = 0, b = 0;
         check(bh_last_list_counts(h_, &a, &b));
@@ -822,6 +830,7 @@ class SplatTrainer {
         c.median_scene_scale = median_;
         c.render_mip = (cfg_.render_mip || s.render_mip) ? 1 : 0;
         c.exact_lists = cfg_.exact_lists ? 1 : 0;
+        c.growth_stop_iter = cfg_.growth_stop_iter;   // from that step on nobody reads the refine weight (train.rs:589-614)
         return c;
     }
     BhTrainState c_state(Splats& s) {

@@ -3,6 +3,8 @@
 #
 #   scripts/ab.sh build <name> "<extra hipcc flags>"            every translation unit with the flags  (e.g. -DBH_BWD_WAVES=5)
 #   scripts/ab.sh build-one <name> <unit> "<extra hipcc flags>"  only <unit>.hip differs from the in-tree build (e.g. rasterize)
+#   scripts/ab.sh build-probe <name> "<extra hipcc flags>"       a MEASUREMENT build: the probe sites (-DBH_K16_PROBE=.., -DBH_NO_ATOMIC, ...; wrong
+#        results by design) are NOT in the shipping sources — probes/probe_sites.patch re-inserts them into a scratch copy, which is built
 #        -> brush_amd/variants/libbrush_hip_<name>.so  (git-ignored; travels to the GPU box; selected with BRUSH_HIP_LIB=...)
 #   scripts/ab.sh stages <variant|default|ENV=VALUE> ...          per-stage times of the headline bench (50 steps) for each argument:
 #        a variant name, `default` (the in-tree build) or an environment setting such as BH_SORT_KPT=8 / BH_NO_LPT=1
@@ -27,6 +29,14 @@ case "$verb" in
     for f in $UNITS; do /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $OUT/obj_$NAME/$f.o & done; wait
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OUT/obj_$NAME/*.o -ldl -o $OUT/libbrush_hip_$NAME.so
     rm -rf $OUT/obj_$NAME; echo built $OUT/libbrush_hip_$NAME.so ;;
+  build-probe)
+    NAME=$1; EXTRA=$2; TMP=$(mktemp -d); mkdir -p $TMP/brush_amd $TMP/include $OUT
+    cp -r $ROOT/brush_amd/csrc $TMP/brush_amd/; cp $ROOT/include/*.h $TMP/include/; rm -f $TMP/brush_amd/csrc/*.o
+    (cd $TMP && patch -p1 -s -F3 < $ROOT/probes/probe_sites.patch) || { echo "probes/probe_sites.patch no longer applies: rebase it on the current kernels"; exit 1; }
+    cd $TMP/brush_amd/csrc
+    for f in $UNITS; do /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $f.o & done; wait
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -ldl -o $OUT/libbrush_hip_$NAME.so
+    rm -rf $TMP; echo built $OUT/libbrush_hip_$NAME.so ;;
   build-one)
     NAME=$1; UNIT=$2; EXTRA=$3; mkdir -p $OUT; cd $ROOT/brush_amd/csrc; make -s -j8 >/dev/null
     /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $UNIT.hip -o $OUT/${UNIT}_$NAME.o

@@ -415,6 +415,15 @@ static void test_loader_controls_comm(const bh::Context& ctx) {
     bh::SplatTrainer trainer(ctx, cfg, 3.0f);
     trainer.set_seed(0xB5EED);
     ctx.set_list_cut_threshold(0);   // (a small scene: let the per-tile cuts engage at all)
+    // bh_set_option: the one configuration entry point (the library reads no environment variable)
+    ctx.set_option("event_waits", "1");   // the host's mid-step waits through events: same results
+    {
+        bool threw = false;
+        try { ctx.set_option("no_such_option", "1"); } catch (const bh::Error& e) { threw = e.code == BH_ERR_INVALID_ARG; }
+        bool threw2 = false;
+        try { ctx.set_option("k16_order", "7"); } catch (const bh::Error& e) { threw2 = e.code == BH_ERR_INVALID_ARG; }
+        CHECK(threw && threw2 && bh::Context::options().size() >= 20, "set_option rejects unknown keys / bad values; %zu keys documented", bh::Context::options().size());
+    }
     ctx.profile(1);
     bool pixels_ok = true, finite = true;
     for (uint32_t epoch = 0; epoch < 3; ++epoch) {

@@ -46,6 +46,53 @@ def test_shipping_library_carries_no_test_hooks():
     assert b"BH_TEST_FAIL_LOSS_AT" in open(_ffi.TEST_HOOKS_LIB_PATH, "rb").read()
 
 
+def test_shipping_library_reads_no_environment_variable():
+    """configuration is bh_set_option; the product does not even import getenv (the test-hook build does, for
+    its two fault-injection variables)."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    from brush_amd import _ffi
+    und = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    und_th = subprocess.run(["nm", "-D", "--undefined-only", _ffi.TEST_HOOKS_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in und_th
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    for var in (b"BH_CUT_MIN_PAIRS", b"BH_EVENT_WAITS", b"BH_K16_ORDER", b"BH_FORCE_PG", b"BH_TILE_SORT_LSD"):
+        assert var not in blob
+
+
+def test_shipping_sources_carry_no_probe_sites():
+    """the measurement-only variants (wrong results by design) live in probes/probe_sites.patch, not one -D
+    away inside the shipping kernels: the only preprocessor conditional left in brush_amd/csrc is the test-hook gate."""
+    import glob
+    bad = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "brush_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "brush_amd", "csrc", "*.h"))):
+        for i, line in enumerate(open(path), 1):
+            m = re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b(.*)", line)
+            if m and "BH_TEST_HOOKS" not in m.group(2) and not re.match(r"\s*#\s*ifndef\s+BRUSH_\w+_H\b", line):
+                bad.append("%s:%d: %s" % (os.path.basename(path), i, line.strip()))
+            if "measurement-only" in line or re.search(r"\bBH_\w*PROBE\b", line):
+                bad.append("%s:%d: %s" % (os.path.basename(path), i, line.strip()))
+    assert not bad, "\n".join(bad)
+    flags = open(os.path.join(ROOT, "brush_amd", "csrc", "Makefile")).read()
+    assert "PROBE" not in flags and "-DBH_" not in flags.replace("-DBH_TEST_HOOKS", "")
+    assert os.path.exists(os.path.join(ROOT, "probes", "probe_sites.patch"))
+
+
+def test_option_keys_are_documented_in_the_header():
+    import __graft_entry__ as g
+    g.build()
+    from brush_amd import _ffi
+    lib = _ffi.load()
+    header = open(os.path.join(ROOT, "include", "brush_hip.h")).read()
+    names = [lib.bh_option_name(i).decode() for i in range(lib.bh_option_count())]
+    assert len(names) == len(set(names)) >= 20 and lib.bh_option_name(len(names)) is None
+    for k in names:
+        assert re.search(r"\b%s\b" % k, header), "option %s missing from include/brush_hip.h" % k
+        assert len(lib.bh_option_help(names.index(k))) > 10
+
+
 def test_camera_setup_matches_oracle_host_math():
     """bh_camera_setup (product host code) vs the oracle's independent restatement of camera.rs."""
     import numpy as np
