@@ -257,6 +257,9 @@ def main():
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse",
                     help="N>1 (cameras and tiles): 'sparse' = mask-keyed exchange (visible flags, then only the gradient rows of splats some rank "
                          "saw; dense fallback above half of the scene), 'dense' = one all-reduce of the whole exchange buffer")
+    ap.add_argument("--allreduce", choices=["ring", "direct"], default="ring",
+                    help="N>1: how long messages of the gradient exchange are summed: 'ring' = ncclAllReduce / all_reduce, 'direct' = reduce-scatter + "
+                         "all-gather over grouped send / recv (every pair of GPUs of the node has its own xGMI link)")
     ap.add_argument("--feed", choices=["resident", "loader"], default="resident",
                     help="'resident' (the headline): the GT batch is already in HBM when the timed region starts; 'loader': every step "
                          "takes a fresh 1080p RGB8 host image through SceneLoader/BatchUploader (pinned ring + copy stream + device "
@@ -375,10 +378,15 @@ def main():
             cams.append(ba.Camera(position=pos, rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"]))
         return cams
 
-    def measure(workload, steps, warmup, with_stages, sh_degree=None, nviews=None, windows=1):
+    def measure(workload, steps, warmup, with_stages, sh_degree=None, nviews=None, windows=1, exchange=None, algo=None, growth_stop_iter=None):
         """Time `windows` windows of `steps` train steps of `workload`, cycling through `nviews` views; returns a dict of raw
-        measurements (rank-local; dt = the median window)."""
+        measurements (rank-local; dt = the median window).  exchange / algo: override --exchange / --allreduce (the N > 1 A/B);
+        growth_stop_iter: TrainConfig.growth_stop_iter (1 = every step runs the blend backward without the refine weight)."""
         sh_degree = args.sh_degree if sh_degree is None else sh_degree
+        exchange = exchange or args.exchange
+        algo = algo or args.allreduce
+        if native:
+            ctx.set_option("grad_allreduce", algo)
         nviews = max(1, args.views if nviews is None else nviews)
         scene, w, h = synth.config_scene(workload, sh_degree, n=args.splats or None)
         n = scene["transforms"].shape[0]
@@ -394,8 +402,11 @@ def main():
             batches.append(ba.SceneBatch(gt, c.uniforms((w, h)), view_id=(0 if args.no_view_ids else v + 1)))
         batch = batches[0]
         # seed: the reference's default step draws the mean noise and jitters the background every step
-        trainer = ba.SplatTrainer(ba.TrainConfig(exact_lists=args.lists == "exact"), median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
-                                  native_comm=native, sparse_exchange=args.exchange == "sparse", seed=None if args.no_noise else 0xB5EED)
+        tcfg = ba.TrainConfig(exact_lists=args.lists == "exact")
+        if growth_stop_iter is not None:
+            tcfg.growth_stop_iter = int(growth_stop_iter)
+        trainer = ba.SplatTrainer(tcfg, median_scene_scale=5.0, process_group=None if native else pg, ctx=ctx, partition=args.parallel,
+                                  native_comm=native, sparse_exchange=exchange == "sparse", seed=None if args.no_noise else 0xB5EED, allreduce=algo)
         loader = None
         if args.feed == "loader":
             # the SAME views and ground-truth images as the resident feed (so that the two rates differ by the feed alone), as decoded
@@ -522,6 +533,8 @@ def main():
         ni_mean = int(round(sum(v["num_intersections"] for v in per_view) / len(per_view)))
         if loader is not None:
             loader.close()
+        if native:
+            ctx.set_option("grad_allreduce", args.allreduce)
         fwd_only = None
         if with_stages == "forward_only":
             # RasterPass::Forward (BASELINE.json configs[1]; crates/brush-bench-test/src/benches.rs:222-243): projection + sorts + lists +
@@ -830,6 +843,34 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    exchange_stages, exchange_ab = None, None
+    if pg is not None and not args.no_extra:
+        # The first multi-GPU run has to explain itself: (a) what the exchange stages cost per step on every rank
+        # (HIP events around FlagExchange / GradExchange / ImageExchange, 10 steps from the same initial state), (b) a 10-step A/B of
+        # the exchange modes and of the two all-reduce algorithms (every figure the MAX over the ranks, like the headline)
+        import torch.distributed as dist
+        mp_ = measure(args.workload, 10, 3, True, windows=1)
+        mine_st = {k: round(ms / max(c, 1) * 1e3, 2) for k, (ms, c) in mp_["stages"].items() if k in ("FlagExchange", "GradExchange", "ImageExchange", "RasterizeBackwards", "OptimizerStep")}
+        mine_st["rank"] = rank
+        exchange_stages = [None] * world
+        dist.all_gather_object(exchange_stages, mine_st)
+        exchange_ab = {"steps": 10, "what": "ms per step (max over ranks), 10 steps after 3 warm-up steps from the same initial state, per exchange mode x all-reduce algorithm"}
+        for ex_mode in ("sparse", "dense"):
+            for alg in ("ring", "direct"):
+                ma = measure(args.workload, 10, 3, False, windows=1, exchange=ex_mode, algo=alg)
+                exchange_ab["%s_%s" % (ex_mode, alg)] = round(ma["dt"] / 10 * 1e3, 4)
+
+    late = None
+    if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats and args.sh_degree == 0:
+        # the second half of a default training run (iter >= growth_stop_iter = 15000 of 30000, config.rs:72): nobody reads the refine
+        # weight any more (train.rs:589-614), bh_train_step runs the blend backward without it.  Same protocol as the headline.
+        ml = measure(args.workload, args.steps, args.warmup, True, windows=1, growth_stop_iter=1)
+        k17 = ml["stages"].get("RasterizeBackwards", (0.0, 0))
+        late = {"what": "the headline's steps with TrainConfig.growth_stop_iter = 1: every step's blend backward runs without the refine weight "
+                        "(what steps >= growth_stop_iter of a training run execute; crates/brush-train/src/train.rs:589-614, config.rs:72)",
+                "ms_per_step": round(ml["dt"] / args.steps * 1e3, 4), "views_per_s": round(args.steps / ml["dt"], 2),
+                "k17_ms_hip_events_around_the_stage": round(k17[0] / max(k17[1], 1), 4)}
+
     if rank == 0:
         steps = args.steps
         dt, st = m["dt"], m["stats"]
@@ -937,8 +978,12 @@ def main():
                        "stochastic_terms": "off (--no-noise)" if args.no_noise else "mean noise drawn on the device (Philox-4x32-10, fused into the update launch) + background jitter, as the reference's default step",
                        "parallelism": ("tiles%d: one view split by strips of tile rows (strip-wise loss with 21-px halo exchange + mask-keyed all-reduce of gradients)" % world if tile_mode else
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
-            "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "rows_last_step": st.exchange_rows, "rows_total": n,
-                          "per_rank": per_rank, "selfcheck": selfcheck} if pg is not None else None),
+            "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "algo": args.allreduce, "rows_last_step": st.exchange_rows, "rows_total": n,
+                          "per_rank": per_rank, "selfcheck": selfcheck,
+                          "stages_us": exchange_stages, "stages_us_are": "us per step on every rank, HIP events around the stage (10 steps): FlagExchange = visible-flag sum + union "
+                                                                         "listing (on the communicator's side stream beside the backward), GradExchange = row gather + all-reduce + scatter "
+                                                                         "(or the dense all-reduce), ImageExchange = the strips' halos (tiles only)",
+                          "ab": exchange_ab} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "fwd_bwd_source": fwd_src,
@@ -959,6 +1004,8 @@ def main():
             out["non_saturating"] = extra
         if sh3 is not None:
             out["sh3"] = sh3
+        if late is not None:
+            out["after_growth_stop"] = late
         if m.get("forward_only"):
             out["forward_only"] = {"workload": "%s, RasterPass::Forward (BASELINE.json configs[1]): packed rgba8 image, no backward state; ms per render call incl. its count readback" % args.workload,
                                    "ms_exact_lists": m["forward_only"]["exact_lists"], "ms_sliced_lists": m["forward_only"]["sliced_lists"],

@@ -52,19 +52,31 @@ int check_hip(bh_ctx* ctx, hipError_t e, const char* what) {
 // Host wait for a tag word a kernel stores into pinned host memory (instead of an event behind the kernel: the barrier packet an
 // event costs is ~6 us of bubble in front of the NEXT kernel).  Spins; every 16 k polls it asks the stream whether it is still
 // alive, so a device fault ends in an error instead of a hang.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
 static int wait_host_tag(bh_ctx* ctx, const volatile uint32_t* word, uint32_t want, const char* what) {
-    for (uint64_t it = 1;; ++it) {
+    // Spins for at most ~2 ms (a healthy step delivers its tag within tens of microseconds), then stops burning the core: an event
+    // behind everything queued so far and a blocking wait on it — the tag's kernel is in front of that event, so afterwards the tag
+    // is there, or its kernel was never launched (an error, not a hang).
+    for (uint64_t it = 1; it < (1ull << 21); ++it) {
         if (*word == want) return 0;
         if ((it & 0x3FFFull) == 0ull) {
             const hipError_t q = hipStreamQuery(ctx->stream);
-            if (q == hipSuccess) {   // everything queued has run: the tag must be there
-                if (*word == want) return 0;
-                return set_error(ctx, BH_ERR_STATE, std::string(what) + ": the kernel that signals the host never stored its tag");
-            }
+            if (q == hipSuccess) break;   // everything queued has run: the tag must be there (checked below)
             if (q != hipErrorNotReady) return check_hip(ctx, q, what);
         }
-        __builtin_ia32_pause();
+        cpu_relax();
     }
+    if (*word == want) return 0;
+    BH_HIP(ctx, hipEventRecord(ctx->readback_ev, ctx->stream));
+    BH_HIP(ctx, hipEventSynchronize(ctx->readback_ev));
+    if (*word == want) return 0;
+    return set_error(ctx, BH_ERR_STATE, std::string(what) + ": the kernel that signals the host never stored its tag");
 }
 
 void* ensure(bh_ctx* ctx, Slot s, size_t bytes) {
@@ -876,8 +888,13 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             // (complete lists by request)
         } else if (!allow_cut) {
             // (the forecast has just failed: this attempt re-seeds the table)
-        } else if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) cut_active = true;
-        else if (view->exact_frames) view->exact_frames--;
+        } else if (view->seeded && view->exact_frames == 0u && view->last_pairs >= ctx->cut_min_pairs) {
+            // (a view whose last cut frame listed nearly everything — a scene whose tiles no longer saturate early: a converging
+            //  training run ends up there, bench.py train_loop — gains nothing from its cuts and pays for them: the near count in K1,
+            //  and a whole second frame whenever a forecast fails.  Such a view renders complete lists, and tries a cut again later)
+            if (view->complete_frames) view->complete_frames--;
+            else cut_active = true;
+        } else if (view->exact_frames) view->exact_frames--;
     }
     uint32_t* near_counts = nullptr;
     uint32_t* tile_order = nullptr;
@@ -1032,7 +1049,13 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             sliced = true;
             budget = near_total;
             ctx->last_slice_share = (float)((double)near_total / (double)ni);
+            view->last_share = ctx->last_slice_share;
+            if (ctx->auto_exact_share > 0.0f && view->last_share > ctx->auto_exact_share) view->complete_frames = AUTO_EXACT_FRAMES;
         } else {
+            if (cut_active) {   // (the cut removed nothing at all)
+                view->last_share = 1.0f;
+                if (ctx->auto_exact_share > 0.0f) view->complete_frames = AUTO_EXACT_FRAMES;
+            }
             // no history for this view yet (or its forecast keeps failing, or it cut nothing): complete lists; the blend
             // kernel seeds / refreshes the view's table
             ctx->last_slice_share = 1.0f;
@@ -1699,7 +1722,8 @@ static int train_step_impl(bh_ctx* ctx, const BhTrainConfig* cfg, BhTrainState* 
     // communicator on the ctx, a proper tile-row window in the camera — the library exchanges the halos itself (comm.hip)
     const ViewUniforms win_u = make_uniforms(batch->camera);
     const bool window_partial = win_u.tile_y0 != 0u || win_u.tile_y1 != win_u.tile_bh;
-    const bool native_tiles = !batch->image_hook && window_partial && ctx->comm != nullptr && !hook;
+    // (a one-rank communicator has no neighbours: a window without strip_loss then runs as it does without a communicator)
+    const bool native_tiles = !batch->image_hook && window_partial && ctx->comm != nullptr && !hook && (batch->strip_loss || ctx->comm_world > 1);
     if (native_tiles && !batch->strip_loss)
         return set_error(ctx, BH_ERR_INVALID_ARG, "train_step: a tile-row window without an image hook needs strip_loss = 1 (the library exchanges the strips' halos, not whole frames)");
     const bool tile_mode = batch->image_hook != nullptr || native_tiles;

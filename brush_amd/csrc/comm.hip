@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -84,9 +85,84 @@ static int rccl_check(bh_ctx* ctx, ncclResult_t rc, const char* what) {
 __global__ void break_allreduce_kernel(float* buf) { buf[0] += 1.0f; }
 #endif
 
+// ---- direct all-reduce: reduce-scatter + all-gather over grouped send / recv ------------------------------------------------------
+// The 8 GPUs of an MI355X node are FULLY connected (7 xGMI links per GPU): every rank can talk to every other at
+// the same time.  The buffer is cut into `world` chunks, rank r owns chunk r:
+//   1. every rank sends chunk p of its buffer to rank p and receives the other ranks' versions of its own chunk (one grouped
+//      exchange: world - 1 sends and receives in flight at once, one per link);
+//   2. one kernel adds the world versions up IN RANK ORDER (the result of a chunk is computed once, by its owner: replicas stay
+//      bit-identical whatever the transport does);
+//   3. every rank sends its finished chunk to everybody and receives theirs in place (the second grouped exchange).
+// Each link carries count / world floats per phase.  Selectable beside ncclAllReduce (bh_set_option grad_allreduce = direct) for
+// the dense gradient block; MAX reductions and short messages stay with ncclAllReduce.
+__global__ __launch_bounds__(256) void reduce_versions_kernel(float* __restrict__ own, const float* __restrict__ others, uint32_t len, uint32_t stride,
+                                                             int rank, int world) {
+    // others: [world - 1][stride], the version of rank p at slot p - (p > rank)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < len; i += gridDim.x * 256u) {
+        float acc = 0.0f;
+        for (int p = 0; p < world; ++p) acc += p == rank ? own[i] : others[(size_t)(p - (p > rank ? 1 : 0)) * stride + i];
+        own[i] = acc;
+    }
+}
+
+// chunk c of `count` floats cut for `world` ranks: [begin, begin + len), chunk sizes a multiple of 4 floats (16-byte aligned pieces)
+void direct_chunk(uint64_t count, int world, int c, uint64_t* begin, uint64_t* len) {
+    const uint64_t per = ((count + (uint64_t)world - 1) / (uint64_t)world + 3ull) & ~3ull;
+    const uint64_t b = (uint64_t)c * per;
+    *begin = b < count ? b : count;
+    *len = b < count ? ((count - b) < per ? (count - b) : per) : 0ull;
+}
+
+static int comm_allreduce_direct(bh_ctx* ctx, float* buf, uint64_t count) {
+    RcclApi& a = rccl();
+    const int W = ctx->comm_world, R = ctx->comm_rank;
+    uint64_t my_b = 0, my_n = 0, b0 = 0, per = 0;
+    direct_chunk(count, W, R, &my_b, &my_n);
+    direct_chunk(count, W, 0, &b0, &per);
+    auto* scratch = (float*)ensure(ctx, SLOT_COMM_SCRATCH, (size_t)(W - 1) * per * 4);
+    if (!scratch) return BH_ERR_OOM;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    // 1. reduce-scatter
+    BH_TRY(rccl_check(ctx, a.GroupStart(), "ncclGroupStart"));
+    int rc = 0;
+    for (int p = 0; p < W && rc == 0; ++p) {
+        if (p == R) continue;
+        uint64_t pb = 0, pn = 0;
+        direct_chunk(count, W, p, &pb, &pn);
+        if (pn) rc = rccl_check(ctx, a.Send(buf + pb, (size_t)pn, ncclFloat32, p, comm, ctx->stream), "ncclSend");
+        if (rc == 0 && my_n) rc = rccl_check(ctx, a.Recv(scratch + (size_t)(p - (p > R ? 1 : 0)) * per, (size_t)my_n, ncclFloat32, p, comm, ctx->stream), "ncclRecv");
+    }
+    int rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
+    if (rc || rc2) return rc ? rc : rc2;
+    // 2. the owner's sum, in rank order
+    if (my_n) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((my_n + 255) / 256, 2048);
+        hipLaunchKernelGGL(reduce_versions_kernel, dim3(blocks), dim3(256), 0, ctx->stream, buf + my_b, scratch, (uint32_t)my_n, (uint32_t)per, R, W);
+        BH_LAUNCH_CHECK(ctx, "reduce_versions_kernel");
+    }
+    // 3. all-gather, in place
+    BH_TRY(rccl_check(ctx, a.GroupStart(), "ncclGroupStart"));
+    for (int p = 0; p < W && rc == 0; ++p) {
+        if (p == R) continue;
+        uint64_t pb = 0, pn = 0;
+        direct_chunk(count, W, p, &pb, &pn);
+        if (my_n) rc = rccl_check(ctx, a.Send(buf + my_b, (size_t)my_n, ncclFloat32, p, comm, ctx->stream), "ncclSend");
+        if (rc == 0 && pn) rc = rccl_check(ctx, a.Recv(buf + pb, (size_t)pn, ncclFloat32, p, comm, ctx->stream), "ncclRecv");
+    }
+    rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
+}
+
 int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op) {
     if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
     if (count == 0) return 0;
+    if (ctx->knob_direct_allreduce && !max_op && ctx->comm_world > 1 && count >= DIRECT_ALLREDUCE_MIN_FLOATS && count / (uint64_t)ctx->comm_world < 0xFFFFFFF0ull) {
+        int rc = comm_allreduce_direct(ctx, buf, count);
+#ifdef BH_TEST_HOOKS
+        if (rc == 0 && ctx->knob_break_allreduce) hipLaunchKernelGGL(break_allreduce_kernel, dim3(1), dim3(1), 0, ctx->stream, buf);
+#endif
+        return rc;
+    }
     // (a one-rank communicator goes through RCCL like any other: the binding is the same code at every world size)
     int rc = rccl_check(ctx, rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, max_op ? ncclMax : ncclSum, (ncclComm_t)ctx->comm, ctx->stream),
                         "ncclAllReduce");
@@ -103,15 +179,18 @@ int comm_allreduce(bh_ctx* ctx, float* buf, uint64_t count, bool max_op) {
 int strip_halo_plan(uint32_t h, uint32_t row_begin_px, uint32_t row_end_px, int rank, int world, uint32_t halo, BhHaloOp out[4]) {
     int k = 0;
     if (row_begin_px >= row_end_px || row_end_px > h) return -1;
+    // What goes to a neighbour is what the NEIGHBOUR expects from the geometry both sides know (where the strips meet, the image
+    // height), never something that depends on this strip's own height: a rank whose strip is too short still posts messages of
+    // the sizes its neighbours wait for (and reports its error afterwards) instead of leaving them blocked in ncclRecv.
     if (rank > 0 && row_begin_px > 0) {
-        const uint32_t up = row_begin_px < halo ? row_begin_px : halo;                                    // rows [b - up, b) come from above
-        const uint32_t mine = (row_end_px - row_begin_px) < halo ? (row_end_px - row_begin_px) : halo;    // my first rows go up
+        const uint32_t up = row_begin_px < halo ? row_begin_px : halo;                    // rows [b - up, b) come from above
+        const uint32_t mine = (h - row_begin_px) < halo ? (h - row_begin_px) : halo;      // the rank above expects the rows [b, b + mine)
         out[k++] = BhHaloOp{/*send=*/1, rank - 1, row_begin_px, mine};
         out[k++] = BhHaloOp{/*send=*/0, rank - 1, row_begin_px - up, up};
     }
     if (rank < world - 1 && row_end_px < h) {
-        const uint32_t down = (h - row_end_px) < halo ? (h - row_end_px) : halo;                          // rows [e, e + down) come from below
-        const uint32_t mine = (row_end_px - row_begin_px) < halo ? (row_end_px - row_begin_px) : halo;    // my last rows go down
+        const uint32_t down = (h - row_end_px) < halo ? (h - row_end_px) : halo;          // rows [e, e + down) come from below
+        const uint32_t mine = row_end_px < halo ? row_end_px : halo;                       // the rank below expects the rows [e - mine, e)
         out[k++] = BhHaloOp{/*send=*/1, rank + 1, row_end_px - mine, mine};
         out[k++] = BhHaloOp{/*send=*/0, rank + 1, row_end_px, down};
     }
@@ -121,8 +200,9 @@ int strip_halo_plan(uint32_t h, uint32_t row_begin_px, uint32_t row_end_px, int 
 int comm_exchange_strip_halos(bh_ctx* ctx, float* img, uint32_t h, uint32_t w, uint32_t row_begin_px, uint32_t row_end_px) {
     if (!ctx->comm) return set_error(ctx, BH_ERR_STATE, "no communicator: call bh_comm_init first");
     constexpr uint32_t HALO = 21;   // one 16-px tile row + the 5-px reach of the 11-tap SSIM window (loss_fused.hip)
-    if (ctx->comm_world > 1 && row_end_px - row_begin_px < HALO)
-        return set_error(ctx, BH_ERR_INVALID_ARG, "strip-wise loss: every rank's strip must be at least 21 pixel rows tall");
+    // (a strip shorter than the halo is this rank's error — but reported AFTER the grouped exchange below, whose message sizes do
+    //  not depend on it: returning here would leave the neighbours blocked in their ncclRecv)
+    const bool too_short = ctx->comm_world > 1 && row_end_px - row_begin_px < HALO;
     BhHaloOp ops[4];
     const int k = strip_halo_plan(h, row_begin_px, row_end_px, ctx->comm_rank, ctx->comm_world, HALO, ops);
     if (k < 0) return set_error(ctx, BH_ERR_INVALID_ARG, "strip halo exchange: bad strip");
@@ -137,7 +217,9 @@ int comm_exchange_strip_halos(bh_ctx* ctx, float* img, uint32_t h, uint32_t w, u
                          : rccl_check(ctx, a.Recv(p, ops[i].rows * row, ncclFloat32, ops[i].peer, (ncclComm_t)ctx->comm, ctx->stream), "ncclRecv");
     }
     const int rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
-    return rc ? rc : rc2;
+    if (rc || rc2) return rc ? rc : rc2;
+    if (too_short) return set_error(ctx, BH_ERR_INVALID_ARG, "strip-wise loss: every rank's strip must be at least 21 pixel rows tall");
+    return 0;
 }
 
 }  // namespace bh
@@ -263,11 +345,35 @@ int bh_comm_selftest(bh_ctx* ctx) {
         const int rc2 = rccl_check(ctx, a.GroupEnd(), "ncclGroupEnd");
         if (rc == 0) rc = rc2;
     }
+    // the direct all-reduce (reduce-scatter + all-gather over grouped send / recv) against ncclAllReduce's sum, on a message long
+    // enough to be cut into chunks with a ragged tail
+    constexpr size_t ND = 70003;
+    float* dd = nullptr;
+    std::vector<float> dgot;
+    if (rc == 0 && W > 1) {
+        std::vector<float> dh(ND);
+        for (size_t i = 0; i < ND; ++i) dh[i] = (float)(R + 1) * (float)((i % 89) + 1) - (float)((i * 7 + (size_t)R) % 13);
+        rc = check_hip(ctx, hipMalloc((void**)&dd, ND * 4), "selftest hipMalloc");
+        if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(dd, dh.data(), ND * 4, hipMemcpyHostToDevice, ctx->stream), "selftest upload");
+        if (rc == 0) rc = comm_allreduce_direct(ctx, dd, ND);
+        dgot.resize(ND);
+        if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(dgot.data(), dd, ND * 4, hipMemcpyDeviceToHost, ctx->stream), "selftest download");
+    }
     std::vector<float> got(total);
     if (rc == 0) rc = check_hip(ctx, hipMemcpyAsync(got.data(), d, total * 4, hipMemcpyDeviceToHost, ctx->stream), "selftest download");
     if (rc == 0) rc = check_hip(ctx, hipStreamSynchronize(ctx->stream), "selftest sync");
     (void)hipFree(d);
+    if (dd) (void)hipFree(dd);
     if (rc != 0) return rc;
+    for (size_t i = 0; i < dgot.size(); ++i) {
+        double sref = 0.0;
+        for (int r = 0; r < W; ++r) sref += (double)((float)(r + 1) * (float)((i % 89) + 1) - (float)((i * 7 + (size_t)r) % 13));
+        if (std::fabs((double)dgot[i] - sref) > 1e-3 * (1.0 + std::fabs(sref))) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "comm_selftest: direct all-reduce (reduce-scatter + all-gather) is wrong at element %zu on rank %d of %d", i, R, W);
+            return set_error(ctx, BH_ERR_HIP, msg);
+        }
+    }
     auto pattern = [&](int r, size_t i) { return (float)(r + 1) * (float)((i % 97) + 1) - ((i & 1) ? 3.0f * (float)r : 0.0f); };
     for (size_t i = 0; i < N; ++i) {
         double s = 0.0;

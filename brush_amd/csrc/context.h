@@ -26,6 +26,8 @@ enum Slot : int {
     SLOT_SORT_VALS_A,
     SLOT_SORT_VALS_B,
     SLOT_SORT_HIST,          // [256 * nblocks] u32
+    SLOT_COMM_SCRATCH,       // direct all-reduce: the other ranks' versions of this rank's chunk (comm.hip)
+    SLOT_SORT_PARTS,         // tile sort: per part [9][bins] pair counts (sort.hip tile_parts_*)
     SLOT_SCAN_SUMS,          // block sums for the scan
     SLOT_GLOBAL_FROM_COMPACT,
     SLOT_DEPTHS_SORTED,
@@ -142,6 +144,8 @@ struct ViewState {
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
 constexpr size_t MAX_VIEW_STATES = 4096;
+constexpr uint64_t DIRECT_ALLREDUCE_MIN_FLOATS = 1u << 16;   // shorter messages are latency-bound: ncclAllReduce
+constexpr uint32_t AUTO_EXACT_FRAMES = 12;   // frames a view renders complete lists after a cut frame that listed > auto_exact_share of its pairs
 // Forward-only frames that name no view (a viewer's free camera, an eval render, a pose-optimised camera: a new hash every frame) get
 // a table only when the same camera is seen a SECOND time, and at most this many of them are kept: such frames cut nothing, the table
 // only orders their blend's tiles.
@@ -372,6 +376,8 @@ struct bh_ctx {
     bool knob_update_early = false;   // BH_UPDATE_EARLY (A/B): the update kernel's blocks of SH degree >= 1 issue all their loads up front
     uint32_t knob_update_rows = 0;    // BH_UPDATE_ROWS: 64 | 128 | 256 splats per block of the update kernel
     uint32_t knob_sort_kpt = 0;       // BH_SORT_KPT: 4 | 8 | 16 keys per thread of the radix sort
+    // the update kernel's dormant marks (sign of m2_sh, optim.hip) are trusted only on the state this ctx updated last step
+    const void* marks_m2_sh = nullptr; const void* marks_m1_t = nullptr; uint32_t marks_n = 0, marks_step = 0;
     bh::Profiler prof;
 };
 

@@ -290,7 +290,9 @@ __global__ __launch_bounds__(OPT_WG) void train_update_kernel(
         const uint64_t i = row0 + threadIdx.x;
         const float rw_raw = in_rw;
         const bool written = !masked || (f2u(rw_raw) >> 31) != 0u;
-        const bool dormant = dorm_ok && !written && f2u(in_m2sh) == 0x80000000u && in_vis == 0.0f;
+        // (the mark is checked against the two moments this thread has loaded anyway: a caller that restored or edited the opacity
+        //  moments without rewriting m2_sh cannot make the step skip a splat whose moments are not zero)
+        const bool dormant = dorm_ok && !written && f2u(in_m2sh) == 0x80000000u && in_vis == 0.0f && in_m1o == 0.0f && in_m2o == 0.0f;
         if (masked) s_mask[threadIdx.x] = written ? 1.0f : (dormant ? 2.0f : 0.0f);
         // (masked: K18 stored the weight with the sign bit as the mark; an unmarked entry is the zero the forward left)
         {
@@ -488,7 +490,12 @@ int launch_train_update(bh_ctx* ctx, const BhTrainState* st, const float* g_t, c
     u.lr_sh = lr_sh; u.lr_opac = lr_opac; u.gscale = gscale;
     u.n = n; u.sh_len = 3 * C; u.vis_clamp = vis_clamp ? 1u : 0u;
     u.masked = masked_rows ? 1u : 0u;
-    u.dormant_skip = ctx->knob_no_dormant ? 0u : 1u;
+    // Marks are trusted only on a state this context updated at the previous step (same tensors, consecutive step count): a state
+    // seen for the first time, re-bound to other tensors (refine, a checkpoint restore) or with a step counter that jumped is
+    // processed in full once — that step re-derives every mark from the moments it finds.
+    const bool same_state = ctx->marks_m2_sh == st->m2_sh && ctx->marks_m1_t == st->m1_transforms && ctx->marks_n == n && ctx->marks_step + 1u == t;
+    ctx->marks_m2_sh = st->m2_sh; ctx->marks_m1_t = st->m1_transforms; ctx->marks_n = n; ctx->marks_step = t;
+    u.dormant_skip = (ctx->knob_no_dormant || !same_state) ? 0u : 1u;
     u.noise_on = noise ? 1u : 0u;
     u.noise_step = noise ? noise->step : 0u;
     u.noise_scale = noise ? noise->scale : 0.0f;

@@ -362,7 +362,7 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
 }
 
 // ---------------------------------------------------------------------------
-// The forward's tile sort + get_tile_offsets (render.rs:228-243, get_tile_offset.rs) in FOUR launches instead of seven.
+// The forward's tile sort + get_tile_offsets (render.rs:228-243, get_tile_offset.rs) in FIVE launches instead of seven.
 //
 // The (tile id, compact splat id) pairs arrive in depth order and leave grouped by tile, depth order kept.  As two LSD passes
 // plus the offsets kernel that is hist / row scan / scatter twice and one more launch: seven dependent launches of 5-18 us
@@ -373,138 +373,186 @@ static int radix_argsort_impl(bh_ctx* ctx, const uint32_t* keys, const uint32_t*
 //     bucket start + pairs of lower tiles + pairs of the same tile owned by earlier waves + rank inside the wave's part,
 // which is the stable order.  Ranking is the scatter kernel's (wave-wide digit matching, no LDS atomics).
 // ---------------------------------------------------------------------------
-#define BH_TB_WG 1024
-constexpr int TB_WG = BH_TB_WG;   // 256 / 512 / 1024 (the first four waves hold the digit totals and the bins)
-constexpr int TB_WAVES = TB_WG / 64;
-constexpr int TB_MAXBINS = 256;   // low_bits <= 8
-constexpr int TB_SLAB = 16;       // pairs per lane fetched ahead of the ranking steps
+// Work is dealt in PARTS, not in buckets: a bucket of `size` pairs is ceil(size / TP_CHUNK) parts and ONE block handles one part,
+// whichever bucket it belongs to — a frame whose pairs sit in a few consecutive tiles (a zoomed-in view: through round 5 one
+// 1024-thread block per bucket made that a cliff, 4 M pairs in one bucket = ~10 ms) sorts as fast as an even one, and complete
+// lists (7.8 M pairs: 30 k per bucket) no longer run 30 ranking steps per wave in a row.  Two launches:
+//   count: every part counts its pairs per (wave, tile of the bucket) and per tile                          -> part tables
+//   place: every part adds up, per tile, the parts of its bucket (all of them: the tile's row of the offsets table and the pairs
+//          of the bucket's lower tiles; the earlier ones: where its own pairs of that tile start) and places its pairs.
+constexpr uint32_t TP_CHUNK = 4096;   // pairs per part
+constexpr int TP_WG = 512;            // 8 waves, 512 contiguous pairs each (8 ranking steps)
+constexpr int TP_WAVES = TP_WG / 64;
+constexpr int TP_STEPS = TP_CHUNK / TP_WG;   // 64-pair steps per wave
+constexpr int TB_MAXBINS = 256;       // low_bits <= 8
+static_assert(TP_CHUNK == (uint32_t)TP_WAVES * 64u * (uint32_t)TP_STEPS, "a part is waves x steps x 64 pairs");
 
-__global__ __launch_bounds__(TB_WG) void tile_bucket_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                           const uint32_t* __restrict__ digit_totals, uint32_t low_bits, uint32_t num_tiles,
-                                                           uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals,
-                                                           uint32_t* __restrict__ tile_offsets) {
-    __shared__ uint32_t s_cnt[TB_WAVES][TB_MAXBINS];   // pairs per (wave, tile of the bucket) -> exclusive over the waves -> running
-    __shared__ uint32_t s_base[TB_MAXBINS];            // pairs of the bucket's lower tiles
-    __shared__ uint32_t s_red[TB_WAVES];
+struct PartInfo { uint32_t bucket, part, parts, first_block, start, size; };
+// Which part block `b` is: parts are numbered bucket by bucket.  Block-uniform; false = no such part (the grid is sized for the
+// worst case n / TP_CHUNK + 256).  s_scan: [2][TP_WAVES] scratch.
+BH_DEV bool find_part(const uint32_t* __restrict__ digit_totals, uint32_t b, uint32_t* s_scan, uint32_t* s_found, PartInfo& out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t d = blockIdx.x;
-    // where the bucket starts: the pairs of all lower high digits (256 totals, left behind by the row scan)
-    {
-        uint32_t t = (tid < RADIX && (uint32_t)tid < d) ? digit_totals[tid] : 0u;
+    const uint32_t size = tid < RADIX ? digit_totals[tid] : 0u;
+    const uint32_t parts = (size + TP_CHUNK - 1u) / TP_CHUNK;
+    uint32_t ip = parts, is = size;   // inclusive scans over the 256 buckets (the first four waves)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-        if (lane == 0) s_red[wave] = t;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tp = __shfl_up(ip, off), ts = __shfl_up(is, off);
+        if (lane >= off) { ip += tp; is += ts; }
     }
-    for (int i = tid; i < TB_WAVES * TB_MAXBINS; i += TB_WG) (&s_cnt[0][0])[i] = 0u;   // (4 words per thread)
+    if (lane == 63) { s_scan[wave] = ip; s_scan[TP_WAVES + wave] = is; }
+    if (tid == 0) s_found[0] = 0xFFFFFFFFu;
     __syncthreads();
-    const uint32_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];   // (the totals live in the first four waves)
-    const uint32_t size = digit_totals[d];
-    if (size == 0u) return;   // block-uniform
+    uint32_t wp = 0, ws = 0;
+#pragma unroll
+    for (int w = 0; w < RADIX / 64; ++w) if (w < wave) { wp += s_scan[w]; ws += s_scan[TP_WAVES + w]; }
+    const uint32_t first = ip - parts + wp;   // exclusive
+    if (tid < RADIX && b >= first && b < first + parts) {
+        s_found[0] = (uint32_t)tid; s_found[1] = first; s_found[2] = parts; s_found[3] = is - size + ws; s_found[4] = size;
+    }
+    __syncthreads();
+    if (s_found[0] == 0xFFFFFFFFu) return false;
+    out.bucket = s_found[0]; out.first_block = s_found[1]; out.parts = s_found[2]; out.start = s_found[3]; out.size = s_found[4];
+    out.part = b - out.first_block;
+    return true;
+}
+
+// lanes of the wave that hold the same tile of the bucket (low_bits ballots)
+BH_DEV unsigned long long tile_peers(uint32_t b, bool valid, uint32_t low_bits) {
+    unsigned long long m = __ballot(valid);
+    for (uint32_t k = 0; k < low_bits; ++k) {
+        const unsigned long long bal = __ballot((b >> k) & 1u);
+        m &= ((b >> k) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+// part_tab: per block [TP_WAVES + 1][bins]: rows 0..7 = pairs per (wave, tile), row 8 = pairs per tile of the whole part
+__global__ __launch_bounds__(TP_WG) void tile_parts_count_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ digit_totals,
+                                                                uint32_t low_bits, uint32_t* __restrict__ part_tab) {
+    __shared__ uint32_t s_cnt[TP_WAVES][TB_MAXBINS];
+    __shared__ uint32_t s_scan[2 * TP_WAVES];
+    __shared__ uint32_t s_found[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PartInfo pi;
+    if (!find_part(digit_totals, blockIdx.x, s_scan, s_found, pi)) return;
     const uint32_t bins = 1u << low_bits, low_mask = bins - 1u;
-    // the wave's contiguous part of the bucket, a multiple of 64 pairs except for the last one
-    const uint32_t per = ((size + TB_WAVES - 1u) / TB_WAVES + 63u) & ~63u;
-    const uint32_t lo = min(size, (uint32_t)wave * per), hi = min(size, lo + per);
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)TP_WAVES * bins; i += TP_WG) s_cnt[i / bins][i % bins] = 0u;
+    __syncthreads();
+    const uint32_t part_lo = pi.part * TP_CHUNK, part_hi = min(pi.size, part_lo + TP_CHUNK);
+    const uint32_t lo = min(part_hi, part_lo + (uint32_t)wave * (64u * TP_STEPS)), hi = min(part_hi, lo + 64u * TP_STEPS);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    auto peers_of = [&](uint32_t b, bool valid) {
-        unsigned long long m = __ballot(valid);
-        for (uint32_t k = 0; k < low_bits; ++k) {
-            const unsigned long long bal = __ballot((b >> k) & 1u);
-            m &= ((b >> k) & 1u) ? bal : ~bal;
-        }
-        return m;
-    };
-    // ---- count: pairs per tile in this wave's part.  A slab of TB_SLAB x 64 pairs is fetched before the first one is looked at:
-    // a step is a chain of LDS round trips that cannot start before its key has arrived, so with a load per step the kernel was
-    // ten dependent global round trips per phase (31 us).  A typical part is ONE slab: its keys and values then stay in registers
-    // for the placement (one global round trip for the whole kernel); longer parts fetch their slabs again.
-    const bool one_slab = hi - lo <= 64u * TB_SLAB;   // wave-uniform
-    uint32_t kk[TB_SLAB], vv[TB_SLAB];
-    for (uint32_t s0 = lo; s0 < hi; s0 += 64u * TB_SLAB) {
+    uint32_t kk[TP_STEPS];
 #pragma unroll
-        for (int k = 0; k < TB_SLAB; ++k) {
-            const uint32_t i = s0 + (uint32_t)k * 64u + (uint32_t)lane;
-            const uint32_t ic = start + (i < hi ? i : lo);   // (clamped, masked below)
-            kk[k] = keys[ic];
-            vv[k] = vals[ic];
-        }
+    for (int k = 0; k < TP_STEPS; ++k) {   // all loads first: the ranking steps are LDS round trips that cannot start before their key
+        const uint32_t i = lo + (uint32_t)k * 64u + (uint32_t)lane;
+        kk[k] = keys[pi.start + (i < hi ? i : (hi > lo ? lo : 0u))];
+    }
 #pragma unroll
-        for (int k = 0; k < TB_SLAB; ++k) {
-            const uint32_t i0 = s0 + (uint32_t)k * 64u;
-            if (i0 >= hi) break;   // wave-uniform
-            const bool valid = i0 + (uint32_t)lane < hi;
-            const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
-            const unsigned long long peers = peers_of(b, valid);
-            // (the leader of each group of equal tiles adds the group's size to a counter only this wave touches — an LDS atomic
-            //  WITHOUT return: nothing in the next step waits for it)
-            if (valid && (peers & lt_mask) == 0ull) atomicAdd(&s_cnt[wave][b], (uint32_t)__popcll(peers));
-        }
+    for (int k = 0; k < TP_STEPS; ++k) {
+        const uint32_t i0 = lo + (uint32_t)k * 64u;
+        if (i0 >= hi) break;   // wave-uniform
+        const bool valid = i0 + (uint32_t)lane < hi;
+        const uint32_t bn = valid ? (kk[k] & low_mask) : 0u;
+        const unsigned long long peers = tile_peers(bn, valid, low_bits);
+        if (valid && (peers & lt_mask) == 0ull) atomicAdd(&s_cnt[wave][bn], (uint32_t)__popcll(peers));   // (no return value: nothing waits for it)
     }
     __syncthreads();
-    // ---- per tile: exclusive scan over the waves; exclusive scan of the tile totals over the bucket; the offsets table
-    uint32_t total = 0;
-    if ((uint32_t)tid < bins) {
+    uint32_t* tab = part_tab + (size_t)blockIdx.x * (TP_WAVES + 1) * bins;
+    for (uint32_t i = (uint32_t)tid; i < bins; i += TP_WG) {
         uint32_t run = 0;
 #pragma unroll
-        for (int w = 0; w < TB_WAVES; ++w) {
-            const uint32_t c = s_cnt[w][tid];
-            s_cnt[w][tid] = run;
+        for (int w = 0; w < TP_WAVES; ++w) {
+            const uint32_t c = s_cnt[w][i];
+            tab[(uint32_t)w * bins + i] = run;   // exclusive over the part's waves
             run += c;
         }
-        total = run;
+        tab[(uint32_t)TP_WAVES * bins + i] = run;
+    }
+}
+
+__global__ __launch_bounds__(TP_WG) void tile_parts_place_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                const uint32_t* __restrict__ digit_totals, uint32_t low_bits, uint32_t num_tiles,
+                                                                const uint32_t* __restrict__ part_tab, uint32_t* __restrict__ out_keys,
+                                                                uint32_t* __restrict__ out_vals, uint32_t* __restrict__ tile_offsets) {
+    __shared__ uint32_t s_cnt[TP_WAVES][TB_MAXBINS];   // running position of (wave, tile) inside the tile's run
+    __shared__ uint32_t s_base[TB_MAXBINS];            // pairs of the bucket's lower tiles
+    __shared__ uint32_t s_acc[2][TP_WG];               // column sums in flight: [0] all parts, [1] the earlier parts
+    __shared__ uint32_t s_scan[2 * TP_WAVES];
+    __shared__ uint32_t s_found[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PartInfo pi;
+    if (!find_part(digit_totals, blockIdx.x, s_scan, s_found, pi)) return;
+    const uint32_t bins = 1u << low_bits, low_mask = bins - 1u;
+    const uint32_t part_lo = pi.part * TP_CHUNK, part_hi = min(pi.size, part_lo + TP_CHUNK);
+    const uint32_t lo = min(part_hi, part_lo + (uint32_t)wave * (64u * TP_STEPS)), hi = min(part_hi, lo + 64u * TP_STEPS);
+    // the part's pairs are on their way while the tables are added up
+    uint32_t kk[TP_STEPS], vv[TP_STEPS];
+#pragma unroll
+    for (int k = 0; k < TP_STEPS; ++k) {
+        const uint32_t i = lo + (uint32_t)k * 64u + (uint32_t)lane;
+        const uint32_t ic = pi.start + (i < hi ? i : (hi > lo ? lo : 0u));
+        kk[k] = keys[ic];
+        vv[k] = vals[ic];
+    }
+    // per tile of the bucket: pairs in all parts / in the parts before this one.  rows = TP_WG / bins parts are read per trip
+    const uint32_t rows = (uint32_t)TP_WG / bins, col = (uint32_t)tid % bins, row = (uint32_t)tid / bins;
+    uint32_t all = 0u, before = 0u;
+    for (uint32_t q = row; q < pi.parts; q += rows) {
+        const uint32_t c = part_tab[((size_t)(pi.first_block + q) * (TP_WAVES + 1) + TP_WAVES) * bins + col];
+        all += c;
+        before += q < pi.part ? c : 0u;
+    }
+    s_acc[0][tid] = all;
+    s_acc[1][tid] = before;
+    __syncthreads();
+    uint32_t total = 0u, mine_before = 0u;
+    if ((uint32_t)tid < bins) {
+        for (uint32_t r = 0; r < rows; ++r) { total += s_acc[0][r * bins + (uint32_t)tid]; mine_before += s_acc[1][r * bins + (uint32_t)tid]; }
     }
     {
-        uint32_t incl = total;   // (threads >= bins contribute 0; bins <= 256 = the first four waves)
+        uint32_t incl = total;   // exclusive scan of the tile totals over the bucket (bins <= 256: the first four waves)
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        __syncthreads();   // s_red was read above by every thread
-        if (lane == 63) s_red[wave] = incl;
+        __syncthreads();   // (s_scan was read by find_part)
+        if (lane == 63) s_scan[wave] = incl;
         __syncthreads();
         uint32_t wofs = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wofs += (w < wave) ? s_red[w] : 0u;
+        for (int w = 0; w < RADIX / 64; ++w) wofs += (w < wave) ? s_scan[w] : 0u;
         if ((uint32_t)tid < bins) {
             const uint32_t excl = incl - total + wofs;
-            s_base[tid] = excl;
-            const uint32_t tile = (d << low_bits) | (uint32_t)tid;
-            if (total != 0u && tile < num_tiles) {   // (an absent tile keeps the zeros the table was cleared to; sentinel ids have no row)
-                tile_offsets[tile * 2] = start + excl;
-                tile_offsets[tile * 2 + 1] = start + excl + total;
+            s_base[tid] = excl + mine_before;   // where THIS part's pairs of the tile start inside the bucket
+            const uint32_t tile = (pi.bucket << low_bits) | (uint32_t)tid;
+            if (pi.part == 0u && total != 0u && tile < num_tiles) {   // (an absent tile keeps the zeros the table was cleared to; sentinel ids have no row)
+                tile_offsets[tile * 2] = pi.start + excl;
+                tile_offsets[tile * 2 + 1] = pi.start + excl + total;
             }
         }
     }
+    const uint32_t* tab = part_tab + (size_t)blockIdx.x * (TP_WAVES + 1) * bins;
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)TP_WAVES * bins; i += TP_WG) s_cnt[i / bins][i % bins] = tab[i];
     __syncthreads();
-    // ---- place
-    for (uint32_t s0 = lo; s0 < hi; s0 += 64u * TB_SLAB) {
-        if (!one_slab) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-            for (int k = 0; k < TB_SLAB; ++k) {
-                const uint32_t i = s0 + (uint32_t)k * 64u + (uint32_t)lane;
-                const uint32_t ic = start + (i < hi ? i : lo);
-                kk[k] = keys[ic];
-                vv[k] = vals[ic];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TB_SLAB; ++k) {
-            const uint32_t i0 = s0 + (uint32_t)k * 64u;
-            if (i0 >= hi) break;   // wave-uniform
-            const bool valid = i0 + (uint32_t)lane < hi;
-            const uint32_t b = valid ? (kk[k] & low_mask) : 0u;
-            const unsigned long long peers = peers_of(b, valid);
-            // the group's leader takes the running count with a RETURNING LDS atomic and hands it to its peers.  A wave's LDS
-            // operations execute in program order, so the steps stay in depth order — but no step's registers depend on the
-            // previous step's (a read followed by a write of read + n did: ten LDS round trips in a row per phase)
-            uint32_t prior = 0u;
-            if (valid && (peers & lt_mask) == 0ull) prior = atomicAdd(&s_cnt[wave][b], (uint32_t)__popcll(peers));
-            prior = (uint32_t)__shfl((int)prior, peers ? __ffsll((long long)peers) - 1 : 0);
-            if (valid) {
-                const uint32_t pos = start + s_base[b] + prior + (uint32_t)__popcll(peers & lt_mask);
-                out_keys[pos] = kk[k];
-                out_vals[pos] = vv[k];
-            }
+    for (int k = 0; k < TP_STEPS; ++k) {
+        const uint32_t i0 = lo + (uint32_t)k * 64u;
+        if (i0 >= hi) break;   // wave-uniform
+        const bool valid = i0 + (uint32_t)lane < hi;
+        const uint32_t bn = valid ? (kk[k] & low_mask) : 0u;
+        const unsigned long long peers = tile_peers(bn, valid, low_bits);
+        // the group's leader takes the running count with a RETURNING LDS atomic and hands it to its peers: a wave's LDS operations
+        // execute in program order, so the steps stay in depth order, and no step's registers depend on the previous step's
+        uint32_t prior = 0u;
+        if (valid && (peers & lt_mask) == 0ull) prior = atomicAdd(&s_cnt[wave][bn], (uint32_t)__popcll(peers));
+        prior = (uint32_t)__shfl((int)prior, peers ? __ffsll((long long)peers) - 1 : 0);
+        if (valid) {
+            const uint32_t pos = pi.start + s_base[bn] + prior + (uint32_t)__popcll(peers & lt_mask);
+            out_keys[pos] = kk[k];
+            out_vals[pos] = vv[k];
         }
     }
 }
@@ -513,11 +561,6 @@ bool tile_sort_supported(uint32_t bits, uint32_t n) { return bits > 8u && bits <
 
 // keys = tile ids (< 2^bits, or the sentinel 0xFFFFFFFF), vals = compact splat ids, n pairs in depth order.  -> out_keys / out_vals
 // sorted by tile (stable) and tile_offsets[tile] = [begin, end) for every tile that has pairs (the table must be zero already).
-// Known cliff: one 1024-thread block finishes each high-digit bucket (2^(bits-8) consecutive tile ids).  When the pairs
-// are concentrated in a few consecutive tiles (an object that fills a small part of the frame), a few blocks do nearly all the work
-// while the others idle: results stay correct, the launch degrades towards one block's throughput.  The digit totals are only
-// known on the device, so the host cannot switch paths per frame; BH_TILE_SORT_LSD=1 selects the skew-insensitive two-pass LSD sort
-// + offsets kernel for such scenes.
 int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t bits, uint32_t num_tiles,
                       uint32_t* out_keys, uint32_t* out_vals, uint32_t* tile_offsets, uint32_t alloc_n) {
     if (!tile_sort_supported(bits, n)) return set_error(ctx, BH_ERR_INVALID_ARG, "tile_sort_offsets: 9..16 key bits, at most 16 M pairs");
@@ -544,8 +587,15 @@ int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, u
     if (kpt == 8u) hipLaunchKernelGGL((radix_scatter_kernel<true, 8>), grid, block, 0, ctx->stream, keys, vals, n, shift, mask, nblocks, hist, totals, mid_k, mid_v, none);
     else hipLaunchKernelGGL((radix_scatter_kernel<true, 16>), grid, block, 0, ctx->stream, keys, vals, n, shift, mask, nblocks, hist, totals, mid_k, mid_v, none);
     BH_LAUNCH_CHECK(ctx, "radix_scatter_kernel");
-    hipLaunchKernelGGL(tile_bucket_kernel, dim3(RADIX), dim3(TB_WG), 0, ctx->stream, mid_k, mid_v, totals, low_bits, num_tiles, out_keys, out_vals, tile_offsets);
-    BH_LAUNCH_CHECK(ctx, "tile_bucket_kernel");
+    // parts of at most TP_CHUNK pairs, numbered bucket by bucket: at most n / TP_CHUNK + one partial part per bucket
+    const uint32_t max_parts = n / TP_CHUNK + RADIX, alloc_parts = alloc_n / TP_CHUNK + RADIX;
+    uint32_t* part_tab = (uint32_t*)ensure(ctx, SLOT_SORT_PARTS, (size_t)alloc_parts * (TP_WAVES + 1) * ((size_t)1 << low_bits) * 4);
+    if (!part_tab) return BH_ERR_OOM;
+    hipLaunchKernelGGL(tile_parts_count_kernel, dim3(max_parts), dim3(TP_WG), 0, ctx->stream, mid_k, totals, low_bits, part_tab);
+    BH_LAUNCH_CHECK(ctx, "tile_parts_count_kernel");
+    hipLaunchKernelGGL(tile_parts_place_kernel, dim3(max_parts), dim3(TP_WG), 0, ctx->stream, mid_k, mid_v, totals, low_bits, num_tiles, part_tab, out_keys, out_vals,
+                       tile_offsets);
+    BH_LAUNCH_CHECK(ctx, "tile_parts_place_kernel");
     return 0;
 }
 

@@ -15,7 +15,7 @@ import torch
 
 from . import _ffi
 from ._ffi import BrushHipError
-from .parallel import (allreduce_exchange, allreduce_refine_maxima, allgather_strips, exchange_strip_halos, strip_spans_px,
+from .parallel import (DIRECT_ALLREDUCE_MIN_FLOATS, allreduce_direct, allreduce_exchange, allreduce_refine_maxima, allgather_strips, exchange_strip_halos, strip_spans_px,
                        strips_allow_halo_loss, tile_rows_for_rank)
 
 
@@ -1033,7 +1033,8 @@ class SplatTrainer:
     rank-local until `sync_refine_stats()` (called by `refine`) MAX-reduces them."""
 
     def __init__(self, config: TrainConfig, median_scene_scale: float = 1.0, process_group=None, ctx: Optional[Context] = None,
-                 partition: str = "cameras", native_comm: bool = False, sparse_exchange: bool = True, seed: Optional[int] = None):
+                 partition: str = "cameras", native_comm: bool = False, sparse_exchange: bool = True, seed: Optional[int] = None,
+                 allreduce: str = "ring"):
         """seed: an int turns on the two stochastic terms of the reference's step — the visibility-gated noise on the
         means (train.rs:389-416) and the background jitter (train.rs:896-908) — drawn by the library's counter-based
         generator as pure functions of (seed, step[, splat]); data-parallel ranks must pass the same seed.  None (the
@@ -1045,6 +1046,12 @@ class SplatTrainer:
         all-gathered before the loss and the partial gradients summed."""
         if partition not in ("cameras", "tiles"):
             raise ValueError("partition must be 'cameras' or 'tiles'")
+        if allreduce not in ("ring", "direct"):
+            raise ValueError("allreduce must be 'ring' (all_reduce / ncclAllReduce) or 'direct' (reduce-scatter + all-gather over point-to-point messages)")
+        # how long messages of the gradient exchange are summed: the collective library's all-reduce, or the direct algorithm for a
+        # fully connected node (comm.hip comm_allreduce_direct; here, for the hook path, parallel.allreduce_direct).  With
+        # native_comm the caller selects it on the context: ctx.set_option("grad_allreduce", "direct")
+        self.allreduce = allreduce
         # native_comm: the ctx carries an RCCL communicator (Context.comm_init) and bh_train_step all-reduces the
         # exchange buffer itself — no torch.distributed, no callback (data parallel over cameras only)
         # (partition "tiles": the library also moves the strips' 21-px halos itself — bh_exchange_strip_halos, strip-wise loss only)
@@ -1142,7 +1149,10 @@ class SplatTrainer:
                 t = views.get(exch_ptr)
                 if t is None or t.numel() < cnt:
                     t = views[exch_ptr] = _view(exch_ptr, (cnt,), torch.float32, dev)
-                allreduce_exchange(t, cnt, pg)
+                if self.allreduce == "direct" and cnt >= DIRECT_ALLREDUCE_MIN_FLOATS:
+                    allreduce_direct(t, cnt, pg)
+                else:
+                    allreduce_exchange(t, cnt, pg)
                 return 0
             except Exception:  # never unwind across the C boundary
                 return 1

@@ -31,6 +31,66 @@ def allreduce_exchange(exchange: torch.Tensor, sum_count: int, group=None):
     return dist.get_world_size(group)
 
 
+DIRECT_ALLREDUCE_MIN_FLOATS = 1 << 16   # as brush_amd/csrc/context.h: shorter messages stay with all_reduce
+
+
+def direct_chunk(count, world, c):
+    """[begin, begin + len) of chunk c when `count` floats are cut for `world` ranks — brush_amd/csrc/comm.hip direct_chunk:
+    ceil(count / world) rounded up to 4 floats per chunk, the tail ragged (or empty)."""
+    per = ((count + world - 1) // world + 3) & ~3
+    b = min(c * per, count)
+    return b, (min(per, count - b) if b < count else 0)
+
+
+def allreduce_direct(exchange: torch.Tensor, sum_count: int, group=None):
+    """The library's direct all-reduce (comm.hip comm_allreduce_direct: reduce-scatter + all-gather over point-to-point messages,
+    for the fully connected xGMI node — every rank sends chunk p to rank p, the owner of a chunk adds the `world` versions up IN
+    RANK ORDER, then sends the finished chunk to everybody) restated over torch.distributed isend / irecv: what the exchange hook
+    runs with SplatTrainer(allreduce="direct"), and what rehearses the algorithm where RCCL cannot run (gloo, ranks sharing a GPU).
+    In place on exchange[:sum_count]; the result is the same on every rank bit for bit."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1 or sum_count == 0:
+        return world
+    flat = exchange[:sum_count]
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"   # (gloo moves host memory)
+    t = flat.cpu() if staged else flat
+    my_b, my_n = direct_chunk(sum_count, world, rank)
+    per = direct_chunk(sum_count, world, 0)[1]
+    scratch = torch.empty((world - 1, max(per, 1)), dtype=t.dtype, device=t.device)
+    peer = lambda p: p if group is None else dist.get_global_rank(group, p)   # noqa: E731
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        pb, pn = direct_chunk(sum_count, world, p)
+        if pn:
+            ops.append(dist.P2POp(dist.isend, t[pb:pb + pn], peer(p), group))
+        if my_n:
+            ops.append(dist.P2POp(dist.irecv, scratch[p - (1 if p > rank else 0), :my_n], peer(p), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    if my_n:
+        acc = torch.zeros(my_n, dtype=t.dtype, device=t.device)
+        for p in range(world):   # rank order, like reduce_versions_kernel
+            acc += t[my_b:my_b + my_n] if p == rank else scratch[p - (1 if p > rank else 0), :my_n]
+        t[my_b:my_b + my_n] = acc
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        pb, pn = direct_chunk(sum_count, world, p)
+        if my_n:
+            ops.append(dist.P2POp(dist.isend, t[my_b:my_b + my_n], peer(p), group))
+        if pn:
+            ops.append(dist.P2POp(dist.irecv, t[pb:pb + pn], peer(p), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    if staged:
+        flat.copy_(t)
+    return world
+
+
 def allreduce_refine_maxima(refine_weight_norm: torch.Tensor, max_screen_size: torch.Tensor, group=None):
     """In place: both running maxima <- max over ranks (one collective on a fused staging tensor).
     Called before refine, so every rank takes the identical prune / split decisions."""

@@ -164,3 +164,48 @@ def test_tile_row_partition_properties():
     assert all(e > b for b, e in rows)
     loads = [sum(w[b:e]) for b, e in rows]
     assert max(loads) <= 0.6 * sum(w)
+
+
+def _direct_worker(rank, world, port, q, counts):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brush_amd.parallel import allreduce_direct, direct_chunk
+    out = []
+    for count in counts:
+        g = torch.Generator().manual_seed(7 * count + rank)
+        buf = torch.randn(count + 13, generator=g)
+        mine = buf.clone()
+        allreduce_direct(buf, count)
+        out.append((mine.numpy(), buf.numpy()))
+        chunks = [direct_chunk(count, world, c) for c in range(world)]
+        assert chunks[0][0] == 0 and all(chunks[c][0] + chunks[c][1] == chunks[c + 1][0] or chunks[c + 1][1] == 0 for c in range(world - 1))
+        assert sum(n for _, n in chunks) == count and all(b % 4 == 0 or n == 0 for b, n in chunks)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_direct_allreduce_reduce_scatter_allgather_over_p2p(world):
+    """parallel.allreduce_direct restates the library's direct all-reduce (comm.hip: every rank sends chunk p to rank p, the owner
+    adds the versions up in rank order and sends the result to everybody): equal on every rank BIT FOR BIT, equal to the sum in rank
+    order, nothing behind `count` touched; ragged and empty tail chunks (count = 5 over 5 ranks: chunks of 4, 1, 0, 0, 0)."""
+    counts = [70003, 65536, 5, 1, 4 * world, 4 * world + 1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q, counts)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, count in enumerate(counts):
+        want = np.zeros(count, np.float32)
+        for r in range(world):
+            want = want + res[r][1][k][0][:count]   # float32, rank order
+        for r in range(world):
+            mine, got = res[r][1][k]
+            assert np.array_equal(got[:count], want), (world, count, r)
+            assert np.array_equal(got[count:], mine[count:])

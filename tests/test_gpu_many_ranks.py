@@ -63,7 +63,7 @@ def _dp_cam(rank, world, w, h):
     return cp
 
 
-def _dp_worker(rank, world, port, q, problem, sparse, steps):
+def _dp_worker(rank, world, port, q, problem, sparse, steps, allreduce="ring"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -74,7 +74,7 @@ def _dp_worker(rank, world, port, q, problem, sparse, steps):
     sc, w, h, median = _dp_problem(problem)
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h, seed=3 + rank).view(np.int32)).to(dev)
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=median, process_group=dist.group.WORLD, sparse_exchange=sparse)
+    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=median, process_group=dist.group.WORLD, sparse_exchange=sparse, allreduce=allreduce)
     batch = ba.SceneBatch(gt, util.hip_camera(ba, _dp_cam(rank, world, w, h)))
     rows, first = [], None
     for _ in range(steps):
@@ -134,6 +134,21 @@ def test_dp_over_cameras_at_4_and_8_ranks_matches_the_oracle_mean_gradient(oracl
     ot = _check_against_oracle_mean(oracle_lib, "small", world, first, vis)
     # after ONE step vis_weight = number of views that reached the splat: compare the two-step count's support
     assert np.array_equal(ot.state["vis"] > 0, vis > 0) or np.mean((ot.state["vis"] > 0) != (vis > 0)) <= 2e-3
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_dense_direct_allreduce_matches_the_oracle_mean_gradient(oracle_lib, world):
+    """the dense gradient block summed by the DIRECT all-reduce (reduce-scatter + all-gather over point-to-point
+    messages: comm.hip comm_allreduce_direct, restated for the hook path in parallel.allreduce_direct) instead of the collective
+    library's all-reduce: same update as the oracle's step on the mean gradient, replicas bit-identical, at 2 / 4 / 8 ranks."""
+    steps = 2
+    res = _run(world, _dp_worker, ("small", False, steps, "direct"))
+    for key in (1, 2, 3):
+        assert len({r[key] for r in res}) == 1, "replicas diverged (field %d)" % key
+    assert res[0][4] == [0] * steps
+    first, (vis, norm, scr) = res[0][5]
+    assert vis.max() == float(world * steps)
+    _check_against_oracle_mean(oracle_lib, "small", world, first, vis)
 
 
 def test_dp_4_ranks_at_1m_1080p_matches_the_oracle_mean_gradient(oracle_lib):
