@@ -12,6 +12,11 @@ if ROOT not in sys.path:
 # default; the parity suite's scenes are small, and it is the mechanism that has to be covered: every context of this session
 # (and of the processes it spawns) cuts whatever the frame's size.  tests/test_gpu_sliced.py checks the default threshold itself.
 os.environ.setdefault("BH_CUT_MIN_PAIRS", "0")
+# ... and keeps cutting however little a cut saves: the product lets a view whose last cut frame listed > 90 % of its pairs render
+# complete lists for a while (option auto_exact_share) — the suite's small scenes barely saturate, so nearly every frame would.
+# tests/test_gpu_options.py::test_views_render_complete_lists_when_cuts_save_nothing covers the product default.
+# (brush_amd/host.py turns these into bh_set_option calls on every Context: the library itself reads no environment variable)
+os.environ.setdefault("BH_OPTIONS", "auto_exact_share=0")
 
 
 def pytest_configure(config):

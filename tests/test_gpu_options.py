@@ -187,3 +187,33 @@ def test_a_moving_viewer_camera_allocates_no_view_tables(dev):
         trainer.step(ba.SceneBatch(gt_dev, cam_at(5.0 + 0.01 * k)), spl)
     assert ctx.view_table_count() == before + 40
     ctx.close()
+
+
+def test_views_render_complete_lists_when_cuts_save_nothing(dev):
+    """a view whose last cut frame listed more than auto_exact_share (default 0.9) of its pairs — a scene that does not
+    saturate early: where a converging training run ends up, bench.py train_loop — renders complete lists for its next 12 frames (no
+    near count in K1, no second attempts) and then tries one cut frame again.  auto_exact_share = 0 keeps cutting."""
+    import brush_amd as ba
+    n, w, h = 8000, 192, 128
+    # (large, mostly opaque splats: the tiles saturate after a fraction of their lists, so a cut frame lists well under 100 %)
+    sc = synth.make_scene(n, 0x61, sh_degree=0, log_scale_range=(math.log(0.05), math.log(0.4)), opacity_range=(0.5, 0.95),
+                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w))
+    cam = util.hip_camera(ba, synth.default_camera_params(w, h))
+    gt_dev = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
+
+    def run(share_option):
+        ctx = ba.Context(dev, options={"cut_min_pairs": 0, "auto_exact_share": share_option})
+        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+        trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx)
+        seq = []
+        for _ in range(30):
+            trainer.step(ba.SceneBatch(gt_dev, cam, view_id=1), spl)
+            seq.append(float(ctx.lib.bh_last_list_share(ctx._h)))
+        ctx.close()
+        return seq
+    off = run("0")
+    assert off[0] == 1.0 and all(0.05 < s < 1.0 for s in off[1:]), off          # frame 1 seeds the table, every later frame is cut
+    lo = min(off[1:]) - 0.02                                                      # a threshold every cut frame of this scene exceeds
+    on = run("%.4f" % lo)
+    assert on[0] == 1.0 and lo < on[1] < 1.0                                      # frame 2 is cut and finds out that it saved too little
+    assert on[2:14] == [1.0] * 12 and lo < on[14] < 1.0 and on[15:27] == [1.0] * 12, on   # 12 complete frames, one probe, 12 more
