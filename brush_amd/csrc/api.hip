@@ -562,6 +562,7 @@ const OptionKey kOptionKeys[] = {
     {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
     {"generic_depth_sort", "0|1: depth order by the generic radix sort + scan instead of the fused split sort"},
     {"tile_sort", "auto|bucket|lsd: the forward's tile sort (auto: bucket sort unless the view's pairs are concentrated in few tiles)"},
+    {"spec_k5", "0|1: queue the list builder before the host has read the frame's counts (default 1; 0: behind the count readback)"},
     {"event_waits", "0|1: the host's mid-step waits use events behind the kernels instead of polled tag words"},
     {"readback_copy", "0|1: counts and gate word reach the host through copy launches"},
     {"force_exchange", "0|1: a one-rank communicator still walks the whole gradient-exchange path (overhead measurement)"},
@@ -626,6 +627,7 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
         else if (v == "bucket") { ctx->knob_tile_sort = 1; ok = true; }
         else if (v == "lsd") { ctx->knob_tile_sort = 2; ok = true; }
     }
+    else if (k == "spec_k5") ok = parse_flag(value, &ctx->knob_spec_k5);
     else if (k == "event_waits") ok = parse_flag(value, &ctx->knob_event_waits);
     else if (k == "readback_copy") ok = parse_flag(value, &ctx->knob_readback_copy);
     else if (k == "force_exchange") ok = parse_flag(value, &ctx->knob_force_exchange);
@@ -827,7 +829,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
 
     // two counter pairs: K1 accumulates into one and clears the other for the next forward (no fill launch)
     constexpr size_t counter_set_bytes = COUNTER_SET_BYTES, counter_set_words = COUNTER_SET_BYTES / 4, counter_read_bytes = COUNTER_READ_BYTES;
-    auto* counter_pairs = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 2 * counter_set_bytes);
+    auto* counter_pairs = (uint32_t*)ensure(ctx, SLOT_COUNTERS, 2 * counter_set_bytes + 64);   // (+ the device copy of this frame's count sums)
+    uint32_t* dev_sums = counter_pairs ? counter_pairs + 2 * counter_set_words : nullptr;
     uint32_t* counters = counter_pairs ? counter_pairs + counter_set_words * (ctx->counter_phase & 1u) : nullptr;
     auto* depth_keys = (uint32_t*)ensure(ctx, SLOT_DEPTH_KEYS, npad * 4);
     auto* isect_counts = (uint32_t*)ensure(ctx, SLOT_ISECT_COUNTS, npad * 4);
@@ -909,6 +912,11 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     uint32_t fb_unsat_tiles = 0;           // ... and how many such tiles there were (empty ones included)
     bool fused_scan = false;
     uint32_t* cum_early = nullptr;
+    bool k5_queued = false;   // K5 was queued before the counts were read (below): valid unless the pairs overflowed its buffers
+    uint32_t spec_pair_cap = 0;
+    float* spec_projected = nullptr;
+    float4* spec_vc = nullptr;
+    uint32_t *spec_tile_ids = nullptr, *spec_isect_gids = nullptr;
     if (n > 0) {
         {
             ProfScope ps(ctx, "ProjectSplats");
@@ -970,9 +978,33 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 // (per-tile cuts: the scan of the NEAR counts = the slot ranges of the near pass's list)
                 if (poll_tag && ++ctx->readback_tag == 0u) ctx->readback_tag = 1u;
                 BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early,
-                                       sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev, poll_tag ? ctx->readback_tag : 0u));
+                                       sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev, poll_tag ? ctx->readback_tag : 0u,
+                                       sums_on_device ? dev_sums : nullptr));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
+            }
+        }
+        // ---- speculative K5: the list builder is queued BEFORE the host has read the counts.  Between the depth sort's last kernel and
+        // K5 the GPU used to idle ~5.5 us every frame — the host learns the counts ~70 us into the frame, but sizing and launching K5
+        // only then made K5's launch latency a bubble (the one idle gap a kernel trace of a step shows, scripts/gap_trace.py).  K5
+        // needs two numbers the host does not have yet: the listed splats (it reads them on the device, where the sort's first kernel
+        // left the sums) and room for the pairs — the pair buffers' CAPACITY is the bound: the arena only grows, so after a view's
+        // first frames it holds what the frame needs; a wave whose slots would not fit emits nothing, the host finds the overflow in
+        // the counts it reads anyway and queues K5 again behind the grown buffers.
+        if (poll_tag && ctx->knob_spec_k5 && !(want_sliced && ctx->slice_fraction > 0.0f)) {
+            const size_t cap_pairs = std::min(ctx->slots[SLOT_TILE_IDS].cap, ctx->slots[SLOT_ISECT_GIDS].cap) / 4;
+            if (cap_pairs >= 4096) {
+                spec_projected = (float*)ensure(ctx, SLOT_PROJECTED, npad * 9 * 4);   // (rows for up to n listed splats)
+                spec_vc = bwd_info ? (float4*)ensure(ctx, SLOT_V_COMBINED, npad * 10 * 4 + 16) : nullptr;
+                if (!spec_projected || (bwd_info && !spec_vc)) return BH_ERR_OOM;
+                spec_tile_ids = (uint32_t*)ctx->slots[SLOT_TILE_IDS].ptr;
+                spec_isect_gids = (uint32_t*)ctx->slots[SLOT_ISECT_GIDS].ptr;
+                spec_pair_cap = (uint32_t)std::min<size_t>(cap_pairs, 0xFFFFFFFEull);
+                ProfScope ps(ctx, "MapGaussiansToIntersect");
+                BH_TRY(launch_map_gaussians(ctx, n, u, proj_by_gid, gfc, spec_projected, cum_early, spec_tile_ids, spec_isect_gids, spec_vc,
+                                            spec_vc ? (uint32_t)(((size_t)n * 10 + 3) / 4) : 0u, 0xFFFFFFFFu, cut_active ? slice_tab : nullptr,
+                                            cut_active ? view->zcut : nullptr, cut_active ? depths_sorted : nullptr, dev_sums + (cut_active ? 3 : 0), spec_pair_cap));
+                k5_queued = true;
             }
         }
         if (poll_tag) BH_TRY(wait_host_tag(ctx, reinterpret_cast<const volatile uint32_t*>(hslots) + HOST_SUM_WORDS - 1u, ctx->readback_tag, "count readback"));
@@ -1020,6 +1052,9 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     void* out_img = ensure(ctx, SLOT_OUT_IMG, pixels * (bwd_info ? 16 : 4));
     if (!cum || !projected || !tile_ids || !isect_gids || !tile_ids_sorted || !isect_gids_sorted || !out_img)
         return BH_ERR_OOM;
+    // the speculative K5 stands if its pairs fitted and none of its buffers has moved since
+    if (k5_queued && ((cut_active ? near_total : ni) > spec_pair_cap || projected != spec_projected || tile_ids != spec_tile_ids || isect_gids != spec_isect_gids))
+        k5_queued = false;
 
     // ---- depth-sliced lists (BH_FLAG_SLICED_LISTS) --------------------------------------------------------------------------
     // The reference lists EVERY (tile, splat) pair and sorts them all (map_gaussians.rs:15-80, render.rs:228-230), although a tile
@@ -1113,6 +1148,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 }
                 if (zcut_lists && near_total == 0u) {
                     // no pair in front of any cut: nothing to emit (and K5 does not run to clear v_combined)
+                } else if (k5_queued && (!bwd_info || vc == spec_vc)) {
+                    ctx->clears.k5_cleared_accum(vc != nullptr);   // (it ran in front of the count readback)
                 } else {
                     ctx->clears.k5_cleared_accum(vc != nullptr);
                     BH_TRY(launch_map_gaussians(ctx, nv, u, proj_by_gid, gfc, projected, cum, tile_ids, isect_gids, vc, vc ? (uint32_t)(((size_t)nv * 10 + 3) / 4) : 0u,

@@ -348,6 +348,7 @@ struct bh_ctx {
     float margin_scale = 1.0f;
     float ctrl_up = 1.5f, ctrl_down = 0.998f, ctrl_floor = 0.5f, ctrl_gap_exp = 1.0f / 3.0f;   // BH_CUT_CTRL="up:down:floor:gap_exp" (A/B)
     uint32_t cut_min_pairs = bh::CUT_MIN_PAIRS;   // bh_set_list_cut_threshold / BH_CUT_MIN_PAIRS
+    bool knob_spec_k5 = true;             // option spec_k5: K5 queued in front of the count readback (api.hip)
     bool knob_event_waits = false;        // BH_EVENT_WAITS (A/B): the host's two mid-step waits use events behind the kernels, as before round 5, instead of polled tag words
     bool knob_readback_copy = false;      // BH_READBACK_COPY (A/B): counts and gate word reach the host through copy launches as before round 4
     bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
@@ -454,7 +455,7 @@ int launch_project_visible(bh_ctx* ctx, uint32_t nv, const float* projected_by_g
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
                          float4* zero_span = nullptr, uint32_t zero_f4 = 0, uint32_t budget = 0xFFFFFFFFu, uint32_t* slice_info = nullptr,
-                         const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr);
+                         const uint32_t* zcut = nullptr, const uint32_t* depth_keys_sorted = nullptr, const uint32_t* nv_dev = nullptr, uint32_t pair_cap = 0xFFFFFFFFu);
 int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                              float* projected, const uint32_t* cum_tiles_hit, uint32_t budget, const uint32_t* done_bits, const uint32_t* gate,
                              uint32_t* counts, uint32_t* block_totals, uint32_t* group_totals, uint32_t* slice_info, uint32_t* tile_ids, uint32_t* isect_gids);
@@ -480,7 +481,7 @@ int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, u
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
                     uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr,
-                    uint32_t rb_tag = 0);
+                    uint32_t rb_tag = 0, uint32_t* rb_dev = nullptr);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 // gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);

@@ -99,7 +99,7 @@ BH_DEV unsigned long long ds_match(uint32_t d) {
 // the previous frame's slicing feedback) is added up by one wave of the first kernel queued behind K1 and stored straight into
 // the pinned host block — [4] u64 totals | [3] u32 feedback (max need, unsaturated pairs, unsaturated tiles).  A blit kernel
 // between K1 and the sort cost 4.5 us of device time plus its two launch gaps in every frame.
-BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __restrict__ host_sums, int lane, uint32_t tag) {
+BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __restrict__ host_sums, int lane, uint32_t tag, uint32_t* __restrict__ dev_sums) {
     const unsigned long long* c64 = reinterpret_cast<const unsigned long long*>(set);
     unsigned long long tot[COUNTER_K1_U64];
 #pragma unroll
@@ -122,6 +122,12 @@ BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __r
         tiles += __shfl_down(tiles, off);
     }
     if (lane == 0) {
+        // (a copy for the kernels queued behind the sort before the host has read anything: the list builder takes the number of
+        //  listed splats from here, api.hip "speculative K5")
+        if (dev_sums) {
+#pragma unroll
+            for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) dev_sums[c] = tot[c] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot[c];
+        }
         volatile unsigned long long* h64 = reinterpret_cast<volatile unsigned long long*>(host_sums);
 #pragma unroll
         for (uint32_t c = 0; c < COUNTER_K1_U64; ++c) h64[c] = tot[c];
@@ -143,13 +149,13 @@ BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __r
 __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ counts,
                                                           uint32_t n, uint32_t nblocks, const uint32_t* __restrict__ minmax,
                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ csum,
-                                                          const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host, uint32_t rb_tag) {
+                                                          const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host, uint32_t rb_tag, uint32_t* __restrict__ rb_dev) {
     __shared__ uint32_t s_hist[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_csum[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
     const int tid = threadIdx.x, wave = tid >> 6;
     if (blockIdx.x == nblocks) {   // (block-uniform: taken before the first barrier)
-        if (wave == 0) counter_sums_to_host(rb_set, rb_host, tid, rb_tag);
+        if (wave == 0) counter_sums_to_host(rb_set, rb_host, tid, rb_tag, rb_dev);
         return;
     }
     for (int i = tid; i < DS_WAVES * DS_RADIX; i += DS_WG) { (&s_hist[0][0])[i] = 0; (&s_csum[0][0])[i] = 0; }
@@ -695,7 +701,7 @@ bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n +
 // rb_host, and the event recorded right behind that kernel (counter_sums_to_host above) — or, rb_tag != 0, no event: the kernel
 // stores the tag behind the sums and the host polls for it.
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag) {
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev) {
     if (n == 0) return 0;
     const uint32_t nblocks = (n + DS_TILE - 1) / DS_TILE;
     // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables
@@ -706,7 +712,7 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
     uint32_t* hist = totals + 2 * DS_RADIX;
     uint32_t* csum = hist + (size_t)DS_RADIX * nblocks;
     hipLaunchKernelGGL(dsort_hist_kernel, dim3(nblocks + (rb_set ? 1u : 0u)), dim3(DS_WG), 0, ctx->stream, keys, counts, n, nblocks, minmax, hist, csum,
-                       rb_set, rb_host, rb_tag);
+                       rb_set, rb_host, rb_tag, rb_dev);
     BH_LAUNCH_CHECK(ctx, "dsort_hist_kernel");
     if (rb_set && !rb_tag) BH_HIP(ctx, hipEventRecord(rb_done, ctx->stream));   // (rb_tag: the host polls the tag word instead)
     hipLaunchKernelGGL(dsort_rowscan_kernel, dim3(DS_RADIX), dim3(DS_WG), 0, ctx->stream, hist, csum, nblocks, totals);

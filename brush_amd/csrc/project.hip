@@ -580,10 +580,19 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     uint32_t* __restrict__ compact_gid_from_isect, float4* __restrict__ zero_span, uint32_t zero_f4, uint32_t budget,
     uint32_t* __restrict__ slice_info, const uint32_t* __restrict__ far_counts, const uint32_t* __restrict__ far_block_totals,
     const uint32_t* __restrict__ far_group_totals, const uint32_t* __restrict__ done_bits, const uint32_t* __restrict__ gate,
-    const uint32_t* __restrict__ zcut, const uint32_t* __restrict__ depth_keys_sorted) {
+    const uint32_t* __restrict__ zcut, const uint32_t* __restrict__ depth_keys_sorted, const uint32_t* __restrict__ nv_dev, uint32_t pair_cap) {
     __shared__ WalkLds s_walk[PROJ_WAVES];
     __shared__ uint32_t s_far[2 * PROJ_WAVES];
     if (FAR && *gate == 0u) return;   // every tile is final: nothing left to list
+    // nv_dev (api.hip "speculative K5"): queued before the host has read the frame's counts — `nv` is only a bound, the number of
+    // listed splats sits on the device (the depth sort's first kernel left it there), and the pair buffers hold pair_cap entries: a
+    // wave whose slot range does not fit emits nothing (the host sees the overflow in the counts and runs the kernel again).
+    if (nv_dev) {
+        const uint32_t live = *nv_dev;
+        nv = live < nv ? live : nv;
+        const size_t zf = ((size_t)nv * 10 + 3) / 4;
+        zero_f4 = zf < (size_t)zero_f4 ? (uint32_t)zf : zero_f4;
+    }
     // zcut != NULL (wave-uniform; FAR = false only): per-tile depth cuts instead of one slot budget — the compact splats are the
     // ones that own a pair in front of some cut, cum_tiles_hit is the scan of K1's near counts, and exactly those pairs are emitted
     const uint32_t tid_lin = blockIdx.x * PROJ_WG + threadIdx.x;
@@ -681,6 +690,7 @@ __global__ __launch_bounds__(PROJ_WG) void map_gaussians_kernel(
     const int first_lane = __builtin_ctzll(mine_mask), last_lane = 63 - __builtin_clzll(mine_mask);
     const uint32_t wave_base = __shfl(base, first_lane);
     const uint32_t wave_total = __shfl(end, last_lane) - wave_base;
+    if (!FAR && (wave_base > pair_cap || wave_total > pair_cap - wave_base)) return;   // (speculative launch only: pair_cap = 0xFFFFFFFF otherwise)
     // Emit order inside one splat is irrelevant: its tile ids are distinct, so after the
     // stable tile sort only the order ACROSS splats (depth order = slot ranges) survives.
     if (FAR) {
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
 int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const float* projected_by_gid, const uint32_t* gid,
                          float* projected, const uint32_t* cum_tiles_hit, uint32_t* tile_ids, uint32_t* isect_gids,
                          float4* zero_span, uint32_t zero_f4, uint32_t budget, uint32_t* slice_info, const uint32_t* zcut,
-                         const uint32_t* depth_keys_sorted) {
+                         const uint32_t* depth_keys_sorted, const uint32_t* nv_dev, uint32_t pair_cap) {
     if (nv == 0) return 0;
     if (zcut && (!slice_info || !depth_keys_sorted)) return set_error(ctx, BH_ERR_INVALID_ARG, "map_gaussians: a depth-cut table needs the slice words and the sorted keys");
     const dim3 grid((nv + PROJ_WG - 1) / PROJ_WG), block(PROJ_WG);
@@ -768,7 +778,7 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
         constexpr int SPW = BH_K5_SPW;
         const dim3 grid16((nv + PROJ_WAVES * SPW - 1) / (PROJ_WAVES * SPW));
         hipLaunchKernelGGL((map_gaussians_kernel<false, SPW>), grid16, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, zcut, depth_keys_sorted);
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, zcut, depth_keys_sorted, nv_dev, pair_cap);
     } else if (ctx->knob_k5_exact_spw != 64u) {
         // complete lists: 32 splats per wave (the wave's flat candidate list is half as long: 50.9 -> 46.9 us at 1 M splats / 9.8 M pairs;
         // 16: 49.5).  BH_K5_EXACT_SPW = 16 | 64 selects the others (A/B).
@@ -776,13 +786,13 @@ int launch_map_gaussians(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, const 
         const dim3 gridn((nv + PROJ_WAVES * spw - 1) / (PROJ_WAVES * spw));
         if (spw == 16u)
             hipLaunchKernelGGL((map_gaussians_kernel<false, 16>), gridn, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
+                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul, nv_dev, pair_cap);
         else
             hipLaunchKernelGGL((map_gaussians_kernel<false, 32>), gridn, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
+                               projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul, nv_dev, pair_cap);
     } else {
         hipLaunchKernelGGL((map_gaussians_kernel<false, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
-                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul);
+                           projected, cum_tiles_hit, tile_ids, isect_gids, zero_span, zero_f4, budget, slice_info, nul, nul, nul, nul, nul, nul, nul, nv_dev, pair_cap);
     }
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel");
     return 0;
@@ -803,7 +813,7 @@ int launch_map_gaussians_far(bh_ctx* ctx, uint32_t nv, const ViewUniforms& u, co
     BH_LAUNCH_CHECK(ctx, "slice_count_kernel");
     hipLaunchKernelGGL((map_gaussians_kernel<true, 64>), grid, block, 0, ctx->stream, nv, u.tile_bw, u.tile_bh, u.tile_y0, u.tile_y1, projected_by_gid, gid,
                        projected, cum_tiles_hit, tile_ids, isect_gids, (float4*)nullptr, 0u, budget, slice_info, (const uint32_t*)counts,
-                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                       (const uint32_t*)block_totals, (const uint32_t*)group_totals, done_bits, gate, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0xFFFFFFFFu);
     BH_LAUNCH_CHECK(ctx, "map_gaussians_kernel<far>");
     return 0;
 }

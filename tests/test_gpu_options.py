@@ -43,7 +43,7 @@ def test_environment_translation_is_the_harness_not_the_library():
     assert got[-2:] == [("k16_order", "2"), ("no_lpt", "1")]
 
 
-@pytest.mark.parametrize("options", [{"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
+@pytest.mark.parametrize("options", [{"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
                                      {"k16_order": 0}, {"k16_order": 2}, {"no_lpt": 1}, {"cut_sort_all": 1}, {"no_view_hash": 1},
                                      {"auto_exact_share": 0}, {"k5_exact_spw": 16}, {"k5_exact_spw": 64}])
 def test_alternative_paths_give_the_default_results(dev, options):
@@ -217,3 +217,40 @@ def test_views_render_complete_lists_when_cuts_save_nothing(dev):
     on = run("%.4f" % lo)
     assert on[0] == 1.0 and lo < on[1] < 1.0                                      # frame 2 is cut and finds out that it saved too little
     assert on[2:14] == [1.0] * 12 and lo < on[14] < 1.0 and on[15:27] == [1.0] * 12, on   # 12 complete frames, one probe, 12 more
+
+
+def test_speculative_list_builder_overflow_is_rendered_again(dev, oracle_lib):
+    """The list builder (K5) is queued before the host has read the frame's counts, with the pair buffers' capacity as its bound: a
+    frame whose pairs do not fit (here: a 20x larger scene on a context that has only seen a small one) must come out exactly as on
+    a fresh context — every aux tensor bit for bit — and so must the frames after it."""
+    import brush_amd as ba
+    w, h = 256, 192
+    cp = synth.default_camera_params(w, h)
+    cam = util.hip_camera(ba, cp)
+    tans = (math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w)
+    small = synth.make_scene(3000, 0x31, sh_degree=0, log_scale_range=(math.log(0.02), math.log(0.2)), tan_half_fov=tans)
+    big = synth.make_scene(60000, 0x32, sh_degree=0, log_scale_range=(math.log(0.02), math.log(0.25)), tan_half_fov=tans)
+
+    def aux_arrays(ctx, sc):
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        img, aux = ba.render_splats(spl, cam, (w, h), (0.1, 0.2, 0.3), ba.RasterPass.Backward, ctx=ctx)
+        ni = aux.num_intersections
+        return dict(img=img.cpu().numpy(), nv=aux.num_visible, ni=ni, gids=util.u32(aux.compact_gid_from_isect)[:ni].copy(), tiles=util.u32(aux.tile_id_from_isect)[:ni].copy(),
+                    offs=util.u32(aux.tile_offsets).copy(), proj=aux.projected_splats.cpu().numpy()[:aux.num_visible].copy(), gfc=util.u32(aux.global_from_compact_gid)[:aux.num_visible].copy())
+    used = ba.Context(dev)
+    for _ in range(3):   # the context's arena now holds the small scene's pairs, and K5 runs in front of the count readback
+        a_small = aux_arrays(used, small)
+    a_big = aux_arrays(used, big)          # 20x the pairs: the speculative launch overflows and is repeated
+    a_big2 = aux_arrays(used, big)         # ... and now fits
+    a_small2 = aux_arrays(used, small)
+    fresh = ba.Context(dev, options={"spec_k5": 0})
+    f_big, f_small = aux_arrays(fresh, big), aux_arrays(fresh, small)
+    assert a_big["ni"] > 8 * a_small["ni"]
+    for got, want in ((a_big, f_big), (a_big2, f_big), (a_small, f_small), (a_small2, f_small)):
+        assert got["nv"] == want["nv"] and got["ni"] == want["ni"]
+        for k in ("img", "gids", "tiles", "offs", "proj", "gfc"):
+            assert np.array_equal(got[k], want[k]), k
+    ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), big["transforms"], big["sh"], big["raw_opac"], bg=(0.1, 0.2, 0.3), flags=oracle_lib.FLAG_BWD_INFO)
+    assert a_big["ni"] == ref.num_intersections and np.array_equal(a_big["gids"], ref.get("compact_gid_from_isect"))
+    used.close()
+    fresh.close()
