@@ -739,7 +739,9 @@ def main():
                            "visible_per_frame": int(round(sum(visible) / max(1, len(visible)))),
                            "k16_ms": round(k16_ms, 4), "k17_ms": round(k17_ms, 4),
                            "k16_ns_per_blended_pair": round(k16_ms * 1e6 / max(mb, 1.0), 4), "k17_ns_per_blended_pair": round(k17_ms * 1e6 / max(mb, 1.0), 4),
-                           "psnr_held_out": psnr, "splats": splats.num_splats()}
+                           "psnr_held_out": psnr, "splats": splats.num_splats(),
+                           # every stage of the probe's steps (HIP events around the stage: multi-launch stages read a few us long)
+                           "stages_us": {k: round(ms / max(1, len(blended)) * 1e3, 1) for k, (ms, c) in prof.items()}}
                     if mode != "exact_lists":
                         cut = [x for x in seg_shares if x < 1.0]
                         seg.update({"near_share_mean": round(sum(seg_shares) / max(1, len(seg_shares)), 4), "second_attempts": far_now - far_seg,
