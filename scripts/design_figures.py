@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 check_only = "--check" in sys.argv[1:]   # exit 1 if DESIGN.md does not carry exactly the figures of the committed profiles
-tag = args_[0] if args_ else "r5"
+tag = args_[0] if args_ else "r6"
 
 
 def load(name):
@@ -25,7 +25,7 @@ def load(name):
 d = load("bench_n1")
 assert d, "profiles/%s_bench_n1.json missing" % tag
 names = [("ProjectSplats", "K1 cull + count (+ fills, tile order)"), ("DepthSort", "K2+K3 depth order + scan (4 launches)"),
-         ("MapGaussiansToIntersect", "K5 map (+ row gather)"), ("TileSort", "K6+K15 tile sort + offsets (4 launches)"), ("Rasterize", "K16 blend"),
+         ("MapGaussiansToIntersect", "K5 map (+ row gather)"), ("TileSort", "K6+K15 tile sort + offsets (5 launches)"), ("Rasterize", "K16 blend"),
          ("ImageLoss", "K19 loss pass A"), ("ImageLossBackward", "K20 loss pass B"), ("RasterizeBackwards", "K17 blend backward"),
          ("ProjectBackwards", "K18 project backward"), ("OptimizerStep", "Adam + stats + noise")]
 rows = ["| stage | µs per step | share of kernel time | bytes (algorithmic) | achieved | note |", "|---|---|---|---|---|---|"]
@@ -65,10 +65,28 @@ if cb:
 tl = d.get("train_loop")
 if tl:
     a, b, c = tl["cuts_view_ids"], tl["cuts_no_ids"], tl["exact_lists"]
-    h.append("**Training loop at the named size** (`train_loop`: %s): cuts keyed by view id **%.4f ms per step** (%d second attempts, near share mean %.2f, %d frames with "
-             "complete lists), keyed by the camera %.4f (%d second attempts), complete lists %.4f — cuts are %.1f %% faster; splats %d → %d over %d refines (%.1f ms each)."
-             % (tl["workload"], a["ms_per_step"], a["second_attempts"], a["near_share"]["mean"], a["frames_with_complete_lists"], b["ms_per_step"], b["second_attempts"],
-                c["ms_per_step"], 100.0 * (c["ms_per_step"] / a["ms_per_step"] - 1.0), a["splats_over_time"][0][1], a["splats_over_time"][-1][1], a["refine_calls"], a["refine_ms_each"]))
+    h.append("**Training loop at the named size on a converging scene** (`train_loop`: %s): per-tile cuts with automatic complete lists **%.4f ms per step** over the run "
+             "(%d second attempts, near share mean %.2f, %d frames with complete lists), keyed by the camera %.4f, complete lists throughout %.4f; held-out PSNR %.1f → %.1f dB; "
+             "splats %d → %d over %d refines (%.1f ms each)."
+             % (tl["workload"], a["ms_per_step"], a["second_attempts"], a["near_share"]["mean"], a["frames_with_complete_lists"], b["ms_per_step"],
+                c["ms_per_step"], a["psnr_held_out"][0], a["psnr_held_out"][1], a["splats_over_time"][0][1], a["splats_over_time"][-1][1], a["refine_calls"], a["refine_ms_each"]))
+    seg_rows = ["| steps | ms/step (cuts) | ms/step (complete lists) | near share | 2nd attempts | pairs / frame | blended / frame | K16 ms (ns/pair) | K17 ms (ns/pair) | PSNR dB |",
+                "|---|---|---|---|---|---|---|---|---|---|"]
+    for sa, sc_ in zip(a["segments"], c["segments"]):
+        seg_rows.append("| %d–%d | %.4f | %.4f | %.2f | %d | %.2f M | %.2f M | %.3f (%.3f) | %.3f (%.3f) | %.1f |" % (
+            sa["steps"][0], sa["steps"][1], sa["ms_per_step"], sc_["ms_per_step"], sa.get("near_share_mean", 1.0), sa.get("second_attempts", 0), sa["pairs_per_frame"] / 1e6,
+            sa["blended_pairs_per_frame"] / 1e6, sa["k16_ms"], sa["k16_ns_per_blended_pair"], sa["k17_ms"], sa["k17_ns_per_blended_pair"], sa["psnr_held_out"]))
+    h.append("\n".join(seg_rows))
+    last = c["segments"][-1]
+    if last.get("stages_us"):
+        st = last["stages_us"]
+        tot_st = sum(st.values())
+        h.append("**The late phase is the representative regime** (steps %d–%d, complete lists, HIP events around every stage over the segment's probe steps; %.0f µs of stages per step): "
+                 % (last["steps"][0], last["steps"][1], tot_st) + "; ".join("%s %.0f µs (%.0f %%)" % (k, v, 100.0 * v / tot_st) for k, v in sorted(st.items(), key=lambda kv: -kv[1])) + ".")
+lt = d.get("after_growth_stop")
+if lt:
+    h.append("After `growth_stop_iter` (the blend backward without the refine weight, same protocol as the headline): %.4f ms per step = %.0f views/s; K17 %.1f µs (HIP events around the stage)."
+             % (lt["ms_per_step"], lt["views_per_s"], lt["k17_ms_hip_events_around_the_stage"] * 1e3))
 ov = d.get("other_view_counts") or {}
 if ov:
     h.append("Other view counts (same scene): " + "; ".join("%d view%s %.3f ms" % (v["views"], "" if v["views"] == 1 else "s", v["ms_per_step"]) for v in ov.values()) + ".")
