@@ -280,10 +280,10 @@ def test_strip_halo_plan_moves_exactly_the_rows_the_strip_loss_reads():
 
 
 def test_design_md_carries_the_figures_of_the_committed_bench_line():
-    """VERDICT r4 weak #10 (doc drift): DESIGN.md's per-kernel table and headline paragraph are GENERATED from profiles/r5_bench_n1.json
+    """VERDICT r4 weak #10 (doc drift): DESIGN.md's per-kernel table and headline paragraph are GENERATED from profiles/r6_bench_n1.json
     and its siblings (scripts/design_figures.py); this fails when somebody commits new profiles without regenerating, or edits the
     generated blocks by hand."""
     import subprocess
     import sys
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_figures.py"), "r5", "--check"], capture_output=True, text=True, cwd=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_figures.py"), "r6", "--check"], capture_output=True, text=True, cwd=ROOT)
     assert p.returncode == 0, p.stdout + p.stderr
