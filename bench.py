@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--near-share", type=float, default=0.0, help="--lists sliced: fix the near slice's share of the pair list (developer A/B; 0 = automatic)")
     ap.add_argument("--loop-steps", type=int, default=3000, help="steps of each mode of the `train_loop` sub-measurement (0 = skip it)")
     ap.add_argument("--loop-segment", type=int, default=500, help="steps per reported segment of `train_loop`")
+    ap.add_argument("--loop-only", default="", help="run ONLY `train_loop`, for these comma-separated modes (cuts_view_ids, cuts_no_ids, exact_lists), and print its object as "
+                                                    "the JSON line — what scripts/late_phase_stats.sh profiles under rocprofv3 (not the contract's line)")
     ap.add_argument("--loop-views", type=int, default=64, help="views of the `train_loop` sub-measurement's orbit")
     ap.add_argument("--parallel", choices=["cameras", "tiles"], default="cameras",
                     help="N>1: 'cameras' = data parallel, one view per rank (weak scaling, the headline); "
@@ -603,7 +605,7 @@ def main():
                           "G_pixel_splat_evals_per_s": round(256.0 * ib / 1e9 / (ms * 1e-3), 1)}
         return hbm, valu
 
-    def train_loop(workload, nviews, total_steps, refine_every=200, segment=500, probe_steps=8):
+    def train_loop(workload, nviews, total_steps, refine_every=200, segment=500, probe_steps=8, modes=("cuts_view_ids", "cuts_no_ids", "exact_lists")):
         """The reference's training LOOP at the named size (crates/brush-process/src/train_stream.rs:220-306: next_batch -> step ->
         refine every `refine_every` steps, brush-train/src/config.rs:59) on a scene that CONVERGES: a hidden TEACHER —
         the named workload's splats — is rendered by this library from `nviews` cameras on an orbit into RGB8 host images before
@@ -666,7 +668,7 @@ def main():
                "segments_are": "ms_per_step: wall time of the segment's steps before its probe (refine calls included); k16 / k17: HIP events around the blend kernels over "
                                "the segment's last %d steps (each followed by a host sync to count the frame's blended pairs; not in the segment's time); psnr: the student "
                                "on two held-out orbit cameras against the teacher" % probe_steps}
-        for mode in ("cuts_view_ids", "cuts_no_ids", "exact_lists"):
+        for mode in modes:
             splats = ba.Splats(st_tr.copy(), st_sh.copy(), st_op.copy(), device=dev)
             cfg = ba.TrainConfig(exact_lists=mode == "exact_lists", refine_every=refine_every)
             trainer = ba.SplatTrainer(cfg, median_scene_scale=5.0, ctx=ctx, seed=0xB5EED)
@@ -773,6 +775,8 @@ def main():
                 ctx.profile(0)
                 loader.close()
             del splats, trainer
+        if len(modes) < 3:
+            return out
         best = min(("cuts_view_ids", "cuts_no_ids", "exact_lists"), key=lambda k: out[k]["ms_per_step"])
         out["fastest"] = best
         out["cuts_vs_exact"] = round(out["exact_lists"]["ms_per_step"] / out["cuts_view_ids"]["ms_per_step"], 4)
@@ -780,6 +784,10 @@ def main():
         out["no_ids_vs_ids"] = round(out["cuts_no_ids"]["ms_per_step"] / out["cuts_view_ids"]["ms_per_step"], 4)
         return out
 
+    if args.loop_only:
+        lo = train_loop(args.workload, max(2, args.loop_views), args.loop_steps, segment=max(50, args.loop_segment), modes=tuple(x for x in args.loop_only.split(",") if x))
+        os.write(real_stdout, (json.dumps({"train_loop": lo}) + "\n").encode())
+        return
     m = measure(args.workload, args.steps, args.warmup, "forward_only" if (world == 1 and not args.no_extra) else True, windows=args.windows)
 
     loop = None
