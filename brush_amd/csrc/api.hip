@@ -560,6 +560,7 @@ const OptionKey kOptionKeys[] = {
     {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
     {"k5_exact_spw", "16|32|64: splats per wave of the list builder for complete lists"},
     {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
+    {"lpt_classes", "log|linear: work classes of the backward's longest-first tile order — two per octave of blended splats, or 1/64 of the mean list length wide"},
     {"generic_depth_sort", "0|1: depth order by the generic radix sort + scan instead of the fused split sort"},
     {"tile_sort", "auto|bucket|lsd: the forward's tile sort (auto: bucket sort unless the view's pairs are concentrated in few tiles)"},
     {"spec_k5", "0|1: queue the list builder before the host has read the frame's counts (default 1; 0: behind the count readback)"},
@@ -620,6 +621,11 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
     else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
     else if (k == "k5_exact_spw") { if ((ok = parse_u32(value, 16, 64, &u) && (u == 16 || u == 32 || u == 64))) ctx->knob_k5_exact_spw = u; }
     else if (k == "no_lpt") ok = parse_flag(value, &ctx->knob_no_lpt);
+    else if (k == "lpt_classes") {
+        const std::string v(value);
+        if (v == "log") { ctx->knob_lpt_linear = false; ok = true; }
+        else if (v == "linear") { ctx->knob_lpt_linear = true; ok = true; }
+    }
     else if (k == "generic_depth_sort") ok = parse_flag(value, &ctx->knob_generic_depth_sort);
     else if (k == "tile_sort") {
         const std::string v(value);
@@ -841,8 +847,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     auto* gfc = (uint32_t*)ensure(ctx, SLOT_GLOBAL_FROM_COMPACT, npad * 4);
     auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
     if (!gfc || !depths_sorted) return BH_ERR_OOM;
-    // [T,2] offsets | 8*16 work-class counters | [8][16][ceil(T/8)] class lists (longest-first tile order of the backward)
-    const size_t lpt_words = 8 * 16 + (size_t)8 * 16 * ((num_tiles + 7) / 8);
+    // [T,2] offsets | 8 x LPT_CLASSES work-class counters | [8][LPT_CLASSES][ceil(T/8)] class lists (longest-first tile order of the backward)
+    const size_t lpt_words = 8 * LPT_CLASSES + (size_t)8 * LPT_CLASSES * ((num_tiles + 7) / 8);
     auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
@@ -927,7 +933,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             prep.visible = visible_words ? reinterpret_cast<uint32_t*>(visible) : nullptr;
             prep.visible_words = (uint32_t)visible_words;
             prep.tile_table = tile_offsets;
-            prep.tile_words = num_tiles * 2 + 8 * 16;
+            prep.tile_words = num_tiles * 2 + 8 * LPT_CLASSES;
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
             prep.list_all_visible = ctx->knob_cut_sort_all;
@@ -1034,7 +1040,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         // arrays, K5's grid, the backward's accumulator and K18 are sized for THEM; num_visible stays the reference's count
         nv = cut_active ? (uint32_t)hc[3] : nv_true;   // (BH_CUT_SORT_ALL: K1 then listed every visible splat, hc[3] == hc[0])
     } else {   // no K1 to clear them on the way
-        BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
+        BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * LPT_CLASSES) * 4, ctx->stream));
         if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
         if (counter_pairs) {   // counter_phase does not flip without K1: clear what this frame's blend kernel will add to
             BH_HIP(ctx, hipMemsetAsync(feedback_next, 0, COUNTER_SLOTS * 12, ctx->stream));
@@ -1122,7 +1128,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
     const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
     const float class_width_raw = (float)ni / (float)(win_tiles ? win_tiles : 1u) / 64.0f;
-    const float class_width = class_width_raw < 8.0f ? 8.0f : class_width_raw;
+    const float class_width = ctx->knob_lpt_linear ? (class_width_raw < 8.0f ? 8.0f : class_width_raw) : 0.0f;   // (0: logarithmic classes, rasterize.hip)
     ctx->lpt = (bwd_info && !ctx->knob_no_lpt) ? tile_offsets + (size_t)num_tiles * 2 : nullptr;
     float* out_f32 = bwd_info ? (float*)out_img : nullptr;
     uint32_t* out_u8 = bwd_info ? nullptr : (uint32_t*)out_img;

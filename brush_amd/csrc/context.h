@@ -143,6 +143,8 @@ struct ViewState {
     bool casual = false;            // created by a forward-only frame keyed by its camera (a viewer / eval render): these compete for CASUAL_VIEW_STATES tables only
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
+// work classes of the blend backward's longest-first tile order (rasterize.hip): counters [8 XCD bands][LPT_CLASSES] behind the tile table
+constexpr uint32_t LPT_CLASSES = 64;
 constexpr size_t MAX_VIEW_STATES = 4096;
 constexpr uint64_t DIRECT_ALLREDUCE_MIN_FLOATS = 1u << 16;   // shorter messages are latency-bound: ncclAllReduce
 constexpr uint32_t AUTO_EXACT_FRAMES = 12;   // frames a view renders complete lists after a cut frame that listed > auto_exact_share of its pairs
@@ -361,7 +363,8 @@ struct bh_ctx {
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
     // developer knobs (A/B measurements): bh_set_option
-    bool knob_no_lpt = false;         // BH_NO_LPT: backward tiles in index order
+    bool knob_no_lpt = false;         // option no_lpt: backward tiles in index order
+    bool knob_lpt_linear = false;     // option lpt_classes=linear: the work classes of rounds 2-5 (rasterize.hip)
     bool knob_force_exchange = false;       // BH_FORCE_PG: run the gradient-exchange path with a one-rank communicator too (overhead measurement)
     bool knob_break_allreduce = false;      // BH_BREAK_ALLREDUCE: corrupt the library's all-reduce (the bench self-check must notice)
     bool knob_generic_depth_sort = false;   // BH_GENERIC_DEPTH_SORT: the forward's depth order by the generic 32-bit radix sort + scan

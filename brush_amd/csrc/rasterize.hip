@@ -82,7 +82,7 @@ int launch_tile_offsets(bh_ctx* ctx, const uint32_t* tile_ids_sorted, uint32_t n
                         uint32_t* tile_offsets, bool pre_zeroed) {
     // the 8 x 16 work-class counters of the backward's tile order sit right behind the table: one fill clears both
     // (pre_zeroed: the forward's K1 already did, project.hip ForwardPrep)
-    if (!pre_zeroed) BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * 16) * 4, ctx->stream));
+    if (!pre_zeroed) BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * LPT_CLASSES) * 4, ctx->stream));
     if (num_isect == 0) return 0;
     hipLaunchKernelGGL(tile_offsets_kernel, dim3((num_isect + 1023) / 1024), dim3(256), 0, ctx->stream, tile_ids_sorted, num_isect, num_tiles, tile_offsets, OffsetsDyn{});
     BH_LAUNCH_CHECK(ctx, "tile_offsets_kernel");
@@ -120,7 +120,6 @@ struct RasterUniforms {
 // so it files the tile, per XCD band, into one of LPT_CLASSES work classes (an atomic append), and the backward
 // maps block j of an XCD to that band's j-th tile in DESCENDING class order: heavy tiles start first, light ones
 // fill the tail.  The band structure (each XCD keeps a contiguous range of tiles for its L2) is unchanged.
-constexpr uint32_t LPT_CLASSES = 16;
 // layout of the LPT scratch: [8 * LPT_CLASSES] counters (zeroed with tile_offsets), then [8][LPT_CLASSES][per] tile lists
 BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return (num_tiles + 7u) / 8u; }
 
@@ -421,7 +420,20 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         if (BWD_INFO) {
             tile_offsets[tile * 2 + 1] = last_useful;
             if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
-                const uint32_t cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
+                // work classes.  Logarithmic, eight per octave of blended splats from 8 up (8, 9, .. 15, 16, 18, .. 30, 32, 36, ..: +-4.5 %
+                // whatever the frame looks like; 2048+ share the top class) — the default since round 6.  Rounds 2-5 used LINEAR classes
+                // 1/64 of the frame's mean LIST length wide, sixteen of them: fine while tiles blend a tenth of their lists, degenerate once
+                // they blend a third — a converging run's late phase filed four tiles in five under the top class and K17 ran 26 % longer
+                // than with an order (0.66 vs 0.49 ms).  rcp_class_width > 0 still selects them (option lpt_classes = linear: A/B).
+                uint32_t cls;
+                if (u.rcp_class_width > 0.0f) {
+                    cls = min(LPT_CLASSES - 1u, (uint32_t)((float)work * u.rcp_class_width));
+                } else if (work < 8u) {
+                    cls = 0u;
+                } else {
+                    const uint32_t p = 28u - (uint32_t)__builtin_clz(work);   // work in [8 << p, 16 << p)
+                    cls = min(LPT_CLASSES - 1u, 1u + 8u * p + ((work >> p) & 7u));
+                }
                 const uint32_t list = (bidx & 7u) * LPT_CLASSES + cls;
                 const uint32_t pos = atomicAdd(&lpt[list], 1u);
                 lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
@@ -484,7 +496,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
                      const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
                      uint32_t* lpt, float class_width, int phase, const RasterSlice* slice) {
     RasterUniforms u;
-    u.rcp_class_width = 1.0f / (class_width > 1.0f ? class_width : 1.0f);
+    u.rcp_class_width = class_width > 0.0f ? 1.0f / (class_width > 1.0f ? class_width : 1.0f) : 0.0f;   // (<= 0: logarithmic classes)
     u.tile_bw = vu.tile_bw;
     u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
     u.tile_begin = vu.tile_bw * vu.tile_y0;
@@ -604,13 +616,10 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
         const uint32_t* cnt = lpt + xcd * LPT_CLASSES;
         uint32_t cls = LPT_CLASSES;
         bool found = false;
-#pragma unroll
-        for (uint32_t c = LPT_CLASSES; c-- > 0u;) {
+        for (uint32_t c = LPT_CLASSES; c-- > 0u && !found;) {   // (uniform: scalar loads of one band's counters, a few hundred cycles per tile at most)
             const uint32_t k = cnt[c];
-            if (!found) {
-                if (j < k) { cls = c; found = true; }
-                else j -= k;
-            }
+            if (j < k) { cls = c; found = true; }
+            else j -= k;
         }
         if (!found) return;  // more blocks than tiles in this band
         local_tile = lpt[8u * LPT_CLASSES + (xcd * LPT_CLASSES + cls) * lpt_band_tiles(u.num_tiles) + j];
