@@ -559,6 +559,7 @@ const OptionKey kOptionKeys[] = {
     {"no_view_hash", "0|1: frames without a view id share ONE table instead of being keyed by their camera"},
     {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
     {"k5_exact_spw", "16|32|64: splats per wave of the list builder for complete lists"},
+    {"bwd_jobs", "0|1: the blend backward works on checkpointed 128-entry segments of the tiles' lists (default 1) or on whole tiles"},
     {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
     {"lpt_classes", "log|linear: work classes of the backward's longest-first tile order — two per octave of blended splats, or 1/64 of the mean list length wide"},
     {"generic_depth_sort", "0|1: depth order by the generic radix sort + scan instead of the fused split sort"},
@@ -620,6 +621,7 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
     else if (k == "no_view_hash") ok = parse_flag(value, &ctx->knob_no_view_hash);
     else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
     else if (k == "k5_exact_spw") { if ((ok = parse_u32(value, 16, 64, &u) && (u == 16 || u == 32 || u == 64))) ctx->knob_k5_exact_spw = u; }
+    else if (k == "bwd_jobs") ok = parse_flag(value, &ctx->knob_bwd_jobs);
     else if (k == "no_lpt") ok = parse_flag(value, &ctx->knob_no_lpt);
     else if (k == "lpt_classes") {
         const std::string v(value);
@@ -848,7 +850,11 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
     if (!gfc || !depths_sorted) return BH_ERR_OOM;
     // [T,2] offsets | 8 x LPT_CLASSES work-class counters | [8][LPT_CLASSES][ceil(T/8)] class lists (longest-first tile order of the backward)
-    const size_t lpt_words = 8 * LPT_CLASSES + (size_t)8 * LPT_CLASSES * ((num_tiles + 7) / 8);
+    // backward jobs (rasterize.hip): checkpoint slots for the frame — a typical frame writes 1 - 2 per tile; a tile that gets none when
+    // they run out keeps the rest of its list as one job
+    const bool bwd_jobs = bwd_info && ctx->knob_bwd_jobs && !ctx->knob_no_lpt && !((flags & BH_FLAG_SLICED_LISTS) && ctx->slice_fraction > 0.0f);
+    const uint32_t ckpt_cap = bwd_jobs ? 2u * num_tiles + 4096u : 0u;
+    const size_t lpt_words = LPT_HEADER_WORDS + (size_t)8 * ((size_t)LPT_CLASSES * ((num_tiles + 7) / 8) + ckpt_cap);
     auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
@@ -933,7 +939,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             prep.visible = visible_words ? reinterpret_cast<uint32_t*>(visible) : nullptr;
             prep.visible_words = (uint32_t)visible_words;
             prep.tile_table = tile_offsets;
-            prep.tile_words = num_tiles * 2 + 8 * LPT_CLASSES;
+            prep.tile_words = num_tiles * 2 + LPT_HEADER_WORDS;
             prep.slice_table = slice_tab;
             prep.slice_words = (uint32_t)slice_words;
             prep.list_all_visible = ctx->knob_cut_sort_all;
@@ -1040,7 +1046,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         // arrays, K5's grid, the backward's accumulator and K18 are sized for THEM; num_visible stays the reference's count
         nv = cut_active ? (uint32_t)hc[3] : nv_true;   // (BH_CUT_SORT_ALL: K1 then listed every visible splat, hc[3] == hc[0])
     } else {   // no K1 to clear them on the way
-        BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + 8 * LPT_CLASSES) * 4, ctx->stream));
+        BH_HIP(ctx, hipMemsetAsync(tile_offsets, 0, ((size_t)num_tiles * 2 + LPT_HEADER_WORDS) * 4, ctx->stream));
         if (visible_words) BH_HIP(ctx, hipMemsetAsync(visible, 0, visible_words * 4, ctx->stream));
         if (counter_pairs) {   // counter_phase does not flip without K1: clear what this frame's blend kernel will add to
             BH_HIP(ctx, hipMemsetAsync(feedback_next, 0, COUNTER_SLOTS * 12, ctx->stream));
@@ -1113,6 +1119,14 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     while (tile_bits < 32 && (num_tiles >> tile_bits) != 0) tile_bits++;  // render.rs:228
     RasterSlice rs;
     rs.cum = cum;
+    ctx->jobs = BwdJobs{};
+    if (bwd_jobs) {
+        rs.jobs.ckpt = (float4*)ensure(ctx, SLOT_BWD_CKPT, (size_t)ckpt_cap * 256 * sizeof(float4));
+        rs.jobs.ckpt_of = (uint32_t*)ensure(ctx, SLOT_BWD_CKPT_OF, (size_t)num_tiles * BWD_MAX_SEGS * 4);
+        rs.jobs.ckpt_cap = ckpt_cap;
+        if (!rs.jobs.ckpt || !rs.jobs.ckpt_of) return BH_ERR_OOM;
+        ctx->jobs = rs.jobs;
+    }
     rs.feedback = nullptr;   // (the slot-budget heuristics that read it are gone: the automatic mode cuts per tile)
     (void)feedback_next;
     if (view) {   // every forward of a view refreshes its table
@@ -1356,6 +1370,7 @@ static ForwardState latest_forward(const bh_ctx* ctx) {
     fs.n = ctx->n; fs.sh_degree = ctx->sh_degree; fs.flags = ctx->flags;
     fs.bg[0] = ctx->bg[0]; fs.bg[1] = ctx->bg[1]; fs.bg[2] = ctx->bg[2];
     fs.lpt = ctx->lpt;
+    fs.jobs = ctx->jobs;
     return fs;
 }
 
@@ -1411,7 +1426,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_out
         if (r.num_intersections > 0)
             BH_TRY(launch_rasterize_backward(ctx, fs.uniforms, fs.bg, fs.flags & BH_FLAG_SMOOTH_CUTOFF,
                                              r.compact_gid_from_isect, r.tile_offsets, r.projected, r.out_img, v_output, v_combined, fs.lpt,
-                                             r.tile_offsets_far, /*want_refine=*/!ctx->bwd_skip_refine));
+                                             r.tile_offsets_far, /*want_refine=*/!ctx->bwd_skip_refine, &fs.jobs));
     }
     {
         ProfScope ps(ctx, "ProjectBackwards");
@@ -1425,7 +1440,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_out
 // the arena slots a BhRenderOut points into (everything a retained forward must keep alive)
 static const Slot kRetainSlots[RETAIN_SLOTS] = {SLOT_OUT_IMG, SLOT_VISIBLE, SLOT_MAX_RADIUS, SLOT_TILE_OFFSETS, SLOT_PROJECTED, SLOT_ISECT_GIDS_SORTED,
                                                 SLOT_TILE_IDS_SORTED, SLOT_GLOBAL_FROM_COMPACT, SLOT_CUM_TILES_HIT, SLOT_ISECT_COUNTS, SLOT_DEPTHS_SORTED,
-                                                SLOT_SLICE};
+                                                SLOT_SLICE, SLOT_BWD_CKPT, SLOT_BWD_CKPT_OF};
 
 }  // namespace bh
 

@@ -27,6 +27,8 @@ enum Slot : int {
     SLOT_SORT_VALS_B,
     SLOT_SORT_HIST,          // [256 * nblocks] u32
     SLOT_COMM_SCRATCH,       // direct all-reduce: the other ranks' versions of this rank's chunk (comm.hip)
+    SLOT_BWD_CKPT,           // backward jobs: the forward blend's pixel-state checkpoints (rasterize.hip)
+    SLOT_BWD_CKPT_OF,        // ... and which slot holds (tile, segment)'s
     SLOT_SORT_PARTS,         // tile sort: per part [9][bins] pair counts (sort.hip tile_parts_*)
     SLOT_SCAN_SUMS,          // block sums for the scan
     SLOT_GLOBAL_FROM_COMPACT,
@@ -143,8 +145,20 @@ struct ViewState {
     bool casual = false;            // created by a forward-only frame keyed by its camera (a viewer / eval render): these compete for CASUAL_VIEW_STATES tables only
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
-// work classes of the blend backward's longest-first tile order (rasterize.hip): counters [8 XCD bands][LPT_CLASSES] behind the tile table
+// work classes of the blend backward's longest-first order (rasterize.hip): counters [8 XCD bands][LPT_CLASSES] behind the tile table
 constexpr uint32_t LPT_CLASSES = 64;
+constexpr uint32_t LPT_HEADER_WORDS = 8 * LPT_CLASSES + 64;   // the counters + 64 control words ([0]: checkpoint slots handed out), cleared with the tile table
+// Backward JOBS (round 6, rasterize.hip): the blend backward's unit of work is not a tile but a segment of BWD_SEG entries of a
+// tile's blended list.  The forward blend leaves the pixel state (colour so far, signed transmittance) of its 256 pixels at every
+// segment boundary — a CHECKPOINT, 4 KB — and files one job per segment; a job starts from its checkpoint instead of replaying
+// the tile from its first splat.  The launch then lasts as long as its total work, not as long as its heaviest tile.
+constexpr uint32_t BWD_SEG = 128;       // list entries per job (two staging batches)
+constexpr uint32_t BWD_MAX_SEGS = 64;   // checkpointed segments per tile; a tile's last job takes whatever lies behind
+struct BwdJobs {                        // all zero: one job per tile (far-sliced frames, option bwd_jobs = 0)
+    float4* ckpt = nullptr;             // [ckpt_cap][4][64] pixel state at a segment's first entry
+    uint32_t* ckpt_of = nullptr;        // [T][BWD_MAX_SEGS]: checkpoint slot of (tile, segment >= 1); only entries of filed jobs are defined
+    uint32_t ckpt_cap = 0;              // slots; a tile that gets none keeps the rest of its list as one job (balance suffers, nothing else)
+};
 constexpr size_t MAX_VIEW_STATES = 4096;
 constexpr uint64_t DIRECT_ALLREDUCE_MIN_FLOATS = 1u << 16;   // shorter messages are latency-bound: ncclAllReduce
 constexpr uint32_t AUTO_EXACT_FRAMES = 12;   // frames a view renders complete lists after a cut frame that listed > auto_exact_share of its pairs
@@ -176,6 +190,7 @@ struct RasterSlice {
     const uint32_t* order = nullptr;       // [8][ceil(Tw/8)] block -> local tile of this launch (K1 sorted each XCD band by the view's last work), or NULL
     uint32_t order_mode = 1;
     uint32_t margin_pct = 150;        // depth-order margin behind a tile's last useful splat, in % of its rank
+    BwdJobs jobs{};                   // BWD_INFO: file the backward's work as jobs with checkpoints (ckpt != NULL)
 };
 
 // The far slice of a depth-sliced forward, ready to be queued: everything launch_* needs (api.hip enqueue_far_slice).
@@ -261,9 +276,10 @@ struct ForwardState {
     uint32_t n = 0, sh_degree = 0, flags = 0;
     float bg[3] = {0, 0, 0};
     uint32_t* lpt = nullptr;   // longest-first tile order of the forward (rasterize.hip), or NULL
+    BwdJobs jobs{};            // ... filed as jobs with checkpoints (ckpt != NULL), or as whole tiles
 };
 // A forward whose arena blocks were detached from the ctx (bh_render_retain): it stays replayable while later forwards run.
-constexpr int RETAIN_SLOTS = 12;
+constexpr int RETAIN_SLOTS = 14;
 struct Retained {
     ForwardState fs;
     Buffer blocks[RETAIN_SLOTS];
@@ -364,6 +380,8 @@ struct bh_ctx {
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
     // developer knobs (A/B measurements): bh_set_option
     bool knob_no_lpt = false;         // option no_lpt: backward tiles in index order
+    bool knob_bwd_jobs = true;        // option bwd_jobs: the blend backward works on checkpointed segments of the tiles' lists (rasterize.hip)
+    bh::BwdJobs jobs{};                   // of the last BWD_INFO forward (with ctx->lpt)
     bool knob_lpt_linear = false;     // option lpt_classes=linear: the work classes of rounds 2-5 (rasterize.hip)
     bool knob_force_exchange = false;       // BH_FORCE_PG: run the gradient-exchange path with a one-rank communicator too (overhead measurement)
     bool knob_break_allreduce = false;      // BH_BREAK_ALLREDUCE: corrupt the library's all-reduce (the bench self-check must notice)
@@ -504,7 +522,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& u, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
                               const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
-                              const uint32_t* tile_offsets_far = nullptr, bool want_refine = true);
+                              const uint32_t* tile_offsets_far = nullptr, bool want_refine = true, const BwdJobs* jobs = nullptr);
 // loss.hip
 int launch_image_loss_forward(bh_ctx* ctx, const float* pred, const uint32_t* gt, uint32_t channels, uint32_t h,
                               uint32_t w, const BhLossConfig& cfg, float* loss_map);

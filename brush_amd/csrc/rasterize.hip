@@ -110,6 +110,7 @@ struct RasterUniforms {
     uint32_t tile_begin;                        // first tile id of the window
     float bg_r, bg_g, bg_b;
     float rcp_class_width;                      // work classes of the backward's longest-first tile order (see LPT below)
+    uint32_t top_extra;                         // extra entries of every band's top-class list (backward jobs), 0 otherwise
 };
 
 // ---- longest-first tile order for the backward ------------------------------------------------------------
@@ -120,8 +121,15 @@ struct RasterUniforms {
 // so it files the tile, per XCD band, into one of LPT_CLASSES work classes (an atomic append), and the backward
 // maps block j of an XCD to that band's j-th tile in DESCENDING class order: heavy tiles start first, light ones
 // fill the tail.  The band structure (each XCD keeps a contiguous range of tiles for its L2) is unchanged.
-// layout of the LPT scratch: [8 * LPT_CLASSES] counters (zeroed with tile_offsets), then [8][LPT_CLASSES][per] tile lists
+// layout of the LPT scratch: LPT_HEADER_WORDS = [8][LPT_CLASSES] counters + 64 control words (zeroed with tile_offsets), then per
+// band the class lists: LPT_CLASSES x `per` entries, the top class with `top_extra` more (all full segments of the backward's jobs
+// land there).  An entry: local tile (24 bits) | segment << 24 | "runs to the tile's end" << 30.
 BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return (num_tiles + 7u) / 8u; }
+BH_DEV size_t lpt_list_offset(uint32_t num_tiles, uint32_t top_extra, uint32_t band, uint32_t cls) {
+    const size_t per = lpt_band_tiles(num_tiles);
+    return (size_t)LPT_HEADER_WORDS + (size_t)band * ((size_t)LPT_CLASSES * per + top_extra) + (size_t)cls * per;
+}
+constexpr uint32_t JOB_TILE_MASK = 0x00FFFFFFu, JOB_SEG_SHIFT = 24u, JOB_SEG_MASK = 0x3Fu, JOB_LAST_BIT = 1u << 30;
 
 // One staged splat = 12 floats (48 B, 16-B aligned rows):
 //   [0..3] x y c00 c01   [4..7] c11 alpha max(r,0) max(g,0)   [8] max(b,0)
@@ -224,6 +232,7 @@ struct SliceArgs {
     const uint32_t* order = nullptr;
     uint32_t order_mode = 1;
     uint32_t* work = nullptr;
+    BwdJobs jobs{};                         // BWD_INFO, ckpt != NULL: checkpoint the pixel state every BWD_SEG entries and file the tile's backward work as jobs
 };
 
 template <bool BWD_INFO, bool SMOOTH, int PHASE>
@@ -283,6 +292,8 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
     uint32_t reached = range_lo;        // one past the last splat the loop looked at (forward-only passes keep no last_useful)
     uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
     asm volatile("" : "+v"(sign_mask));
+    uint32_t n_ck = 0;                  // checkpoints this tile has written (segments 1 .. n_ck start from one)
+    bool ck_ok = true;
 
     // (A per-batch variant without the v_min of the 0.999 clamp — the backward's trick — was measured here: the second copy of
     //  the loop costs 16 VGPRs, 8 -> 7 waves per SIMD, 160 -> 170 us.)
@@ -290,6 +301,27 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         const bool live = any_live();
         if (__ballot(live) == 0ull) break;
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
+        if (BWD_INFO && PHASE != 2) {
+            // backward jobs: the pixels' state in front of entry k * BWD_SEG of the list is where job k of this tile starts
+            const uint32_t done = batch_start - range_lo;
+            if (sl.jobs.ckpt && ck_ok && done != 0u && (done % BWD_SEG) == 0u) {   // (wave-uniform)
+                const uint32_t seg = done / BWD_SEG;
+                uint32_t slot = 0xFFFFFFFFu;
+                if (seg < BWD_MAX_SEGS) {
+                    if (lane == 0) slot = atomicAdd(lpt + 8u * LPT_CLASSES, 1u);   // (control word 0: slots handed out this frame)
+                    slot = (uint32_t)__shfl((int)slot, 0);
+                }
+                if (slot < sl.jobs.ckpt_cap) {
+                    float4* ck = sl.jobs.ckpt + (size_t)slot * 256u + (uint32_t)lane;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) ck[q * 64] = make_float4(pr[q], pg[q], pb[q], tr[q]);
+                    if (lane == 0) sl.jobs.ckpt_of[(size_t)tile * BWD_MAX_SEGS + seg] = slot;
+                    n_ck = seg;
+                } else {
+                    ck_ok = false;   // out of slots (or of segments): the rest of this tile's list stays one job
+                }
+            }
+        }
         __syncthreads();  // previous batch fully consumed (single wave: cheap)
         const uint32_t cg = stage_batch<SMOOTH, true>(isect_gids, projected, batch_start, cnt, lane, s_splat);
         __syncthreads();
@@ -406,6 +438,21 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
             }
         }
     }
+    if (BWD_INFO && PHASE != 2 && lpt && sl.jobs.ckpt) {
+        // the tile's backward work as JOBS of BWD_SEG list entries (lane s files segment s): segments 1 .. n_ck start from a checkpoint,
+        // the last job takes whatever lies behind the last checkpoint.  Classes: full segments on top, the tails by their length.
+        const uint32_t jwork = last_useful - range_lo;
+        const uint32_t nj = min((jwork + BWD_SEG - 1u) / BWD_SEG, n_ck + 1u);
+        if ((uint32_t)lane < nj) {
+            const uint32_t lo = (uint32_t)lane * BWD_SEG;
+            const bool last = (uint32_t)lane + 1u == nj;
+            const uint32_t size = (last ? jwork : lo + BWD_SEG) - lo;
+            const uint32_t cls = size >= BWD_SEG ? LPT_CLASSES - 1u : (size * (LPT_CLASSES - 1u)) / BWD_SEG;
+            const uint32_t band = bidx & 7u;
+            const uint32_t pos = atomicAdd(&lpt[band * LPT_CLASSES + cls], 1u);
+            lpt[lpt_list_offset(u.num_tiles, u.top_extra, band, cls) + pos] = local_tile | ((uint32_t)lane << JOB_SEG_SHIFT) | (last ? JOB_LAST_BIT : 0u);
+        }
+    }
     if (lane == 0) {
         if (PHASE == 1) atomicOr(&sl.done_bits[tile >> 5], 1u << (tile & 31u));
         uint32_t work = (BWD_INFO ? last_useful : reached) - range_lo;
@@ -419,7 +466,7 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         // rasterize.rs:183-189: shrink the tile's end to one past the last useful splat
         if (BWD_INFO) {
             tile_offsets[tile * 2 + 1] = last_useful;
-            if (lpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
+            if (lpt && !sl.jobs.ckpt) {  // file the tile under its backward work class (longest-first order, see LPT above)
                 // work classes.  Logarithmic, eight per octave of blended splats from 8 up (8, 9, .. 15, 16, 18, .. 30, 32, 36, ..: +-4.5 %
                 // whatever the frame looks like; 2048+ share the top class) — the default since round 6.  Rounds 2-5 used LINEAR classes
                 // 1/64 of the frame's mean LIST length wide, sixteen of them: fine while tiles blend a tenth of their lists, degenerate once
@@ -436,7 +483,7 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
                 }
                 const uint32_t list = (bidx & 7u) * LPT_CLASSES + cls;
                 const uint32_t pos = atomicAdd(&lpt[list], 1u);
-                lpt[8u * LPT_CLASSES + list * lpt_band_tiles(u.num_tiles) + pos] = local_tile;
+                lpt[lpt_list_offset(u.num_tiles, u.top_extra, bidx & 7u, cls) + pos] = local_tile | JOB_LAST_BIT;
             }
         }
         // per-tile depth cut for this view's NEXT frame: a saturated tile needs the splats up to its last useful one — plus a margin
@@ -522,7 +569,9 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.order = slice->order;
         sl.order_mode = slice->order_mode;
         sl.work = slice->work;
+        if (bwd_info && phase != 2 && lpt) sl.jobs = slice->jobs;
     }
+    u.top_extra = sl.jobs.ckpt ? sl.jobs.ckpt_cap : 0u;
     if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
@@ -599,20 +648,30 @@ constexpr int BWD_WAVES = 3;   // waves per SIMD the backward is compiled for (f
 // consumer, refine()'s growth selection, stops reading it at growth_stop_iter (train.rs:589-614), i.e. for the second half of a
 // default training run.  bh_train_step selects it from BhTrainConfig.growth_stop_iter; bh_render_backward* always compute it.
 // The nine other sums are bit-identical either way (same instructions in the same order).
-template <bool SMOOTH, bool REFINE>
+// JOBS = true (round 6): the unit of work is a SEGMENT of BWD_SEG entries of a tile's blended list (context.h BwdJobs).  A block
+// takes jobs j, j + blocks per band, ... of its XCD band in descending class order (full segments first, then the tiles' tails by
+// length); a job of segment s > 0 starts from the checkpoint the forward blend left in front of the segment's first entry instead
+// of replaying the tile from its first splat: the pixels' transmittance as it was there (bit for bit: the replay's decisions are
+// the forward's), and the remaining colour = final colour - colour so far.  Gradients of the segments of a tile add up in the
+// accumulator like those of different tiles.  Why: one wave per TILE made the launch last as long as its heaviest tile (a lone
+// wave retires an op every ~5 cycles, one of five on a SIMD every ~13): 409 us for a frame whose heaviest tile blends 879 splats
+// while the mean tile blends 58 (an object in front of an empty background), and 1.6 rounds of whole tiles on the uniform frame.
+template <bool SMOOTH, bool REFINE, bool JOBS>
 __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                                const uint32_t* __restrict__ tile_offsets,
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
                                                                const float* __restrict__ v_output,
                                                                float* __restrict__ v_combined, const uint32_t* __restrict__ lpt,
-                                                               const uint32_t* __restrict__ tile_offsets_far) {
+                                                               const uint32_t* __restrict__ tile_offsets_far, BwdJobs jb) {
     __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    uint32_t local_tile;
+  for (uint32_t jidx = blockIdx.x >> 3;; jidx += gridDim.x >> 3) {   // (JOBS: a block's jobs; otherwise one tile, left by `return`)
+    uint32_t local_tile, seg = 0u;
+    bool to_end = true;
     if (lpt) {
-        // block j of XCD x takes the j-th tile of band x in descending work-class order (wave-uniform scalar code)
+        // block j of XCD x takes the j-th entry of band x in descending work-class order (wave-uniform scalar code)
         const uint32_t xcd = blockIdx.x & 7u;
-        uint32_t j = blockIdx.x >> 3;
+        uint32_t j = jidx;
         const uint32_t* cnt = lpt + xcd * LPT_CLASSES;
         uint32_t cls = LPT_CLASSES;
         bool found = false;
@@ -621,8 +680,10 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
             if (j < k) { cls = c; found = true; }
             else j -= k;
         }
-        if (!found) return;  // more blocks than tiles in this band
-        local_tile = lpt[8u * LPT_CLASSES + (xcd * LPT_CLASSES + cls) * lpt_band_tiles(u.num_tiles) + j];
+        if (!found) return;  // no entry left in this band
+        const uint32_t entry = lpt[lpt_list_offset(u.num_tiles, u.top_extra, xcd, cls) + j];
+        local_tile = entry & JOB_TILE_MASK;
+        if (JOBS) { seg = (entry >> JOB_SEG_SHIFT) & JOB_SEG_MASK; to_end = (entry & JOB_LAST_BIT) != 0u; }
     } else {
         local_tile = tile_of_block(blockIdx.x, u.num_tiles);
         if (local_tile >= u.num_tiles) return;
@@ -630,10 +691,14 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
     const uint32_t tile = u.tile_begin + local_tile;
     // the tile's blended splats, front to back: one list (the exact path), or the near slice's followed by the far slice's
     // (depth-sliced forward; the far table is all zero for a tile the near slice finished)
-    const uint32_t seg_lo0 = tile_offsets[tile * 2], seg_hi0 = tile_offsets[tile * 2 + 1];
+    uint32_t seg_lo0 = tile_offsets[tile * 2], seg_hi0 = tile_offsets[tile * 2 + 1];
     uint32_t seg_lo1 = 0, seg_hi1 = 0;
-    if (tile_offsets_far) { seg_lo1 = tile_offsets_far[tile * 2]; seg_hi1 = tile_offsets_far[tile * 2 + 1]; }
-    if (seg_hi0 <= seg_lo0 && seg_hi1 <= seg_lo1) return;
+    if (!JOBS && tile_offsets_far) { seg_lo1 = tile_offsets_far[tile * 2]; seg_hi1 = tile_offsets_far[tile * 2 + 1]; }
+    if (JOBS) {   // this job's part of the tile's list
+        seg_lo0 += seg * BWD_SEG;
+        if (!to_end) seg_hi0 = seg_lo0 + BWD_SEG;
+        if (seg_hi0 <= seg_lo0) continue;
+    } else if (seg_hi0 <= seg_lo0 && seg_hi1 <= seg_lo1) return;
     const int lane = threadIdx.x;
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
@@ -680,6 +745,19 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
             sS[q] = sw[q] = 0.0f;
             vox[q] = voy[q] = voz[q] = 0.0f;
             w2q[q] = h2q[q] = 0.0f;
+        }
+    }
+    if (JOBS && seg != 0u) {
+        // start from the forward's checkpoint in front of this segment: (colour so far, signed transmittance) per pixel
+        const float4* ck = jb.ckpt + (size_t)jb.ckpt_of[(size_t)tile * BWD_MAX_SEGS + seg] * 256u + (uint32_t)lane;
+        float4 c4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = ck[q * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // remaining . v_rgb = (final - so far) . v_rgb: the tile's start value minus what the earlier segments subtracted
+            sS[q] -= __builtin_fmaf(c4[q].z, voz[q], __builtin_fmaf(c4[q].y, voy[q], c4[q].x * vox[q]));
+            sw[q] = (sw[q] != 0.0f && c4[q].w > 0.0f) ? c4[q].w : 0.0f;   // (a finished pixel carries its final T with the sign flipped; outside the image: 0)
         }
     }
 
@@ -793,8 +871,8 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
     };
 
 #pragma nounroll
-    for (int seg = 0; seg < 2; ++seg) {   // ONE copy of the batch loop for both segments (its body is ~1.6 k instructions)
-        const uint32_t range_lo = seg ? seg_lo1 : seg_lo0, range_hi = seg ? seg_hi1 : seg_hi0;
+    for (int part = 0; part < (JOBS ? 1 : 2); ++part) {   // ONE copy of the batch loop for both segments (its body is ~1.6 k instructions)
+        const uint32_t range_lo = part ? seg_lo1 : seg_lo0, range_hi = part ? seg_hi1 : seg_hi0;
         for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
             const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
             __syncthreads();
@@ -805,23 +883,25 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
             else run_batch(std::false_type{}, cnt);
         }
     }
+    if (!JOBS) return;
+  }
 }
 
-template <bool SMOOTH, bool REFINE>
+template <bool SMOOTH, bool REFINE, bool JOBS>
 static void launch_rasterize_backward_t(hipStream_t stream, dim3 grid, hipEvent_t ea, hipEvent_t eb, const RasterUniforms& u, const uint32_t* isect_gids,
                                         const uint32_t* tile_offsets, const float* projected, const float* out_img, const float* v_output, float* v_combined,
-                                        const uint32_t* lpt, const uint32_t* tile_offsets_far) {
+                                        const uint32_t* lpt, const uint32_t* tile_offsets_far, const BwdJobs& jb) {
     const dim3 block(64);
     if (ea)   // profiling level 2 (bench.py's timed region): the launch carries its own start / stop events (context.h)
-        hipExtLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE>), grid, block, 0, stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+        hipExtLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE, JOBS>), grid, block, 0, stream, ea, eb, 0, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far, jb);
     else
-        hipLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+        hipLaunchKernelGGL((rasterize_backward_kernel<SMOOTH, REFINE, JOBS>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far, jb);
 }
 
 int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool smooth,
                               const uint32_t* isect_gids, const uint32_t* tile_offsets, const float* projected,
                               const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
-                              const uint32_t* tile_offsets_far, bool want_refine) {
+                              const uint32_t* tile_offsets_far, bool want_refine, const BwdJobs* jobs) {
     RasterUniforms u;
     u.rcp_class_width = 1.0f;
     u.tile_bw = vu.tile_bw;
@@ -830,14 +910,30 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     u.img_w = vu.img_w;
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
-    const uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
+    // the forward filed jobs (segments with checkpoints) or whole tiles: the backward reads the lists the way they were written
+    const bool by_jobs = jobs && jobs->ckpt && lpt && !tile_offsets_far;
+    const BwdJobs jb = by_jobs ? *jobs : BwdJobs{};
+    u.top_extra = by_jobs ? jb.ckpt_cap : 0u;
+    // whole tiles: one block per tile.  Jobs: two blocks per tile (a typical frame has 1.5 - 2.5 jobs per tile); a block takes
+    // every (blocks per band)-th job of its band, so any number of jobs is covered
+    const uint32_t per = (u.num_tiles + 7u) / 8u;
+    const uint32_t nblocks = (by_jobs ? 2u : 1u) * per * 8u;
     const dim3 grid(nblocks);
     hipEvent_t ea = ctx->prof.ext_a, eb = ctx->prof.ext_b;
     ctx->prof.ext_a = ctx->prof.ext_b = nullptr;
-    if (smooth && want_refine) launch_rasterize_backward_t<true, true>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else if (smooth) launch_rasterize_backward_t<true, false>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else if (want_refine) launch_rasterize_backward_t<false, true>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
-    else launch_rasterize_backward_t<false, false>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far);
+#define BH_K17(S, R, J) launch_rasterize_backward_t<S, R, J>(ctx->stream, grid, ea, eb, u, isect_gids, tile_offsets, projected, out_img, v_output, v_combined, lpt, tile_offsets_far, jb)
+    if (by_jobs) {
+        if (smooth && want_refine) BH_K17(true, true, true);
+        else if (smooth) BH_K17(true, false, true);
+        else if (want_refine) BH_K17(false, true, true);
+        else BH_K17(false, false, true);
+    } else {
+        if (smooth && want_refine) BH_K17(true, true, false);
+        else if (smooth) BH_K17(true, false, false);
+        else if (want_refine) BH_K17(false, true, false);
+        else BH_K17(false, false, false);
+    }
+#undef BH_K17
     BH_LAUNCH_CHECK(ctx, "rasterize_backward_kernel");
     return 0;
 }
