@@ -850,11 +850,9 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     auto* depths_sorted = (uint32_t*)ensure(ctx, SLOT_DEPTHS_SORTED, npad * 4);
     if (!gfc || !depths_sorted) return BH_ERR_OOM;
     // [T,2] offsets | 8 x LPT_CLASSES work-class counters | [8][LPT_CLASSES][ceil(T/8)] class lists (longest-first tile order of the backward)
-    // backward jobs (rasterize.hip): checkpoint slots for the frame — a typical frame writes 1 - 2 per tile; a tile that gets none when
-    // they run out keeps the rest of its list as one job
+    // backward jobs (rasterize.hip): the blend backward works on checkpointed segments of the tiles' lists
     const bool bwd_jobs = bwd_info && ctx->knob_bwd_jobs && !ctx->knob_no_lpt && !((flags & BH_FLAG_SLICED_LISTS) && ctx->slice_fraction > 0.0f);
-    const uint32_t ckpt_cap = bwd_jobs ? 2u * num_tiles + 4096u : 0u;
-    const size_t lpt_words = LPT_HEADER_WORDS + (size_t)8 * ((size_t)LPT_CLASSES * ((num_tiles + 7) / 8) + ckpt_cap);
+    const size_t lpt_words = LPT_HEADER_WORDS + (size_t)8 * LPT_CLASSES * ((num_tiles + 7) / 8);
     auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
@@ -1121,10 +1119,14 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     rs.cum = cum;
     ctx->jobs = BwdJobs{};
     if (bwd_jobs) {
+        // checkpoint slots are addressed by list position (context.h BwdJobs): listed pairs / BWD_SEG + tiles of them
+        const uint32_t listed = cut_active ? near_total : ni;
+        const uint32_t ckpt_cap = (uint32_t)std::min<uint64_t>((uint64_t)listed / BWD_SEG + num_tiles + 1u, BWD_CKPT_MAX_SLOTS);
         rs.jobs.ckpt = (float4*)ensure(ctx, SLOT_BWD_CKPT, (size_t)ckpt_cap * 256 * sizeof(float4));
-        rs.jobs.ckpt_of = (uint32_t*)ensure(ctx, SLOT_BWD_CKPT_OF, (size_t)num_tiles * BWD_MAX_SEGS * 4);
         rs.jobs.ckpt_cap = ckpt_cap;
-        if (!rs.jobs.ckpt || !rs.jobs.ckpt_of) return BH_ERR_OOM;
+        rs.jobs.top_cap = (num_tiles + 7u) / 8u + ckpt_cap;   // (a band's full segments: at most one per checkpoint + one per tile)
+        rs.jobs.top_list = (uint32_t*)ensure(ctx, SLOT_BWD_TOPLIST, (size_t)8 * rs.jobs.top_cap * 4);
+        if (!rs.jobs.ckpt || !rs.jobs.top_list) return BH_ERR_OOM;
         ctx->jobs = rs.jobs;
     }
     rs.feedback = nullptr;   // (the slot-budget heuristics that read it are gone: the automatic mode cuts per tile)
@@ -1440,7 +1442,7 @@ static int backward_impl(bh_ctx* ctx, const ForwardState& fs, const float* v_out
 // the arena slots a BhRenderOut points into (everything a retained forward must keep alive)
 static const Slot kRetainSlots[RETAIN_SLOTS] = {SLOT_OUT_IMG, SLOT_VISIBLE, SLOT_MAX_RADIUS, SLOT_TILE_OFFSETS, SLOT_PROJECTED, SLOT_ISECT_GIDS_SORTED,
                                                 SLOT_TILE_IDS_SORTED, SLOT_GLOBAL_FROM_COMPACT, SLOT_CUM_TILES_HIT, SLOT_ISECT_COUNTS, SLOT_DEPTHS_SORTED,
-                                                SLOT_SLICE, SLOT_BWD_CKPT, SLOT_BWD_CKPT_OF};
+                                                SLOT_SLICE, SLOT_BWD_CKPT, SLOT_BWD_TOPLIST};
 
 }  // namespace bh
 

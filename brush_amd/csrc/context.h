@@ -28,7 +28,7 @@ enum Slot : int {
     SLOT_SORT_HIST,          // [256 * nblocks] u32
     SLOT_COMM_SCRATCH,       // direct all-reduce: the other ranks' versions of this rank's chunk (comm.hip)
     SLOT_BWD_CKPT,           // backward jobs: the forward blend's pixel-state checkpoints (rasterize.hip)
-    SLOT_BWD_CKPT_OF,        // ... and which slot holds (tile, segment)'s
+    SLOT_BWD_TOPLIST,        // ... and the bands' top-class job lists
     SLOT_SORT_PARTS,         // tile sort: per part [9][bins] pair counts (sort.hip tile_parts_*)
     SLOT_SCAN_SUMS,          // block sums for the scan
     SLOT_GLOBAL_FROM_COMPACT,
@@ -155,10 +155,15 @@ constexpr uint32_t LPT_HEADER_WORDS = 8 * LPT_CLASSES + 64;   // the counters + 
 constexpr uint32_t BWD_SEG = 128;       // list entries per job (two staging batches)
 constexpr uint32_t BWD_MAX_SEGS = 64;   // checkpointed segments per tile; a tile's last job takes whatever lies behind
 struct BwdJobs {                        // all zero: one job per tile (far-sliced frames, option bwd_jobs = 0)
-    float4* ckpt = nullptr;             // [ckpt_cap][4][64] pixel state at a segment's first entry
-    uint32_t* ckpt_of = nullptr;        // [T][BWD_MAX_SEGS]: checkpoint slot of (tile, segment >= 1); only entries of filed jobs are defined
-    uint32_t ckpt_cap = 0;              // slots; a tile that gets none keeps the rest of its list as one job (balance suffers, nothing else)
+    float4* ckpt = nullptr;             // [ckpt_cap][4][64] pixel state at a segment's first entry.  Slot of (tile, segment s >= 1) =
+                                        // (first list entry of the tile) / BWD_SEG + tile + s - 1: unique without an atomic or a table, because the
+                                        // tiles' lists lie one behind the other (< listed pairs / BWD_SEG + tiles slots; a slot >= ckpt_cap does not exist:
+                                        // that tile keeps the rest of its list as one job)
+    uint32_t ckpt_cap = 0;
+    uint32_t* top_list = nullptr;       // [8][top_cap] the bands' TOP class (every full segment lands there: more entries than tiles)
+    uint32_t top_cap = 0;
 };
+constexpr uint32_t BWD_CKPT_MAX_SLOTS = 96u * 1024u;   // 384 MB of checkpoints at most (frames with > ~11 M listed pairs split only their first tiles)
 constexpr size_t MAX_VIEW_STATES = 4096;
 constexpr uint64_t DIRECT_ALLREDUCE_MIN_FLOATS = 1u << 16;   // shorter messages are latency-bound: ncclAllReduce
 constexpr uint32_t AUTO_EXACT_FRAMES = 12;   // frames a view renders complete lists after a cut frame that listed > auto_exact_share of its pairs

@@ -110,7 +110,6 @@ struct RasterUniforms {
     uint32_t tile_begin;                        // first tile id of the window
     float bg_r, bg_g, bg_b;
     float rcp_class_width;                      // work classes of the backward's longest-first tile order (see LPT below)
-    uint32_t top_extra;                         // extra entries of every band's top-class list (backward jobs), 0 otherwise
 };
 
 // ---- longest-first tile order for the backward ------------------------------------------------------------
@@ -121,14 +120,14 @@ struct RasterUniforms {
 // so it files the tile, per XCD band, into one of LPT_CLASSES work classes (an atomic append), and the backward
 // maps block j of an XCD to that band's j-th tile in DESCENDING class order: heavy tiles start first, light ones
 // fill the tail.  The band structure (each XCD keeps a contiguous range of tiles for its L2) is unchanged.
-// layout of the LPT scratch: LPT_HEADER_WORDS = [8][LPT_CLASSES] counters + 64 control words (zeroed with tile_offsets), then per
-// band the class lists: LPT_CLASSES x `per` entries, the top class with `top_extra` more (all full segments of the backward's jobs
-// land there).  An entry: local tile (24 bits) | segment << 24 | "runs to the tile's end" << 30.
+// layout of the LPT scratch: LPT_HEADER_WORDS = [8][LPT_CLASSES] counters + 64 spare words (zeroed with tile_offsets), then
+// [8][LPT_CLASSES][per] class lists.  Backward jobs: a band's TOP class (every full segment) has more entries than the band has
+// tiles and lives in BwdJobs::top_list.  An entry: local tile (24 bits) | segment << 24 | "runs to the tile's end" << 30.
 BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return (num_tiles + 7u) / 8u; }
-BH_DEV size_t lpt_list_offset(uint32_t num_tiles, uint32_t top_extra, uint32_t band, uint32_t cls) {
-    const size_t per = lpt_band_tiles(num_tiles);
-    return (size_t)LPT_HEADER_WORDS + (size_t)band * ((size_t)LPT_CLASSES * per + top_extra) + (size_t)cls * per;
+BH_DEV size_t lpt_list_offset(uint32_t num_tiles, uint32_t band, uint32_t cls) {
+    return (size_t)LPT_HEADER_WORDS + ((size_t)band * LPT_CLASSES + cls) * lpt_band_tiles(num_tiles);
 }
+BH_DEV uint32_t ckpt_slot(uint32_t range_lo, uint32_t tile, uint32_t seg) { return range_lo / BWD_SEG + tile + seg - 1u; }
 constexpr uint32_t JOB_TILE_MASK = 0x00FFFFFFu, JOB_SEG_SHIFT = 24u, JOB_SEG_MASK = 0x3Fu, JOB_LAST_BIT = 1u << 30;
 
 // One staged splat = 12 floats (48 B, 16-B aligned rows):
@@ -236,7 +235,7 @@ struct SliceArgs {
 };
 
 template <bool BWD_INFO, bool SMOOTH, int PHASE>
-__global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+__global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                       uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
                                                       const uint32_t* __restrict__ global_from_compact,
                                                       float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
@@ -292,8 +291,6 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
     uint32_t reached = range_lo;        // one past the last splat the loop looked at (forward-only passes keep no last_useful)
     uint32_t sign_mask = 0x80000000u;   // kept in a VGPR: an SGPR operand halves a VALU op's issue rate
     asm volatile("" : "+v"(sign_mask));
-    uint32_t n_ck = 0;                  // checkpoints this tile has written (segments 1 .. n_ck start from one)
-    bool ck_ok = true;
 
     // (A per-batch variant without the v_min of the 0.999 clamp — the backward's trick — was measured here: the second copy of
     //  the loop costs 16 VGPRs, 8 -> 7 waves per SIMD, 160 -> 170 us.)
@@ -304,21 +301,12 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         if (BWD_INFO && PHASE != 2) {
             // backward jobs: the pixels' state in front of entry k * BWD_SEG of the list is where job k of this tile starts
             const uint32_t done = batch_start - range_lo;
-            if (sl.jobs.ckpt && ck_ok && done != 0u && (done % BWD_SEG) == 0u) {   // (wave-uniform)
-                const uint32_t seg = done / BWD_SEG;
-                uint32_t slot = 0xFFFFFFFFu;
-                if (seg < BWD_MAX_SEGS) {
-                    if (lane == 0) slot = atomicAdd(lpt + 8u * LPT_CLASSES, 1u);   // (control word 0: slots handed out this frame)
-                    slot = (uint32_t)__shfl((int)slot, 0);
-                }
+            if (sl.jobs.ckpt && done != 0u && (done % BWD_SEG) == 0u && done / BWD_SEG < BWD_MAX_SEGS) {   // (wave-uniform, scalar)
+                const uint32_t slot = ckpt_slot(range_lo, tile, done / BWD_SEG);
                 if (slot < sl.jobs.ckpt_cap) {
                     float4* ck = sl.jobs.ckpt + (size_t)slot * 256u + (uint32_t)lane;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) ck[q * 64] = make_float4(pr[q], pg[q], pb[q], tr[q]);
-                    if (lane == 0) sl.jobs.ckpt_of[(size_t)tile * BWD_MAX_SEGS + seg] = slot;
-                    n_ck = seg;
-                } else {
-                    ck_ok = false;   // out of slots (or of segments): the rest of this tile's list stays one job
                 }
             }
         }
@@ -439,9 +427,14 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
         }
     }
     if (BWD_INFO && PHASE != 2 && lpt && sl.jobs.ckpt) {
-        // the tile's backward work as JOBS of BWD_SEG list entries (lane s files segment s): segments 1 .. n_ck start from a checkpoint,
-        // the last job takes whatever lies behind the last checkpoint.  Classes: full segments on top, the tails by their length.
+        // the tile's backward work as JOBS of BWD_SEG list entries (lane s files segment s).  Checkpoints exist in front of every
+        // segment the batch loop entered (up to BWD_MAX_SEGS, and while their slots exist); the last job takes whatever lies behind
+        // the last checkpoint.  Classes: full segments in the top class, the tails by their length.
         const uint32_t jwork = last_useful - range_lo;
+        const uint32_t last_batch = reached > range_lo ? ((reached - 1u - range_lo) / BATCH) * BATCH : 0u;   // first entry of the last batch the loop entered
+        uint32_t n_ck = min(last_batch / BWD_SEG, BWD_MAX_SEGS - 1u);
+        const uint32_t slot0 = ckpt_slot(range_lo, tile, 1u);
+        n_ck = slot0 < sl.jobs.ckpt_cap ? min(n_ck, sl.jobs.ckpt_cap - slot0) : 0u;
         const uint32_t nj = min((jwork + BWD_SEG - 1u) / BWD_SEG, n_ck + 1u);
         if ((uint32_t)lane < nj) {
             const uint32_t lo = (uint32_t)lane * BWD_SEG;
@@ -450,7 +443,9 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
             const uint32_t cls = size >= BWD_SEG ? LPT_CLASSES - 1u : (size * (LPT_CLASSES - 1u)) / BWD_SEG;
             const uint32_t band = bidx & 7u;
             const uint32_t pos = atomicAdd(&lpt[band * LPT_CLASSES + cls], 1u);
-            lpt[lpt_list_offset(u.num_tiles, u.top_extra, band, cls) + pos] = local_tile | ((uint32_t)lane << JOB_SEG_SHIFT) | (last ? JOB_LAST_BIT : 0u);
+            const uint32_t entry = local_tile | ((uint32_t)lane << JOB_SEG_SHIFT) | (last ? JOB_LAST_BIT : 0u);
+            if (cls == LPT_CLASSES - 1u) sl.jobs.top_list[(size_t)band * sl.jobs.top_cap + pos] = entry;
+            else lpt[lpt_list_offset(u.num_tiles, band, cls) + pos] = entry;
         }
     }
     if (lane == 0) {
@@ -483,7 +478,7 @@ __global__ __launch_bounds__(64) void rasterize_kernel(RasterUniforms u, const u
                 }
                 const uint32_t list = (bidx & 7u) * LPT_CLASSES + cls;
                 const uint32_t pos = atomicAdd(&lpt[list], 1u);
-                lpt[lpt_list_offset(u.num_tiles, u.top_extra, bidx & 7u, cls) + pos] = local_tile | JOB_LAST_BIT;
+                lpt[lpt_list_offset(u.num_tiles, bidx & 7u, cls) + pos] = local_tile | JOB_LAST_BIT;
             }
         }
         // per-tile depth cut for this view's NEXT frame: a saturated tile needs the splats up to its last useful one — plus a margin
@@ -571,7 +566,6 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.work = slice->work;
         if (bwd_info && phase != 2 && lpt) sl.jobs = slice->jobs;
     }
-    u.top_extra = sl.jobs.ckpt ? sl.jobs.ckpt_cap : 0u;
     if (sl.zcut && (!sl.depth_keys_sorted && sl.nv)) sl.zcut = nullptr;
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
@@ -681,7 +675,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
             else j -= k;
         }
         if (!found) return;  // no entry left in this band
-        const uint32_t entry = lpt[lpt_list_offset(u.num_tiles, u.top_extra, xcd, cls) + j];
+        const uint32_t entry = (JOBS && cls == LPT_CLASSES - 1u) ? jb.top_list[(size_t)xcd * jb.top_cap + j] : lpt[lpt_list_offset(u.num_tiles, xcd, cls) + j];
         local_tile = entry & JOB_TILE_MASK;
         if (JOBS) { seg = (entry >> JOB_SEG_SHIFT) & JOB_SEG_MASK; to_end = (entry & JOB_LAST_BIT) != 0u; }
     } else {
@@ -692,6 +686,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
     // the tile's blended splats, front to back: one list (the exact path), or the near slice's followed by the far slice's
     // (depth-sliced forward; the far table is all zero for a tile the near slice finished)
     uint32_t seg_lo0 = tile_offsets[tile * 2], seg_hi0 = tile_offsets[tile * 2 + 1];
+    const uint32_t list_lo = seg_lo0;
     uint32_t seg_lo1 = 0, seg_hi1 = 0;
     if (!JOBS && tile_offsets_far) { seg_lo1 = tile_offsets_far[tile * 2]; seg_hi1 = tile_offsets_far[tile * 2 + 1]; }
     if (JOBS) {   // this job's part of the tile's list
@@ -699,7 +694,8 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
         if (!to_end) seg_hi0 = seg_lo0 + BWD_SEG;
         if (seg_hi0 <= seg_lo0) continue;
     } else if (seg_hi0 <= seg_lo0 && seg_hi1 <= seg_lo1) return;
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
+    if (JOBS) asm volatile("" : "+v"(lane));   // (per job: nothing derived from the lane stays in a register across the job loop)
     const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
     const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
@@ -749,7 +745,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
     }
     if (JOBS && seg != 0u) {
         // start from the forward's checkpoint in front of this segment: (colour so far, signed transmittance) per pixel
-        const float4* ck = jb.ckpt + (size_t)jb.ckpt_of[(size_t)tile * BWD_MAX_SEGS + seg] * 256u + (uint32_t)lane;
+        const float4* ck = jb.ckpt + (size_t)ckpt_slot(list_lo, tile, seg) * 256u + (uint32_t)lane;
         float4 c4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) c4[q] = ck[q * 64];
@@ -911,9 +907,9 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     u.img_h = vu.img_h;
     u.bg_r = bg[0]; u.bg_g = bg[1]; u.bg_b = bg[2];
     // the forward filed jobs (segments with checkpoints) or whole tiles: the backward reads the lists the way they were written
-    const bool by_jobs = jobs && jobs->ckpt && lpt && !tile_offsets_far;
+    // (jobs are only filed by frames whose far segments are empty: complete lists and per-tile cuts, whose far table is all zero — api.hip)
+    const bool by_jobs = jobs && jobs->ckpt && lpt;
     const BwdJobs jb = by_jobs ? *jobs : BwdJobs{};
-    u.top_extra = by_jobs ? jb.ckpt_cap : 0u;
     // whole tiles: one block per tile.  Jobs: two blocks per tile (a typical frame has 1.5 - 2.5 jobs per tile); a block takes
     // every (blocks per band)-th job of its band, so any number of jobs is covered
     const uint32_t per = (u.num_tiles + 7u) / 8u;
