@@ -381,42 +381,50 @@ def test_6m_4k_sh3_sliced_equals_exact(dev):
 
 
 def test_train_step_returns_while_its_forward_is_still_running(dev, scene_1m):
-    """VERDICT r5 #3, as far as this library goes: the one thing the host waits for inside bh_train_step is the frame's counts, which
-    the depth sort's first kernel stores ~70 us into the frame (the list builder is queued in front of that wait and takes the splat
-    count on the device).  Everything behind it — tile sort, blend, loss, backward, update — is queued while the GPU is still busy with
-    the front of the frame: from an idle stream the call returns in less time than the forward's kernels take, with the stream still
-    busy.  (A step queued behind a running one returns as soon as the GPU has reached its counts: a trainer runs ~one backward ahead.)"""
+    """VERDICT r5 #3, as far as this library goes.  With COMPLETE lists the one thing the host waits for inside bh_train_step is the
+    frame's counts, which the depth sort's first kernel stores ~70 us into the frame (the list builder is queued in front of that wait
+    and takes the splat count on the device); everything behind it — tile sort, blend, loss, backward, update — is queued while the
+    GPU is still busy with the front of the frame: from an idle stream the call returns in less time than the forward's kernels take,
+    with the stream still busy.  A frame with CUT lists also waits for its near blend (one word says whether the forecast held, before
+    a backward may be queued): it returns with the loss, the backward and the update still in front of the GPU.  (A step queued behind
+    a running one returns as soon as the GPU has reached that point of it: a trainer runs ~one backward ahead.)"""
     import time
     import brush_amd as ba
     sc, w, h = scene_1m
     cp = synth.default_camera_params(w, h)
-    ctx = ba.Context(dev)
-    spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
     gt = torch.from_numpy(synth.synthetic_gt_packed(w, h).view(np.int32)).to(dev)
-    trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=5.0, ctx=ctx, seed=1)
-    batch = ba.SceneBatch(gt, util.hip_camera(ba, cp), view_id=1)
-    for _ in range(6):
-        trainer.step(batch, spl)
-    ctx.sync()
-    ctx.profile(1)
-    ctx.profile_fetch()
-    for _ in range(4):
-        trainer.step(batch, spl)
-    ctx.sync()
-    prof = ctx.profile_fetch()
-    ctx.profile(0)
-    fwd_ms = sum(prof[k][0] / prof[k][1] for k in ("ProjectSplats", "DepthSort", "MapGaussiansToIntersect", "TileSort", "Rasterize") if k in prof)
-    host_ms, busy = [], []
     stream = torch.cuda.current_stream(dev)
-    for _ in range(8):
+    for exact in (True, False):
+        ctx = ba.Context(dev)
+        spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+        trainer = ba.SplatTrainer(ba.TrainConfig(exact_lists=exact), median_scene_scale=5.0, ctx=ctx, seed=1)
+        batch = ba.SceneBatch(gt, util.hip_camera(ba, cp), view_id=1)
+        for _ in range(6):
+            trainer.step(batch, spl)
         ctx.sync()
-        t0 = time.perf_counter()
-        trainer.step(batch, spl)
-        host_ms.append((time.perf_counter() - t0) * 1e3)
-        busy.append(not stream.query())
-    ctx.sync()
-    host_ms.sort()
-    print("train step: the call returns after %.3f ms (median of 8, idle stream); its forward's kernels take %.3f ms" % (host_ms[4], fwd_ms))
-    assert all(busy), "the stream was idle when bh_train_step returned"
-    assert host_ms[4] < fwd_ms, (host_ms, fwd_ms)
-    ctx.close()
+        ctx.profile(1)
+        ctx.profile_fetch()
+        for _ in range(4):
+            trainer.step(batch, spl)
+        ctx.sync()
+        prof = ctx.profile_fetch()
+        ctx.profile(0)
+        fwd_ms = sum(prof[k][0] / prof[k][1] for k in ("ProjectSplats", "DepthSort", "MapGaussiansToIntersect", "TileSort", "Rasterize") if k in prof)
+        step_ms = sum(v[0] / v[1] for v in prof.values())
+        host_ms, busy = [], []
+        for _ in range(8):
+            ctx.sync()
+            t0 = time.perf_counter()
+            trainer.step(batch, spl)
+            host_ms.append((time.perf_counter() - t0) * 1e3)
+            busy.append(not stream.query())
+        ctx.sync()
+        host_ms.sort()
+        print("%s lists: bh_train_step returns after %.3f ms (median of 8, idle stream); its forward's kernels take %.3f ms, the step's %.3f ms"
+              % ("complete" if exact else "cut", host_ms[4], fwd_ms, step_ms))
+        assert all(busy), "the stream was idle when bh_train_step returned"
+        if exact:
+            assert host_ms[4] < fwd_ms, (host_ms, fwd_ms)
+        else:
+            assert host_ms[4] < 0.75 * step_ms, (host_ms, step_ms)
+        ctx.close()
