@@ -825,6 +825,24 @@ def main():
                  "roofline": ehbm, "roofline_valu": evalu,
                  "stages_ms": {k: round(ms / max(c, 1), 4) for k, (ms, c) in me["stages"].items()}}
 
+    centered = None
+    if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats and args.sh_degree == 0:
+        # an object in front of an empty background (what a NeRF-synthetic view looks like to the blend kernels: half of the tiles are
+        # empty, the heaviest blends 15x the mean): the frame on which one wave per TILE made the backward last as long as its
+        # heaviest tile.  With the backward's jobs (checkpointed 128-entry segments, the default) and, same call, with whole tiles.
+        c_steps = max(10, min(args.steps, 30))
+        mc = measure("1m_1080p_centered", c_steps, 3, True)
+        ctx.set_option("bwd_jobs", 0)
+        try:
+            mc0 = measure("1m_1080p_centered", c_steps, 3, True)
+        finally:
+            ctx.set_option("bwd_jobs", 1)
+        stg = lambda mm, k: round(mm["stages"].get(k, (0.0, 0))[0] / max(mm["stages"].get(k, (0.0, 1))[1], 1), 4)   # noqa: E731
+        centered = {"workload": "1m_1080p_centered: the configs[2] splats squeezed into the central half of the frustum (NOT a BASELINE.json config; an object-centric frame: "
+                                "%d intersections, %d blended)" % (mc["ni"], mc["isect_blended"]),
+                    "steps": c_steps, "ms_per_step": round(mc["dt"] / c_steps * 1e3, 4), "k16_ms": stg(mc, "Rasterize"), "k17_ms": stg(mc, "RasterizeBackwards"),
+                    "whole_tile_backward": {"option": "bwd_jobs=0", "ms_per_step": round(mc0["dt"] / c_steps * 1e3, 4), "k17_ms": stg(mc0, "RasterizeBackwards")}}
+
     sh3 = None
     if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats and args.sh_degree == 0:
         s3_steps = max(10, min(args.steps, 30))
@@ -1016,6 +1034,8 @@ def main():
             out["sh3"] = sh3
         if late is not None:
             out["after_growth_stop"] = late
+        if centered is not None:
+            out["object_centric"] = centered
         if m.get("forward_only"):
             out["forward_only"] = {"workload": "%s, RasterPass::Forward (BASELINE.json configs[1]): packed rgba8 image, no backward state; ms per render call incl. its count readback" % args.workload,
                                    "ms_exact_lists": m["forward_only"]["exact_lists"], "ms_sliced_lists": m["forward_only"]["sliced_lists"],

@@ -43,7 +43,7 @@ def test_environment_translation_is_the_harness_not_the_library():
     assert got[-2:] == [("k16_order", "2"), ("no_lpt", "1")]
 
 
-@pytest.mark.parametrize("options", [{"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
+@pytest.mark.parametrize("options", [{"bwd_jobs": 0}, {"lpt_classes": "linear"}, {"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
                                      {"k16_order": 0}, {"k16_order": 2}, {"no_lpt": 1}, {"cut_sort_all": 1}, {"no_view_hash": 1},
                                      {"auto_exact_share": 0}, {"k5_exact_spw": 16}, {"k5_exact_spw": 64}])
 def test_alternative_paths_give_the_default_results(dev, options):
@@ -254,3 +254,35 @@ def test_speculative_list_builder_overflow_is_rendered_again(dev, oracle_lib):
     assert a_big["ni"] == ref.num_intersections and np.array_equal(a_big["gids"], ref.get("compact_gid_from_isect"))
     used.close()
     fresh.close()
+
+
+def test_backward_jobs_equal_the_whole_tile_backward_on_a_skewed_frame(dev, oracle_lib):
+    """The blend backward works on checkpointed 128-entry segments of the tiles' lists (context.h BwdJobs): on a frame whose work is
+    concentrated in a few tiles — large opaque-ish splats in the image centre, tiles with hundreds of blended entries next to empty
+    ones, several segments per tile — the gradients equal the whole-tile backward's (option bwd_jobs = 0) and the oracle's."""
+    import brush_amd as ba
+    n, w, h = 30000, 320, 256
+    sc = synth.make_scene(n, 0x71, sh_degree=1, log_scale_range=(math.log(0.03), math.log(0.25)), opacity_range=(0.02, 0.3), spread=0.45,
+                          tan_half_fov=(math.tan(math.radians(30)), math.tan(math.radians(30)) * h / w))
+    cp = synth.default_camera_params(w, h)
+    cam = util.hip_camera(ba, cp)
+    rng = np.random.default_rng(4)
+    v_out = torch.from_numpy((rng.normal(size=(h, w, 4)) * 1e-3).astype(np.float32)).to(dev)
+    got = {}
+    for jobs in (1, 0):
+        ctx = ba.Context(dev, options={"bwd_jobs": jobs})
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        r = ba.render_splats_bwd(spl, cam, (w, h), (0.1, 0.2, 0.3), v_out, ctx=ctx)
+        to = r["aux"].tile_offsets.to(torch.int64)
+        work = (to[:, 1] - to[:, 0]).clamp(min=0)
+        got[jobs] = {k: r[k].cpu().numpy() for k in ("v_transforms", "v_sh_coeffs", "v_raw_opacities", "v_refine_weight")}
+        ctx.close()
+    assert int(work.max()) > 4 * 128 and int((work == 0).sum()) > work.numel() // 4, (int(work.max()), int((work == 0).sum()))   # several segments per heavy tile, many empty tiles
+    ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=(0.1, 0.2, 0.3), flags=oracle_lib.FLAG_BWD_INFO)
+    ref.backward(v_out.cpu().numpy())
+    want = {"v_transforms": ref.get("v_transforms").reshape(-1, 10), "v_sh_coeffs": ref.get("v_coeffs").reshape(got[1]["v_sh_coeffs"].shape),
+            "v_raw_opacities": ref.get("v_raw_opac").reshape(-1), "v_refine_weight": ref.get("v_refine").reshape(-1)}
+    for k, wv in want.items():
+        m = max(float(np.abs(wv).max()), 1e-30)
+        assert float(np.abs(got[1][k] - wv).max()) <= 1e-4 * m, k        # the north star's gradient tolerance, vs the oracle
+        assert float(np.abs(got[1][k] - got[0][k]).max()) <= 2e-6 * m, k   # vs the whole-tile backward: rounding
