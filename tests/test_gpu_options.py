@@ -277,7 +277,7 @@ def test_backward_jobs_equal_the_whole_tile_backward_on_a_skewed_frame(dev, orac
         work = (to[:, 1] - to[:, 0]).clamp(min=0)
         got[jobs] = {k: r[k].cpu().numpy() for k in ("v_transforms", "v_sh_coeffs", "v_raw_opacities", "v_refine_weight")}
         ctx.close()
-    assert int(work.max()) > 4 * 128 and int((work == 0).sum()) > work.numel() // 4, (int(work.max()), int((work == 0).sum()))   # several segments per heavy tile, many empty tiles
+    assert int(work.max()) > 4 * 128 and float(work.float().median()) < float(work.max()) / 8.0, (int(work.max()), float(work.float().median()))   # several segments per heavy tile, most tiles light
     ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"], bg=(0.1, 0.2, 0.3), flags=oracle_lib.FLAG_BWD_INFO)
     ref.backward(v_out.cpu().numpy())
     want = {"v_transforms": ref.get("v_transforms").reshape(-1, 10), "v_sh_coeffs": ref.get("v_coeffs").reshape(got[1]["v_sh_coeffs"].shape),
