@@ -589,7 +589,9 @@ def main():
                "frac_listed": round(listed / 1e9 / (dom_ms * 1e-3) / HBM_PEAK_GBS, 4) if dom_ms > 0 else 0.0,
                "note": "achieved = bytes the launch touches (80 B per BLENDED intersection + 32 B per pixel) / measured duration. frac_listed is the "
                        "SURVEY 8d figure that charges every LISTED intersection (80*I + 32*P): the kernel stops each tile once all its pixels "
-                       "saturate, so that figure counts reads it never makes and can exceed 1. The kernel is VALU-issue bound: see roofline_valu."}
+                       "saturate, so that figure counts reads it never makes and can exceed 1. The kernel is VALU-issue bound: see roofline_valu. "
+                       "`traffic` exceeds the algorithmic bytes by design since round 6: the backward works on 128-entry segments of the tiles' lists, each of "
+                       "which reads a 4 KB pixel-state checkpoint and its tile's pixels (DESIGN.md 4, K17) - with whole tiles (option bwd_jobs=0) the ratio is 0.97."}
         valu = {}
         for stage, kern in (("RasterizeBackwards", "rasterize_backward_kernel"), ("Rasterize", "rasterize_kernel")):
             ms, calls = m["stages"].get(stage, (0.0, 0))
