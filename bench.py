@@ -1059,7 +1059,7 @@ def main():
 
 
 KERNEL_STAGE = (("project_forward_kernel", "ProjectSplats"), ("dsort_", "DepthSort"), ("map_gaussians_kernel", "MapGaussiansToIntersect"),
-                ("slice_count_kernel", "MapGaussiansToIntersect"), ("radix_", "TileSort"), ("tile_bucket_kernel", "TileSort"), ("scan_", "MapGaussiansToIntersect"),
+                ("slice_count_kernel", "MapGaussiansToIntersect"), ("radix_", "TileSort"), ("tile_parts_", "TileSort"), ("scan_", "MapGaussiansToIntersect"),
                 ("tile_offsets_kernel", "GetTileOffsets"), ("rasterize_backward_kernel", "RasterizeBackwards"), ("rasterize_kernel", "Rasterize"),
                 ("loss_fused_forward_kernel", "ImageLoss"), ("loss_fused_backward_kernel", "ImageLossBackward"),
                 ("project_backward_kernel", "ProjectBackwards"), ("train_update_kernel", "OptimizerStep"), ("project_visible_kernel", "ProjectVisible"))
