@@ -272,6 +272,20 @@ def test_strip_halo_plan_moves_exactly_the_rows_the_strip_loss_reads():
             lo, hi = max(0, b - 21), min(h, e + 21)
             assert np.array_equal(staged[r][lo:hi], truth[lo:hi]), (h, world, r)
     assert lib.bh_strip_halo_plan(100, 50, 40, 0, 2, (_ffi.BhHaloOp * 4)()) < 0   # begin >= end
+    # a rank whose strip is SHORTER than the halo (its own error) must still post messages of the sizes its neighbours
+    # wait for — the exchange completes, then that rank reports the error (comm.hip) — instead of leaving them blocked in ncclRecv:
+    # every send of the short rank matches its neighbour's receive, row for row
+    h, spans = 200, [(0, 96), (96, 112), (112, 200)]   # the middle strip: one tile row = 16 px < 21
+    plans = []
+    for r, (b, e) in enumerate(spans):
+        ops = (_ffi.BhHaloOp * 4)()
+        k = lib.bh_strip_halo_plan(h, b, e, r, 3, ops)
+        plans.append([(ops[i].send, ops[i].peer, ops[i].row_begin_px, ops[i].rows) for i in range(k)])
+    for r, plan in enumerate(plans):
+        for send, peer, row0, rows in plan:
+            other = [(p0, pr) for (ps, pp, p0, pr) in plans[peer] if ps != send and pp == r]
+            assert other == [(row0, rows)], (r, peer, send, (row0, rows), other)
+            assert 0 <= row0 and row0 + rows <= h
     # the Python mirror's wrapper says the same
     from brush_amd.host import Context
     assert Context.strip_halo_plan(1080, 360, 720, 1, 3) == [(True, 0, 360, 21), (False, 0, 339, 21), (True, 2, 699, 21), (False, 2, 720, 21)]
