@@ -380,6 +380,8 @@ def main():
             cams.append(ba.Camera(position=pos, rotation=rot, fov_x=cp["fov_x"], fov_y=cp["fov_y"], center_uv=cp["center_uv"]))
         return cams
 
+    direct_checked = [False]
+
     def measure(workload, steps, warmup, with_stages, sh_degree=None, nviews=None, windows=1, exchange=None, algo=None, growth_stop_iter=None):
         """Time `windows` windows of `steps` train steps of `workload`, cycling through `nviews` views; returns a dict of raw
         measurements (rank-local; dt = the median window).  exchange / algo: override --exchange / --allreduce (the N > 1 A/B);
@@ -389,6 +391,9 @@ def main():
         algo = algo or args.allreduce
         if native:
             ctx.set_option("grad_allreduce", algo)
+            if algo == "direct" and world > 1 and not direct_checked[0]:
+                ctx.comm_selftest()   # (with the option set it also checks the direct all-reduce against ncclAllReduce's sum: collective, once)
+                direct_checked[0] = True
         nviews = max(1, args.views if nviews is None else nviews)
         scene, w, h = synth.config_scene(workload, sh_degree, n=args.splats or None)
         n = scene["transforms"].shape[0]
@@ -873,23 +878,6 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
-    exchange_stages, exchange_ab = None, None
-    if pg is not None and not args.no_extra:
-        # The first multi-GPU run has to explain itself (VERDICT r5 #6): (a) what the exchange stages cost per step on every rank
-        # (HIP events around FlagExchange / GradExchange / ImageExchange, 10 steps from the same initial state), (b) a 10-step A/B of
-        # the exchange modes and of the two all-reduce algorithms (every figure the MAX over the ranks, like the headline)
-        import torch.distributed as dist
-        mp_ = measure(args.workload, 10, 3, True, windows=1)
-        mine_st = {k: round(ms / max(c, 1) * 1e3, 2) for k, (ms, c) in mp_["stages"].items() if k in ("FlagExchange", "GradExchange", "ImageExchange", "RasterizeBackwards", "OptimizerStep")}
-        mine_st["rank"] = rank
-        exchange_stages = [None] * world
-        dist.all_gather_object(exchange_stages, mine_st)
-        exchange_ab = {"steps": 10, "what": "ms per step (max over ranks), 10 steps after 3 warm-up steps from the same initial state, per exchange mode x all-reduce algorithm"}
-        for ex_mode in ("sparse", "dense"):
-            for alg in ("ring", "direct"):
-                ma = measure(args.workload, 10, 3, False, windows=1, exchange=ex_mode, algo=alg)
-                exchange_ab["%s_%s" % (ex_mode, alg)] = round(ma["dt"] / 10 * 1e3, 4)
-
     late = None
     if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats and args.sh_degree == 0:
         # the second half of a default training run (iter >= growth_stop_iter = 15000 of 30000, config.rs:72): nobody reads the refine
@@ -901,6 +889,7 @@ def main():
                 "ms_per_step": round(ml["dt"] / args.steps * 1e3, 4), "views_per_s": round(args.steps / ml["dt"], 2),
                 "k17_ms_hip_events_around_the_stage": round(k17[0] / max(k17[1], 1), 4)}
 
+    final_out = None
     if rank == 0:
         steps = args.steps
         dt, st = m["dt"], m["stats"]
@@ -1010,10 +999,10 @@ def main():
                                        "dp%d over cameras (RCCL all-reduce of gradients%s)" % (world, ", library-owned communicator" if native else ", torch.distributed hook")) if world > 1 else "single GPU"},
             "exchange": ({"mode": args.exchange, "comm": "native" if native else "torch", "algo": args.allreduce, "rows_last_step": st.exchange_rows, "rows_total": n,
                           "per_rank": per_rank, "selfcheck": selfcheck,
-                          "stages_us": exchange_stages, "stages_us_are": "us per step on every rank, HIP events around the stage (10 steps): FlagExchange = visible-flag sum + union "
+                          "stages_us": None, "stages_us_are": "us per step on every rank, HIP events around the stage (10 steps): FlagExchange = visible-flag sum + union "
                                                                          "listing (on the communicator's side stream beside the backward), GradExchange = row gather + all-reduce + scatter "
                                                                          "(or the dense all-reduce), ImageExchange = the strips' halos (tiles only)",
-                          "ab": exchange_ab} if pg is not None else None),
+                          "ab": None} if pg is not None else None),
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "fwd_bwd_source": fwd_src,
@@ -1044,7 +1033,65 @@ def main():
                                    "near_share": m["forward_only"].get("near_share"), "far_slices_queued": m["forward_only"].get("far_slices_queued")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["scene"], m["cp"], w, h)
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        final_out = out
+    # ---- N > 1 side measurements, behind the line's own figures and under a watchdog: a collective that hangs here (the direct
+    # all-reduce has never met a second rank on hardware) costs the side measurements, not the line
+    exchange_stages, exchange_ab = None, None
+    if pg is not None and not args.no_extra:
+        import threading
+
+        def bail():
+            if rank == 0 and final_out is not None:
+                final_out["exchange"]["ab"] = "side measurements did not finish within 300 s (hung collective?): the line's own figures were taken before them"
+                os.write(real_stdout, (json.dumps(final_out) + "\n").encode())
+            sys.stderr.write("bench.py: the exchange side measurements hung - leaving without them\n")
+            sys.stderr.flush()
+            os._exit(0)
+        side_timer = threading.Timer(300.0, bail)
+        side_timer.daemon = True
+        side_timer.start()
+    if pg is not None and not args.no_extra:
+        # The first multi-GPU run has to explain itself (VERDICT r5 #6): (a) what the exchange stages cost per step on every rank
+        # (HIP events around FlagExchange / GradExchange / ImageExchange, 10 steps from the same initial state), (b) a 10-step A/B of
+        # the exchange modes and of the two all-reduce algorithms (every figure the MAX over the ranks, like the headline)
+        import torch.distributed as dist
+        # (side measurements: whatever goes wrong here must not cost the run its line — the error is recorded instead; a rank that fails
+        #  tells the others, so that nobody waits in a collective the failing rank never enters)
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        try:
+            mp_ = measure(args.workload, 10, 3, True, windows=1)
+            mine_st = {k: round(ms / max(c, 1) * 1e3, 2) for k, (ms, c) in mp_["stages"].items() if k in ("FlagExchange", "GradExchange", "ImageExchange", "RasterizeBackwards", "OptimizerStep")}
+            ok = True
+        except Exception as e:
+            mine_st, ok = {"error": repr(e)}, False
+        mine_st["rank"] = rank
+        exchange_stages = [None] * world
+        dist.all_gather_object(exchange_stages, mine_st)
+        exchange_ab = {"steps": 10, "what": "ms per step (max over ranks), 10 steps after 3 warm-up steps from the same initial state, per exchange mode x all-reduce algorithm"}
+        if all_ok(ok):
+            for ex_mode in ("sparse", "dense"):
+                for alg in ("ring", "direct"):
+                    try:
+                        ma = measure(args.workload, 10, 3, False, windows=1, exchange=ex_mode, algo=alg)
+                        val, ok = round(ma["dt"] / 10 * 1e3, 4), True
+                    except Exception as e:
+                        val, ok = "error: %r" % (e,), False
+                    exchange_ab["%s_%s" % (ex_mode, alg)] = val
+                    if not all_ok(ok):
+                        exchange_ab["aborted_after"] = "%s_%s" % (ex_mode, alg)
+                        break
+                if "aborted_after" in exchange_ab:
+                    break
+
+        side_timer.cancel()
+        if rank == 0 and final_out is not None:
+            final_out["exchange"]["stages_us"] = exchange_stages
+            final_out["exchange"]["ab"] = exchange_ab
+    if rank == 0 and final_out is not None:
+        os.write(real_stdout, (json.dumps(final_out) + "\n").encode())
     if pg is not None:
         import torch.distributed as dist
         # the library's communicator goes first, while RCCL is certainly still alive (left to the interpreter's teardown it was

@@ -350,7 +350,7 @@ int bh_comm_selftest(bh_ctx* ctx) {
     constexpr size_t ND = 70003;
     float* dd = nullptr;
     std::vector<float> dgot;
-    if (rc == 0 && W > 1) {
+    if (rc == 0 && W > 1 && ctx->knob_direct_allreduce) {   // (only on a ctx that is going to use it: option grad_allreduce = direct)
         std::vector<float> dh(ND);
         for (size_t i = 0; i < ND; ++i) dh[i] = (float)(R + 1) * (float)((i % 89) + 1) - (float)((i * 7 + (size_t)R) % 13);
         rc = check_hip(ctx, hipMalloc((void**)&dd, ND * 4), "selftest hipMalloc");

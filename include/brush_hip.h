@@ -295,8 +295,9 @@ int bh_prefix_sum(bh_ctx* ctx, const uint32_t* in, uint32_t n, uint32_t* out);
  * the same pairs grouped by tile, depth order kept (stable), and tile_offsets[2 t .. 2 t + 1] = [begin, end) of tile t's run
  * (0, 0 for a tile without pairs; the table is written entirely).  A tile id is < num_tiles or the reference's sentinel
  * 0xFFFFFFFF (map_gaussians.rs:73-79): sentinel rows sort behind every tile and get no row.  All pointers device; inputs and outputs must not overlap.  bh_render_forward
- * uses the same code: for 9..16 id bits and up to 16 M pairs that is four launches (high digit first, then one block per bucket
- * of tiles finishes the order and writes the rows), otherwise the two LSD passes of bh_radix_argsort and an offsets kernel. */
+ * uses the same code: for 9..16 id bits and up to 16 M pairs that is five launches (a stable pass on the high digit, then the
+ * rest in parts of 4096 pairs — a count launch and a place launch — whichever tiles the pairs belong to: a list whose pairs sit in a few
+ * consecutive tiles sorts as fast as an even one), otherwise the two LSD passes of bh_radix_argsort and an offsets kernel. */
 int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const uint32_t* compact_gids, uint32_t n, uint32_t num_tiles,
                          uint32_t* tile_ids_sorted, uint32_t* compact_gids_sorted, uint32_t* tile_offsets /*[2 * num_tiles]*/);
 
@@ -487,7 +488,8 @@ int bh_allgather_bytes(bh_ctx* ctx, const void* send, void* recv /*world * bytes
 int bh_comm_rank(bh_ctx* ctx);  /* 0 without a communicator */
 /* Every RCCL entry point the library binds (all-reduce SUM / MAX, all-gather, grouped send / recv) on small rank-dependent
  * patterns, checked on the host; blocking, collective (every rank calls it).  Run it once after bh_comm_init before trusting an
- * exchange: a build whose communicator has never met more than one rank finds out here, not in a gradient. */
+ * exchange: a build whose communicator has never met more than one rank finds out here, not in a gradient.  With option
+ * grad_allreduce = direct set on the ctx it also checks the direct all-reduce against ncclAllReduce's sum. */
 int bh_comm_selftest(bh_ctx* ctx);
 /* One frame split over the ranks by strips of tile rows, strip-wise loss: fetch the 21 pixel rows above and below
  * this rank's strip [row_begin_px, row_end_px) of img [H,W,4] from the neighbouring ranks, and hand them this strip's first / last
