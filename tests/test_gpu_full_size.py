@@ -428,3 +428,41 @@ def test_train_step_returns_while_its_forward_is_still_running(dev, scene_1m):
         else:
             assert host_ms[4] < 0.75 * step_ms, (host_ms, step_ms)
         ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["after_growth_stop", "whole_tile_backward"])
+def test_1m_1080p_step_variants_vs_oracle(dev, oracle_lib, scene_1m, variant):
+    """configs[2] at its full size through the two other backward variants: the step from `growth_stop_iter` on (the blend backward
+    without the refine weight: parameters, moments, vis_weight and max_screen_size are the oracle's, refine_weight_norm stays zero)
+    and the whole-tile backward (option bwd_jobs = 0: the rounds 2-5 unit of work) — each ONE complete step vs the oracle's."""
+    import brush_amd as ba
+    sc, w, h = scene_1m
+    cp = synth.default_camera_params(w, h)
+    cam, ocam = util.hip_camera(ba, cp), oracle_lib.camera(**cp)
+    gt = synth.synthetic_gt_packed(w, h)
+    bg = (0.1, 0.2, 0.3)
+    cfg = ba.TrainConfig(growth_stop_iter=1) if variant == "after_growth_stop" else ba.TrainConfig()
+    ctx = ba.Context(dev, options={"bwd_jobs": 0} if variant == "whole_tile_backward" else None)
+    spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
+    trainer = ba.SplatTrainer(cfg, median_scene_scale=5.0, ctx=ctx)
+    otr = util.OracleTrainer(oracle_lib, cfg, median_scene_scale=5.0)
+    osc = {k: a.copy() for k, a in sc.items()}
+    trainer.step(ba.SceneBatch(torch.from_numpy(gt.view(np.int32)).to(dev), cam), spl, background=bg)
+    st = trainer.stats(ctx)
+    o = otr.step(osc, ocam, gt, bg)
+    assert st.num_visible == o["num_visible"] and st.num_intersections == o["num_intersections"]
+    assert abs(st.loss - o["loss"]) <= 1e-5 * max(1.0, abs(o["loss"]))
+    tr = spl.transforms.cpu().numpy()
+    util.assert_adam_close(tr[:, 3:7], osc["transforms"][:, 3:7], cfg.lr_rotation, 1, "rotation")
+    util.assert_adam_close(tr[:, 7:10], osc["transforms"][:, 7:10], cfg.lr_scale, 1, "scale")
+    util.assert_adam_close(tr[:, 0:3], osc["transforms"][:, 0:3], o["lr_mean"], 1, "mean", extra_abs=1e-7)
+    util.assert_adam_close(spl.raw_opacities.cpu().numpy(), osc["raw_opac"], cfg.lr_opac, 1, "opacity")
+    util.assert_adam_close(spl.sh_coeffs.cpu().numpy(), osc["sh"], cfg.lr_coeffs_dc, 1, "sh")
+    s = trainer.state
+    assert np.array_equal(s["vis_weight"].cpu().numpy(), otr.state["vis"])
+    assert np.array_equal(s["max_screen_size"].cpu().numpy(), otr.state["screen"])
+    if variant == "after_growth_stop":
+        assert float(s["refine_weight_norm"].abs().max()) == 0.0 and float(otr.state["refine"].max()) > 0.0
+    else:
+        assert util.rel_linf(s["refine_weight_norm"].cpu().numpy(), otr.state["refine"]) <= 1e-4
+    ctx.close()
