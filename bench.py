@@ -1006,7 +1006,11 @@ def main():
             "fwd_ms": round(fwd_ms, 4),
             "fwd_bwd_ms": round(fwd_ms + bwd_ms, 4),
             "fwd_bwd_source": fwd_src,
-            "kernel_trace": ({"steps": ktrace["steps"], "kernels": ktrace["kernels"]} if ktrace else None),
+            "kernel_trace": ({"steps": ktrace["steps"], "kernels": ktrace["kernels"], "wall_us_per_step": ktrace.get("wall_us_per_step"),
+                              "idle_us_per_step": ktrace.get("idle_us_per_step"),
+                              "idle_is": "inside the SAME (child) run: from the first kernel's start to the last kernel's end of the timed steps, minus the kernels' "
+                                         "own durations - the step's true idle time (kernel_ms_per_step vs ms_per_step compares two different runs, one of them "
+                                         "under the profiler)"} if ktrace else None),
             "kernel_ms_per_step": round(sum(e["ms"] for e in stage_out.values()), 4),
             "roofline": hbm,
             "roofline_valu": valu,
@@ -1159,10 +1163,15 @@ def kernel_trace_inrun(args):
         if win is None:
             return None
         per_stage, per_kernel = {}, {}
+        t_first, t_last, busy_ns = None, None, 0.0   # the trace's own wall time of the timed steps, and what of it is not kernel time
         for r in rows:
             name = r["Kernel_Name"]
             if "bh::" not in name or not (win[0] < float(r["End_Timestamp"]) <= win[1]):
                 continue
+            a, b = float(r["Start_Timestamp"]), float(r["End_Timestamp"])
+            t_first = a if t_first is None else min(t_first, a)
+            t_last = b if t_last is None else max(t_last, b)
+            busy_ns += b - a
             short = name.replace("void ", "").replace("bh::", "").split("(")[0]
             us = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
             k = per_kernel.setdefault(short, {"us_per_step": 0.0, "avg_us": 0.0, "calls": 0})
@@ -1175,7 +1184,10 @@ def kernel_trace_inrun(args):
                 if key in short:
                     per_stage[stage] = per_stage.get(stage, 0.0) + k["us_per_step"]
                     break
-        return {"steps": args.steps, "stages_us": {k: round(v, 2) for k, v in per_stage.items()}, "kernels": per_kernel}
+        span_us = (t_last - t_first) / 1e3 / args.steps if t_first is not None else None
+        return {"steps": args.steps, "stages_us": {k: round(v, 2) for k, v in per_stage.items()}, "kernels": per_kernel,
+                "wall_us_per_step": (round(span_us, 2) if span_us else None),
+                "idle_us_per_step": (round(span_us - busy_ns / 1e3 / args.steps, 2) if span_us else None)}
     except Exception:
         return None
     finally:
