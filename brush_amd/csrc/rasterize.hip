@@ -771,21 +771,23 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
     auto run_batch = [&](auto clamp_tag, const uint32_t cnt) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         for (uint32_t t = 0; t < cnt; ++t) {
-            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00 c01
-            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11 a r g (clamped)
+            const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
+            const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g (clamped)
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b cut
-            const float c00 = s0.z, c01 = s0.w, c11 = s1.x, color_a = s1.y;
+            // (the diagonal is staged HALVED, as in the forward: sigma needs no multiply by 1/2 per pixel-quadrant, and the replay's
+            //  arithmetic is the forward's instruction for instruction; the full diagonal terms the refine weight wants are 2 x these)
+            const float h00 = s0.z, c01 = s0.w, h11 = s1.x, color_a = s1.y;
             const float cr = s1.z, cgc = s1.w, cb = s2.x;
             const uint32_t cut_bits = f2u(s2.y);
             float dxp[2], dyp[2], a_xx[2], b_x[2], c_y[2], e_x[2], e_y[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 dxp[k] = pcx[k] - s0.x;  // pixel - mean (forward convention)
-                e_x[k] = c00 * dxp[k];
+                e_x[k] = h00 * dxp[k];          // (c00 / 2) dx
                 a_xx[k] = e_x[k] * dxp[k];
                 b_x[k] = c01 * dxp[k];
                 dyp[k] = pcy[k] - s0.y;
-                c_y[k] = c11 * dyp[k];
+                c_y[k] = h11 * dyp[k];          // (c11 / 2) dy
                 e_y[k] = c01 * dyp[k];
             }
             bool any = false;
@@ -793,8 +795,8 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
             for (int q = 0; q < 4; ++q) {
                 const int k = q & 1, m = q >> 1;
                 // --- replay: identical arithmetic to the forward kernel -------------
-                const float qv = __builtin_fmaf(c_y[m], dyp[m], a_xx[k]);
-                const float sigma = __builtin_fmaf(b_x[k], dyp[m], 0.5f * qv);
+                const float half_qv = __builtin_fmaf(c_y[m], dyp[m], a_xx[k]);
+                const float sigma = __builtin_fmaf(b_x[k], dyp[m], half_qv);
                 // live pixel and 0 <= sigma <= sigma_cut  (the forward's single-compare form of this test — sign bit of a negative
                 // "finished" T ORed into the key — was measured here too: +1 %, four more VGPRs push the kernel over 96)
                 const bool pre = sw[q] > 0.0f && f2u(sigma) <= cut_bits;
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
                         aVs += v_sigma;
                         // refine weight: |(v_xy.x W, v_xy.y H)| / max(A, 1e-5), v_xy = -v_sigma conic (pixel - mean)   (…:340-349)
                         if (REFINE) {
-                            const float ex = e_x[k] + e_y[m], ey = b_x[k] + c_y[m];
+                            const float ex = __builtin_fmaf(2.0f, e_x[k], e_y[m]), ey = __builtin_fmaf(2.0f, c_y[m], b_x[k]);   // conic (pixel - mean)
                             // (|(W vx, H vy)| / A = sqrt((W/A)^2 vx^2 + (H/A)^2 vy^2): the per-pixel 1/A lives in w2q / h2q)
                             const float n2 = __builtin_fmaf(h2q[q] * ey, ey, w2q[q] * (ex * ex));
                             aRf = __builtin_fmaf(__builtin_fabsf(v_sigma), __builtin_amdgcn_sqrtf(n2), aRf);
@@ -872,7 +874,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
         for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
             const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
             __syncthreads();
-            stage_batch<SMOOTH, false>(isect_gids, projected, batch_start, cnt, lane, s_splat);
+            stage_batch<SMOOTH, true>(isect_gids, projected, batch_start, cnt, lane, s_splat);
             __syncthreads();
             const bool mine_clamps = (uint32_t)lane < cnt && s_splat[lane * SPLAT_STRIDE + 5] > 0.999f;
             if (__ballot(mine_clamps) != 0ull) run_batch(std::true_type{}, cnt);
