@@ -204,7 +204,8 @@ _lib = None
 _lib_th = None
 # the test suite's fault-injection build (csrc/Makefile, -DBH_TEST_HOOKS): never loaded by product code
 TEST_HOOKS_LIB_PATH = os.path.join(_DIR, "libbrush_hip_testhooks.so")
-TEST_HOOK_SYMBOLS = {"bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32])}
+TEST_HOOK_SYMBOLS = {"bh_debug_fill_train_scratch": (C.c_int, [C.c_void_p, C.c_uint32]),
+                     "bh_debug_split_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)])}
 
 
 class BrushHipError(RuntimeError):

@@ -558,6 +558,8 @@ const OptionKey kOptionKeys[] = {
     {"auto_exact_share", "0..1: a view whose last cut frame listed more than this share of its pairs renders complete lists (default 0.9; 0 = never)"},
     {"no_view_hash", "0|1: frames without a view id share ONE table instead of being keyed by their camera"},
     {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
+    {"k16_split", "0..1000: forward blend: a tile whose forecast work is at least max(256, k16_split / 100 x its band's mean) is blended by four quadrant waves (default 250; 0: no tile is split)"},
+    {"k16_split_min", "1..1023: a tile below this many blended splats (forecast) is never split (default 256)"},
     {"k5_exact_spw", "16|32|64: splats per wave of the list builder for complete lists"},
     {"bwd_jobs", "0|1: the blend backward works on checkpointed 128-entry segments of the tiles' lists (default 1) or on whole tiles"},
     {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
@@ -620,6 +622,8 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
     }
     else if (k == "no_view_hash") ok = parse_flag(value, &ctx->knob_no_view_hash);
     else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
+    else if (k == "k16_split") { if ((ok = parse_u32(value, 0, 1000, &u))) ctx->knob_k16_split = u; }
+    else if (k == "k16_split_min") { if ((ok = parse_u32(value, 1, 1023, &u))) ctx->knob_k16_split_min = u; }
     else if (k == "k5_exact_spw") { if ((ok = parse_u32(value, 16, 64, &u) && (u == 16 || u == 32 || u == 64))) ctx->knob_k5_exact_spw = u; }
     else if (k == "bwd_jobs") ok = parse_flag(value, &ctx->knob_bwd_jobs);
     else if (k == "no_lpt") ok = parse_flag(value, &ctx->knob_no_lpt);
@@ -911,6 +915,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     }
     uint32_t* near_counts = nullptr;
     uint32_t* tile_order = nullptr;
+    uint32_t* tile_split = nullptr;
     if (cut_active) {
         near_counts = (uint32_t*)ensure(ctx, SLOT_NEAR_COUNTS, npad * 4);
         if (!near_counts) return BH_ERR_OOM;
@@ -943,13 +948,19 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             prep.list_all_visible = ctx->knob_cut_sort_all;
             if (view && ctx->knob_k16_order && n >= 8u * 256u) {   // the forward blend's tile order from the view's last per-tile work (K1's blocks 0..7 sort it: the grid must have them)
                 const uint32_t win_t = u.tile_bw * (u.tile_y1 - u.tile_y0);
-                tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, (size_t)8 * ((win_t + 7u) / 8u) * 4);
+                tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, ((size_t)8 * ((win_t + 7u) / 8u) + SPLIT_TAIL_WORDS) * 4);
                 if (!tile_order) return BH_ERR_OOM;
                 prep.order_work = view->zcut + (size_t)num_tiles;
                 prep.order_out = tile_order;
                 prep.order_tiles = win_t;
                 prep.order_tile_begin = u.tile_bw * u.tile_y0;
                 prep.order_mode = ctx->knob_k16_order;
+                if (ctx->knob_k16_split && ctx->knob_k16_order == 1u) {   // split tiles (context.h SPLIT_MAX): K1's order blocks pick them
+                    tile_split = tile_order + (size_t)8 * ((win_t + 7u) / 8u);
+                    prep.split_out = tile_split;
+                    prep.split_factor = (float)ctx->knob_k16_split * 0.01f;
+                    prep.split_min = ctx->knob_k16_split_min;
+                }
             }
             if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
                 (reinterpret_cast<uintptr_t>(ctx->ext_grad_begin) & 15u) == 0 && ctx->ext_grad_floats / 4 <= 0xFFFFFFFFull) {
@@ -1140,6 +1151,10 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         rs.work = view->zcut + (size_t)num_tiles;
         rs.order = tile_order;
         rs.order_mode = ctx->knob_k16_order;
+        rs.split = tile_split;
+#ifdef BH_TEST_HOOKS
+        ctx->last_split = tile_split;
+#endif
     }
     // work classes ~1/64 of the mean list length wide (a tile typically blends ~10 % of its list before it saturates)
     const uint32_t win_tiles = u.tile_bw * (u.tile_y1 - u.tile_y0);
@@ -1687,6 +1702,15 @@ extern "C" int bh_tile_sort_offsets(bh_ctx* ctx, const uint32_t* tile_ids, const
 }
 
 #ifdef BH_TEST_HOOKS
+// the split counts K1 left for the context's last forward (context.h SPLIT_MAX); returns 1 and fills out[8], or 0 when that frame split nothing by construction
+extern "C" int bh_debug_split_counts(bh_ctx* ctx, uint32_t* out) {
+    if (!ctx || !out) return BH_ERR_INVALID_ARG;
+    if (!ctx->last_split) return 0;
+    BH_HIP(ctx, hipSetDevice(ctx->device));
+    BH_HIP(ctx, hipMemcpyAsync(out, ctx->last_split, 8 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
 extern "C" int bh_debug_fill_train_scratch(bh_ctx* ctx, uint32_t pattern) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     const Buffer& s = ctx->slots[SLOT_GRADS];

@@ -275,12 +275,17 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         const uint32_t per = (prep.order_tiles + 7u) / 8u;
         const uint32_t first = blockIdx.x * per;
         const uint32_t cnt = first < prep.order_tiles ? (prep.order_tiles - first < per ? prep.order_tiles - first : per) : 0u;
+        __shared__ uint32_t s_band_work;
         for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += PROJ_WG) s_bins[i] = 0u;
+        if (threadIdx.x == 0) s_band_work = 0u;
         __syncthreads();
+        uint32_t my_work = 0u;
         for (uint32_t i = threadIdx.x; i < cnt; i += PROJ_WG) {
             const uint32_t wk = prep.order_work[prep.order_tile_begin + first + i];
             atomicAdd(&s_bins[ORDER_BINS - 1u - (wk < ORDER_BINS ? wk : ORDER_BINS - 1u)], 1u);   // bin 0 = the most work
+            my_work += wk < ORDER_BINS ? wk : ORDER_BINS - 1u;
         }
+        if (prep.split_out && my_work) atomicAdd(&s_band_work, my_work);
         __syncthreads();
         // exclusive scan of the bins (one thread per 4 bins + a wave scan over the 256 partial sums)
         {
@@ -298,6 +303,24 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < ORDER_BINS / PROJ_WG; ++k) s_bins[b0 + k] = s_part[threadIdx.x] + loc[k];
+        }
+        __syncthreads();
+        // split tiles (context.h SPLIT_MAX): the band's leading ranks whose forecast work is several times the band's mean are blended
+        // by four quadrant waves each.  s_bins[b] = tiles with MORE work than bin b's: the start of the bin of `thr - 1` counts the
+        // tiles with work >= thr.  The band's scratch rows are cleared here, by the block that decides.
+        if (prep.split_out) {
+            if (threadIdx.x == 0) {
+                const float mean = cnt ? (float)s_band_work / (float)cnt : 0.0f;
+                const float thr_f = fmaxf((float)prep.split_min, prep.split_factor * mean);
+                uint32_t h = 0u;
+                if (prep.order_mode == 1u && thr_f < (float)(ORDER_BINS - 1u)) {
+                    const uint32_t thr = (uint32_t)ceilf(thr_f);
+                    h = s_bins[ORDER_BINS - thr];
+                }
+                prep.split_out[blockIdx.x] = h < SPLIT_MAX ? h : SPLIT_MAX;
+            }
+            uint32_t* scr = prep.split_out + 8u + blockIdx.x * (SPLIT_MAX * 4u);
+            for (uint32_t i = threadIdx.x; i < SPLIT_MAX * 4u; i += PROJ_WG) scr[i] = 0u;
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < per; i += PROJ_WG) {

@@ -230,42 +230,41 @@ struct SliceArgs {
     // are spread over the whole range instead of being eight neighbours.  work[tile]: what this frame's tiles blended, for next time.
     const uint32_t* order = nullptr;
     uint32_t order_mode = 1;
+    uint32_t* split = nullptr;              // split tiles (context.h SPLIT_MAX): split_count[8] | split_scratch[8][SPLIT_MAX][4], or NULL
     uint32_t* work = nullptr;
     BwdJobs jobs{};                         // BWD_INFO, ckpt != NULL: checkpoint the pixel state every BWD_SEG entries and file the tile's backward work as jobs
 };
 
-template <bool BWD_INFO, bool SMOOTH, int PHASE>
-__global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
-                                                      uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
-                                                      const uint32_t* __restrict__ global_from_compact,
-                                                      float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
-                                                      float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
-    __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
-    constexpr int NQ = 4;
+// One tile by its one wave (NQ == 4: four pixels per lane, one per 8 x 8 quadrant), or ONE QUADRANT of a split tile (NQ == 1: one pixel
+// per lane, quadrant qsel; context.h SPLIT_MAX).  The per-pixel arithmetic is the same fold over the same splats in the same order
+// either way.  The four quadrant waves of a split tile are independent blocks: each stops when ITS 64 pixels are done, stores its
+// pixels (and, where the tile may be parked, their raw state), merges (last useful entry, entry reached, unsaturated) into the tile's
+// scratch row with atomics, and the last of them to arrive does the tile's bookkeeping with the merged values — which are the
+// whole-tile wave's: a splat is useful to the tile iff it is to a quadrant, the tile is saturated iff all four are.  Checkpoints for
+// the backward's jobs: a quadrant writes its 64 pixels of every checkpoint it passes, and when it stops early those of every LATER
+// segment of the list too (its state no longer changes) — the last finisher cannot know where the slowest quadrant will stop.
+template <bool BWD_INFO, bool SMOOTH, int PHASE, int NQ>
+BH_DEV void blend_tile(const RasterUniforms& u, const uint32_t* __restrict__ isect_gids, uint32_t* __restrict__ tile_offsets,
+                       const float* __restrict__ projected, const uint32_t* __restrict__ global_from_compact, float* __restrict__ out_img,
+                       uint32_t* __restrict__ out_packed, float* __restrict__ visible, uint32_t* __restrict__ lpt, const SliceArgs& sl,
+                       float* s_splat, const uint32_t local_tile, const uint32_t qsel, uint32_t* split_row) {
+    constexpr int NK = NQ == 4 ? 2 : 1;
     const uint32_t bidx = blockIdx.x;
-    uint32_t local_tile;
-    if (sl.order) {
-        const uint32_t per = (u.num_tiles + 7u) / 8u;
-        uint32_t j = bidx >> 3;
-        if (sl.order_mode == 2u) {   // dealt: consecutive blocks of a band take every seg-th rank (the grid covers 8 * seg ranks per band)
-            const uint32_t seg = (per + 7u) / 8u;
-            j = (j & 7u) * seg + (j >> 3);
-        }
-        local_tile = j < per ? sl.order[(bidx & 7u) * per + j] : 0xFFFFFFFFu;
-    } else {
-        local_tile = tile_of_block(bidx, u.num_tiles);
-    }
-    if (local_tile >= u.num_tiles) return;
     const uint32_t tile = u.tile_begin + local_tile;
     if (PHASE == 2) {
         if (*sl.unsat_count == 0u) return;                                     // the near slice finished the frame
         if ((sl.done_bits[tile >> 5] >> (tile & 31u)) & 1u) return;            // ... or this tile
     }
     const int lane = threadIdx.x;
-    const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH, ty0 = (tile / u.tile_bw) * TILE_WIDTH;
+    const uint32_t tx0 = (tile % u.tile_bw) * TILE_WIDTH + (NQ == 1 ? 8u * (qsel & 1u) : 0u);
+    const uint32_t ty0 = (tile / u.tile_bw) * TILE_WIDTH + (NQ == 1 ? 8u * (qsel >> 1) : 0u);
     const uint32_t px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
-    const float pcx[2] = {(float)px0 + 0.5f, (float)(px0 + 8) + 0.5f};
-    const float pcy[2] = {(float)py0 + 0.5f, (float)(py0 + 8) + 0.5f};
+    float pcx[NK], pcy[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        pcx[k] = (float)(px0 + 8 * k) + 0.5f;
+        pcy[k] = (float)(py0 + 8 * k) + 0.5f;
+    }
     // transmittance; a finished pixel keeps its final T with the sign flipped
     float tr[NQ], pr[NQ], pg[NQ], pb[NQ];
     auto any_live = [&]() {
@@ -294,7 +293,8 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
 
     // (A per-batch variant without the v_min of the 0.999 clamp — the backward's trick — was measured here: the second copy of
     //  the loop costs 16 VGPRs, 8 -> 7 waves per SIMD, 160 -> 170 us.)
-    for (uint32_t batch_start = range_lo; batch_start < range_hi; batch_start += BATCH) {
+    uint32_t batch_start = range_lo;
+    for (; batch_start < range_hi; batch_start += BATCH) {
         const bool live = any_live();
         if (__ballot(live) == 0ull) break;
         const uint32_t cnt = min((uint32_t)BATCH, range_hi - batch_start);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
                 if (slot < sl.jobs.ckpt_cap) {
                     float4* ck = sl.jobs.ckpt + (size_t)slot * 256u + (uint32_t)lane;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) ck[q * 64] = make_float4(pr[q], pg[q], pb[q], tr[q]);
+                    for (int q = 0; q < NQ; ++q) ck[(NQ == 1 ? qsel : (uint32_t)q) * 64u] = make_float4(pr[q], pg[q], pb[q], tr[q]);
                 }
             }
         }
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut
             const uint32_t cut_bits = f2u(s2.y);
-            float a_xx[2], b_x[2], c_y[2], dy[2];
+            float a_xx[NK], b_x[NK], c_y[NK], dy[NK];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 const float dx = pcx[k] - s0.x;
                 a_xx[k] = (s0.z * dx) * dx;
                 b_x[k] = s0.w * dx;
@@ -374,18 +374,77 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
         }
     }
     const bool live_end = any_live();
-    const bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
+    bool saturated = __ballot(live_end) == 0ull;   // every pixel of the tile is done: no later splat can change it
 
     // (per-tile depth cuts: a tile whose near list was NOT cut holds everything there is — unsaturated or not, it is final)
     const bool near_complete = PHASE == 1 && sl.cut_active != 0u && (sl.zcut[tile] & 1u) == 0u;   // (bit 0: K1 met a pair behind the cut)
-    if (PHASE == 1 && !saturated && !near_complete) {
-        // park the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
+    auto store_pixels = [&]() {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
+            if (px < u.img_w && py < u.img_h) {
+                const float tf = __builtin_fabsf(tr[q]);
+                const float fr = pr[q] + tf * u.bg_r;
+                const float fg = pg[q] + tf * u.bg_g;
+                const float fb = pb[q] + tf * u.bg_b;
+                const float fa = 1.0f - tf;
+                const size_t pix = (size_t)px + (size_t)py * u.img_w;
+                if (BWD_INFO) {
+                    *reinterpret_cast<float4*>(&out_img[pix * 4]) = make_float4(fr, fg, fb, fa);
+                } else {
+                    const uint32_t r8 = (uint32_t)clampf(fr * 255.0f, 0.0f, 255.0f);
+                    const uint32_t g8 = (uint32_t)clampf(fg * 255.0f, 0.0f, 255.0f);
+                    const uint32_t b8 = (uint32_t)clampf(fb * 255.0f, 0.0f, 255.0f);
+                    const uint32_t a8 = (uint32_t)clampf(fa * 255.0f, 0.0f, 255.0f);
+                    out_packed[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+                }
+            }
+        }
+    };
+    auto park_pixels = [&]() {   // the raw state; the far slice (listed for the unsaturated tiles only) resumes it in PHASE 2
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
             if (px < u.img_w && py < u.img_h)
                 *reinterpret_cast<float4*>(&sl.state[((size_t)px + (size_t)py * u.img_w) * 4]) = make_float4(pr[q], pg[q], pb[q], tr[q]);
         }
+    };
+    if (NQ == 1) {
+        if (BWD_INFO && PHASE != 2 && sl.jobs.ckpt) {
+            // this quadrant's part of every checkpoint behind the point where it stopped (its state is final from here on)
+            uint32_t done = ((batch_start - range_lo + BWD_SEG - 1u) / BWD_SEG) * BWD_SEG;
+            if (done == 0u) done = BWD_SEG;
+            for (; done < range_hi - range_lo && done / BWD_SEG < BWD_MAX_SEGS; done += BWD_SEG) {
+                const uint32_t slot = ckpt_slot(range_lo, tile, done / BWD_SEG);
+                if (slot >= sl.jobs.ckpt_cap) break;
+                sl.jobs.ckpt[(size_t)slot * 256u + qsel * 64u + (uint32_t)lane] = make_float4(pr[0], pg[0], pb[0], tr[0]);
+            }
+        }
+        // whether the TILE is parked is only known to the last finisher: a quadrant leaves both — its raw state (PHASE 2 resumes all
+        // 256 pixels from there) and its pixels as they stand (final unless PHASE 2 overwrites them)
+        if (PHASE == 1 && !near_complete) park_pixels();
+        store_pixels();
+        uint32_t ticket = 0u, m_useful = 0u, m_reached = 0u, m_unsat = 0u;
+        if (lane == 0) {
+            if (last_useful > range_lo) atomicMax(&split_row[1], last_useful);
+            if (reached > range_lo) atomicMax(&split_row[2], reached);
+            if (!saturated) atomicOr(&split_row[3], 1u);
+            __threadfence();
+            ticket = atomicAdd(&split_row[0], 1u);
+            if (ticket == 3u) {
+                m_useful = atomicOr(&split_row[1], 0u);
+                m_reached = atomicOr(&split_row[2], 0u);
+                m_unsat = atomicOr(&split_row[3], 0u);
+            }
+        }
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != 3u) return;
+        last_useful = max(range_lo, (uint32_t)__builtin_amdgcn_readfirstlane(m_useful));
+        reached = max(range_lo, (uint32_t)__builtin_amdgcn_readfirstlane(m_reached));
+        saturated = __builtin_amdgcn_readfirstlane(m_unsat) == 0u;
+    }
+    if (PHASE == 1 && !saturated && !near_complete) {
+        if (NQ == 4) park_pixels();
         if (lane == 0) {
             if (BWD_INFO) tile_offsets[tile * 2 + 1] = last_useful;
             atomicAdd(sl.unsat_count, 1u);
@@ -405,34 +464,16 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
         return;
     }
 
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const uint32_t px = px0 + 8 * (q & 1), py = py0 + 8 * (q >> 1);
-        if (px < u.img_w && py < u.img_h) {
-            const float tf = __builtin_fabsf(tr[q]);
-            const float fr = pr[q] + tf * u.bg_r;
-            const float fg = pg[q] + tf * u.bg_g;
-            const float fb = pb[q] + tf * u.bg_b;
-            const float fa = 1.0f - tf;
-            const size_t pix = (size_t)px + (size_t)py * u.img_w;
-            if (BWD_INFO) {
-                *reinterpret_cast<float4*>(&out_img[pix * 4]) = make_float4(fr, fg, fb, fa);
-            } else {
-                const uint32_t r8 = (uint32_t)clampf(fr * 255.0f, 0.0f, 255.0f);
-                const uint32_t g8 = (uint32_t)clampf(fg * 255.0f, 0.0f, 255.0f);
-                const uint32_t b8 = (uint32_t)clampf(fb * 255.0f, 0.0f, 255.0f);
-                const uint32_t a8 = (uint32_t)clampf(fa * 255.0f, 0.0f, 255.0f);
-                out_packed[pix] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-            }
-        }
-    }
+    if (NQ == 4) store_pixels();
     if (BWD_INFO && PHASE != 2 && lpt && sl.jobs.ckpt) {
         // the tile's backward work as JOBS of BWD_SEG list entries (lane s files segment s).  Checkpoints exist in front of every
-        // segment the batch loop entered (up to BWD_MAX_SEGS, and while their slots exist); the last job takes whatever lies behind
-        // the last checkpoint.  Classes: full segments in the top class, the tails by their length.
+        // segment the batch loop entered (a split tile: in front of every segment of its list) — up to BWD_MAX_SEGS, and while their
+        // slots exist; the last job takes whatever lies behind the last checkpoint.  Classes: full segments in the top class, the
+        // tails by their length.
         const uint32_t jwork = last_useful - range_lo;
         const uint32_t last_batch = reached > range_lo ? ((reached - 1u - range_lo) / BATCH) * BATCH : 0u;   // first entry of the last batch the loop entered
-        uint32_t n_ck = min(last_batch / BWD_SEG, BWD_MAX_SEGS - 1u);
+        const uint32_t ck_span = NQ == 1 ? (range_hi > range_lo ? range_hi - 1u - range_lo : 0u) : last_batch;
+        uint32_t n_ck = min(ck_span / BWD_SEG, BWD_MAX_SEGS - 1u);
         const uint32_t slot0 = ckpt_slot(range_lo, tile, 1u);
         n_ck = slot0 < sl.jobs.ckpt_cap ? min(n_ck, sl.jobs.ckpt_cap - slot0) : 0u;
         const uint32_t nj = min((jwork + BWD_SEG - 1u) / BWD_SEG, n_ck + 1u);
@@ -523,6 +564,45 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
     }
 }
 
+template <bool BWD_INFO, bool SMOOTH, int PHASE>
+__global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+                                                      uint32_t* __restrict__ tile_offsets, const float* __restrict__ projected,
+                                                      const uint32_t* __restrict__ global_from_compact,
+                                                      float* __restrict__ out_img, uint32_t* __restrict__ out_packed,
+                                                      float* __restrict__ visible, uint32_t* __restrict__ lpt, SliceArgs sl) {
+    __shared__ __attribute__((aligned(16))) float s_splat[BATCH * SPLAT_STRIDE];
+    const uint32_t bidx = blockIdx.x;
+    uint32_t local_tile, qsel = 4u;   // qsel < 4: this block is one quadrant wave of a split tile
+    uint32_t* split_row = nullptr;
+    if (sl.order) {
+        const uint32_t per = (u.num_tiles + 7u) / 8u;
+        uint32_t j = bidx >> 3;
+        if (PHASE != 2 && sl.split) {
+            // the first split[band] ranks of the band (its heaviest tiles by forecast) take four blocks each, everyone else moves up
+            const uint32_t band = bidx & 7u;
+            const uint32_t h = sl.split[band];
+            if (j < 4u * h) {
+                qsel = j & 3u;
+                j >>= 2;
+                split_row = sl.split + 8u + (band * SPLIT_MAX + j) * 4u;
+            } else {
+                j -= 3u * h;
+            }
+        } else if (sl.order_mode == 2u) {   // dealt: consecutive blocks of a band take every seg-th rank (the grid covers 8 * seg ranks per band)
+            const uint32_t seg = (per + 7u) / 8u;
+            j = (j & 7u) * seg + (j >> 3);
+        }
+        local_tile = j < per ? sl.order[(bidx & 7u) * per + j] : 0xFFFFFFFFu;
+    } else {
+        local_tile = tile_of_block(bidx, u.num_tiles);
+    }
+    if (local_tile >= u.num_tiles) return;
+    if (PHASE != 2 && qsel < 4u)
+        blend_tile<BWD_INFO, SMOOTH, PHASE, 1>(u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl, s_splat, local_tile, qsel, split_row);
+    else
+        blend_tile<BWD_INFO, SMOOTH, PHASE, 4>(u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl, s_splat, local_tile, 0u, nullptr);
+}
+
 template <bool BWD_INFO, bool SMOOTH>
 static void launch_rasterize_phase(int phase, dim3 grid, hipStream_t stream, const RasterUniforms& u, const uint32_t* isect_gids, uint32_t* tile_offsets,
                                    const float* projected, const uint32_t* gfc, float* out_img, uint32_t* out_packed, float* visible, uint32_t* lpt,
@@ -563,6 +643,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
         sl.margin_pct = slice->margin_pct;
         sl.order = slice->order;
         sl.order_mode = slice->order_mode;
+        sl.split = (phase != 2 && slice->order && slice->order_mode == 1u) ? slice->split : nullptr;
         sl.work = slice->work;
         if (bwd_info && phase != 2 && lpt) sl.jobs = slice->jobs;
     }
@@ -572,6 +653,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;
     uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
     if (sl.order && sl.order_mode == 2u) nblocks = (((u.num_tiles + 7u) / 8u + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
+    if (sl.split) nblocks += 8u * 3u * SPLIT_MAX;   // three more blocks for each tile a band may split (blocks behind the band's last rank leave at once)
     const dim3 grid(nblocks);
     if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
