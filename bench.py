@@ -844,11 +844,18 @@ def main():
             mc0 = measure("1m_1080p_centered", c_steps, 3, True)
         finally:
             ctx.set_option("bwd_jobs", 1)
+        # ... and with every tile blended by ONE wave (no split tiles: the forward then lasts as long as its heaviest tile)
+        ctx.set_option("k16_split", 0)
+        try:
+            mc1 = measure("1m_1080p_centered", c_steps, 3, True)
+        finally:
+            ctx.set_option("k16_split", 250)
         stg = lambda mm, k: round(mm["stages"].get(k, (0.0, 0))[0] / max(mm["stages"].get(k, (0.0, 1))[1], 1), 4)   # noqa: E731
         centered = {"workload": "1m_1080p_centered: the configs[2] splats squeezed into the central half of the frustum (NOT a BASELINE.json config; an object-centric frame: "
                                 "%d intersections, %d blended)" % (mc["ni"], mc["isect_blended"]),
                     "steps": c_steps, "ms_per_step": round(mc["dt"] / c_steps * 1e3, 4), "k16_ms": stg(mc, "Rasterize"), "k17_ms": stg(mc, "RasterizeBackwards"),
-                    "whole_tile_backward": {"option": "bwd_jobs=0", "ms_per_step": round(mc0["dt"] / c_steps * 1e3, 4), "k17_ms": stg(mc0, "RasterizeBackwards")}}
+                    "whole_tile_backward": {"option": "bwd_jobs=0", "ms_per_step": round(mc0["dt"] / c_steps * 1e3, 4), "k17_ms": stg(mc0, "RasterizeBackwards")},
+                    "one_wave_per_tile_forward": {"option": "k16_split=0", "ms_per_step": round(mc1["dt"] / c_steps * 1e3, 4), "k16_ms": stg(mc1, "Rasterize")}}
 
     sh3 = None
     if world == 1 and not args.no_extra and args.workload == "1m_1080p" and args.feed == "resident" and not args.splats and args.sh_degree == 0:

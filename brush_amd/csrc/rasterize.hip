@@ -315,7 +315,68 @@ BH_DEV void blend_tile(const RasterUniforms& u, const uint32_t* __restrict__ ise
         __syncthreads();
         unsigned long long contrib_mask = 0ull;
         reached = batch_start + cnt;
-        for (uint32_t t = 0; t < cnt; ++t) {
+        uint32_t t_first = 0u;
+        if (NQ == 1) {
+            // A quadrant wave runs (nearly) alone on its SIMD at the end of the launch: what it costs is the LATENCY of a splat's
+            // dependent chain (sigma -> exp polynomial -> alpha -> T), an op every 6-10 cycles.  Two splats at a time: their sigma /
+            // exp / alpha chains are independent of the pixel state and of each other and are written side by side (the scheduler
+            // interleaves them); the two state updates follow in list order with exactly the one-splat arithmetic, the second splat's
+            // live test on the state the first one left.  The pair is skipped when neither can reach its cutoff anywhere (the second
+            // splat's test on the state BEFORE the first: conservative).
+            auto sigma_of = [&](const float4& s0, const float4& s1) {
+                const float dx = pcx[0] - s0.x;
+                const float a_xx = (s0.z * dx) * dx;
+                const float b_x = s0.w * dx;
+                const float dy = pcy[0] - s0.y;
+                const float c_y = s1.x * dy;
+                return __builtin_fmaf(b_x, dy, __builtin_fmaf(c_y, dy, a_xx));
+            };
+            auto apply = [&](const float4& s1, const float2& s2, const float alpha, const bool pre) {
+                const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
+                const bool ok = pre && w_cut > 0.0f;
+                const float alpha_eff = SMOOTH ? alpha * w_cut : alpha;
+                const float next_t = tr[0] * (1.0f - alpha_eff);
+                const bool sat = next_t <= 1.0e-4f;
+                const bool contrib = ok && !sat;
+                const float vis = contrib ? alpha_eff * tr[0] : 0.0f;
+                pr[0] = __builtin_fmaf(s1.z, vis, pr[0]);
+                pg[0] = __builtin_fmaf(s1.w, vis, pg[0]);
+                pb[0] = __builtin_fmaf(s2.x, vis, pb[0]);
+                tr[0] = ok ? (sat ? -tr[0] : next_t) : tr[0];
+                return contrib;
+            };
+            bool stopped = false;
+            uint32_t t = 0u;
+            for (; t + 1u < cnt; t += 2u) {
+                const float4 a0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);
+                const float4 a1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);
+                const float2 a2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);
+                const float4 b0 = *reinterpret_cast<const float4*>(&s_splat[(t + 1u) * SPLAT_STRIDE]);
+                const float4 b1 = *reinterpret_cast<const float4*>(&s_splat[(t + 1u) * SPLAT_STRIDE + 4]);
+                const float2 b2 = *reinterpret_cast<const float2*>(&s_splat[(t + 1u) * SPLAT_STRIDE + 8]);
+                const float sig_a = sigma_of(a0, a1), sig_b = sigma_of(b0, b1);
+                const uint32_t dead = f2u(tr[0]) & sign_mask;
+                const bool pre_a = (dead | f2u(sig_a)) <= f2u(a2.y);
+                const bool cand_b = (dead | f2u(sig_b)) <= f2u(b2.y);
+                if (__ballot(pre_a || cand_b) != 0ull) {
+                    const float al_a = __builtin_fminf(0.999f, a1.y * exp_blend(-sig_a));
+                    const float al_b = __builtin_fminf(0.999f, b1.y * exp_blend(-sig_b));
+                    const bool any_a = apply(a1, a2, al_a, pre_a);
+                    const bool pre_b = ((f2u(tr[0]) & sign_mask) | f2u(sig_b)) <= f2u(b2.y);
+                    const bool any_b = apply(b1, b2, al_b, pre_b);
+                    if (BWD_INFO) {
+                        if (__ballot(any_a) != 0ull) { contrib_mask |= 1ull << t; last_useful = batch_start + t + 1u; }
+                        if (__ballot(any_b) != 0ull) { contrib_mask |= 2ull << t; last_useful = batch_start + t + 2u; }
+                    }
+                }
+                if (((t + 1u) & 7u) == 7u) {   // (the one-splat loop's test behind every 8th splat)
+                    const bool still = any_live();
+                    if (__ballot(still) == 0ull) { reached = batch_start + t + 2u; stopped = true; break; }
+                }
+            }
+            t_first = stopped ? cnt : t;   // an odd batch's last splat goes through the one-splat loop below
+        }
+        for (uint32_t t = t_first; t < cnt; ++t) {
             const float4 s0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);      // x y c00/2 c01
             const float4 s1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);  // c11/2 a r g
             const float2 s2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);  // b sigma_cut

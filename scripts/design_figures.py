@@ -99,6 +99,15 @@ if s3:
 if ns:
     h.append("Non-saturating scene: %.3f ms per step, K17 at %.2f / K16 at %.2f of the VALU peak." % (
         ns["ms_per_step"], ns["roofline_valu"].get("rasterize_backward_kernel", {}).get("frac", 0.0), ns["roofline_valu"].get("rasterize_kernel", {}).get("frac", 0.0)))
+oc = d.get("object_centric")
+if oc:
+    line = "Object-centric frame (half of the tiles empty, the heaviest blends 15x the mean; not a BASELINE config): %.3f ms per step, K16 %.0f µs, K17 %.0f µs" % (
+        oc["ms_per_step"], oc["k16_ms"] * 1e3, oc["k17_ms"] * 1e3)
+    if oc.get("one_wave_per_tile_forward"):
+        line += "; with one wave per tile in the forward (`k16_split=0`) %.3f ms, K16 %.0f µs" % (oc["one_wave_per_tile_forward"]["ms_per_step"], oc["one_wave_per_tile_forward"]["k16_ms"] * 1e3)
+    if oc.get("whole_tile_backward"):
+        line += "; with whole tiles in the backward (`bwd_jobs=0`) %.3f ms, K17 %.0f µs" % (oc["whole_tile_backward"]["ms_per_step"], oc["whole_tile_backward"]["k17_ms"] * 1e3)
+    h.append(line + ".")
 sib = []
 for name, label in (("bench_exact_lists_n1", "complete lists"), ("bench_no_view_ids_n1", "no view ids (keyed by camera)"), ("bench_sh3_n1", "SH degree 3"), ("bench_6m_4k_sh3_n1", "6 M / 4K / SH 3 on ONE GPU"),
                     ("bench_feed_loader_n1", "loader feed (PCIe-inclusive)"), ("bench_no_noise_n1", "without the stochastic terms"),
