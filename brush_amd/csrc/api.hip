@@ -558,7 +558,9 @@ const OptionKey kOptionKeys[] = {
     {"auto_exact_share", "0..1: a view whose last cut frame listed more than this share of its pairs renders complete lists (default 0.9; 0 = never)"},
     {"no_view_hash", "0|1: frames without a view id share ONE table instead of being keyed by their camera"},
     {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
+    {"band_mode", "0|1: XCD bands of the blend kernels — contiguous eighths of the tile range, or dealt in chunks of 8 adjacent tiles (default 1)"},
     {"k16_split", "0..1000: forward blend: a tile whose forecast work is at least max(256, k16_split / 100 x its band's mean) is blended by four quadrant waves (default 250; 0: no tile is split)"},
+    {"k16_split_of_max", "0..100: ... and at least this many percent of its band's heaviest tile (default 45)"},
     {"k16_split_min", "1..1023: a tile below this many blended splats (forecast) is never split (default 256)"},
     {"k5_exact_spw", "16|32|64: splats per wave of the list builder for complete lists"},
     {"bwd_jobs", "0|1: the blend backward works on checkpointed 128-entry segments of the tiles' lists (default 1) or on whole tiles"},
@@ -622,7 +624,9 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
     }
     else if (k == "no_view_hash") ok = parse_flag(value, &ctx->knob_no_view_hash);
     else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
+    else if (k == "band_mode") { if ((ok = parse_u32(value, 0, 1, &u))) ctx->knob_band_mode = u; }
     else if (k == "k16_split") { if ((ok = parse_u32(value, 0, 1000, &u))) ctx->knob_k16_split = u; }
+    else if (k == "k16_split_of_max") { if ((ok = parse_u32(value, 0, 100, &u))) ctx->knob_k16_split_of_max = u; }
     else if (k == "k16_split_min") { if ((ok = parse_u32(value, 1, 1023, &u))) ctx->knob_k16_split_min = u; }
     else if (k == "k5_exact_spw") { if ((ok = parse_u32(value, 16, 64, &u) && (u == 16 || u == 32 || u == 64))) ctx->knob_k5_exact_spw = u; }
     else if (k == "bwd_jobs") ok = parse_flag(value, &ctx->knob_bwd_jobs);
@@ -856,7 +860,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
     // [T,2] offsets | 8 x LPT_CLASSES work-class counters | [8][LPT_CLASSES][ceil(T/8)] class lists (longest-first tile order of the backward)
     // backward jobs (rasterize.hip): the blend backward works on checkpointed segments of the tiles' lists
     const bool bwd_jobs = bwd_info && ctx->knob_bwd_jobs && !ctx->knob_no_lpt && !((flags & BH_FLAG_SLICED_LISTS) && ctx->slice_fraction > 0.0f);
-    const size_t lpt_words = LPT_HEADER_WORDS + (size_t)8 * LPT_CLASSES * ((num_tiles + 7) / 8);
+    const size_t lpt_words = LPT_HEADER_WORDS + (size_t)8 * LPT_CLASSES * band_slots(num_tiles);
     auto* tile_offsets = (uint32_t*)ensure(ctx, SLOT_TILE_OFFSETS, ((size_t)num_tiles * 2 + lpt_words) * 4);
     auto* visible = (bwd_info && ctx->ext_visible) ? ctx->ext_visible : (float*)ensure(ctx, SLOT_VISIBLE, (bwd_info ? npad : 1) * 4);
     if (!tile_offsets || !visible) return BH_ERR_OOM;
@@ -948,18 +952,20 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
             prep.list_all_visible = ctx->knob_cut_sort_all;
             if (view && ctx->knob_k16_order && n >= 8u * 256u) {   // the forward blend's tile order from the view's last per-tile work (K1's blocks 0..7 sort it: the grid must have them)
                 const uint32_t win_t = u.tile_bw * (u.tile_y1 - u.tile_y0);
-                tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, ((size_t)8 * ((win_t + 7u) / 8u) + SPLIT_TAIL_WORDS) * 4);
+                tile_order = (uint32_t*)ensure(ctx, SLOT_TILE_ORDER, ((size_t)8 * band_slots(win_t) + SPLIT_TAIL_WORDS) * 4);
                 if (!tile_order) return BH_ERR_OOM;
                 prep.order_work = view->zcut + (size_t)num_tiles;
                 prep.order_out = tile_order;
                 prep.order_tiles = win_t;
                 prep.order_tile_begin = u.tile_bw * u.tile_y0;
                 prep.order_mode = ctx->knob_k16_order;
+                prep.band_mode = ctx->knob_band_mode;
                 if (ctx->knob_k16_split && ctx->knob_k16_order == 1u) {   // split tiles (context.h SPLIT_MAX): K1's order blocks pick them
-                    tile_split = tile_order + (size_t)8 * ((win_t + 7u) / 8u);
+                    tile_split = tile_order + (size_t)8 * band_slots(win_t);
                     prep.split_out = tile_split;
                     prep.split_factor = (float)ctx->knob_k16_split * 0.01f;
                     prep.split_min = ctx->knob_k16_split_min;
+                    prep.split_of_max = (float)ctx->knob_k16_split_of_max * 0.01f;
                 }
             }
             if (bwd_info && ctx->ext_grad_begin && ctx->ext_grad_floats && (ctx->ext_grad_floats & 3u) == 0 &&
@@ -1135,7 +1141,7 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
         const uint32_t ckpt_cap = (uint32_t)std::min<uint64_t>((uint64_t)listed / BWD_SEG + num_tiles + 1u, BWD_CKPT_MAX_SLOTS);
         rs.jobs.ckpt = (float4*)ensure(ctx, SLOT_BWD_CKPT, (size_t)ckpt_cap * 256 * sizeof(float4));
         rs.jobs.ckpt_cap = ckpt_cap;
-        rs.jobs.top_cap = (num_tiles + 7u) / 8u + ckpt_cap;   // (a band's full segments: at most one per checkpoint + one per tile)
+        rs.jobs.top_cap = band_slots(num_tiles) + ckpt_cap;   // (a band's full segments: at most one per checkpoint + one per tile)
         rs.jobs.top_list = (uint32_t*)ensure(ctx, SLOT_BWD_TOPLIST, (size_t)8 * rs.jobs.top_cap * 4);
         if (!rs.jobs.ckpt || !rs.jobs.top_list) return BH_ERR_OOM;
         ctx->jobs = rs.jobs;

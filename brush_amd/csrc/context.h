@@ -163,13 +163,27 @@ struct BwdJobs {                        // all zero: one job per tile (far-slice
     uint32_t* top_list = nullptr;       // [8][top_cap] the bands' TOP class (every full segment lands there: more entries than tiles)
     uint32_t top_cap = 0;
 };
+// XCD BANDS.  The dispatcher deals consecutive workgroups to the eight XCDs in turn, so block b of a blend launch runs on XCD b & 7 and
+// takes the (b >> 3)-th tile of BAND b & 7.  band_mode 0: a band is a contiguous eighth of the tile index range (whole tile rows: the
+// XCD's L2 sees one spatially coherent strip of the frame).  band_mode 1 (round 6): bands are dealt in chunks of BAND_CHUNK horizontally
+// adjacent tiles, chunk c to band c & 7 — every XCD gets an even share of any frame (an object in front of an empty background leaves
+// the top and bottom strips with nothing to do: two of eight XCDs idle through both blend kernels, and the object's heaviest tiles
+// share the L2 and the SIMDs of two others).  Every band has band_slots() slots; a slot may name no tile (>= num_tiles).
+constexpr uint32_t BAND_CHUNK = 4;   // (2 / 4 / 8 / 16 measured: profiles/EXPERIMENTS.md)
+inline __host__ __device__ uint32_t band_slots(uint32_t num_tiles) {
+    const uint32_t p = (num_tiles + 7u) / 8u;
+    return ((p + BAND_CHUNK - 1u) / BAND_CHUNK) * BAND_CHUNK;
+}
+inline __host__ __device__ uint32_t band_tile(uint32_t band, uint32_t i, uint32_t per, uint32_t mode) {
+    return mode ? ((i / BAND_CHUNK) * 8u + band) * BAND_CHUNK + (i % BAND_CHUNK) : band * per + i;
+}
 // SPLIT TILES (round 6, rasterize.hip): the forward blend cannot be cut along a tile's list (a pixel's stop rule needs everything in
 // front of it), so a launch lasts as long as its heaviest tile — one wave working through its list at a lone wave's pace.  The few
 // tiles whose forecast work (the view's last frame) is several times their band's mean are blended by FOUR waves, one per 8 x 8 pixel
 // quadrant (four independent one-wave blocks; the last of them to finish does the tile's bookkeeping).  K1's order blocks decide which:
 // the first split_count[band] ranks of a band's descending order.  Layout behind the order table [8][per]:
 //   split_count[8] | split_scratch[8][SPLIT_MAX][4] = finished quadrants | max last useful entry | max entry reached | 1 = a quadrant is unsaturated
-constexpr uint32_t SPLIT_MAX = 64;          // split tiles per XCD band at most (the grid carries 3 * SPLIT_MAX extra blocks per band)
+constexpr uint32_t SPLIT_MAX = 128;         // split tiles per XCD band at most (the grid carries 3 * SPLIT_MAX extra blocks per band)
 constexpr uint32_t SPLIT_MIN_WORK = 256;    // a tile below this many blended splats is never split
 constexpr uint32_t SPLIT_TAIL_WORDS = 8u + 8u * SPLIT_MAX * 4u;
 constexpr uint32_t BWD_CKPT_MAX_SLOTS = 96u * 1024u;   // 384 MB of checkpoints at most (frames with > ~11 M listed pairs split only their first tiles)
@@ -387,8 +401,10 @@ struct bh_ctx {
     bool knob_no_view_hash = false;       // BH_NO_VIEW_HASH (A/B): frames without a view id share ONE table (rounds 4's behaviour) instead of being keyed by their camera
     bool knob_fixed_margin = false;       // BH_CUT_MARGIN_FIXED (A/B): the margin is BH_CUT_MARGIN_PCT for every frame (rounds 4's behaviour), not adaptive
     bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
+    uint32_t knob_band_mode = 1;          // XCD bands of the blend kernels: 0 contiguous eighths of the tile range, 1 dealt in chunks of 8 tiles
     uint32_t knob_k16_split = 250;        // forward blend: split tiles at >= max(SPLIT_MIN_WORK, this / 100 x the band's mean forecast work); 0: never
     uint32_t knob_k16_split_min = bh::SPLIT_MIN_WORK;
+    uint32_t knob_k16_split_of_max = 45;  // ... and this many percent of the band's heaviest tile
     const uint32_t* last_split = nullptr; // (test-hooks build: bh_debug_split_counts) the last forward's split counts, or NULL
     uint32_t knob_k16_order = 1;          // BH_K16_ORDER: 0 index order, 1 by the view's last per-tile work (descending), 2 dealt (A/B)
     uint32_t knob_cut_margin_pct = 150;   // BH_CUT_MARGIN_PCT: margin behind a tile's last useful splat, % of its depth rank (A/B)
@@ -482,9 +498,11 @@ struct ForwardPrep {
     uint32_t* order_out = nullptr;                // [8][ceil(order_tiles/8)] local tile ids, 0xFFFFFFFF behind a short band
     uint32_t order_tiles = 0, order_tile_begin = 0;
     uint32_t order_mode = 1;                      // 1: descending work   2: dealt (consecutive blocks take every 8th rank)
+    uint32_t band_mode = 0;                       // context.h XCD BANDS
     uint32_t* split_out = nullptr;                // split_count[8] | split_scratch (SPLIT_TAIL_WORDS), or NULL: no tile is split
     float split_factor = 2.5f;                    // a tile is split when its forecast work >= max(split_min, split_factor * the band's mean)
     uint32_t split_min = SPLIT_MIN_WORK;
+    float split_of_max = 0.45f;                   // ... and >= this share of the band's heaviest tile
     bool list_all_visible = false;                // A/B knob BH_CUT_SORT_ALL: per-tile cuts sort and number EVERY visible splat
 };
 int launch_project_forward(bh_ctx* ctx, const ViewUniforms& u, uint32_t n, bool mip, uint32_t sh_degree, const float* transforms,

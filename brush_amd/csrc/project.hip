@@ -272,21 +272,27 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // eight tiles are a stratified sample instead of eight neighbours.  8 of ~4000 blocks spend a few microseconds on it.
     if (prep.order_out && blockIdx.x < 8u) {   // block-uniform
         __shared__ uint32_t s_bins[ORDER_BINS];
-        const uint32_t per = (prep.order_tiles + 7u) / 8u;
-        const uint32_t first = blockIdx.x * per;
-        const uint32_t cnt = first < prep.order_tiles ? (prep.order_tiles - first < per ? prep.order_tiles - first : per) : 0u;
-        __shared__ uint32_t s_band_work;
+        // (slot i of band b names local tile band_tile(b, i): context.h XCD BANDS; a slot behind the window's last tile names none)
+        const uint32_t per = band_slots(prep.order_tiles);
+        __shared__ uint32_t s_band_work, s_band_cnt, s_band_tail, s_band_max;
         for (uint32_t i = threadIdx.x; i < ORDER_BINS; i += PROJ_WG) s_bins[i] = 0u;
-        if (threadIdx.x == 0) s_band_work = 0u;
+        if (threadIdx.x == 0) s_band_work = s_band_cnt = s_band_tail = s_band_max = 0u;
         __syncthreads();
-        uint32_t my_work = 0u;
-        for (uint32_t i = threadIdx.x; i < cnt; i += PROJ_WG) {
-            const uint32_t wk = prep.order_work[prep.order_tile_begin + first + i];
+        uint32_t my_work = 0u, my_cnt = 0u, my_max = 0u;
+        for (uint32_t i = threadIdx.x; i < per; i += PROJ_WG) {
+            const uint32_t lt = band_tile(blockIdx.x, i, per, prep.band_mode);
+            if (lt >= prep.order_tiles) continue;
+            const uint32_t wk = prep.order_work[prep.order_tile_begin + lt];
             atomicAdd(&s_bins[ORDER_BINS - 1u - (wk < ORDER_BINS ? wk : ORDER_BINS - 1u)], 1u);   // bin 0 = the most work
             my_work += wk < ORDER_BINS ? wk : ORDER_BINS - 1u;
+            my_max = max(my_max, wk < ORDER_BINS ? wk : ORDER_BINS - 1u);
+            my_cnt++;
         }
         if (prep.split_out && my_work) atomicAdd(&s_band_work, my_work);
+        if (my_cnt) atomicAdd(&s_band_cnt, my_cnt);
+        if (prep.split_out && my_max) atomicMax(&s_band_max, my_max);
         __syncthreads();
+        const uint32_t cnt = s_band_cnt;
         // exclusive scan of the bins (one thread per 4 bins + a wave scan over the 256 partial sums)
         {
             __shared__ uint32_t s_part[PROJ_WG];
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         if (prep.split_out) {
             if (threadIdx.x == 0) {
                 const float mean = cnt ? (float)s_band_work / (float)cnt : 0.0f;
-                const float thr_f = fmaxf((float)prep.split_min, prep.split_factor * mean);
+                // (relative to the band's heaviest tile as well: a quadrant wave walks an entry in ~0.19 us where a whole-tile wave takes ~0.44 beside
+                //  it, so tiles below ~0.45 x the maximum finish before the split maximum does — splitting them only costs instructions)
+                const float thr_f = fmaxf(fmaxf((float)prep.split_min, prep.split_factor * mean), prep.split_of_max * (float)s_band_max);
                 uint32_t h = 0u;
                 if (prep.order_mode == 1u && thr_f < (float)(ORDER_BINS - 1u)) {
                     const uint32_t thr = (uint32_t)ceilf(thr_f);
@@ -324,12 +332,13 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < per; i += PROJ_WG) {
-            if (i < cnt) {
-                const uint32_t wk = prep.order_work[prep.order_tile_begin + first + i];
+            const uint32_t lt = band_tile(blockIdx.x, i, per, prep.band_mode);
+            if (lt < prep.order_tiles) {
+                const uint32_t wk = prep.order_work[prep.order_tile_begin + lt];
                 const uint32_t rank = atomicAdd(&s_bins[ORDER_BINS - 1u - (wk < ORDER_BINS ? wk : ORDER_BINS - 1u)], 1u);
-                prep.order_out[blockIdx.x * per + rank] = first + i;
+                prep.order_out[blockIdx.x * per + rank] = lt;
             } else {
-                prep.order_out[blockIdx.x * per + i] = 0xFFFFFFFFu;   // (a short last band: ranks cnt.. stay empty)
+                prep.order_out[blockIdx.x * per + cnt + atomicAdd(&s_band_tail, 1u)] = 0xFFFFFFFFu;   // (slots without a tile: the ranks behind the band's last tile stay empty)
             }
         }
         __syncthreads();

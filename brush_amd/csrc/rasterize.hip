@@ -110,6 +110,7 @@ struct RasterUniforms {
     uint32_t tile_begin;                        // first tile id of the window
     float bg_r, bg_g, bg_b;
     float rcp_class_width;                      // work classes of the backward's longest-first tile order (see LPT below)
+    uint32_t band_mode;                         // context.h XCD BANDS
 };
 
 // ---- longest-first tile order for the backward ------------------------------------------------------------
@@ -123,7 +124,7 @@ struct RasterUniforms {
 // layout of the LPT scratch: LPT_HEADER_WORDS = [8][LPT_CLASSES] counters + 64 spare words (zeroed with tile_offsets), then
 // [8][LPT_CLASSES][per] class lists.  Backward jobs: a band's TOP class (every full segment) has more entries than the band has
 // tiles and lives in BwdJobs::top_list.  An entry: local tile (24 bits) | segment << 24 | "runs to the tile's end" << 30.
-BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return (num_tiles + 7u) / 8u; }
+BH_DEV uint32_t lpt_band_tiles(uint32_t num_tiles) { return band_slots(num_tiles); }
 BH_DEV size_t lpt_list_offset(uint32_t num_tiles, uint32_t band, uint32_t cls) {
     return (size_t)LPT_HEADER_WORDS + ((size_t)band * LPT_CLASSES + cls) * lpt_band_tiles(num_tiles);
 }
@@ -136,6 +137,7 @@ constexpr uint32_t JOB_TILE_MASK = 0x00FFFFFFu, JOB_SEG_SHIFT = 24u, JOB_SEG_MAS
 //   [10] colour gate bits (raw r/g/b >= 0)   [11] compact gid
 constexpr int SPLAT_STRIDE = 12;
 constexpr int BATCH = 64;
+constexpr uint32_t SPLIT_GROUP = 4;   // splats a quadrant wave of a split tile takes at a time (rasterize_kernel, NQ == 1)
 constexpr float SIGMA_CUT_MARGIN = 0.01f;  // >> the error of bh_logf/exp_blend (~1e-7)
 
 // exp(x) for the blend loops, x = -sigma <= 0 wherever the result is used (lanes that fail the
@@ -158,10 +160,11 @@ BH_DEV float exp_blend(float x) {
     return u2f(f2u(p) + (f2u(s) << 23));
 }
 
-// 8 XCDs take workgroups round-robin; give each XCD a contiguous band of tiles.
-BH_DEV uint32_t tile_of_block(uint32_t b, uint32_t num_tiles) {
-    const uint32_t per = (num_tiles + 7u) / 8u;
-    return (b & 7u) * per + (b >> 3);
+// 8 XCDs take workgroups round-robin; each XCD owns a band of tiles (context.h XCD BANDS).  (>= num_tiles: the slot names no tile)
+BH_DEV uint32_t tile_of_block(uint32_t b, uint32_t num_tiles, uint32_t band_mode) {
+    const uint32_t per = band_slots(num_tiles);
+    const uint32_t i = b >> 3;
+    return i < per ? band_tile(b & 7u, i, per, band_mode) : 0xFFFFFFFFu;
 }
 
 // Stage one batch of up to 64 splats of this tile into LDS (lane i stages splat i).
@@ -323,14 +326,6 @@ BH_DEV void blend_tile(const RasterUniforms& u, const uint32_t* __restrict__ ise
             // interleaves them); the two state updates follow in list order with exactly the one-splat arithmetic, the second splat's
             // live test on the state the first one left.  The pair is skipped when neither can reach its cutoff anywhere (the second
             // splat's test on the state BEFORE the first: conservative).
-            auto sigma_of = [&](const float4& s0, const float4& s1) {
-                const float dx = pcx[0] - s0.x;
-                const float a_xx = (s0.z * dx) * dx;
-                const float b_x = s0.w * dx;
-                const float dy = pcy[0] - s0.y;
-                const float c_y = s1.x * dy;
-                return __builtin_fmaf(b_x, dy, __builtin_fmaf(c_y, dy, a_xx));
-            };
             auto apply = [&](const float4& s1, const float2& s2, const float alpha, const bool pre) {
                 const float w_cut = SMOOTH ? alpha_cutoff_weight(alpha) : (alpha >= ALPHA_CUTOFF_MID ? 1.0f : 0.0f);
                 const bool ok = pre && w_cut > 0.0f;
@@ -347,31 +342,112 @@ BH_DEV void blend_tile(const RasterUniforms& u, const uint32_t* __restrict__ ise
             };
             bool stopped = false;
             uint32_t t = 0u;
-            for (; t + 1u < cnt; t += 2u) {
-                const float4 a0 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE]);
-                const float4 a1 = *reinterpret_cast<const float4*>(&s_splat[t * SPLAT_STRIDE + 4]);
-                const float2 a2 = *reinterpret_cast<const float2*>(&s_splat[t * SPLAT_STRIDE + 8]);
-                const float4 b0 = *reinterpret_cast<const float4*>(&s_splat[(t + 1u) * SPLAT_STRIDE]);
-                const float4 b1 = *reinterpret_cast<const float4*>(&s_splat[(t + 1u) * SPLAT_STRIDE + 4]);
-                const float2 b2 = *reinterpret_cast<const float2*>(&s_splat[(t + 1u) * SPLAT_STRIDE + 8]);
-                const float sig_a = sigma_of(a0, a1), sig_b = sigma_of(b0, b1);
+            constexpr uint32_t G = SPLIT_GROUP;   // splats per group (a power of two <= 8: the saturation test sits behind every 8th splat)
+            // (per-lane bookkeeping instead of a ballot and five scalar ops per splat: which splats of the batch this LANE blended — OR-reduced
+            //  over the wave behind the batch)
+            uint32_t lane_lo = 0u, lane_hi = 0u;
+            for (; t + G <= cnt; t += G) {
+                float4 g0[G], g1[G];
+                float2 g2[G];
+                float sig[G], al[G];
+                bool cand[G];
+#pragma unroll
+                for (uint32_t g = 0; g < G; ++g) {
+                    g0[g] = *reinterpret_cast<const float4*>(&s_splat[(t + g) * SPLAT_STRIDE]);
+                    g1[g] = *reinterpret_cast<const float4*>(&s_splat[(t + g) * SPLAT_STRIDE + 4]);
+                    g2[g] = *reinterpret_cast<const float2*>(&s_splat[(t + g) * SPLAT_STRIDE + 8]);
+                }
+                // sigma of the G splats, step by step ACROSS the group: the scheduler otherwise emits one splat's chain after the other
+                // (it schedules for register pressure), and a lone wave then pays the full dependent-op latency on every instruction
+                {
+                    float dx[G], dy[G], axx[G], bx[G], cy[G];
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) { dx[g] = pcx[0] - g0[g].x; dy[g] = pcy[0] - g0[g].y; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) { axx[g] = g0[g].z * dx[g]; bx[g] = g0[g].w * dx[g]; cy[g] = g1[g].x * dy[g]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) axx[g] = axx[g] * dx[g];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) axx[g] = __builtin_fmaf(cy[g], dy[g], axx[g]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) sig[g] = __builtin_fmaf(bx[g], dy[g], axx[g]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const uint32_t dead = f2u(tr[0]) & sign_mask;
-                const bool pre_a = (dead | f2u(sig_a)) <= f2u(a2.y);
-                const bool cand_b = (dead | f2u(sig_b)) <= f2u(b2.y);
-                if (__ballot(pre_a || cand_b) != 0ull) {
-                    const float al_a = __builtin_fminf(0.999f, a1.y * exp_blend(-sig_a));
-                    const float al_b = __builtin_fminf(0.999f, b1.y * exp_blend(-sig_b));
-                    const bool any_a = apply(a1, a2, al_a, pre_a);
-                    const bool pre_b = ((f2u(tr[0]) & sign_mask) | f2u(sig_b)) <= f2u(b2.y);
-                    const bool any_b = apply(b1, b2, al_b, pre_b);
-                    if (BWD_INFO) {
-                        if (__ballot(any_a) != 0ull) { contrib_mask |= 1ull << t; last_useful = batch_start + t + 1u; }
-                        if (__ballot(any_b) != 0ull) { contrib_mask |= 2ull << t; last_useful = batch_start + t + 2u; }
+                bool any_cand = false;
+#pragma unroll
+                for (uint32_t g = 0; g < G; ++g) {
+                    cand[g] = (dead | f2u(sig[g])) <= f2u(g2[g].y);   // (the first splat's is its exact live test; the others' are conservative)
+                    any_cand = any_cand || cand[g];
+                }
+                if (__ballot(any_cand) != 0ull) {
+                    // exp_blend(-sigma) of the group, the same way (the arithmetic of exp_blend, statement for statement)
+                    {
+                        float sx[G], f[G], pp[G];
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) sx[g] = __builtin_fmaf(-sig[g], 1.44269504088896341f, 12582912.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) f[g] = 12582912.0f - sx[g];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) f[g] = __builtin_fmaf(-sig[g], 1.44269504088896341f, f[g]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) pp[g] = __builtin_fmaf(1.3274633092805743e-3f, f[g], 9.671961888670921e-3f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) pp[g] = __builtin_fmaf(pp[g], f[g], 5.5506784468889236e-2f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) pp[g] = __builtin_fmaf(pp[g], f[g], 2.4022234976291656e-1f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) pp[g] = __builtin_fmaf(pp[g], f[g], 6.931470632553101e-1f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) pp[g] = __builtin_fmaf(pp[g], f[g], 1.0f);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) al[g] = g1[g].y * u2f(f2u(pp[g]) + (f2u(sx[g]) << 23));
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (uint32_t g = 0; g < G; ++g) al[g] = __builtin_fminf(0.999f, al[g]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    uint32_t bits = 0u;
+#pragma unroll
+                    for (uint32_t g = 0; g < G; ++g) {
+                        const bool pre = g == 0u ? cand[0] : ((f2u(tr[0]) & sign_mask) | f2u(sig[g])) <= f2u(g2[g].y);
+                        const bool any_g = apply(g1[g], g2[g], al[g], pre);
+                        if (BWD_INFO) bits |= any_g ? (1u << g) : 0u;
+                    }
+                    if (BWD_INFO) {   // (t is a multiple of G: the group's bits do not straddle the two words)
+                        if (t < 32u) lane_lo |= bits << t;
+                        else lane_hi |= bits << (t - 32u);
                     }
                 }
-                if (((t + 1u) & 7u) == 7u) {   // (the one-splat loop's test behind every 8th splat)
+                if (((t + G - 1u) & 7u) == 7u) {   // (the one-splat loop's test behind every 8th splat)
                     const bool still = any_live();
-                    if (__ballot(still) == 0ull) { reached = batch_start + t + 2u; stopped = true; break; }
+                    if (__ballot(still) == 0ull) { reached = batch_start + t + G; stopped = true; break; }
+                }
+            }
+            if (BWD_INFO) {
+                // OR over the wave (DPP within rows of 16, then across rows through the swaps' cheaper cousins: readlane of four row leaders)
+                uint32_t lo = lane_lo, hi = lane_hi;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    lo |= (uint32_t)__shfl_xor((int)lo, off);
+                    hi |= (uint32_t)__shfl_xor((int)hi, off);
+                }
+                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(lo);
+                if (m != 0ull) {
+                    contrib_mask |= m;
+                    last_useful = batch_start + 64u - (uint32_t)__builtin_clzll(m);
                 }
             }
             t_first = stopped ? cnt : t;   // an odd batch's last splat goes through the one-splat loop below
@@ -636,7 +712,7 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
     uint32_t local_tile, qsel = 4u;   // qsel < 4: this block is one quadrant wave of a split tile
     uint32_t* split_row = nullptr;
     if (sl.order) {
-        const uint32_t per = (u.num_tiles + 7u) / 8u;
+        const uint32_t per = band_slots(u.num_tiles);
         uint32_t j = bidx >> 3;
         if (PHASE != 2 && sl.split) {
             // the first split[band] ranks of the band (its heaviest tiles by forecast) take four blocks each, everyone else moves up
@@ -655,7 +731,7 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
         }
         local_tile = j < per ? sl.order[(bidx & 7u) * per + j] : 0xFFFFFFFFu;
     } else {
-        local_tile = tile_of_block(bidx, u.num_tiles);
+        local_tile = tile_of_block(bidx, u.num_tiles, u.band_mode);
     }
     if (local_tile >= u.num_tiles) return;
     if (PHASE != 2 && qsel < 4u)
@@ -679,6 +755,7 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
                      const uint32_t* global_from_compact, float* out_img, uint32_t* out_packed, float* visible,
                      uint32_t* lpt, float class_width, int phase, const RasterSlice* slice) {
     RasterUniforms u;
+    u.band_mode = ctx->knob_band_mode;
     u.rcp_class_width = class_width > 0.0f ? 1.0f / (class_width > 1.0f ? class_width : 1.0f) : 0.0f;   // (<= 0: logarithmic classes)
     u.tile_bw = vu.tile_bw;
     u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
@@ -712,8 +789,8 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (phase != 0 && (!sl.done_bits || !sl.unsat_count || !sl.state || (phase == 2 && !sl.offsets_near)))
         return set_error(ctx, BH_ERR_INVALID_ARG, "launch_rasterize: sliced phase without its scratch");
     if (sl.feedback && !sl.cum) sl.feedback = nullptr;
-    uint32_t nblocks = ((u.num_tiles + 7u) / 8u) * 8u;
-    if (sl.order && sl.order_mode == 2u) nblocks = (((u.num_tiles + 7u) / 8u + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
+    uint32_t nblocks = band_slots(u.num_tiles) * 8u;
+    if (sl.order && sl.order_mode == 2u) nblocks = ((band_slots(u.num_tiles) + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
     if (sl.split) nblocks += 8u * 3u * SPLIT_MAX;   // three more blocks for each tile a band may split (blocks behind the band's last rank leave at once)
     const dim3 grid(nblocks);
     if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
@@ -822,7 +899,7 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
         local_tile = entry & JOB_TILE_MASK;
         if (JOBS) { seg = (entry >> JOB_SEG_SHIFT) & JOB_SEG_MASK; to_end = (entry & JOB_LAST_BIT) != 0u; }
     } else {
-        local_tile = tile_of_block(blockIdx.x, u.num_tiles);
+        local_tile = tile_of_block(blockIdx.x, u.num_tiles, u.band_mode);
         if (local_tile >= u.num_tiles) return;
     }
     const uint32_t tile = u.tile_begin + local_tile;
@@ -1044,6 +1121,7 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
                               const float* out_img, const float* v_output, float* v_combined, const uint32_t* lpt,
                               const uint32_t* tile_offsets_far, bool want_refine, const BwdJobs* jobs) {
     RasterUniforms u;
+    u.band_mode = ctx->knob_band_mode;
     u.rcp_class_width = 1.0f;
     u.tile_bw = vu.tile_bw;
     u.num_tiles = vu.tile_bw * (vu.tile_y1 - vu.tile_y0);
@@ -1057,7 +1135,7 @@ int launch_rasterize_backward(bh_ctx* ctx, const ViewUniforms& vu, const float b
     const BwdJobs jb = by_jobs ? *jobs : BwdJobs{};
     // whole tiles: one block per tile.  Jobs: two blocks per tile (a typical frame has 1.5 - 2.5 jobs per tile); a block takes
     // every (blocks per band)-th job of its band, so any number of jobs is covered
-    const uint32_t per = (u.num_tiles + 7u) / 8u;
+    const uint32_t per = band_slots(u.num_tiles);
     const uint32_t nblocks = (by_jobs ? 2u : 1u) * per * 8u;
     const dim3 grid(nblocks);
     hipEvent_t ea = ctx->prof.ext_a, eb = ctx->prof.ext_b;

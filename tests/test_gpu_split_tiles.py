@@ -45,14 +45,14 @@ def test_split_tiles_give_the_whole_tile_results(dev, case):
     import brush_amd as ba
     if case == "object_centric":       # heavy tiles in the middle, empty ones around: the product's rule picks the split tiles
         sc, cp = _scene(60000, 0xA1, spread=0.35)
-        split = {"k16_split": 150, "k16_split_min": 32}
+        split = {"k16_split": 150, "k16_split_min": 32, "k16_split_of_max": 30}
     elif case == "uniform_all_split":  # every tile with any work is split (64 per band at most)
         sc, cp = _scene(20000, 0xA2, spread=1.5)
-        split = {"k16_split": 1, "k16_split_min": 1}
+        split = {"k16_split": 1, "k16_split_min": 1, "k16_split_of_max": 0}
     else:                              # faint splats: nothing saturates, lists of many segments (checkpoints of quadrants that stop at different entries)
         sc, cp = _scene(40000, 0xA3, spread=0.6, scales=(0.02, 0.12))
         sc["raw_opac"][:] = np.float32(-2.5)
-        split = {"k16_split": 1, "k16_split_min": 1}
+        split = {"k16_split": 1, "k16_split_min": 1, "k16_split_of_max": 0}
     ref = _frames(ba, dev, sc, cp, {"k16_split": 0})
     got = _frames(ba, dev, sc, cp, split)
     assert got["nv"] == ref["nv"] and got["ni"] == ref["ni"]
@@ -77,7 +77,7 @@ def test_split_tiles_are_actually_split(dev):
     import ctypes as C
     from brush_amd import _ffi
     sc, cp = _scene(60000, 0xA1, spread=0.35)
-    ctx = ba.Context(dev, lib=_ffi.load_test_hooks(), options={"cut_min_pairs": 0, "k16_split": 150, "k16_split_min": 32})
+    ctx = ba.Context(dev, lib=_ffi.load_test_hooks(), options={"cut_min_pairs": 0, "k16_split": 150, "k16_split_min": 32, "k16_split_of_max": 30})
 
     def split_counts():
         out = (C.c_uint32 * 8)()
@@ -89,7 +89,7 @@ def test_split_tiles_are_actually_split(dev):
     for _ in range(2):
         ba.render_splats(spl, cam, (W, H), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
     counts = split_counts()
-    assert counts is not None and len(counts) == 8 and 0 < sum(counts) <= 8 * 64
+    assert counts is not None and len(counts) == 8 and 0 < sum(counts) <= 8 * 128
     ctx.set_option("k16_split", 0)
     ba.render_splats(spl, cam, (W, H), (0.0, 0.0, 0.0), ba.RasterPass.Backward, ctx=ctx)
     assert split_counts() is None
@@ -109,7 +109,7 @@ def test_split_tiles_in_cut_list_train_steps(dev):
         p["pos"] = (dx, 0.0, 0.0)
         cams.append(util.hip_camera(ba, p))
     runs = []
-    for opts in ({"k16_split": 0}, {"k16_split": 1, "k16_split_min": 1}):
+    for opts in ({"k16_split": 0}, {"k16_split": 1, "k16_split_min": 1, "k16_split_of_max": 0}):
         ctx = ba.Context(dev, options=dict({"cut_min_pairs": 0, "auto_exact_share": 0}, **opts))
         spl = ba.Splats(sc["transforms"].copy(), sc["sh"].copy(), sc["raw_opac"].copy(), device=dev)
         trainer = ba.SplatTrainer(ba.TrainConfig(), median_scene_scale=3.0, ctx=ctx)
