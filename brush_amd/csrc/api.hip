@@ -559,6 +559,7 @@ const OptionKey kOptionKeys[] = {
     {"no_view_hash", "0|1: frames without a view id share ONE table instead of being keyed by their camera"},
     {"k16_order", "0 index order | 1 by the view's last per-tile work | 2 dealt: the forward blend's tile order"},
     {"band_mode", "0|1: XCD bands of the blend kernels — contiguous eighths of the tile range, or dealt in chunks of 8 adjacent tiles (default 1)"},
+    {"k16_waves", "0..8: forward blend: resident one-wave tiles per SIMD (0 = 8 = all resident at once; fewer: the lighter tiles are dispatched as the heavier ones finish)"},
     {"k16_split", "0..1000: forward blend: a tile whose forecast work is at least max(256, k16_split / 100 x its band's mean) is blended by four quadrant waves (default 250; 0: no tile is split)"},
     {"k16_split_of_max", "0..100: ... and at least this many percent of its band's heaviest tile (default 45)"},
     {"k16_split_min", "1..1023: a tile below this many blended splats (forecast) is never split (default 256)"},
@@ -625,6 +626,7 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
     else if (k == "no_view_hash") ok = parse_flag(value, &ctx->knob_no_view_hash);
     else if (k == "k16_order") { if ((ok = parse_u32(value, 0, 2, &u))) ctx->knob_k16_order = u; }
     else if (k == "band_mode") { if ((ok = parse_u32(value, 0, 1, &u))) ctx->knob_band_mode = u; }
+    else if (k == "k16_waves") { if ((ok = parse_u32(value, 0, 8, &u))) ctx->knob_k16_waves = u; }
     else if (k == "k16_split") { if ((ok = parse_u32(value, 0, 1000, &u))) ctx->knob_k16_split = u; }
     else if (k == "k16_split_of_max") { if ((ok = parse_u32(value, 0, 100, &u))) ctx->knob_k16_split_of_max = u; }
     else if (k == "k16_split_min") { if ((ok = parse_u32(value, 1, 1023, &u))) ctx->knob_k16_split_min = u; }

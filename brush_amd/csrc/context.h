@@ -402,6 +402,7 @@ struct bh_ctx {
     bool knob_fixed_margin = false;       // BH_CUT_MARGIN_FIXED (A/B): the margin is BH_CUT_MARGIN_PCT for every frame (rounds 4's behaviour), not adaptive
     bool knob_cut_sort_all = false;       // BH_CUT_SORT_ALL (A/B): with per-tile cuts, still sort every visible splat
     uint32_t knob_band_mode = 1;          // XCD bands of the blend kernels: 0 contiguous eighths of the tile range, 1 dealt in chunks of 8 tiles
+    uint32_t knob_k16_waves = 0;          // forward blend: resident waves per SIMD (0 / 8: all eight; fewer: later tiles are dispatched as earlier ones finish)
     uint32_t knob_k16_split = 250;        // forward blend: split tiles at >= max(SPLIT_MIN_WORK, this / 100 x the band's mean forecast work); 0: never
     uint32_t knob_k16_split_min = bh::SPLIT_MIN_WORK;
     uint32_t knob_k16_split_of_max = 45;  // ... and this many percent of the band's heaviest tile

@@ -741,13 +741,13 @@ __global__ __launch_bounds__(64, 8) void rasterize_kernel(RasterUniforms u, cons
 }
 
 template <bool BWD_INFO, bool SMOOTH>
-static void launch_rasterize_phase(int phase, dim3 grid, hipStream_t stream, const RasterUniforms& u, const uint32_t* isect_gids, uint32_t* tile_offsets,
+static void launch_rasterize_phase(int phase, dim3 grid, uint32_t lds_pad, hipStream_t stream, const RasterUniforms& u, const uint32_t* isect_gids, uint32_t* tile_offsets,
                                    const float* projected, const uint32_t* gfc, float* out_img, uint32_t* out_packed, float* visible, uint32_t* lpt,
                                    const SliceArgs& sl) {
     const dim3 block(64);
-    if (phase == 1) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 1>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
-    else if (phase == 2) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 2>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
-    else hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 0>), grid, block, 0, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
+    if (phase == 1) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 1>), grid, block, lds_pad, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
+    else if (phase == 2) hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 2>), grid, block, lds_pad, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
+    else hipLaunchKernelGGL((rasterize_kernel<BWD_INFO, SMOOTH, 0>), grid, block, lds_pad, stream, u, isect_gids, tile_offsets, projected, gfc, out_img, out_packed, visible, lpt, sl);
 }
 
 int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], bool bwd_info, bool smooth,
@@ -793,9 +793,17 @@ int launch_rasterize(bh_ctx* ctx, const ViewUniforms& vu, const float bg[3], boo
     if (sl.order && sl.order_mode == 2u) nblocks = ((band_slots(u.num_tiles) + 7u) / 8u) * 64u;   // 8 bands x 8 x seg ranks
     if (sl.split) nblocks += 8u * 3u * SPLIT_MAX;   // three more blocks for each tile a band may split (blocks behind the band's last rank leave at once)
     const dim3 grid(nblocks);
-    if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
-    else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
-    else launch_rasterize_phase<false, false>(phase, grid, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
+    // resident waves per SIMD (option k16_waves): unused dynamic LDS caps how many one-wave blocks a CU holds (160 KB per CU, 4 SIMDs); the
+    // blocks behind the first round are dispatched as slots free up, in block order — which with the order table is descending forecast work
+    uint32_t lds_pad = 0;
+    if (ctx->knob_k16_waves >= 1u && ctx->knob_k16_waves < 8u && sl.order && sl.order_mode == 1u && phase != 2) {
+        const uint32_t per_block = (160u * 1024u) / (4u * ctx->knob_k16_waves);
+        const uint32_t fixed = BATCH * SPLAT_STRIDE * 4u;
+        lds_pad = per_block > fixed + 64u ? ((per_block - fixed - 64u) & ~63u) : 0u;
+    }
+    if (bwd_info && smooth) launch_rasterize_phase<true, true>(phase, grid, lds_pad, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
+    else if (bwd_info) launch_rasterize_phase<true, false>(phase, grid, lds_pad, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
+    else launch_rasterize_phase<false, false>(phase, grid, lds_pad, ctx->stream, u, isect_gids, tile_offsets, projected, global_from_compact, out_img, out_packed, visible, lpt, sl);
     BH_LAUNCH_CHECK(ctx, "rasterize_kernel");
     return 0;
 }
@@ -856,7 +864,7 @@ BH_DEV float blend_exp_bwd(float x) {
     return exp_blend(x);
 }
 
-constexpr int BWD_WAVES = 3;   // waves per SIMD the backward is compiled for (four cost nothing and bought nothing: profiles/EXPERIMENTS.md)
+constexpr int BWD_WAVES = 5;   // waves per SIMD the default variant (hard cutoff, refine weight) is compiled for: 96 VGPRs; the variant without the refine weight gets 6 (80 VGPRs), the smooth-cutoff variants one fewer each.  (Rounds 2-5 compiled for 3 and the allocator happened to stop at 95 / 79; any change to the job prologue moved it to 99-109, i.e. to FOUR waves.)
 // REFINE = false: the refine weight (…:340-349: a per-pixel norm — two fmas, a quarter-rate v_sqrt, an fma per contributing
 // pixel-quadrant, a third of the gradient block — and the two per-pixel registers its 1/A factors live in) is left out: its one
 // consumer, refine()'s growth selection, stops reading it at growth_stop_iter (train.rs:589-614), i.e. for the second half of a
@@ -871,7 +879,7 @@ constexpr int BWD_WAVES = 3;   // waves per SIMD the backward is compiled for (f
 // wave retires an op every ~5 cycles, one of five on a SIMD every ~13): 409 us for a frame whose heaviest tile blends 879 splats
 // while the mean tile blends 58 (an object in front of an empty background), and 1.6 rounds of whole tiles on the uniform frame.
 template <bool SMOOTH, bool REFINE, bool JOBS>
-__global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
+__global__ __launch_bounds__(64, (BWD_WAVES - (SMOOTH ? 1 : 0) + (REFINE ? 0 : 1))) void rasterize_backward_kernel(RasterUniforms u, const uint32_t* __restrict__ isect_gids,
                                                                const uint32_t* __restrict__ tile_offsets,
                                                                const float* __restrict__ projected,
                                                                const float* __restrict__ out_img,
@@ -887,12 +895,25 @@ __global__ __launch_bounds__(64, BWD_WAVES) void rasterize_backward_kernel(Raste
         const uint32_t xcd = blockIdx.x & 7u;
         uint32_t j = jidx;
         const uint32_t* cnt = lpt + xcd * LPT_CLASSES;
+        // Which class holds the band's j-th entry, in descending class order: the counters are fetched EIGHT at a time (independent scalar
+        // loads, one wait).  Rounds 2-6 walked them with one dependent load per class: nothing for a job of the top class, but up to 64
+        // round trips — 14-25 us under load (per-block trace of the launch, scripts/k17_trace.py) — for the short tails that sit in the
+        // low classes and are taken LAST: the launch's own tail was made of waves looking for their job.  (One counter per lane and a
+        // wave scan finds the class in one round trip, but its vector code cost the hot loop registers: 95 -> 109 VGPRs, measured slower.)
         uint32_t cls = LPT_CLASSES;
         bool found = false;
-        for (uint32_t c = LPT_CLASSES; c-- > 0u && !found;) {   // (uniform: scalar loads of one band's counters, a few hundred cycles per tile at most)
-            const uint32_t k = cnt[c];
-            if (j < k) { cls = c; found = true; }
-            else j -= k;
+        static_assert(LPT_CLASSES % 8u == 0u, "classes are walked in groups of eight");
+        for (uint32_t base = LPT_CLASSES; base > 0u && !found; base -= 8u) {   // (uniform)
+            uint32_t k[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) k[i] = cnt[base - 1u - i];
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                if (!found) {
+                    if (j < k[i]) { cls = base - 1u - i; found = true; }
+                    else j -= k[i];
+                }
+            }
         }
         if (!found) return;  // no entry left in this band
         const uint32_t entry = (JOBS && cls == LPT_CLASSES - 1u) ? jb.top_list[(size_t)xcd * jb.top_cap + j] : lpt[lpt_list_offset(u.num_tiles, xcd, cls) + j];

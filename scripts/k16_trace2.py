@@ -50,3 +50,14 @@ for name, m in (("split quadrant waves", q > 0), ("whole tiles", q == 0)):
     big = wk >= 256
     if big.sum():
         print("   blocks that walked >= 256 entries: n %d, us per entry mean %.3f min %.3f max %.3f" % (big.sum(), (d[big] / wk[big]).mean(), (d[big] / wk[big]).min(), (d[big] / wk[big]).max()))
+# occupancy over time: waves in flight per 10 us bucket (8192 slots), and when each XCD (band) finished
+span = t1.max()
+nb_ = int(span * us / 10) + 1
+occ = np.zeros(nb_)
+for b in range(nb_):
+    lo_, hi_ = b * 10 / us, (b + 1) * 10 / us
+    occ[b] = (np.minimum(t1, hi_) - np.maximum(t0, lo_)).clip(min=0).sum() / (10 / us)
+print("waves in flight per 10 us bucket:", " ".join("%d" % o for o in occ))
+band = idx & 7
+print("last end per XCD band (us):", " ".join("%.0f" % (t1[band == b].max() * us) for b in range(8) if (band == b).any()))
+print("busy wave-us per XCD band:", " ".join("%.0f" % ((t1[band == b] - t0[band == b]).sum() * us) for b in range(8) if (band == b).any()))
