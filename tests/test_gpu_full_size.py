@@ -37,6 +37,37 @@ def test_1m_1080p_forward_exact_vs_oracle(dev, oracle_lib, scene_1m):
     assert d.max() <= 1e-6, "L-inf %g" % d.max()
 
 
+def test_1m_1080p_object_centric_split_tiles_exact_vs_oracle(dev, oracle_lib):
+    """The object-centric frame at full size (half of the tiles empty, the heaviest blends 15x the mean): on the view's THIRD frame the
+    forward blend splits its heaviest tiles over four quadrant waves (the first two frames leave the per-tile forecast) — image, list
+    ends and visible flags against the oracle, and the backward through the checkpoints the quadrant waves left."""
+    import ctypes as C
+    import brush_amd as ba
+    from brush_amd import _ffi
+    sc, w, h = synth.config_scene("1m_1080p_centered", 0)
+    cp = synth.default_camera_params(w, h)
+    ctx = ba.Context(dev, lib=_ffi.load_test_hooks())
+    spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+    cam = util.hip_camera(ba, cp)
+    rng = np.random.default_rng(9)
+    v_out = torch.from_numpy((rng.uniform(-1, 1, (h, w, 4)) / (h * w)).astype(np.float32)).to(dev)
+    for _ in range(3):
+        res = ba.render_splats_bwd(spl, cam, (w, h), (0, 0, 0), v_out, ctx=ctx)
+    counts = (C.c_uint32 * 8)()
+    assert ctx.lib.bh_debug_split_counts(ctx._h, counts) == 1 and sum(counts) >= 64, list(counts)   # the rule fired: this IS the split path
+    aux = res["aux"]
+    ref = oracle_lib.Render().forward(oracle_lib.camera(**cp), sc["transforms"], sc["sh"], sc["raw_opac"])
+    assert aux.num_visible == ref.num_visible and aux.num_intersections == ref.num_intersections
+    assert np.array_equal(util.u32(aux.tile_offsets).reshape(-1), ref.get("tile_offsets"))
+    assert np.array_equal(aux.visible.cpu().numpy(), ref.get("visible"))
+    d = np.abs(res["img"].cpu().numpy() - ref.image())
+    assert d.max() <= 1e-6, "L-inf %g" % d.max()
+    ref.backward(v_out.cpu().numpy())
+    from test_gpu_backward import assert_grads_match
+    assert_grads_match(res, ref)
+    ctx.close()
+
+
 def test_1m_1080p_properties(dev, scene_1m):
     """Size-independent invariants at full size: sortedness, per-tile depth order, scan
     totals, count consistency, image alpha in [0,1], determinism, forward-only == packed(f32)."""

@@ -23,7 +23,7 @@ def test_set_option_validates_keys_and_values(dev):
     import brush_amd as ba
     ctx = ba.Context(dev)
     keys = ctx.options()
-    assert {"cut_min_pairs", "event_waits", "readback_copy", "tile_sort", "k16_order", "grad_allreduce", "auto_exact_share"} <= set(keys)
+    assert {"cut_min_pairs", "event_waits", "readback_copy", "tile_sort", "k16_order", "grad_allreduce", "auto_exact_share", "band_mode", "k16_split", "k16_waves"} <= set(keys)
     assert all(len(v) > 10 for v in keys.values())   # one line of documentation each
     ctx.set_option("cut_min_pairs", 0)
     ctx.set_option("tile_sort", "lsd")
@@ -45,7 +45,8 @@ def test_environment_translation_is_the_harness_not_the_library():
 
 @pytest.mark.parametrize("options", [{"bwd_jobs": 0}, {"lpt_classes": "linear"}, {"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
                                      {"k16_order": 0}, {"k16_order": 2}, {"no_lpt": 1}, {"cut_sort_all": 1}, {"no_view_hash": 1},
-                                     {"auto_exact_share": 0}, {"k5_exact_spw": 16}, {"k5_exact_spw": 64}])
+                                     {"auto_exact_share": 0}, {"k5_exact_spw": 16}, {"k5_exact_spw": 64},
+                                     {"band_mode": 0}, {"k16_waves": 5}, {"k16_split": 0}, {"k16_split": 1, "k16_split_min": 1, "k16_split_of_max": 0}])
 def test_alternative_paths_give_the_default_results(dev, options):
     """Six alternating cut-list train steps (the host's mid-step waits, the sorts, the tile orders, the list builder's shapes) under
     each option against a context with the defaults: images bit-identical at every step, parameters equal up to atomic order."""
