@@ -16,3 +16,12 @@ for comm in native torch; do for ex in sparse dense; do
   BH_FORCE_PG=1 MASTER_PORT=$((29600 + RANDOM % 200)) timeout 200 python bench.py --steps 20 --warmup 5 --comm $comm --exchange $ex --no-cpu-baseline --no-extra --no-pmc > $O/${TAG}_bench_pg1_${comm}_${ex}.json 2>> $O/${TAG}_bench.err; echo "pg1 $comm $ex rc $?"
 done; done
 timeout 600 bash scripts/profile_bench.sh $TAG > $O/${TAG}_profile.log 2>&1; echo "profile rc $?"
+# the converging run's late phase under rocprofv3 (kernel trace only): per-kernel table of its last 400 steps, both list modes
+for mode in exact_lists cuts_view_ids; do
+  (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_${TAG}_loop_$mode -o loop -- python $GRAFT_REPO_ROOT/bench.py --loop-only $mode --loop-steps 3000 > $GRAFT_REPO_ROOT/$O/${TAG}_loop_only_$mode.json 2>> $GRAFT_REPO_ROOT/$O/${TAG}_bench.err)
+  f=$(find $O/prof_${TAG}_loop_$mode -name "*kernel_trace.csv" | head -1)
+  python scripts/late_phase_stats.py "$f" $O/${TAG}_late_phase_kstats_$mode.csv 400; echo "late phase $mode rc $?"
+  rm -rf $O/prof_${TAG}_loop_$mode
+done
+# the GPU suite's log of the same tree
+timeout 1500 python -m pytest tests -m gpu -q > $O/${TAG}_gpu_tests.log 2>&1; echo "gpu tests rc $?"; tail -1 $O/${TAG}_gpu_tests.log
