@@ -596,7 +596,9 @@ def main():
                        "SURVEY 8d figure that charges every LISTED intersection (80*I + 32*P): the kernel stops each tile once all its pixels "
                        "saturate, so that figure counts reads it never makes and can exceed 1. The kernel is VALU-issue bound: see roofline_valu. "
                        "`traffic` exceeds the algorithmic bytes by design since round 6: the backward works on 128-entry segments of the tiles' lists, each of "
-                       "which reads a 4 KB pixel-state checkpoint and its tile's pixels (DESIGN.md 4, K17) - with whole tiles (option bwd_jobs=0) the ratio is 0.97."}
+                       "which reads a 4 KB pixel-state checkpoint and its tile's pixels (DESIGN.md 4, K17), and the XCD bands are dealt in chunks of four tiles, so a splat's "
+                       "row is fetched into every L2 whose XCD blends one of its tiles (FETCH_SIZE counts L2 misses, Infinity-Cache hits included) - with whole tiles and "
+                       "contiguous bands (options bwd_jobs=0, band_mode=0) the ratio is 0.97."}
         valu = {}
         for stage, kern in (("RasterizeBackwards", "rasterize_backward_kernel"), ("Rasterize", "rasterize_kernel")):
             ms, calls = m["stages"].get(stage, (0.0, 0))
