@@ -297,7 +297,7 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
                 forget(old, recycled == nullptr && old->second.tile_bw == tile_bw && old->second.tile_bh == tile_bh);
             }
         }
-        const size_t max_views = std::min(MAX_VIEW_STATES, std::max<size_t>(8, VIEW_TABLE_BYTES / (2 * words * 4)));
+        const size_t max_views = std::min(MAX_VIEW_STATES, std::max<size_t>(8, VIEW_TABLE_BYTES / ((2 * words + VIEW_SPL_WORDS) * 4)));
         while (ctx->views.size() >= max_views) {
             auto old = ctx->views.begin();
             for (auto k = ctx->views.begin(); k != ctx->views.end(); ++k)
@@ -308,14 +308,14 @@ static ViewState* view_state(bh_ctx* ctx, uint64_t key, uint32_t tile_bw, uint32
         vs.tile_bw = tile_bw;
         vs.tile_bh = tile_bh;
         vs.casual = casual;
-        // [T] depth cuts (all "everything") | [T] per-tile work of the last frame (all zero)
+        // [T] depth cuts (all "everything") | [T] per-tile work of the last frame (all zero) | [VIEW_SPL_WORDS] depth-sort splitter tables (none valid)
         vs.zcut = recycled;
-        if (!vs.zcut && hipMalloc((void**)&vs.zcut, 2 * words * 4) != hipSuccess) {
+        if (!vs.zcut && hipMalloc((void**)&vs.zcut, (2 * words + VIEW_SPL_WORDS) * 4) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
         if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut), (int)ZCUT_ALL, words, ctx->stream) != hipSuccess ||
-            hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut + words), 0, words, ctx->stream) != hipSuccess) {
+            hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(vs.zcut + words), 0, words + VIEW_SPL_WORDS, ctx->stream) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(vs.zcut);
             return nullptr;
@@ -503,6 +503,7 @@ void bh_destroy(bh_ctx* ctx) {
     for (auto& b : ctx->pool)
         if (b.ptr) (void)hipFree(b.ptr);
     if (ctx->host_counters) (void)hipHostFree(ctx->host_counters);
+    if (ctx->dsort_spl) (void)hipFree(ctx->dsort_spl);
     if (ctx->readback_ev) (void)hipEventDestroy(ctx->readback_ev);
     if (ctx->gate_ev) (void)hipEventDestroy(ctx->gate_ev);
     if (ctx->comm) (void)bh_comm_destroy(ctx);
@@ -568,6 +569,7 @@ const OptionKey kOptionKeys[] = {
     {"no_lpt", "0|1: the blend backward takes its tiles in index order"},
     {"lpt_classes", "log|linear: work classes of the backward's longest-first tile order — two per octave of blended splats, or 1/64 of the mean list length wide"},
     {"generic_depth_sort", "0|1: depth order by the generic radix sort + scan instead of the fused split sort"},
+    {"dsort_splitters", "0|1: the fused depth sort splits at the 254 depth quantiles of the view's previous frame (default 1) or always linearly over the frame's key range"},
     {"tile_sort", "auto|bucket|lsd: the forward's tile sort (auto: bucket sort unless the view's pairs are concentrated in few tiles)"},
     {"spec_k5", "0|1: queue the list builder before the host has read the frame's counts (default 1; 0: behind the count readback)"},
     {"event_waits", "0|1: the host's mid-step waits use events behind the kernels instead of polled tag words"},
@@ -639,6 +641,7 @@ extern "C" int bh_set_option(bh_ctx* ctx, const char* key, const char* value) {
         else if (v == "linear") { ctx->knob_lpt_linear = true; ok = true; }
     }
     else if (k == "generic_depth_sort") ok = parse_flag(value, &ctx->knob_generic_depth_sort);
+    else if (k == "dsort_splitters") ok = parse_flag(value, &ctx->knob_dsort_splitters);
     else if (k == "tile_sort") {
         const std::string v(value);
         if (v == "auto") { ctx->knob_tile_sort = 0; ok = true; }
@@ -1008,7 +1011,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 if (poll_tag && ++ctx->readback_tag == 0u) ctx->readback_tag = 1u;
                 BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early,
                                        sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev, poll_tag ? ctx->readback_tag : 0u,
-                                       sums_on_device ? dev_sums : nullptr));
+                                       sums_on_device ? dev_sums : nullptr,
+                                       view ? view->zcut + 2 * (size_t)num_tiles + (cut_active ? DSORT_SPL_STRIDE : 0u) : nullptr));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
@@ -1365,6 +1369,8 @@ int bh_forget_views(bh_ctx* ctx) {
     if (!ctx) return BH_ERR_INVALID_ARG;
     BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
+    // (the depth sort's splitter tables are per-ctx state of the same kind: a run that starts over starts from the linear split)
+    if (ctx->dsort_spl) BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream));
     if (ctx->views.empty()) return 0;
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // queued kernels may still use the tables
     deliver_pending_loss(ctx);

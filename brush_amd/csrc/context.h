@@ -131,7 +131,8 @@ constexpr uint32_t ZCUT_ALL = 0xFFFFFFFEu;
 BH_DEV bool zcut_near(uint32_t key, uint32_t cut) { return (key >> 1) <= (cut >> 1); }
 struct ViewState {
     uint32_t* zcut = nullptr;       // [tile_bw * tile_bh] device; directly behind it: work[tile_bw * tile_bh], the splats every tile blended at the
-                                    // view's last frame (the forward blend's tile order, rasterize.hip)
+                                    // view's last frame (the forward blend's tile order, rasterize.hip); behind that: [VIEW_SPL_WORDS] the depth
+                                    // sort's splitter tables of the view
     uint32_t tile_bw = 0, tile_bh = 0;
     bool seeded = false;            // a forward of this view has written the table
     uint32_t exact_frames = 0;      // frames to render with complete lists before the cut is trusted again (the forecast kept failing)
@@ -187,6 +188,8 @@ constexpr uint32_t SPLIT_MAX = 128;         // split tiles per XCD band at most 
 constexpr uint32_t SPLIT_MIN_WORK = 256;    // a tile below this many blended splats is never split
 constexpr uint32_t SPLIT_TAIL_WORDS = 8u + 8u * SPLIT_MAX * 4u;
 constexpr uint32_t BWD_CKPT_MAX_SLOTS = 96u * 1024u;   // 384 MB of checkpoints at most (frames with > ~11 M listed pairs split only their first tiles)
+constexpr uint32_t DSORT_SPL_STRIDE = 260;            // words of one depth-sort splitter table (depth_sort.hip SPLITTERS)
+constexpr uint32_t VIEW_SPL_WORDS = 2 * DSORT_SPL_STRIDE;   // a view keeps two behind its tile table: [0] frames with complete lists, [1] cut lists
 constexpr size_t MAX_VIEW_STATES = 4096;
 constexpr uint64_t DIRECT_ALLREDUCE_MIN_FLOATS = 1u << 16;   // shorter messages are latency-bound: ncclAllReduce
 constexpr uint32_t AUTO_EXACT_FRAMES = 12;   // frames a view renders complete lists after a cut frame that listed > auto_exact_share of its pairs
@@ -412,6 +415,8 @@ struct bh_ctx {
     bh::FarJob far_job;
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
+    uint32_t* dsort_spl = nullptr;    // [DSORT_SPL_STRIDE] device: the depth sort's splitter table (depth_sort.hip SPLITTERS) of frames without a view
+    bool knob_dsort_splitters = true; // option dsort_splitters: the split digit from the previous frame's quantiles (0: always the linear split)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
     // developer knobs (A/B measurements): bh_set_option
     bool knob_no_lpt = false;         // option no_lpt: backward tiles in index order
@@ -542,7 +547,7 @@ int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, u
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
                     uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr,
-                    uint32_t rb_tag = 0, uint32_t* rb_dev = nullptr);
+                    uint32_t rb_tag = 0, uint32_t* rb_dev = nullptr, uint32_t* spl = nullptr);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 // gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);

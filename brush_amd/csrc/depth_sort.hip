@@ -34,35 +34,53 @@ constexpr int DS_RADIX = 256;
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 
 struct DepthSplit {
-    uint32_t kmin;
+    uint32_t kmin, kmax;
     uint32_t scale;      // digit = ((key - kmin) * scale) >> 32: the visible range [kmin, kmax] spread over ALL of the digits 0..254
-    uint32_t sub_bits;   // the keys of one bucket span less than 2^sub_bits
     bool any_visible;
+    const uint32_t* spl; // LDS: [255] splitters of the frame before (SPLITTERS below) or NULL: the linear split
 };
+// SPLITTERS (round 6).  A linear split of the key range is balanced only while the depths are spread evenly over it: a scene whose
+// splats crowd into a thin shell of depths (or one with a few far outliers) puts most keys into a handful of the 255 buckets, and the
+// bucket kernel lasts as long as its largest bucket (beyond FAST_CAP keys: the chunked many-pass path — 2 ms instead of 20 us for half
+// a million keys in one bucket).  The bucket kernel already holds every bucket SORTED — so it leaves the 254 exact quantiles of the
+// frame's visible keys behind (spl[j] = the key of rank (j + 1) Nv / 255), and the next frame OF THE SAME VIEW takes the number of
+// splitters <= key as its digit: an eight-step search in LDS.  A view's depth distribution changes slowly from one visit to the next;
+// a frame whose key range [kmin, kmax] has moved by more than a sixteenth of the table's (another list mode, a scene that has been
+// replaced) ignores the table — keys beyond the last splitter would all land in one bucket — and splits linearly, as does a
+// view's first frame.  The permutation is the stable sort's whatever the digits are.  One table per view and list mode (api.hip keeps
+// them behind the view's tile table; frames without a view share one per ctx); it is read by the histogram and split kernels and
+// rewritten IN PLACE by the bucket kernel behind them.
+//   table [DSORT_SPL_STRIDE]: [0..253] splitters, ascending | [254] 0xFFFFFFFF (the search's sentinel) | [255] != 0: valid |
+//                             [256] kmin, [257] kmax of the frame that wrote it
+constexpr uint32_t SPL_WORDS = 258;
+static_assert(SPL_WORDS <= DSORT_SPL_STRIDE, "context.h reserves the table");
+constexpr uint32_t SPL_MIN_KEYS = 16384;   // frames with fewer visible keys leave no table (the linear split serves them)
 BH_DEV DepthSplit make_split(uint32_t kmax, uint32_t nmin) {
     DepthSplit sp;
     sp.any_visible = nmin != 0u;      // ~key of a visible key is never 0 (the key would be 0xFFFFFFFF)
     sp.kmin = ~nmin;
+    sp.kmax = kmax;
     const uint32_t range = sp.any_visible ? kmax - sp.kmin : 0u;
     // largest scale with (range * scale) >> 32 <= 254
     sp.scale = (uint32_t)min((unsigned long long)0xFFFFFFFFull, (255ull << 32) / ((unsigned long long)range + 1ull));
     if ((((unsigned long long)range * sp.scale) >> 32) > 254ull) sp.scale -= 1u;
-    // a bucket holds the keys k with floor(k * scale / 2^32) = d: an interval of at most ceil(2^32 / scale) + 1 values
-    const uint32_t span = (uint32_t)(((1ull << 32) + sp.scale - 1ull) / (unsigned long long)(sp.scale ? sp.scale : 1u)) + 1u;
-    uint32_t b = 0;
-    while (b < 32u && (span >> b) != 0u) ++b;
-    sp.sub_bits = range == 0u ? 0u : b;
+    sp.spl = nullptr;
     return sp;
 }
 
 // Every block derives the split from K1's 128 (max key, max ~key) pairs itself: 1 KB of L2 hits and one block reduction —
 // cheaper than a launch or a grid-wide hand-over.
-BH_DEV DepthSplit depth_split(const uint32_t* __restrict__ minmax, uint32_t* s_red /*[2 * DS_WAVES]*/) {
+BH_DEV DepthSplit depth_split(const uint32_t* __restrict__ minmax, uint32_t* s_red /*[2 * DS_WAVES]*/, const uint32_t* __restrict__ spl_in /*NULL: linear*/,
+                              uint32_t* s_spl /*[SPL_WORDS]*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t a = 0, b = 0;
     if (tid < (int)COUNTER_SLOTS) {
         a = minmax[2 * tid];
         b = minmax[2 * tid + 1];
+    }
+    if (spl_in != nullptr) {   // (the barriers below publish it)
+        s_spl[tid] = spl_in[tid];
+        if (tid < (int)SPL_WORDS - DS_WG) s_spl[DS_WG + tid] = spl_in[DS_WG + tid];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -75,10 +93,23 @@ BH_DEV DepthSplit depth_split(const uint32_t* __restrict__ minmax, uint32_t* s_r
 #pragma unroll
     for (int w = 0; w < DS_WAVES; ++w) { kmax = max(kmax, s_red[w]); nmin = max(nmin, s_red[DS_WAVES + w]); }
     __syncthreads();
-    return make_split(kmax, nmin);
+    DepthSplit sp = make_split(kmax, nmin);
+    if (spl_in != nullptr && sp.any_visible && s_spl[255] != 0u) {   // a valid table: does this frame's key range still match its frame's?
+        const uint32_t tmin = s_spl[256], tmax = s_spl[257], tol = (tmax - tmin) >> 4;
+        const uint32_t dmin = sp.kmin > tmin ? sp.kmin - tmin : tmin - sp.kmin, dmax = sp.kmax > tmax ? sp.kmax - tmax : tmax - sp.kmax;
+        if (dmin <= tol && dmax <= tol) sp.spl = s_spl;
+    }
+    return sp;
 }
 BH_DEV uint32_t depth_digit(uint32_t key, const DepthSplit& sp) {
-    return key == CULLED_KEY ? 255u : min(254u, (uint32_t)(((unsigned long long)(key - sp.kmin) * sp.scale) >> 32));
+    if (key == CULLED_KEY) return 255u;
+    if (sp.spl != nullptr) {   // (block-uniform) number of splitters <= key: 0..254 (spl[254] = 0xFFFFFFFF > every visible key)
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t step = 128u; step != 0u; step >>= 1) d += sp.spl[d + step - 1u] <= key ? step : 0u;
+        return d;
+    }
+    return min(254u, (uint32_t)(((unsigned long long)(key - sp.kmin) * sp.scale) >> 32));
 }
 
 // lanes of this wave whose digit equals mine
@@ -149,17 +180,19 @@ BH_DEV void counter_sums_to_host(const uint32_t* __restrict__ set, uint32_t* __r
 __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ counts,
                                                           uint32_t n, uint32_t nblocks, const uint32_t* __restrict__ minmax,
                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ csum,
-                                                          const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host, uint32_t rb_tag, uint32_t* __restrict__ rb_dev) {
+                                                          const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host, uint32_t rb_tag, uint32_t* __restrict__ rb_dev,
+                                                          const uint32_t* __restrict__ spl_in) {
     __shared__ uint32_t s_hist[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_csum[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
+    __shared__ uint32_t s_spl[SPL_WORDS];
     const int tid = threadIdx.x, wave = tid >> 6;
     if (blockIdx.x == nblocks) {   // (block-uniform: taken before the first barrier)
         if (wave == 0) counter_sums_to_host(rb_set, rb_host, tid, rb_tag, rb_dev);
         return;
     }
     for (int i = tid; i < DS_WAVES * DS_RADIX; i += DS_WG) { (&s_hist[0][0])[i] = 0; (&s_csum[0][0])[i] = 0; }
-    const DepthSplit sp = depth_split(minmax, s_red);   // (contains the barrier behind the clears)
+    const DepthSplit sp = depth_split(minmax, s_red, spl_in, s_spl);   // (contains the barrier behind the clears)
     const uint32_t base = blockIdx.x * DS_TILE;
     // culled keys (digit 255) are neither counted nor moved: nothing reads the order's tail behind the visible splats, and with
     // per-tile cuts three quarters of the keys are culled — their LDS atomics would all land on one counter
@@ -368,12 +401,14 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
 __global__ __launch_bounds__(DS_WG) void dsort_split_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nblocks,
                                                            const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ offsets /*row-scanned hist*/,
                                                            const uint32_t* __restrict__ digit_totals, uint32_t* __restrict__ out_keys,
-                                                           uint32_t* __restrict__ out_vals, uint32_t* __restrict__ fin_keys, uint32_t* __restrict__ fin_vals) {
+                                                           uint32_t* __restrict__ out_vals, uint32_t* __restrict__ fin_keys, uint32_t* __restrict__ fin_vals,
+                                                           const uint32_t* __restrict__ spl_in) {
     __shared__ ChunkLds<DS_WG> L;
     __shared__ uint32_t s_base[DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
+    __shared__ uint32_t s_spl[SPL_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const DepthSplit sp = depth_split(minmax, s_red);
+    const DepthSplit sp = depth_split(minmax, s_red, spl_in, s_spl);
     // destination of this block's first element of digit `tid`: keys with a smaller digit + this digit's keys in earlier blocks
     {
         const uint32_t gt = digit_totals[tid];
@@ -461,53 +496,80 @@ BH_DEV void bk_scan_counts(const uint32_t* vals, uint32_t size, const uint32_t* 
     }
 }
 
+// Block-wide smallest key (-> lo) and the width in bits of the bucket's key span, from every thread's (min, max); s_w: [2 * BK_WAVES].
+// (Taken from the keys themselves, not from the split: a bucket of a crowded depth range is narrower than its share of the frame's
+// range and needs fewer counting passes.)
+BH_DEV uint32_t bk_key_bits(uint32_t& lo, uint32_t hi, uint32_t* s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if (lane == 0) { s_w[wave] = lo; s_w[BK_WAVES + wave] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BK_WAVES; ++w) { lo = min(lo, s_w[w]); hi = max(hi, s_w[BK_WAVES + w]); }
+    __syncthreads();
+    return hi > lo ? 32u - (uint32_t)__clz(hi - lo) : 0u;
+}
+
+// spl_out (optional): the next frame's splitter table (SPLITTERS above) — the block that holds rank (j + 1) Nv / 255 writes splitter j.
+BH_DEV void bk_write_splitters(const uint32_t* sorted /*the bucket's keys, ascending (LDS or global)*/, uint32_t start, uint32_t size, uint32_t nv,
+                               uint32_t* __restrict__ spl_out) {
+    const uint32_t j = threadIdx.x;
+    if (spl_out == nullptr || nv < SPL_MIN_KEYS || j >= 254u) return;
+    const uint32_t r = (uint32_t)(((unsigned long long)(j + 1u) * nv) / 255ull);
+    if (r >= start && r - start < size) spl_out[j] = sorted[r - start];
+}
+
 __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restrict__ a_keys, uint32_t* __restrict__ a_vals /*the split's output (scratch)*/,
                                                             uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals,
                                                             const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ digit_totals,
-                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ cum /*NULL: no scan*/) {
+                                                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ cum /*NULL: no scan*/,
+                                                            uint32_t* __restrict__ spl_out /*NULL: no table for the next frame*/) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // FAST_LDS_WORDS: the resident path's arrays | the chunked path's ChunkLds
     __shared__ uint32_t s_base[DS_RADIX];
     __shared__ uint32_t s_hist[DS_RADIX];
     __shared__ uint32_t s_red[2 * BK_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    // the split parameters (as depth_split, for this block shape)
-    DepthSplit sp;
-    uint32_t gt_pre, ct_pre;
+    // where this bucket starts, and how many tiles the buckets in front of it hit
+    uint32_t start, size, tiles_before, nv;
     {
+        const uint32_t gt = tid < DS_RADIX ? digit_totals[tid] : 0u;
+        const uint32_t ct = tid < 255 ? digit_totals[DS_RADIX + tid] : 0u;
+        uint32_t tot;
+        const uint32_t gex = bk_excl_scan(gt, nv, s_red);   // (digit 255 is never counted: the total is the number of visible keys)
+        const uint32_t cex = bk_excl_scan(ct, tot, s_red);
+        if (tid < DS_RADIX) { s_base[tid] = gex; s_hist[tid] = cex; }
+        __syncthreads();
+        start = s_base[b];
+        size = s_base[b + 1u] - start;     // (b <= 254)
+        tiles_before = s_hist[b];
+        __syncthreads();
+    }
+    if (b == 0u && spl_out != nullptr) {   // the table's sentinel, its validity word and the frame's key range (block-uniform branch)
         uint32_t x = 0, y = 0;
         if (tid < (int)COUNTER_SLOTS) { x = minmax[2 * tid]; y = minmax[2 * tid + 1]; }
-        gt_pre = tid < DS_RADIX ? digit_totals[tid] : 0u;        // (issued together with the minmax loads: one round trip)
-        ct_pre = tid < 255 ? digit_totals[DS_RADIX + tid] : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             x = max(x, (uint32_t)__shfl_xor((int)x, off));
             y = max(y, (uint32_t)__shfl_xor((int)y, off));
         }
-        if (lane == 0) { s_red[wave] = x; s_red[BK_WAVES + wave] = y; }
+        if (lane == 0) { s_red[wave] = x; s_red[BK_WAVES + wave] = y; }   // (waves >= 2 hold zeros: neutral)
         __syncthreads();
-        uint32_t kmax = 0, nmin = 0;
-#pragma unroll
-        for (int w = 0; w < BK_WAVES; ++w) { kmax = max(kmax, s_red[w]); nmin = max(nmin, s_red[BK_WAVES + w]); }
-        __syncthreads();
-        sp = make_split(kmax, nmin);
-    }
-    // where this bucket starts, and how many tiles the buckets in front of it hit
-    uint32_t start, size, tiles_before;
-    {
-        const uint32_t gt = gt_pre, ct = ct_pre;
-        uint32_t tot;
-        const uint32_t gex = bk_excl_scan(gt, tot, s_red);
-        const uint32_t cex = bk_excl_scan(ct, tot, s_red);
-        if (tid < DS_RADIX) { s_base[tid] = gex; s_hist[tid] = cex; }
-        __syncthreads();
-        start = s_base[b];
-        size = digit_totals[b];
-        tiles_before = s_hist[b];
+        if (tid == 0) {
+            uint32_t kmax = 0, nmin = 0;
+            for (int w = 0; w < BK_WAVES; ++w) { kmax = max(kmax, s_red[w]); nmin = max(nmin, s_red[BK_WAVES + w]); }
+            spl_out[254] = 0xFFFFFFFFu;
+            spl_out[255] = nv >= SPL_MIN_KEYS ? 1u : 0u;
+            spl_out[256] = ~nmin;
+            spl_out[257] = kmax;
+        }
         __syncthreads();
     }
     if (size == 0u) return;
-    const uint32_t bits = sp.sub_bits;   // the keys of a bucket span less than 2^bits (0: one distinct key — nothing to sort)
     if (size <= (uint32_t)FAST_CAP) {
         // ---- resident path (the usual case): the whole bucket lives in LDS and is sorted there by stable counting passes on
         // (key - the bucket's smallest key), digits of up to 9 bits, ping-pong between two (key, splat id) buffers; global
@@ -518,20 +580,15 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         // buffer c: keys at s_dyn + 2 c FAST_CAP, splat ids FAST_CAP behind them
         uint32_t* fcnt = s_dyn + 4 * FAST_CAP;                 // [BK_WAVES][FAST_NDIG]
         uint32_t* fdb = fcnt + BK_WAVES * FAST_NDIG;           // [FAST_NDIG]
-        uint32_t lo = 0xFFFFFFFFu;
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
         for (uint32_t i = tid; i < size; i += BK_WG) {
             const uint32_t k = a_keys[start + i];
             s_dyn[i] = k;
             s_dyn[FAST_CAP + i] = a_vals[start + i];
             lo = min(lo, k);
+            hi = max(hi, k);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
-        if (lane == 0) s_red[wave] = lo;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < BK_WAVES; ++w) lo = min(lo, s_red[w]);
-        __syncthreads();
+        const uint32_t bits = bk_key_bits(lo, hi, s_red);      // the bucket's keys span less than 2^bits (0: one distinct key — nothing to sort)
         const uint32_t passes = (bits + 8u) / 9u;              // 0 for bits == 0
         const uint32_t base_w = passes ? bits / passes : 0u, wide = passes ? bits % passes : 0u;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -596,6 +653,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         }
         const uint32_t* fk = s_dyn + cur * (2 * FAST_CAP); const uint32_t* fv = fk + FAST_CAP;
         uint32_t* spare = s_dyn + (cur ^ 1u) * (2 * FAST_CAP);   // the other buffer: 2 * FAST_CAP words
+        bk_write_splitters(fk, start, size, nv, spl_out);
         // on the way out: the tile count of every splat, all gathers in flight at once
         for (uint32_t i = tid; i < size; i += BK_WG) {
             const uint32_t v = fv[i];
@@ -637,15 +695,13 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
     // stable LSD passes scratch -> out -> scratch -> out, 4096 keys at a time, running digit bases carried from chunk to chunk.
     // An ODD number of passes lands in `out` (0 bits: one pass of width 0 = a stable copy).
     ChunkLds<BK_WG>& L = *reinterpret_cast<ChunkLds<BK_WG>*>(s_dyn);
-    uint32_t lo = 0xFFFFFFFFu;
-    for (uint32_t i = tid; i < size; i += BK_WG) lo = min(lo, a_keys[start + i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
-    if (lane == 0) s_red[wave] = lo;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < BK_WAVES; ++w) lo = min(lo, s_red[w]);
-    __syncthreads();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = tid; i < size; i += BK_WG) {
+        const uint32_t k = a_keys[start + i];
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    const uint32_t bits = bk_key_bits(lo, hi, s_red);
     // (digits of at most 8 bits — the 256-entry tables — and an odd count: 1 pass up to 8 bits, 3 up to 24, 5 beyond.  K1 rejects
     //  |z| > 1e10, which keeps a bucket's span below 2^24 today; the 5-pass case is there so that nothing depends on it.)
     const uint32_t passes = bits <= 8u ? 1u : (bits <= 24u ? 3u : 5u);
@@ -684,6 +740,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         uint32_t* tk = src_k; src_k = dst_k; dst_k = tk;
         uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
     }
+    bk_write_splitters(out_keys + start, start, size, nv, spl_out);
     if (cum != nullptr) bk_scan_counts(out_vals + start, size, counts, tiles_before, cum + start, &L.keys[0], s_red);
 }
 
@@ -700,10 +757,22 @@ bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n +
 // rb_set / rb_host / rb_done (optional, all or none): the counter set whose sums the first kernel stores into the pinned host block
 // rb_host, and the event recorded right behind that kernel (counter_sums_to_host above) — or, rb_tag != 0, no event: the kernel
 // stores the tag behind the sums and the host polls for it.
+// spl (optional): the view's splitter table [DSORT_SPL_STRIDE] for this list mode (SPLITTERS above); NULL: the ctx's.
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev) {
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev, uint32_t* spl) {
     if (n == 0) return 0;
     const uint32_t nblocks = (n + DS_TILE - 1) / DS_TILE;
+    // the splitter table (SPLITTERS above): the caller's (a view's) or, for a frame without a view, the ctx's own
+    if (!ctx->knob_dsort_splitters) spl = nullptr;
+    else if (spl == nullptr) {
+        if (ctx->dsort_spl == nullptr) {
+            if (hipMalloc((void**)&ctx->dsort_spl, DSORT_SPL_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); ctx->dsort_spl = nullptr; return BH_ERR_OOM; }
+            BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream));
+        }
+        spl = ctx->dsort_spl;
+    }
+    const uint32_t* spl_in = spl;
+    uint32_t* spl_out = spl;
     // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables
     uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)2 * DS_RADIX * nblocks + 2 * DS_RADIX) * 4);
     uint32_t* a_keys = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, (size_t)n * 4);
@@ -712,19 +781,19 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
     uint32_t* hist = totals + 2 * DS_RADIX;
     uint32_t* csum = hist + (size_t)DS_RADIX * nblocks;
     hipLaunchKernelGGL(dsort_hist_kernel, dim3(nblocks + (rb_set ? 1u : 0u)), dim3(DS_WG), 0, ctx->stream, keys, counts, n, nblocks, minmax, hist, csum,
-                       rb_set, rb_host, rb_tag, rb_dev);
+                       rb_set, rb_host, rb_tag, rb_dev, spl_in);
     BH_LAUNCH_CHECK(ctx, "dsort_hist_kernel");
     if (rb_set && !rb_tag) BH_HIP(ctx, hipEventRecord(rb_done, ctx->stream));   // (rb_tag: the host polls the tag word instead)
     hipLaunchKernelGGL(dsort_rowscan_kernel, dim3(DS_RADIX), dim3(DS_WG), 0, ctx->stream, hist, csum, nblocks, totals);
     BH_LAUNCH_CHECK(ctx, "dsort_rowscan_kernel");
-    hipLaunchKernelGGL(dsort_split_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, n, nblocks, minmax, hist, totals, a_keys, a_vals, out_keys, out_vals);
+    hipLaunchKernelGGL(dsort_split_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, n, nblocks, minmax, hist, totals, a_keys, a_vals, out_keys, out_vals, spl_in);
     BH_LAUNCH_CHECK(ctx, "dsort_split_kernel");
     // buckets 0..254; the culled splats (digit 255: all keys 0xFFFFFFFF, already in splat-id order) went straight to the output
     if (!ctx->dsort_lds_raised) {   // 146 KB of dynamic LDS: above the 64 KB default, opt in once per ctx (the attribute is per device)
         BH_HIP(ctx, hipFuncSetAttribute((const void*)dsort_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST_LDS_WORDS * 4)));
         ctx->dsort_lds_raised = true;
     }
-    hipLaunchKernelGGL(dsort_bucket_kernel, dim3(DS_RADIX - 1), dim3(BK_WG), FAST_LDS_WORDS * 4, ctx->stream, a_keys, a_vals, out_keys, out_vals, minmax, totals, counts, cum);
+    hipLaunchKernelGGL(dsort_bucket_kernel, dim3(DS_RADIX - 1), dim3(BK_WG), FAST_LDS_WORDS * 4, ctx->stream, a_keys, a_vals, out_keys, out_vals, minmax, totals, counts, cum, spl_out);
     BH_LAUNCH_CHECK(ctx, "dsort_bucket_kernel");
     return 0;
 }

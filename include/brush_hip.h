@@ -177,7 +177,7 @@ const char* bh_version(void);
  * this setter (value as text; BH_ERR_INVALID_ARG for an unknown key or a value out of range).  Options choose between paths that
  * produce the SAME results — A/B measurements and the tests of the alternative paths — never between results:
  *   cut_min_pairs u32 | cut_margin_pct 0..10000 | cut_margin_fixed 0|1 | cut_ctrl up:down:floor:gap_exp | cut_sort_all 0|1 |
- *   auto_exact_share 0..1 | no_view_hash 0|1 | k16_order 0|1|2 | band_mode 0|1 | k16_waves 0..8 | k16_split 0..1000 | k16_split_min 1..1023 | k16_split_of_max 0..100 | k5_exact_spw 16|32|64 | bwd_jobs 0|1 | no_lpt 0|1 | lpt_classes log|linear | generic_depth_sort 0|1 |
+ *   auto_exact_share 0..1 | no_view_hash 0|1 | k16_order 0|1|2 | band_mode 0|1 | k16_waves 0..8 | k16_split 0..1000 | k16_split_min 1..1023 | k16_split_of_max 0..100 | k5_exact_spw 16|32|64 | bwd_jobs 0|1 | no_lpt 0|1 | lpt_classes log|linear | generic_depth_sort 0|1 | dsort_splitters 0|1 |
  *   tile_sort auto|bucket|lsd | spec_k5 0|1 | event_waits 0|1 | readback_copy 0|1 | force_exchange 0|1 | zero_grads 0|1 | loss_bands 0|1 |
  *   update_rows 0|64|128|256 | update_early 0|1 | no_dormant 0|1 | sort_kpt 0|4|8|16 | grad_allreduce ring|direct
  * bh_option_count / bh_option_name / bh_option_help enumerate them with one line of documentation each (host strings). */

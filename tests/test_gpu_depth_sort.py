@@ -1,7 +1,8 @@
 """The forward's fused depth ordering (brush_amd/csrc/depth_sort.hip: one most-significant-digit split on the visible key range +
 one kernel that finishes every bucket and writes the scan of the tile counts) must produce exactly what the generic stable
 32-bit radix sort + prefix sum produce (BH_GENERIC_DEPTH_SORT=1 selects those): same permutation (ties in splat-id order),
-same sorted depths, same cum_tiles_hit — on ordinary scenes and on depth distributions shaped to break a range split:
+same sorted depths, same cum_tiles_hit — with the split at the previous frame's depth quantiles (the default; here the
+previous frame is a DIFFERENT scene every other time) and with the linear split (option dsort_splitters=0) — on ordinary scenes and on depth distributions shaped to break a range split:
 all splats at one depth, two tight clusters plus a far outlier (one bucket holds nearly everything: the chunked many-pass
 path), a huge dynamic range, a single visible splat, nothing visible."""
 import math
@@ -58,35 +59,45 @@ import test_gpu_depth_sort as T
 dev = torch.device("cuda:0")
 cp = synth.default_camera_params(640, 360)
 res = {}
+# every scene twice in a row, all in ONE context: the first frame of a scene splits its keys at the quantiles of the scene BEFORE it
+# (nothing in common with its own depths), the second at its own
 for name, sc in T._scenes().items():
+  for rep in ("", ".again"):
     spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
     img, aux = ba.render_splats(spl, util.hip_camera(ba, cp), (640, 360), (0, 0, 0), ba.RasterPass.Backward)
     nv = aux.num_visible
-    res[name + ".nv"] = np.array([nv, aux.num_intersections])
-    res[name + ".gfc"] = util.u32(aux.global_from_compact_gid)[:nv]
-    res[name + ".depths"] = aux.depths_sorted.cpu().numpy()[:nv]
-    res[name + ".cum"] = util.u32(aux.cum_tiles_hit)[:nv]
-    res[name + ".isect"] = util.u32(aux.compact_gid_from_isect)
-    res[name + ".img"] = img.cpu().numpy()
+    res[name + rep + ".nv"] = np.array([nv, aux.num_intersections])
+    res[name + rep + ".gfc"] = util.u32(aux.global_from_compact_gid)[:nv]
+    res[name + rep + ".depths"] = aux.depths_sorted.cpu().numpy()[:nv]
+    res[name + rep + ".cum"] = util.u32(aux.cum_tiles_hit)[:nv]
+    res[name + rep + ".isect"] = util.u32(aux.compact_gid_from_isect)
+    res[name + rep + ".img"] = img.cpu().numpy()
 np.savez(sys.argv[1], **res)
 """
 
 
 def test_fused_depth_order_equals_generic_sort_and_scan(dev, tmp_path):
     outs = {}
-    for mode in ("fused", "generic"):
+    for mode in ("fused", "linear", "generic"):
         env = dict(os.environ)
         env.pop("BH_GENERIC_DEPTH_SORT", None)
+        env.pop("BH_OPTIONS", None)
         if mode == "generic":
             env["BH_GENERIC_DEPTH_SORT"] = "1"
+        if mode == "linear":
+            env["BH_OPTIONS"] = "dsort_splitters=0"   # the linear split of the key range for every frame
         f = str(tmp_path / (mode + ".npz"))
         r = subprocess.run([sys.executable, "-c", _CHILD % (ROOT, ROOT), f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[mode] = np.load(f)
     a, b = outs["fused"], outs["generic"]
-    assert sorted(a.files) == sorted(b.files)
+    for other in (outs["generic"], outs["linear"]):
+        assert sorted(a.files) == sorted(other.files)
+        for k in a.files:
+            assert np.array_equal(a[k], other[k]), k
     for k in a.files:
-        assert np.array_equal(a[k], b[k]), k
+        if ".again" in k:
+            assert np.array_equal(a[k], a[k.replace(".again", "")]), k
     # the scenes do what they were built for
     assert a["ordinary.nv"][0] > 20_000 and a["one_depth.nv"][0] > 20_000 and a["clusters_and_outlier.nv"][0] > 60_000
     assert a["huge_range.nv"][0] > 15_000 and a["single_visible.nv"][0] == 1 and a["none_visible.nv"][0] == 0

@@ -43,7 +43,7 @@ def test_environment_translation_is_the_harness_not_the_library():
     assert got[-2:] == [("k16_order", "2"), ("no_lpt", "1")]
 
 
-@pytest.mark.parametrize("options", [{"bwd_jobs": 0}, {"lpt_classes": "linear"}, {"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1},
+@pytest.mark.parametrize("options", [{"bwd_jobs": 0}, {"lpt_classes": "linear"}, {"spec_k5": 0}, {"event_waits": 1}, {"readback_copy": 1}, {"tile_sort": "lsd"}, {"tile_sort": "bucket"}, {"generic_depth_sort": 1}, {"dsort_splitters": 0},
                                      {"k16_order": 0}, {"k16_order": 2}, {"no_lpt": 1}, {"cut_sort_all": 1}, {"no_view_hash": 1},
                                      {"auto_exact_share": 0}, {"k5_exact_spw": 16}, {"k5_exact_spw": 64},
                                      {"band_mode": 0}, {"k16_waves": 5}, {"k16_split": 0}, {"k16_split": 1, "k16_split_min": 1, "k16_split_of_max": 0}])
