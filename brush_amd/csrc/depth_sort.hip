@@ -181,7 +181,7 @@ __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __res
                                                           uint32_t n, uint32_t nblocks, const uint32_t* __restrict__ minmax,
                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ csum,
                                                           const uint32_t* __restrict__ rb_set, uint32_t* __restrict__ rb_host, uint32_t rb_tag, uint32_t* __restrict__ rb_dev,
-                                                          const uint32_t* __restrict__ spl_in) {
+                                                          const uint32_t* __restrict__ spl_in, uint8_t* __restrict__ digits /*[n]: every key's split digit, for the split kernel*/) {
     __shared__ uint32_t s_hist[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_csum[DS_WAVES][DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __res
             atomicAdd(&s_hist[wave][d], 1u);
             atomicAdd(&s_csum[wave][d], cnt);
         }
+        return d;
     };
     if (base + (uint32_t)DS_TILE <= n && ((reinterpret_cast<uintptr_t>(keys) | reinterpret_cast<uintptr_t>(counts)) & 15u) == 0) {
         // every chunk but the last: 16-byte loads (which thread counts which key is irrelevant to a histogram)
@@ -210,18 +211,21 @@ __global__ __launch_bounds__(DS_WG) void dsort_hist_kernel(const uint32_t* __res
         uint4 kv[DS_KPT / 4], cv[DS_KPT / 4];
 #pragma unroll
         for (int k = 0; k < DS_KPT / 4; ++k) { kv[k] = k4[k * DS_WG + tid]; cv[k] = c4[k * DS_WG + tid]; }
+        // (the digits leave as bytes, four per store: the split kernel reads them back instead of searching the splitters twice per key)
+        uint32_t* d4 = reinterpret_cast<uint32_t*>(digits + base);
 #pragma unroll
         for (int k = 0; k < DS_KPT / 4; ++k) {
-            count_one(kv[k].x, cv[k].x);
-            count_one(kv[k].y, cv[k].y);
-            count_one(kv[k].z, cv[k].z);
-            count_one(kv[k].w, cv[k].w);
+            const uint32_t d0 = count_one(kv[k].x, cv[k].x);
+            const uint32_t d1 = count_one(kv[k].y, cv[k].y);
+            const uint32_t d2 = count_one(kv[k].z, cv[k].z);
+            const uint32_t d3 = count_one(kv[k].w, cv[k].w);
+            d4[k * DS_WG + tid] = d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < DS_KPT; ++k) {
             const uint32_t idx = base + k * DS_WG + tid;
-            if (idx < n) count_one(keys[idx], counts[idx]);
+            if (idx < n) digits[idx] = (uint8_t)count_one(keys[idx], counts[idx]);
         }
     }
     __syncthreads();
@@ -296,13 +300,15 @@ struct ChunkLds {
     uint32_t wsum[WG / 64];
     uint32_t keys[DS_TILE];
     uint32_t vals[DS_TILE];
+    uint8_t digs[DS_TILE];              // (callers with precomputed digits: the re-ordered elements' digits)
 };
 // WG threads (a multiple of 256): thread (wave w, lane l) ranks elements w * 64 * KPT + k * 64 + l; digit `tid` of the 256 is
 // looked after by thread `tid` (threads >= 256 only rank and move).
 template <int WG, class DigitFn>
 BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256] running destinations (LDS)*/, const uint32_t* __restrict__ src_k,
                           const uint32_t* __restrict__ src_v /*NULL: the element index*/, uint32_t first, uint32_t count, uint32_t* __restrict__ dst_k,
-                          uint32_t* __restrict__ dst_v, DigitFn digit, uint32_t* __restrict__ alt_k = nullptr, uint32_t* __restrict__ alt_v = nullptr) {
+                          uint32_t* __restrict__ dst_v, DigitFn digit, uint32_t* __restrict__ alt_k = nullptr, uint32_t* __restrict__ alt_v = nullptr,
+                          const uint8_t* __restrict__ pre_dig = nullptr /*[.. first + count): the elements' digits, already computed (block-uniform)*/) {
     constexpr int WAVES = WG / 64, KPT = DS_TILE / WG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < WAVES * DS_RADIX; i += WG) (&L.cnt[0][0])[i] = 0;
@@ -317,8 +323,13 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
             key[k] = src_k[first + e];
             val[k] = src_v ? src_v[first + e] : first + e;
         }
+        if (pre_dig) {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) dig[k] = digit(key[k]);
+            for (int k = 0; k < KPT; ++k) dig[k] = pre_dig[first + wave_first + k * 64 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) dig[k] = digit(key[k]);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
@@ -327,7 +338,7 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
             key[k] = valid ? src_k[first + e] : 0u;
             val[k] = valid ? (src_v ? src_v[first + e] : first + e) : 0u;
             // invalid tail elements take digit 255 and sit at the highest in-chunk positions: they never disturb a valid rank
-            dig[k] = valid ? digit(key[k]) : 255u;
+            dig[k] = valid ? (pre_dig ? (uint32_t)pre_dig[first + e] : digit(key[k])) : 255u;
         }
     }
 #pragma unroll
@@ -379,6 +390,7 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
         const uint32_t lpos = L.dbase[dig[k]] + L.cnt[wave][dig[k]] + rank[k];
         L.keys[lpos] = key[k];
         L.vals[lpos] = val[k];
+        if (pre_dig) L.digs[lpos] = (uint8_t)dig[k];
     }
     __syncthreads();
 #pragma unroll
@@ -386,7 +398,7 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
         const uint32_t e = k * WG + tid;
         if (e < count) {   // valid elements occupy the first `count` re-ordered positions (the tail sorts last)
             const uint32_t kk = L.keys[e];
-            const uint32_t d = digit(kk);
+            const uint32_t d = pre_dig ? (uint32_t)L.digs[e] : digit(kk);
             const uint32_t pos = L.gofs[d] + e;
             // alt_* != NULL (the depth split): digit 255 = the culled splats, whose place in the order nobody reads — not written at all
             if (alt_k != nullptr && d == 255u) continue;
@@ -399,16 +411,14 @@ BH_DEV void scatter_chunk(ChunkLds<WG>& L, uint32_t* __restrict__ s_base /*[256]
 
 // ---- 1c: the split itself: stable scatter of (key, splat id) by split digit --------------------------------------------------
 __global__ __launch_bounds__(DS_WG) void dsort_split_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nblocks,
-                                                           const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ offsets /*row-scanned hist*/,
+                                                           const uint32_t* __restrict__ offsets /*row-scanned hist*/,
                                                            const uint32_t* __restrict__ digit_totals, uint32_t* __restrict__ out_keys,
                                                            uint32_t* __restrict__ out_vals, uint32_t* __restrict__ fin_keys, uint32_t* __restrict__ fin_vals,
-                                                           const uint32_t* __restrict__ spl_in) {
+                                                           const uint8_t* __restrict__ digits /*[n] the histogram kernel's*/) {
     __shared__ ChunkLds<DS_WG> L;
     __shared__ uint32_t s_base[DS_RADIX];
     __shared__ uint32_t s_red[2 * DS_WAVES];
-    __shared__ uint32_t s_spl[SPL_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const DepthSplit sp = depth_split(minmax, s_red, spl_in, s_spl);
     // destination of this block's first element of digit `tid`: keys with a smaller digit + this digit's keys in earlier blocks
     {
         const uint32_t gt = digit_totals[tid];
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(DS_WG) void dsort_split_kernel(const uint32_t* __re
     __syncthreads();
     const uint32_t first = blockIdx.x * DS_TILE;
     const uint32_t count = n - first < (uint32_t)DS_TILE ? n - first : (uint32_t)DS_TILE;
-    scatter_chunk<DS_WG>(L, s_base, keys, nullptr, first, count, out_keys, out_vals, [&](uint32_t k) { return depth_digit(k, sp); }, fin_keys, fin_vals);
+    scatter_chunk<DS_WG>(L, s_base, keys, nullptr, first, count, out_keys, out_vals, [](uint32_t) { return 0u; }, fin_keys, fin_vals, digits);
 }
 
 // ---- 2: one block per bucket: sort on the low bits, then the scan of the tile counts --------------------------------------------
@@ -773,20 +783,21 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
     }
     const uint32_t* spl_in = spl;
     uint32_t* spl_out = spl;
-    // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables
-    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)2 * DS_RADIX * nblocks + 2 * DS_RADIX) * 4);
+    // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables, then the keys' digits (bytes)
+    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)2 * DS_RADIX * nblocks + 2 * DS_RADIX) * 4 + (size_t)nblocks * DS_TILE);
     uint32_t* a_keys = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, (size_t)n * 4);
     uint32_t* a_vals = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, (size_t)n * 4);
     if (!totals || !a_keys || !a_vals) return BH_ERR_OOM;
     uint32_t* hist = totals + 2 * DS_RADIX;
     uint32_t* csum = hist + (size_t)DS_RADIX * nblocks;
+    uint8_t* digits = reinterpret_cast<uint8_t*>(csum + (size_t)DS_RADIX * nblocks);   // [nblocks * DS_TILE] every key's split digit (hist -> split)
     hipLaunchKernelGGL(dsort_hist_kernel, dim3(nblocks + (rb_set ? 1u : 0u)), dim3(DS_WG), 0, ctx->stream, keys, counts, n, nblocks, minmax, hist, csum,
-                       rb_set, rb_host, rb_tag, rb_dev, spl_in);
+                       rb_set, rb_host, rb_tag, rb_dev, spl_in, digits);
     BH_LAUNCH_CHECK(ctx, "dsort_hist_kernel");
     if (rb_set && !rb_tag) BH_HIP(ctx, hipEventRecord(rb_done, ctx->stream));   // (rb_tag: the host polls the tag word instead)
     hipLaunchKernelGGL(dsort_rowscan_kernel, dim3(DS_RADIX), dim3(DS_WG), 0, ctx->stream, hist, csum, nblocks, totals);
     BH_LAUNCH_CHECK(ctx, "dsort_rowscan_kernel");
-    hipLaunchKernelGGL(dsort_split_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, n, nblocks, minmax, hist, totals, a_keys, a_vals, out_keys, out_vals, spl_in);
+    hipLaunchKernelGGL(dsort_split_kernel, dim3(nblocks), dim3(DS_WG), 0, ctx->stream, keys, n, nblocks, hist, totals, a_keys, a_vals, out_keys, out_vals, digits);
     BH_LAUNCH_CHECK(ctx, "dsort_split_kernel");
     // buckets 0..254; the culled splats (digit 255: all keys 0xFFFFFFFF, already in splat-id order) went straight to the output
     if (!ctx->dsort_lds_raised) {   // 146 KB of dynamic LDS: above the 64 KB default, opt in once per ctx (the attribute is per device)
