@@ -108,9 +108,12 @@ struct KeepNearOfCut {
 // (One LDS atomic per hit lane in the counting callers: a variant in which the first lane of each splat's run of candidates adds
 // the run's hits — ballot + popcount, one plain LDS update per splat and step — measured the same, 58.1 vs 57.6 us: the walk is
 // bound by the ~60 VALU instructions of the test, two IEEE divisions among them, not by the LDS.)
-template <class OnHit, class Keep = KeepAllTiles>
+// pre(tx, ty) is evaluated for every candidate BEFORE the contribution test and its value handed to on_hit: a load issued there (K1's
+// read of the tile's depth cut) is in flight during the ~100 instructions of the test instead of a dependent round trip behind it.
+struct NoPrefetch { BH_DEV uint32_t operator()(uint32_t, uint32_t) const { return 0u; } };
+template <class OnHit, class Keep = KeepAllTiles, class Pre = NoPrefetch>
 BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, float my, Sym2 conic, float pt, TileBbox bb,
-                               OnHit on_hit, Keep keep = Keep{}, uint32_t zkey = 0u) {
+                               OnHit on_hit, Keep keep = Keep{}, uint32_t zkey = 0u, Pre pre = Pre{}) {
     const uint32_t incl = wave_inclusive_scan_u32(nb, lane);
     const uint32_t start = incl - nb;
     const bool nz = nb > 0u;
@@ -159,7 +162,8 @@ BH_DEV uint32_t flat_tile_walk(WalkLds& w, int lane, uint32_t nb, float mx, floa
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
-            if (keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty);
+            const uint32_t fetched = pre(tx, ty);
+            if (keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r])) on_hit(r, tx, ty, fetched);
         }
         before += (uint32_t)__popcll(marks);
     }
@@ -423,15 +427,18 @@ __global__ __launch_bounds__(PROJ_WG) void project_forward_kernel(
     // every later hit of the tile repeated the atomic).  The blend kernel then knows whose near list is incomplete — an
     // unmarked tile holds everything there is, however its cut reads.
     const uint32_t tile_bw = u.tile_bw;
-    const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty) {
+    struct CutOfTile {   // (zcut == NULL: no load)
+        const uint32_t* zcut;
+        uint32_t tile_bw;
+        BH_DEV uint32_t operator()(uint32_t tx, uint32_t ty) const { return zcut ? zcut[tx + ty * tile_bw] : 0u; }
+    };
+    const uint32_t wrank = flat_tile_walk(w, lane, nb, mx, my, conic, pt, bb, [&](uint32_t r, uint32_t tx, uint32_t ty, uint32_t cut) {
         atomicAdd(&w.count[r], 1u);
         if (zcut) {
-            const uint32_t t = tx + ty * tile_bw;
-            const uint32_t cut = zcut[t];
             if (zcut_near(w.zkey[r], cut)) atomicAdd(&w.near[r], 1u);
-            else if ((cut & 1u) == 0u) zcut[t] = cut | 1u;
+            else if ((cut & 1u) == 0u) zcut[tx + ty * tile_bw] = cut | 1u;
         }
-    }, KeepAllTiles{}, key);
+    }, KeepAllTiles{}, key, CutOfTile{zcut, tile_bw});
     const uint32_t tiles_hit = nb ? w.count[wrank] : 0u;
     const uint32_t near_hit = (nb && zcut) ? w.near[wrank] : 0u;
     // per-tile cuts: a visible splat without a single pair in front of a cut takes no part in this frame's lists — it gets the
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(PROJ_WG) void slice_count_kernel(uint32_t nv, uint3
     WalkLds& w = s_walk[wave];
     uint32_t hits = 0;
     if (__ballot(nb > 0u) != 0ull) {
-        const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); },
+        const uint32_t wrank = flat_tile_walk(w, lane, nb, xy_x, xy_y, conic, pt, bb, [&](uint32_t r, uint32_t, uint32_t, uint32_t) { atomicAdd(&w.count[r], 1u); },
                                               KeepLiveTiles{done_bits, tile_bw});
         hits = nb ? w.count[wrank] : 0u;
     }
