@@ -89,8 +89,9 @@ BH_DEV uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
 // (valid when nb > 0): per-splat results are read back from w.count[rank].
 // keep(tx, ty) is evaluated BEFORE the contribution test: the depth-sliced forward's second slice walks only the tiles that are
 // still unsaturated (a bit test against a 1 KB table instead of the ellipse-rectangle test); K1 / the exact path keep everything.
-struct KeepAllTiles { BH_DEV bool operator()(const WalkLds&, uint32_t, uint32_t, uint32_t) const { return true; } };
+struct KeepAllTiles { static constexpr bool EAGER = false; BH_DEV bool operator()(const WalkLds&, uint32_t, uint32_t, uint32_t) const { return true; } };
 struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are final
+    static constexpr bool EAGER = false;
     const uint32_t* done_bits;
     uint32_t tile_bw;
     BH_DEV bool operator()(const WalkLds&, uint32_t, uint32_t tx, uint32_t ty) const {
@@ -102,7 +103,13 @@ struct KeepLiveTiles {   // bit (tile) of done_bits set = the tile's pixels are 
 struct KeepNearOfCut {
     const uint32_t* zcut;
     uint32_t tile_bw;
-    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return zcut_near(w.zkey[r], zcut[tx + ty * tile_bw]); }
+    // EAGER (flat_tile_walk_emit): the cut is fetched, the contribution test runs WHILE the load is in flight, then the two are combined —
+    // instead of load, wait, compare, branch, test.  The near slice's K5 is bound by its longest wave's chain of walk steps, not by issue
+    // slots: the tests of the candidates behind their cuts (two thirds of them) cost nothing that shows.
+    static constexpr bool EAGER = true;
+    BH_DEV uint32_t fetch(uint32_t tx, uint32_t ty) const { return zcut[tx + ty * tile_bw]; }
+    BH_DEV bool decide(const WalkLds& w, uint32_t r, uint32_t cut) const { return zcut_near(w.zkey[r], cut); }
+    BH_DEV bool operator()(const WalkLds& w, uint32_t r, uint32_t tx, uint32_t ty) const { return decide(w, r, fetch(tx, ty)); }
 };
 
 // (One LDS atomic per hit lane in the counting callers: a variant in which the first lane of each splat's run of candidates adds
@@ -222,7 +229,14 @@ BH_DEV uint32_t flat_tile_walk_emit(WalkLds& w, int lane, uint32_t nb, float mx,
             const uint32_t row = walk_row(i, bw, w.magic[r]);
             const uint32_t tx = (box & 0xFFFFu) + (i - __umul24(row, bw));   // row * bw <= i < 2^24
             const uint32_t ty = (box >> 16) + row;
-            hit = keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
+            if constexpr (Keep::EAGER) {
+                const uint32_t cut = keep.fetch(tx, ty);
+                uint32_t contributes = will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]) ? 1u : 0u;
+                asm volatile("" : "+v"(contributes));   // (the test is not to be sunk behind the load's wait)
+                hit = contributes != 0u && keep.decide(w, r, cut);
+            } else {
+                hit = keep(w, r, tx, ty) && will_primitive_contribute(tx, ty, w.mx[r], w.my[r], Sym2{w.c00[r], w.c01[r], w.c11[r]}, w.pt[r]);
+            }
             tile = tx + ty * tile_bw;
             owner = cg0 + w.lane_of[r];
         }
