@@ -585,7 +585,7 @@ def main():
         touched = 80 * ib + 32 * pixels
         listed = 80 * ni + 32 * pixels
         ach = touched / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-        hbm = {"bound": "hbm (reported because the contract asks for it: the kernel is VALU-issue bound, see roofline_valu)", "kernel": "rasterize_backward_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        hbm = {"bound": "hbm", "bound_note": "reported because the contract asks for it: the kernel is VALU-issue bound, see roofline_valu", "kernel": "rasterize_backward_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(ach / HBM_PEAK_GBS, 4), "bytes_per_launch": touched, "avg_launch_ms": round(dom_ms, 4),
                "avg_launch_ms_clock": "HIP events carried by the kernel's own dispatch packet (hipExtLaunchKernelGGL start / stop events on the ctx stream), every launch "
                                       "of the timed steps of every window, mean over them and over the views.  kernel_trace.kernels holds the same kernel's begin/end "
