@@ -1012,7 +1012,8 @@ int bh::forward_impl(bh_ctx* ctx, const BhCamera* cam, uint32_t n, uint32_t sh_d
                 BH_TRY(depth_sort_scan(ctx, depth_keys, counters + COUNTER_MINMAX_WORD, cut_active ? near_counts : isect_counts, n, depths_sorted, gfc, cum_early,
                                        sums_on_device ? counters : nullptr, ctx->host_counters + 16, ctx->readback_ev, poll_tag ? ctx->readback_tag : 0u,
                                        sums_on_device ? dev_sums : nullptr,
-                                       view ? view->zcut + 2 * (size_t)num_tiles + (cut_active ? DSORT_SPL_STRIDE : 0u) : nullptr));
+                                       view ? view->zcut + 2 * (size_t)num_tiles + (cut_active ? DSORT_SPL_STRIDE : 0u) : nullptr,
+                                       view ? &view->spl_written[cut_active ? 1 : 0] : nullptr));
             } else {
                 BH_TRY(radix_argsort(ctx, depth_keys, nullptr, n, 32, depths_sorted, gfc));
             }
@@ -1370,7 +1371,7 @@ int bh_forget_views(bh_ctx* ctx) {
     BH_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->far_job.pending) BH_TRY(finish_far_slice(ctx, nullptr));
     // (the depth sort's splitter tables are per-ctx state of the same kind: a run that starts over starts from the linear split)
-    if (ctx->dsort_spl) BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream));
+    if (ctx->dsort_spl) { BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream)); ctx->dsort_spl_written = false; }
     if (ctx->views.empty()) return 0;
     BH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // queued kernels may still use the tables
     deliver_pending_loss(ctx);

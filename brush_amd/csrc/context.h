@@ -143,6 +143,7 @@ struct ViewState {
     uint32_t last_pairs = 0;        // num_intersections of the view's last frame
     float last_share = 0.0f;        // share of its pairs the view's last CUT frame listed (0: none yet)
     uint32_t complete_frames = 0;   // frames to render with complete lists because cutting saved (almost) nothing last time; then one probe frame
+    bool spl_written[2] = {false, false};   // the view's depth-sort splitter tables ([0] complete lists, [1] cut lists) have been written by a frame
     bool casual = false;            // created by a forward-only frame keyed by its camera (a viewer / eval render): these compete for CASUAL_VIEW_STATES tables only
 };
 constexpr uint32_t CUT_MIN_PAIRS = 1500000u;   // frames with fewer pairs keep complete lists (nothing to save)
@@ -416,6 +417,7 @@ struct bh_ctx {
     uint32_t refine_n = 0, refine_new_n = 0;  // a bh_refine_plan awaiting its bh_refine_apply
     bool dsort_lds_raised = false;    // likewise dsort_bucket_kernel (depth_sort.hip)
     uint32_t* dsort_spl = nullptr;    // [DSORT_SPL_STRIDE] device: the depth sort's splitter table (depth_sort.hip SPLITTERS) of frames without a view
+    bool dsort_spl_written = false;   // a frame has written it (until then a frame sorts a sample first)
     bool knob_dsort_splitters = true; // option dsort_splitters: the split digit from the previous frame's quantiles (0: always the linear split)
     bool adam_lds_raised = false;     // adam_rowreduced_kernel's > 64 KB dynamic-LDS opt-in was made on this ctx's device
     // developer knobs (A/B measurements): bh_set_option
@@ -547,7 +549,7 @@ int tile_sort_offsets(bh_ctx* ctx, const uint32_t* keys, const uint32_t* vals, u
 bool depth_sort_supported(uint32_t n);
 int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
                     uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set = nullptr, uint32_t* rb_host = nullptr, hipEvent_t rb_done = nullptr,
-                    uint32_t rb_tag = 0, uint32_t* rb_dev = nullptr, uint32_t* spl = nullptr);
+                    uint32_t rb_tag = 0, uint32_t* rb_dev = nullptr, uint32_t* spl = nullptr, bool* spl_written = nullptr);
 // scan.hip — inclusive scan; if `gather` != nullptr the input is in[gather[i]]. exclusive: out[i] = sum_{j<i}.
 // gate != NULL: a device word; 0 there turns the launches into no-ops (the depth-sliced forward's second slice)
 int prefix_sum(bh_ctx* ctx, const uint32_t* in, const uint32_t* gather, uint32_t n, uint32_t* out, bool exclusive, const uint32_t* gate = nullptr);

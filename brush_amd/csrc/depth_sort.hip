@@ -55,6 +55,13 @@ struct DepthSplit {
 constexpr uint32_t SPL_WORDS = 258;
 static_assert(SPL_WORDS <= DSORT_SPL_STRIDE, "context.h reserves the table");
 constexpr uint32_t SPL_MIN_KEYS = 16384;   // frames with fewer visible keys leave no table (the linear split serves them)
+// A frame that finds NO table (a view's first frame in this list mode; the host knows) does not fall back to the linear split blindly:
+// every SPL_SAMPLE_STRIDE-th key is sorted first — the same four kernels on 1/64 of the keys, linear split (a crowded sample is a few
+// thousand keys in one bucket: nothing) — and the bucket kernel of THAT run leaves the sample's quantiles as the frame's table.  ~30 us,
+// once per view and list mode; without it the first frame of a scene whose depths crowd into a thin shell took 2.4 ms instead of 0.44.
+constexpr uint32_t SPL_SAMPLE_STRIDE = 64;
+constexpr uint32_t SPL_SAMPLE_MIN_N = 1u << 17;     // smaller frames are sorted as they come
+constexpr uint32_t SPL_SAMPLE_MIN_KEYS = 1024;      // visible keys of the sample below which it leaves no table
 BH_DEV DepthSplit make_split(uint32_t kmax, uint32_t nmin) {
     DepthSplit sp;
     sp.any_visible = nmin != 0u;      // ~key of a visible key is never 0 (the key would be 0xFFFFFFFF)
@@ -526,9 +533,9 @@ BH_DEV uint32_t bk_key_bits(uint32_t& lo, uint32_t hi, uint32_t* s_w) {
 
 // spl_out (optional): the next frame's splitter table (SPLITTERS above) — the block that holds rank (j + 1) Nv / 255 writes splitter j.
 BH_DEV void bk_write_splitters(const uint32_t* sorted /*the bucket's keys, ascending (LDS or global)*/, uint32_t start, uint32_t size, uint32_t nv,
-                               uint32_t* __restrict__ spl_out) {
+                               uint32_t* __restrict__ spl_out, uint32_t spl_min_keys) {
     const uint32_t j = threadIdx.x;
-    if (spl_out == nullptr || nv < SPL_MIN_KEYS || j >= 254u) return;
+    if (spl_out == nullptr || nv < spl_min_keys || j >= 254u) return;
     const uint32_t r = (uint32_t)(((unsigned long long)(j + 1u) * nv) / 255ull);
     if (r >= start && r - start < size) spl_out[j] = sorted[r - start];
 }
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
                                                             uint32_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals,
                                                             const uint32_t* __restrict__ minmax, const uint32_t* __restrict__ digit_totals,
                                                             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cum /*NULL: no scan*/,
-                                                            uint32_t* __restrict__ spl_out /*NULL: no table for the next frame*/) {
+                                                            uint32_t* __restrict__ spl_out /*NULL: no table for the next frame*/, uint32_t spl_min_keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // FAST_LDS_WORDS: the resident path's arrays | the chunked path's ChunkLds
     __shared__ uint32_t s_base[DS_RADIX];
     __shared__ uint32_t s_hist[DS_RADIX];
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
             uint32_t kmax = 0, nmin = 0;
             for (int w = 0; w < BK_WAVES; ++w) { kmax = max(kmax, s_red[w]); nmin = max(nmin, s_red[BK_WAVES + w]); }
             spl_out[254] = 0xFFFFFFFFu;
-            spl_out[255] = nv >= SPL_MIN_KEYS ? 1u : 0u;
+            spl_out[255] = nv >= spl_min_keys ? 1u : 0u;
             spl_out[256] = ~nmin;
             spl_out[257] = kmax;
         }
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         }
         const uint32_t* fk = s_dyn + cur * (2 * FAST_CAP); const uint32_t* fv = fk + FAST_CAP;
         uint32_t* spare = s_dyn + (cur ^ 1u) * (2 * FAST_CAP);   // the other buffer: 2 * FAST_CAP words
-        bk_write_splitters(fk, start, size, nv, spl_out);
+        bk_write_splitters(fk, start, size, nv, spl_out, spl_min_keys);
         // on the way out: the tile count of every splat, all gathers in flight at once
         for (uint32_t i = tid; i < size; i += BK_WG) {
             const uint32_t v = fv[i];
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(BK_WG) void dsort_bucket_kernel(uint32_t* __restric
         uint32_t* tk = src_k; src_k = dst_k; dst_k = tk;
         uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
     }
-    bk_write_splitters(out_keys + start, start, size, nv, spl_out);
+    bk_write_splitters(out_keys + start, start, size, nv, spl_out, spl_min_keys);
     if (cum != nullptr) bk_scan_counts(out_vals + start, size, counts, tiles_before, cum + start, &L.keys[0], s_red);
 }
 
@@ -767,27 +774,18 @@ bool depth_sort_supported(uint32_t n) { return n > 0 && n <= DSORT_MAX_N && (n +
 // rb_set / rb_host / rb_done (optional, all or none): the counter set whose sums the first kernel stores into the pinned host block
 // rb_host, and the event recorded right behind that kernel (counter_sums_to_host above) — or, rb_tag != 0, no event: the kernel
 // stores the tag behind the sums and the host polls for it.
-// spl (optional): the view's splitter table [DSORT_SPL_STRIDE] for this list mode (SPLITTERS above); NULL: the ctx's.
-int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
-                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev, uint32_t* spl) {
-    if (n == 0) return 0;
+// spl (optional): the view's splitter table [DSORT_SPL_STRIDE] for this list mode (SPLITTERS above) and the host's note whether a frame has
+// written it yet; NULL: the ctx's.
+__global__ __launch_bounds__(256) void dsort_sample_kernel(const uint32_t* __restrict__ keys, uint32_t stride, uint32_t m, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < m) out[i] = keys[(size_t)i * stride];
+}
+
+// the four launches; scratch sized by the caller
+static int dsort_launches(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys, uint32_t* out_vals,
+                          uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev, uint32_t* totals,
+                          uint32_t* a_keys, uint32_t* a_vals, const uint32_t* spl_in, uint32_t* spl_out, uint32_t spl_min_keys) {
     const uint32_t nblocks = (n + DS_TILE - 1) / DS_TILE;
-    // the splitter table (SPLITTERS above): the caller's (a view's) or, for a frame without a view, the ctx's own
-    if (!ctx->knob_dsort_splitters) spl = nullptr;
-    else if (spl == nullptr) {
-        if (ctx->dsort_spl == nullptr) {
-            if (hipMalloc((void**)&ctx->dsort_spl, DSORT_SPL_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); ctx->dsort_spl = nullptr; return BH_ERR_OOM; }
-            BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream));
-        }
-        spl = ctx->dsort_spl;
-    }
-    const uint32_t* spl_in = spl;
-    uint32_t* spl_out = spl;
-    // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables, then the keys' digits (bytes)
-    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)2 * DS_RADIX * nblocks + 2 * DS_RADIX) * 4 + (size_t)nblocks * DS_TILE);
-    uint32_t* a_keys = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, (size_t)n * 4);
-    uint32_t* a_vals = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, (size_t)n * 4);
-    if (!totals || !a_keys || !a_vals) return BH_ERR_OOM;
     uint32_t* hist = totals + 2 * DS_RADIX;
     uint32_t* csum = hist + (size_t)DS_RADIX * nblocks;
     uint8_t* digits = reinterpret_cast<uint8_t*>(csum + (size_t)DS_RADIX * nblocks);   // [nblocks * DS_TILE] every key's split digit (hist -> split)
@@ -804,10 +802,47 @@ int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, c
         BH_HIP(ctx, hipFuncSetAttribute((const void*)dsort_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST_LDS_WORDS * 4)));
         ctx->dsort_lds_raised = true;
     }
-    hipLaunchKernelGGL(dsort_bucket_kernel, dim3(DS_RADIX - 1), dim3(BK_WG), FAST_LDS_WORDS * 4, ctx->stream, a_keys, a_vals, out_keys, out_vals, minmax, totals, counts, cum, spl_out);
+    hipLaunchKernelGGL(dsort_bucket_kernel, dim3(DS_RADIX - 1), dim3(BK_WG), FAST_LDS_WORDS * 4, ctx->stream, a_keys, a_vals, out_keys, out_vals, minmax, totals, counts, cum, spl_out,
+                       spl_min_keys);
     BH_LAUNCH_CHECK(ctx, "dsort_bucket_kernel");
     return 0;
 }
 
-}  // namespace bh
+int depth_sort_scan(bh_ctx* ctx, const uint32_t* keys, const uint32_t* minmax, const uint32_t* counts, uint32_t n, uint32_t* out_keys,
+                    uint32_t* out_vals, uint32_t* cum, const uint32_t* rb_set, uint32_t* rb_host, hipEvent_t rb_done, uint32_t rb_tag, uint32_t* rb_dev, uint32_t* spl,
+                    bool* spl_written) {
+    if (n == 0) return 0;
+    const uint32_t nblocks = (n + DS_TILE - 1) / DS_TILE;
+    // the splitter table (SPLITTERS above): the caller's (a view's) or, for a frame without a view, the ctx's own
+    if (!ctx->knob_dsort_splitters) spl = nullptr;
+    else if (spl == nullptr) {
+        if (ctx->dsort_spl == nullptr) {
+            if (hipMalloc((void**)&ctx->dsort_spl, DSORT_SPL_STRIDE * 4) != hipSuccess) { (void)hipGetLastError(); ctx->dsort_spl = nullptr; return BH_ERR_OOM; }
+            BH_HIP(ctx, hipMemsetAsync(ctx->dsort_spl, 0, DSORT_SPL_STRIDE * 4, ctx->stream));
+            ctx->dsort_spl_written = false;
+        }
+        spl = ctx->dsort_spl;
+        spl_written = &ctx->dsort_spl_written;
+    }
+    // [512] digit totals (keys | tile counts), then the two [256][nblocks] tables, then the keys' digits (bytes)
+    uint32_t* totals = (uint32_t*)ensure(ctx, SLOT_SORT_HIST, ((size_t)2 * DS_RADIX * nblocks + 2 * DS_RADIX) * 4 + (size_t)nblocks * DS_TILE);
+    uint32_t* a_keys = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_A, (size_t)n * 4);
+    uint32_t* a_vals = (uint32_t*)ensure(ctx, SLOT_SORT_VALS_A, (size_t)n * 4);
+    if (!totals || !a_keys || !a_vals) return BH_ERR_OOM;
+    if (spl && spl_written && !*spl_written && n >= SPL_SAMPLE_MIN_N) {
+        // no table yet: the sample's quantiles first (see SPL_SAMPLE_STRIDE).  Its sorted output lands in the real run's output buffers,
+        // which the real run overwrites; its "tile counts" are the sample keys themselves (no scan is asked for).
+        const uint32_t m = n / SPL_SAMPLE_STRIDE;
+        uint32_t* sample = (uint32_t*)ensure(ctx, SLOT_SORT_KEYS_B, (size_t)m * 4);
+        if (!sample) return BH_ERR_OOM;
+        hipLaunchKernelGGL(dsort_sample_kernel, dim3((m + 255u) / 256u), dim3(256), 0, ctx->stream, keys, SPL_SAMPLE_STRIDE, m, sample);
+        BH_LAUNCH_CHECK(ctx, "dsort_sample_kernel");
+        BH_TRY(dsort_launches(ctx, sample, minmax, sample, m, out_keys, out_vals, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, totals, a_keys, a_vals, nullptr, spl,
+                              SPL_SAMPLE_MIN_KEYS));
+    }
+    BH_TRY(dsort_launches(ctx, keys, minmax, counts, n, out_keys, out_vals, cum, rb_set, rb_host, rb_done, rb_tag, rb_dev, totals, a_keys, a_vals, spl, spl, SPL_MIN_KEYS));
+    if (spl && spl_written) *spl_written = true;
+    return 0;
+}
 
+}  // namespace bh

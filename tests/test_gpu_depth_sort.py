@@ -105,3 +105,38 @@ def test_fused_depth_order_equals_generic_sort_and_scan(dev, tmp_path):
     assert np.all(d == d[0]) and np.all(np.diff(a["one_depth.gfc"].astype(np.int64)) > 0), "ties keep splat-id order"
     for name in ("ordinary", "clusters_and_outlier", "huge_range"):
         assert np.all(np.diff(a[name + ".depths"]) >= 0)
+
+
+def test_first_frame_of_a_view_sorts_a_sample_first(dev):
+    """A frame that finds no splitter table (a view's first frame) sorts every 64th key first and splits at THAT sample's quantiles
+    (depth_sort.hip SPL_SAMPLE_STRIDE; frames of >= 131072 splats): on a scene whose depths crowd into a thin shell — the case the
+    sample is there for — the first and the second frame of a fresh context equal the generic sort's, order, scan and image."""
+    import brush_amd as ba
+    n = 300_000
+    rng = np.random.default_rng(23)
+    sc = synth.make_scene(n, 0x71, sh_degree=0, log_scale_range=(math.log(0.01), math.log(0.04)))
+    z = np.where(rng.random(n) < 0.97, 6.0 + rng.random(n) * 0.05, 2.0 + rng.random(n) * 10.0).astype(np.float32)
+    f = z / sc["transforms"][:, 2]
+    sc["transforms"][:, 0] *= f
+    sc["transforms"][:, 1] *= f
+    sc["transforms"][:, 2] = z
+    cp = synth.default_camera_params(640, 360)
+    cam = util.hip_camera(ba, cp)
+    got = {}
+    for name, opts in (("generic", {"generic_depth_sort": 1}), ("sampled", {}), ("linear", {"dsort_splitters": 0})):
+        ctx = ba.Context(dev, options=opts)
+        spl = ba.Splats(sc["transforms"], sc["sh"], sc["raw_opac"], device=dev)
+        frames = []
+        for _ in range(2):
+            img, aux = ba.render_splats(spl, cam, (640, 360), (0, 0, 0), ba.RasterPass.Backward, ctx=ctx)
+            nv = aux.num_visible
+            frames.append((nv, util.u32(aux.global_from_compact_gid)[:nv].copy(), util.u32(aux.cum_tiles_hit)[:nv].copy(), img.cpu().numpy()))
+        got[name] = frames
+        ctx.close()
+    assert got["generic"][0][0] > 131072 // 2
+    for name in ("sampled", "linear"):
+        for k in range(2):
+            a, b = got["generic"][k], got[name][k]
+            assert a[0] == b[0], (name, k)
+            for x, y in zip(a[1:], b[1:]):
+                assert np.array_equal(x, y), (name, k)
